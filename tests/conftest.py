@@ -1,0 +1,66 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when no device is present and they were not deselected.
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    def __init__(self, name):
+        self._z = np.load(os.path.join(GOLDEN, name + ".npz"))
+
+    def __getitem__(self, k):
+        return torch.from_numpy(self._z[k])
+
+    def get(self, k, default=None):
+        return torch.from_numpy(self._z[k]) if k in self._z.files else default
+
+    def keys(self):
+        return self._z.files
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+
+    return load
+
+
+def rel_err(y, ref):
+    """Parity metric: max|y-ref|/max|ref| and relative L2."""
+    y, ref = y.detach().double().cpu(), ref.detach().double().cpu()
+    d = y - ref
+    peak = float(d.abs().max() / ref.abs().max().clamp_min(1e-30))
+    l2 = float(d.norm() / ref.norm().clamp_min(1e-30))
+    return peak, l2
+
+
+def assert_close(y, ref, tol=1e-5, what=""):
+    assert y.shape == ref.shape, f"{what}: shape {tuple(y.shape)} vs {tuple(ref.shape)}"
+    peak, l2 = rel_err(y, ref)
+    assert peak <= tol and l2 <= tol, f"{what}: peak-rel {peak:.3e}, rel-L2 {l2:.3e} > {tol:g}"

@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the upstream reference itself.
+
+Runs ONLY in the build container (needs /root/reference and the four
+third-party stand-ins in tests/golden/_shims).  Writes small .npz / .json
+fixtures next to this file; those are data (inputs + expected outputs), the
+reference's source never leaves /root/reference.
+
+    python tests/golden/make_golden.py
+
+Groups follow SURVEY.md §8c (G1..G9).
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(1, "/root/reference/src")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import grafx  # noqa: E402  (the upstream reference)
+from grafx.data import GRAFX, NodeConfigs, convert_to_tensor  # noqa: E402
+from grafx.processors import (  # noqa: E402
+    BiquadFilter,
+    Compressor,
+    NoiseGate,
+    ParametricEqualizer,
+    STFTMaskedNoiseReverb,
+    StereoGain,
+)
+from grafx.processors.core.convolution import convolve  # noqa: E402
+from grafx.processors.core.envelope import Ballistics, TruncatedOnePoleIIRFilter  # noqa: E402
+from grafx.processors.core.iir import IIRFilter  # noqa: E402
+from grafx.render import prepare_render, render_grafx, reorder_for_fast_render  # noqa: E402
+from grafx.utils import create_empty_parameters  # noqa: E402
+
+assert grafx.__file__.startswith("/root/reference"), grafx.__file__
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (npy(v) if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def grads(y, params, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(y.shape, generator=g)
+    gs = torch.autograd.grad((y * w).sum(), list(params.values()))
+    return w, {f"grad_{k}": v for k, v in zip(params.keys(), gs)}
+
+
+# ----------------------------------------------------------------------------- G1 convolve
+def g1():
+    out = {}
+    torch.manual_seed(1)
+    for (L, N) in [(1024, 128), (1025, 128), (1024, 127), (1000, 301)]:
+        xs = torch.randn(3, 2, L)
+        hs = torch.randn(3, 2, N) / N**0.5
+        out[f"x_L{L}_N{N}"], out[f"h_L{L}_N{N}"] = xs, hs
+        for (C, Cf) in [(1, 1), (2, 1), (1, 2), (2, 2)]:
+            x, h = xs[:, :C], hs[:, :Cf]  # channel-sliced views of the stored pair
+            tag = f"L{L}_N{N}_C{C}_Cf{Cf}"
+            for mode in ("causal", "zerophase"):
+                out[f"y_{mode}_{tag}"] = convolve(x, h, mode=mode)
+    save("g1_convolve", **out)
+
+
+# ----------------------------------------------------------------------------- G2 IIRFilter fsm
+def g2():
+    out = {}
+    torch.manual_seed(2)
+    for N in (256, 257, 500):
+        for K in (1, 6):
+            flt = IIRFilter(order=2, backend="fsm", flashfftconv=False, fsm_fir_len=N)
+            Bs = torch.randn(3, 2, K, 3) * 0.3 + torch.tensor([1.0, 0, 0])
+            r = torch.rand(3, 2, K) * 0.9
+            th = torch.rand(3, 2, K) * 3.1
+            As = torch.stack([torch.ones_like(r), -2 * r * torch.cos(th), r * r], -1)
+            x = torch.randn(3, 2, 1023)
+            tag = f"N{N}_K{K}"
+            resp = IIRFilter.iir_fsm(Bs, As, delays=flt.delays).prod(-2)
+            fir = torch.fft.irfft(resp, dim=-1, n=N)
+            out[f"Bs_{tag}"], out[f"As_{tag}"], out[f"x_{tag}"] = Bs, As, x
+            out[f"fir_{tag}"], out[f"y_{tag}"] = fir, flt(x, Bs, As)
+    save("g2_iir_fsm", **out)
+
+
+# ----------------------------------------------------------------------------- G3 PEQ
+def g3():
+    out = {}
+    for ch in ("mono", "stereo", "midside"):
+        for N in (256, 257):
+            for std in (0.01, 1.0):
+                torch.manual_seed(3)
+                peq = ParametricEqualizer(num_filters=6, processor_channel=ch, flashfftconv=False, fsm_fir_len=N)
+                shp = peq.parameter_size()["w0"]
+                p = {k: (std * torch.randn(3, *shp)).requires_grad_() for k in ("w0", "q_inv", "log_gain")}
+                x = torch.randn(3, 2, 1023)
+                y = peq(x, **p)
+                tag = f"{ch}_N{N}_std{std}"
+                w, gr = grads(y, p, 30)
+                out[f"x_{tag}"], out[f"y_{tag}"], out[f"w_{tag}"] = x, y, w
+                for k, v in p.items():
+                    out[f"{k}_{tag}"] = v
+                for k, v in gr.items():
+                    out[f"{k}_{tag}"] = v
+    save("g3_peq", **out)
+
+
+# ----------------------------------------------------------------------------- G4 biquad / gain
+def g4():
+    out = {}
+    torch.manual_seed(4)
+    for K in (1, 4):
+        for N in (256, 257):
+            for normalized in (False, True):
+                bq = BiquadFilter(num_filters=K, normalized=normalized, flashfftconv=False, fsm_fir_len=N)
+                p = {"Bs": 0.3 * torch.randn(3, K, 3), "A1_pre": torch.randn(3, K), "A2_pre": torch.randn(3, K)}
+                if normalized:
+                    p["A0"] = 1 + 0.2 * torch.randn(3, K)
+                x = torch.randn(3, 2, 1023)
+                tag = f"K{K}_N{N}_norm{int(normalized)}"
+                out[f"x_{tag}"], out[f"y_{tag}"] = x, bq(x, **p)
+                for k, v in p.items():
+                    out[f"{k}_{tag}"] = v
+    x, lg = torch.randn(3, 2, 777), torch.randn(3, 2)
+    out["gain_x"], out["gain_log_gain"], out["gain_y"] = x, lg, StereoGain()(x, lg)
+    save("g4_biquad_gain", **out)
+
+
+# ----------------------------------------------------------------------------- G5 reverb
+def g5():
+    out = {}
+    for ir_len in (3000, 3001):
+        for ch in ("pseudo_midside", "midside", "stereo"):
+            torch.manual_seed(5)
+            rv = STFTMaskedNoiseReverb(ir_len=ir_len, processor_channel=ch, flashfftconv=False)
+            p = {k: torch.randn(2, 2, 193).requires_grad_() for k in ("init_log_magnitude", "delta_log_magnitude")}
+            x = torch.randn(2, 2, 2048)
+            y = rv(x, **p)
+            tag = f"ir{ir_len}_{ch}"
+            if ch == "pseudo_midside":
+                out[f"ir_{tag}"] = rv.compute_ir(p["init_log_magnitude"], p["delta_log_magnitude"])
+                out[f"noise_stft_re_{tag}"] = rv.noise_stft.real[0, :, :8, :8]
+                out[f"noise_stft_im_{tag}"] = rv.noise_stft.imag[0, :, :8, :8]
+                out[f"noise_stft_abs_sum_{tag}"] = rv.noise_stft.abs().double().sum()
+                w, gr = grads(y, p, 50)
+                out[f"w_{tag}"] = w
+                for k, v in gr.items():
+                    out[f"{k}_{tag}"] = v
+            out[f"x_{tag}"], out[f"y_{tag}"] = x, y
+            for k, v in p.items():
+                out[f"{k}_{tag}"] = v
+    torch.manual_seed(55)
+    rv = STFTMaskedNoiseReverb(ir_len=3001, gain_envelope=True, flashfftconv=False)
+    p = {k: torch.randn(2, *s) for k, s in rv.parameter_size().items()}
+    x = torch.randn(2, 2, 2048)
+    out["x_genv"], out["y_genv"] = x, rv(x, **p)
+    for k, v in p.items():
+        out[f"{k}_genv"] = v
+    save("g5_reverb", **out)
+
+
+# ----------------------------------------------------------------------------- G6 dynamics
+def g6():
+    out = {}
+    for cls in (Compressor, NoiseGate):
+        for knee in ("hard", "quadratic", "exponential"):
+            for sm, iir_len in (("iir", 512), ("iir", 511), (None, 0), ("ballistics", 0)):
+                torch.manual_seed(6)
+                x = torch.randn(3, 2, 1280) * torch.logspace(-2, 0, 3)[:, None, None]
+                out["x_shared"] = x
+                kw = dict(energy_smoother=sm, knee=knee, flashfftconv=False)
+                if sm == "iir":
+                    kw["iir_len"] = iir_len
+                m = cls(**kw)
+                p = {k: torch.randn(3, s).requires_grad_() for k, s in m.parameter_size().items()}
+                y = m(x, **p)
+                tag = f"{cls.__name__}_{knee}_{sm}_{iir_len}"
+                out[f"y_{tag}"] = y
+                for k, v in p.items():
+                    out[f"{k}_{tag}"] = v
+                if sm == "iir" and iir_len == 511 and knee == "quadratic":
+                    w, gr = grads(y, p, 60)
+                    out[f"w_{tag}"] = w
+                    for k, v in gr.items():
+                        out[f"{k}_{tag}"] = v
+    # gain smoothers
+    for gs, in_log in (("iir", False), ("iir", True), ("ballistics", False)):
+        torch.manual_seed(66)
+        m = Compressor(energy_smoother="iir", gain_smoother=gs, gain_smooth_in_log=in_log, iir_len=511, flashfftconv=False)
+        p = {k: torch.randn(3, s) for k, s in m.parameter_size().items()}
+        x = torch.randn(3, 2, 2048)
+        tag = f"gs_{gs}_{int(in_log)}"
+        out[f"x_{tag}"], out[f"y_{tag}"] = x, m(x, **p)
+        for k, v in p.items():
+            out[f"{k}_{tag}"] = v
+    save("g6_dynamics", **out)
+
+
+# ----------------------------------------------------------------------------- G7 / G9 smoothers
+def g7_g9():
+    out = {}
+    torch.manual_seed(7)
+    z = torch.tensor([[-3.0], [0.0], [2.5], [6.0], [14.0]])
+    for n in (512, 511):
+        f = TruncatedOnePoleIIRFilter(iir_len=n, flashfftconv=False)
+        u = torch.rand(5, 2048)
+        out[f"onepole_h_{n}"] = f.compute_impulse(z)
+        out[f"onepole_u_{n}"], out[f"onepole_y_{n}"] = u, f(u, z)
+    out["onepole_z"] = z
+    u, zb = torch.rand(4, 1500) * 2, torch.randn(4, 2) * 2
+    out["ball_u"], out["ball_z"], out["ball_y"] = u, zb, Ballistics()(u, zb)  # provisional: recalled torchcomp semantics
+    save("g7_g9_smoothers", **out)
+
+
+# ----------------------------------------------------------------------------- G8 routing + renders
+def access_json(a):
+    idx = a.idx.tolist() if isinstance(a.idx, torch.Tensor) else (list(a.idx) if a.idx is not None else None)
+    return {"method": a.method, "idx": idx}
+
+
+def render_data_json(rd):
+    return {
+        "method": rd.method, "num_nodes": int(rd.num_nodes), "max_order": int(rd.max_order), "siso_only": bool(rd.siso_only),
+        "iter_list": [{
+            "node_type": it.node_type,
+            "source_reads": [access_json(a) for a in it.source_reads],
+            "aggregations": [access_json(a) for a in it.aggregations],
+            "parameter_read": access_json(it.parameter_read),
+            "dest_write": access_json(it.dest_write),
+        } for it in rd.iter_list],
+    }
+
+
+def build_console(n_ch=32, n_bus=4):
+    G = GRAFX(config=NodeConfigs(["eq", "compressor", "reverb"]))
+    out_id = G.add("out")
+    buses = [G.add("mix") for _ in range(n_bus)]
+    send = G.add("mix")
+    for ch in range(n_ch):
+        _, last = G.add_serial_chain(["in", "eq", "compressor"])
+        G.connect(last, buses[ch // (n_ch // n_bus)])
+        G.connect(last, send)
+    for b in buses:
+        e = G.add("eq")
+        c = G.add("compressor")
+        G.connect(b, e)
+        G.connect(e, c)
+        G.connect(c, out_id)
+    r = G.add("reverb")
+    G.connect(send, r)
+    G.connect(r, out_id)
+    return G
+
+
+def tensor_json(G_t):
+    return {"node_types": G_t.node_types.tolist(), "edge_indices": G_t.edge_indices.tolist(),
+            "rendering_orders": G_t.rendering_orders.tolist(), "type_sequence": list(G_t.type_sequence)}
+
+
+def g8():
+    meta, arrays = {}, {}
+    # cfg-1 plumbing graph: in -> gain -> biquad -> out
+    torch.manual_seed(0)
+    G = GRAFX(config=NodeConfigs(["gain", "biquad"]))
+    _, last = G.add_serial_chain(["in", "gain", "biquad"])
+    G.connect(last, G.add("out"))
+    procs = {"gain": StereoGain(), "biquad": BiquadFilter(num_filters=1, flashfftconv=False, fsm_fir_len=257)}
+    for method in ("beam", "greedy", "one-by-one"):
+        G_t = reorder_for_fast_render(convert_to_tensor(G), method=method)
+        rd = prepare_render(G_t)
+        meta[f"cfg1_{method}"] = {"tensor": tensor_json(G_t), "render": render_data_json(rd)}
+    G_t = reorder_for_fast_render(convert_to_tensor(G), method="beam")
+    rd = prepare_render(G_t)
+    params = create_empty_parameters(procs, G, std=1e-2)
+    x = torch.randn(1, 2, 2048)
+    y, _, buf = render_grafx(procs, x, params, rd)
+    arrays["cfg1_x"], arrays["cfg1_y"], arrays["cfg1_buf"] = x, y, buf
+    for t, d in params.items():
+        for k, v in d.items():
+            arrays[f"cfg1_p_{t}_{k}"] = v
+
+    # console graphs: full 32-channel (routing only + tiny render) and an 8-channel/2-bus variant
+    for name, (n_ch, n_bus) in {"console32": (32, 4), "console8": (8, 2)}.items():
+        G = build_console(n_ch, n_bus)
+        for method in ("beam", "greedy", "one-by-one"):
+            G_t = reorder_for_fast_render(convert_to_tensor(G), method=method)
+            rd = prepare_render(G_t)
+            meta[f"{name}_{method}"] = {"tensor": tensor_json(G_t), "render": render_data_json(rd)}
+        meta[f"{name}_raw"] = {"node_types": convert_to_tensor(G).node_types.tolist(),
+                               "edge_indices": convert_to_tensor(G).edge_indices.tolist()}
+    torch.manual_seed(8)
+    G = build_console(8, 2)
+    procs = {
+        "eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=257),
+        "compressor": Compressor(energy_smoother="iir", iir_len=255, flashfftconv=False),
+        "reverb": STFTMaskedNoiseReverb(ir_len=1501, flashfftconv=False),
+    }
+    G_t = reorder_for_fast_render(convert_to_tensor(G), method="beam")
+    rd = prepare_render(G_t)
+    params = create_empty_parameters(procs, G, std=0.3)
+    x = torch.randn(2, 8, 2, 1024)
+    y, _, buf = render_grafx(procs, x, params, rd)
+    arrays["console8_x"], arrays["console8_y"] = x, y
+    arrays["console8_buf_last8"] = buf[:, -8:]
+    for t, d in params.items():
+        for k, v in d.items():
+            arrays[f"console8_p_{t}_{k}"] = v
+    with open(os.path.join(HERE, "g8_routing.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    print("g8_routing.json", os.path.getsize(os.path.join(HERE, "g8_routing.json")) // 1024, "KiB")
+    save("g8_render", **arrays)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8()
