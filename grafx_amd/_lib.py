@@ -1,0 +1,57 @@
+"""ctypes binding of libgrafx_amd.so (the C ABI declared in include/grafx_amd.h).
+
+Loading is strict: if the library is missing the import raises with the build
+command — there is no Python/CPU fallback for the hot path.
+"""
+import ctypes
+import os
+
+from .build import LIB
+
+i64, f32p, vp, sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t
+
+
+class RowMap(ctypes.Structure):
+    _fields_ = [("inner", i64), ("stride_outer", i64), ("stride_inner", i64), ("stride_ch", i64)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/grafx_amd.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "gfx_abi_version": (ctypes.c_int, []),
+    "gfx_device_info": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]),
+    "gfx_fftconv_nparts": (i64, [i64]),
+    "gfx_fir_spectrum_bytes": (sz, [i64, i64]),
+    "gfx_fftconv_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64]),
+    "gfx_fir_spectrum_f32": (ctypes.c_int, [f32p, f32p, i64, vp, i64, i64, vp]),
+    "gfx_fftconv_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise ImportError(
+                f"{LIB} not found: the HIP extension is not built. Run `python -m grafx_amd.build` "
+                "(or __graft_entry__.build()). grafx_amd has no CPU fallback for the processors."
+            )
+        handle = ctypes.CDLL(LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = ABI drift, fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+class GfxError(RuntimeError):
+    pass
+
+
+_CODES = {-1: "GFX_EINVAL (bad argument)", -2: "GFX_ENOSPC (workspace too small)", -3: "GFX_ELAUNCH (HIP launch failed)"}
+
+
+def check(code, what):
+    if code != 0:
+        raise GfxError(f"{what} failed: {_CODES.get(code, code)}")

@@ -1,0 +1,85 @@
+"""GPU parity: overlap-save FFT convolution kernels vs the CPU oracle (through the C ABI)."""
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import lti
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x, h, off, Lout):
+    from grafx_amd import ops
+
+    R, Cf, N = h.shape
+    Hs = ops.fir_spectrum(h.cuda().reshape(R * Cf, N))
+    return ops.fftconv(x.cuda(), Hs, N, Cf, Lout=Lout, off=off).cpu()
+
+
+def _full(x, h):
+    # float64 oracle of the full linear convolution
+    return lti.linear_convolve(x.double(), h.double(), mode="full")
+
+
+@pytest.mark.parametrize("L,N", [(1024, 128), (1000, 301), (40000, 4001), (16384, 1), (20000, 8193), (5, 3)])
+@pytest.mark.parametrize("C,Cf", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_single_partition_causal(L, N, C, Cf):
+    torch.manual_seed(L + N)
+    x, h = torch.randn(3, C, L), torch.randn(3, Cf, N) / N**0.5
+    y = _run(x, h, 0, L)
+    assert_close(y, _full(x, h)[..., :L].float(), 1e-5, "causal")
+
+
+@pytest.mark.parametrize("L,N", [(30000, 8200), (50000, 20001), (9000, 60001), (70000, 16385)])
+def test_multi_partition_causal(L, N):
+    torch.manual_seed(L + N)
+    x, h = torch.randn(2, 2, L), torch.randn(2, 2, N) / N**0.5
+    y = _run(x, h, 0, L)
+    assert_close(y, _full(x, h)[..., :L].float(), 1e-5, "partitioned causal")
+
+
+@pytest.mark.parametrize("L,N", [(5000, 2047), (5001, 300), (20000, 9001)])
+def test_zerophase_and_full(L, N):
+    torch.manual_seed(7)
+    x, h = torch.randn(2, 2, L), torch.randn(2, 1, N) / N**0.5
+    full = _full(x, h).float()
+    assert_close(_run(x, h, N // 2, L), full[..., N // 2 : N // 2 + L], 1e-5, "zerophase")
+    assert_close(_run(x, h, 0, L + N - 1), full, 1e-5, "full")
+
+
+def test_matches_reference_golden_even_P(golden):
+    g = golden("g1_convolve")
+    for (L, N) in [(1025, 128), (1024, 127)]:  # P even: reference == linear convolution
+        x, h = g[f"x_L{L}_N{N}"], g[f"h_L{L}_N{N}"]
+        assert_close(_run(x, h, 0, L), g[f"y_causal_L{L}_N{N}_C2_Cf2"], 1e-5, "golden causal")
+        assert_close(_run(x, h, N // 2, L), g[f"y_zerophase_L{L}_N{N}_C2_Cf2"], 1e-5, "golden zerophase")
+
+
+def test_strided_buffer_io():
+    """Read from / write into slices of a (B, V, C, L) signal buffer in place."""
+    from grafx_amd import ops
+
+    torch.manual_seed(3)
+    B, V, C, L, N = 3, 7, 2, 20000, 4001
+    buf = torch.randn(B, V, C, L).cuda()
+    h = (torch.randn(B * 2, 1, N) / N**0.5)
+    Hs = ops.fir_spectrum(h.cuda().reshape(B * 2, N))
+    src, dst = buf[:, 1:3], buf[:, 4:6]
+    want = lti.linear_convolve(src.cpu().reshape(B * 2, C, L).double(), h.double(), "causal").float()
+    before = buf.clone()
+    ops.fftconv(src, Hs, N, 1, out=dst)
+    assert_close(dst.cpu().reshape(B * 2, C, L), want, 1e-5, "strided")
+    assert torch.equal(buf[:, :4], before[:, :4]) and torch.equal(buf[:, 6:], before[:, 6:])
+
+
+def test_linearity_and_shift_at_full_size():
+    """Size-independent properties at BASELINE scale (L = 2^17, N = 4001)."""
+    torch.manual_seed(11)
+    L, N = 131072, 4001
+    x1, x2 = torch.randn(4, 2, L), torch.randn(4, 2, L)
+    h = torch.randn(4, 1, N) / N**0.5
+    y1, y2, y12 = _run(x1, h, 0, L), _run(x2, h, 0, L), _run(x1 + 2 * x2, h, 0, L)
+    assert_close(y12, y1 + 2 * y2, 2e-6, "linearity")
+    d = torch.zeros(4, 2, L)
+    d[..., 5] = 1.0
+    assert_close(_run(d, h, 0, L)[..., 5 : 5 + N], h.expand(4, 2, N), 2e-6, "impulse response")
