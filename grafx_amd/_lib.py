@@ -24,6 +24,25 @@ SIGNATURES = {
     "gfx_fftconv_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64]),
     "gfx_fir_spectrum_f32": (ctypes.c_int, [f32p, f32p, i64, vp, i64, i64, vp]),
     "gfx_fftconv_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
+    "gfx_iir_fsm_plan_bytes": (sz, [i64]),
+    "gfx_iir_fsm_plan_f32": (ctypes.c_int, [vp, i64, vp]),
+    "gfx_iir_fsm_fir_f32": (ctypes.c_int, [f32p, f32p, vp, f32p, i64, i64, i64, vp]),
+    "gfx_peq_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, ctypes.c_int, vp]),
+    "gfx_biquad_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, vp]),
+    "gfx_dynamics_fused_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64,
+                                              ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, vp]),
+    "gfx_energy_f32": (ctypes.c_int, [f32p, RowMap, f32p, i64, i64, i64, vp]),
+    "gfx_onepole_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, i64, i64, ctypes.c_int, vp]),
+    "gfx_onepole_fir_f32": (ctypes.c_int, [f32p, f32p, i64, i64, vp]),
+    "gfx_ballistics_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, vp]),
+    "gfx_dyn_gain_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    "gfx_apply_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, ctypes.c_int, vp]),
+    "gfx_stereo_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, vp]),
+    "gfx_istft_basis_bytes": (sz, [i64]),
+    "gfx_istft_basis_f32": (ctypes.c_int, [f32p, f32p, i64, vp]),
+    "gfx_stft_reverb_workspace_bytes": (sz, [i64, i64, i64]),
+    "gfx_stft_reverb_ir_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, i64, i64, i64,
+                                              ctypes.c_int, vp, sz, vp]),
 }
 
 _lib = None

@@ -1,0 +1,495 @@
+// Dynamics path: energy envelope, one-pole / ballistics smoothing, gain computer, gain apply.
+//
+// Replaces (reference src/grafx/processors):
+//   Compressor.forward / NoiseGate.forward + gain_{hard,quad,exp}_knee   dynamics.py:361-489, 598-721
+//   TruncatedOnePoleIIRFilter (h = (1-a) a^n, n < N; relu(convolve))       core/envelope.py:34-60
+//   Ballistics -> torchcomp.compressor_core (third-party recursion)        core/envelope.py:84-101
+//
+// The truncated one-pole FIR is applied as its exact recursive form
+//     y[n] = (1-a) * (u[n] - a^N * u[n-N]),   u[n] = a*u[n-1] + e[n]
+// with a workgroup-wide prefix scan (wave shuffles + one LDS hop) over 1024-sample tiles, one
+// workgroup streaming each row: x is read once and y written once (8 B per channel-sample).
+// The a^N correction only runs for rows where it is not negligible (a^N > 1e-9).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/grafx_amd.h"
+
+namespace gfx {
+
+constexpr int DT = 256;            // threads per workgroup
+constexpr int DE = 4;              // samples per thread per tile
+constexpr int DTILE = DT * DE;     // 1024 samples per tile
+
+__device__ __forceinline__ int64_t drow_off(const gfx_rowmap_t& m, int64_t r, int c) {
+    return (r / m.inner) * m.stride_outer + (r % m.inner) * m.stride_inner + (int64_t)c * m.stride_ch;
+}
+
+__device__ __forceinline__ float sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float softplusf(float v) { return v > 20.0f ? v : log1pf(expf(v)); }  // torch threshold=20
+
+// a^k for integer k >= 0, rounded once from double (keeps long decays accurate)
+__device__ __forceinline__ float powk(double log_a, double k) { return (float)exp(k * log_a); }
+
+struct OnePole {
+    float a;          // pole (already clamped)
+    float one_m_a;    // 1 - a
+    float ap[DE + 1]; // a^0 .. a^DE
+    float a_lane;     // a^(DE * lane)
+    float a_step[6];  // a^(DE * 2^d), d = 0..5 (in-wave scan offsets)
+    float a_wave;     // a^(DE * 64)
+    float a_N;        // a^N
+    bool trunc;       // a^N not negligible
+};
+
+__device__ __forceinline__ void onepole_setup(OnePole& p, float z_alpha, int64_t N, int lane) {
+    // core/envelope.py:51-54: alpha = clamp(sigmoid(z), max = 1 - 1e-5)
+    p.a = fminf(sigmoidf(z_alpha), 1.0f - 1e-5f);
+    p.one_m_a = 1.0f - p.a;
+    const double la = log((double)p.a);
+#pragma unroll
+    for (int i = 0; i <= DE; ++i) p.ap[i] = powk(la, i);
+    p.a_lane = powk(la, DE * lane);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) p.a_step[d] = powk(la, DE << d);
+    p.a_wave = powk(la, DE * 64);
+    p.a_N = powk(la, (double)N);
+    p.trunc = p.a_N > 1e-9f;
+}
+
+// One tile of the recursion u[n] = a u[n-1] + e[n] across the workgroup.
+//   e[0..DE)  : this thread's inputs (tile-local positions DE*t .. DE*t+DE-1)
+//   carry     : u at the end of the previous tile (same in every thread); updated
+//   slots     : 4 floats of LDS for this tile parity
+// returns u for the thread's DE positions.
+__device__ __forceinline__ void scan_tile(const OnePole& p, const float (&e)[DE], float (&u)[DE], float& carry,
+                                          float* slots, int lane, int wave) {
+    float loc[DE];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DE; ++i) {
+        s = fmaf(p.a, s, e[i]);
+        loc[i] = s;
+    }
+    // inclusive scan of thread totals inside the wave: S_t += a^(DE*2^d) * S_(t - 2^d)
+    float inc = s;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        const float up = __shfl_up(inc, 1 << d, 64);
+        if (lane >= (1 << d)) inc = fmaf(p.a_step[d], up, inc);
+    }
+    if (lane == 63) slots[wave] = inc;
+    float excl = __shfl_up(inc, 1, 64);
+    if (lane == 0) excl = 0.0f;
+    __syncthreads();
+    float state = carry;  // u entering wave 0
+    float entering = state;
+#pragma unroll
+    for (int w = 0; w < DT / 64; ++w) {
+        if (w == wave) entering = state;
+        state = fmaf(p.a_wave, state, slots[w]);
+    }
+    carry = state;
+    const float pre = fmaf(p.a_lane, entering, excl);  // u just before this thread's first sample
+#pragma unroll
+    for (int i = 0; i < DE; ++i) u[i] = fmaf(p.ap[i + 1], pre, loc[i]);
+}
+
+// ---- gain computer -----------------------------------------------------------------------------
+struct Knee {
+    float T, R, invR, W, k, er;  // threshold (already -6), ratio, 1/ratio, half knee width, exp knee, exp(log_ratio)
+    int kind;                    // 0 hard, 1 quadratic, 2 exponential
+    int gate;                    // 0 compressor, 1 noise gate
+};
+
+__device__ __forceinline__ void knee_setup(Knee& q, float log_threshold, float log_ratio, float log_knee, int kind,
+                                           int gate) {
+    q.T = log_threshold - 6.0f;            // dynamics.py:395 / 630
+    q.er = expf(log_ratio);
+    q.R = 1.0f + q.er;
+    q.invR = 1.0f / q.R;
+    q.k = expf(log_knee);
+    q.W = q.k / 2.0f;
+    q.kind = kind;
+    q.gate = gate;
+}
+
+// log-gain g(G) for log-energy G
+__device__ __forceinline__ float log_gain(const Knee& q, float G) {
+    const float d = G - q.T;
+    if (!q.gate) {
+        if (q.kind == 0) return fminf(G, q.T + d / q.R) - G;                                   // dynamics.py:444-453
+        if (q.kind == 1) {                                                                     // 456-475
+            const bool below = G < (q.T - q.W), above = G > (q.T + q.W);
+            const float mid = G + (q.invR - 1.0f) * ((d + q.W) * (d + q.W)) / (4.0f * q.W);
+            const float out = below ? G : (above ? (q.T + d / q.R) : mid);
+            return out - G;
+        }
+        return (q.invR - 1.0f) * softplusf(q.k * d) / q.k;                                     // 478-489
+    }
+    if (q.kind == 0) return fminf(G, q.R * d + q.T) - G;                                       // 676-686
+    if (q.kind == 1) {                                                                         // 688-707
+        const bool below = G < (q.T - q.W), above = G > (q.T + q.W);
+        const float mid = G + (1.0f - q.R) * ((d - q.W) * (d - q.W)) / (4.0f * q.W);
+        const float out = below ? (q.R * d + q.T) : (above ? G : mid);
+        return out - G;
+    }
+    return -q.er * softplusf(q.k * (-d)) / q.k;                                                // 709-721
+}
+
+// ---- loads / stores of 4 consecutive samples with bounds -----------------------------------------
+__device__ __forceinline__ void load4(const float* __restrict__ row, int64_t n, int64_t L, bool vec, float (&v)[DE]) {
+    if (vec && n + DE <= L && n >= 0) {
+        const float4 q = *reinterpret_cast<const float4*>(row + n);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < DE; ++i) v[i] = (n + i >= 0 && n + i < L) ? row[n + i] : 0.0f;
+    }
+}
+__device__ __forceinline__ void store4(float* __restrict__ row, int64_t n, int64_t L, bool vec, const float (&v)[DE]) {
+    if (vec && n + DE <= L) {
+        *reinterpret_cast<float4*>(row + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DE; ++i)
+            if (n + i < L) row[n + i] = v[i];
+    }
+}
+__device__ __forceinline__ bool vec_ok(const float* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct DynArgs {
+    gfx_rowmap_t xmap, ymap;
+    int64_t R, L, N;       // rows, length, one-pole FIR length (iir smoother)
+    int C;                 // channels
+    int smoother;          // 0 none, 1 truncated one-pole
+    int knee, gate;
+};
+
+// ---- fused compressor / gate: energy -> one-pole -> log -> knee -> exp -> multiply -----------------
+template <bool TRUNC>
+__device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
+                                           const float* x1, float* y0, float* y1, float* slots, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
+    const float invC = 1.0f / (float)a.C;
+    float carry = 0.0f, carry2 = 0.0f;
+    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int64_t n = tile * DTILE + DE * t;
+        float xa[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, e[DE], env[DE];
+        load4(x0, n, a.L, vx, xa);
+        if (a.C == 2) load4(x1, n, a.L, vx, xb);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            const float sq = a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i];
+            e[i] = sq * invC;  // dynamics.py:390 energy = x.square().mean(-2)
+        }
+        if (a.smoother == 1) {
+            float u[DE];
+            scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
+            if (TRUNC) {
+                float da[DE], db[DE], e2[DE], u2[DE];
+                load4(x0, n - a.N, a.L, false, da);
+                if (a.C == 2) load4(x1, n - a.N, a.L, false, db);
+#pragma unroll
+                for (int i = 0; i < DE; ++i)
+                    e2[i] = (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC;
+                scan_tile(p, e2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
+#pragma unroll
+                for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < DE; ++i) env[i] = fmaxf(p.one_m_a * u[i], 0.0f);  // relu, envelope.py:48
+        } else {
+#pragma unroll
+            for (int i = 0; i < DE; ++i) env[i] = e[i];
+        }
+        float ga[DE], gb[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            const float G = logf(env[i] + 1e-5f);            // dynamics.py:394
+            const float g = expf(log_gain(q, G));            // 402-403
+            ga[i] = g * xa[i];
+            gb[i] = g * xb[i];
+        }
+        store4(y0, n, a.L, vx, ga);
+        if (a.C == 2) store4(y1, n, a.L, vx, gb);
+    }
+}
+
+__global__ __launch_bounds__(DT) void dyn_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ log_threshold,
+                                                       const float* __restrict__ log_ratio,
+                                                       const float* __restrict__ log_knee,
+                                                       const float* __restrict__ z_alpha, DynArgs a) {
+    __shared__ float slots[16];
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    OnePole p;
+    p.trunc = false;
+    if (a.smoother == 1) onepole_setup(p, z_alpha[r], a.N, t & 63);
+    Knee q;
+    knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, a.knee, a.gate);
+    const float* x0 = x + drow_off(a.xmap, r, 0);
+    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
+    float* y0 = y + drow_off(a.ymap, r, 0);
+    float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
+    if (p.trunc)
+        dyn_stream<true>(a, p, q, x0, x1, y0, y1, slots, t);
+    else
+        dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t);
+}
+
+// ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
+// energy: e[r,n] = mean_c x[r,c,n]^2
+__global__ void energy_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, float* __restrict__ e, int64_t R, int64_t L, int C) {
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y) {
+        const float* x0 = x + drow_off(xmap, r, 0);
+        const float* x1 = x + drow_off(xmap, r, C == 2 ? 1 : 0);
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x) {
+            const float a = x0[n], b = x1[n];
+            e[r * L + n] = (C == 2 ? (a * a + b * b) : a * a) * invC;
+        }
+    }
+}
+
+// truncated one-pole on (R, L) rows -> (R, Lout); Lout may extend to L + N - 1 (full convolution)
+template <bool TRUNC>
+__device__ __forceinline__ void onepole_stream(const OnePole& p, const float* u_in, float* out, int64_t L,
+                                               int64_t Lout, int64_t N, int relu, float* slots, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    const bool vi = vec_ok(u_in), vo = vec_ok(out);
+    float carry = 0.0f, carry2 = 0.0f;
+    const int64_t ntiles = (Lout + DTILE - 1) / DTILE;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int64_t n = tile * DTILE + DE * t;
+        float e[DE], u[DE];
+        load4(u_in, n, L, vi, e);
+        scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
+        if (TRUNC) {
+            float e2[DE], u2[DE];
+            load4(u_in, n - N, L, false, e2);
+            scan_tile(p, e2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            u[i] = p.one_m_a * u[i];
+            if (relu) u[i] = fmaxf(u[i], 0.0f);
+        }
+        store4(out, n, Lout, vo, u);
+    }
+}
+
+__global__ __launch_bounds__(DT) void onepole_kernel(const float* __restrict__ u, const float* __restrict__ z_alpha,
+                                                     float* __restrict__ out, int64_t L, int64_t Lout, int64_t N,
+                                                     int relu) {
+    __shared__ float slots[16];
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    OnePole p;
+    onepole_setup(p, z_alpha[r], N, t & 63);
+    // the FIR has exactly N taps: when Lout > L the tail still needs the a^N term once n >= N
+    if (p.trunc)
+        onepole_stream<true>(p, u + r * L, out + r * Lout, L, Lout, N, relu, slots, t);
+    else
+        onepole_stream<false>(p, u + r * L, out + r * Lout, L, Lout, N, relu, slots, t);
+}
+
+// one-pole FIR taps themselves, h[n] = (1-a) * exp(n * log a)  (envelope.py:51-60), for the generic conv path
+__global__ void onepole_fir_kernel(const float* __restrict__ z_alpha, float* __restrict__ h, int64_t R, int64_t N) {
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y) {
+        const float a = fminf(sigmoidf(z_alpha[r]), 1.0f - 1e-5f);
+        const float la = logf(a);
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+            h[r * N + n] = (1.0f - a) * expf((float)n * la);
+    }
+}
+
+// ballistics (torchcomp.compressor_core as recalled — PARITY UNPINNED, see oracle/__init__.py):
+//   y[-1] = 1;  c = (x[n] < y[n-1]) ? at : rt;  y[n] = (1-c) y[n-1] + c x[n]
+// One wave per 64 rows; 64x64 tiles staged through LDS so HBM access stays coalesced while each
+// lane walks its own row sequentially.
+constexpr int BROWS = 64, BCOLS = 64, BPAD = BCOLS + 4;
+__global__ __launch_bounds__(64) void ballistics_kernel(const float* __restrict__ u, const float* __restrict__ z_alpha,
+                                                        float* __restrict__ y, int64_t R, int64_t L) {
+    __shared__ __attribute__((aligned(16))) float tile[BROWS * BPAD];
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * BROWS;
+    const int64_t my = r0 + lane;
+    float at = 0.0f, rt = 0.0f;
+    if (my < R) {
+        at = sigmoidf(z_alpha[2 * my]);       // envelope.py:97-99
+        rt = sigmoidf(z_alpha[2 * my + 1]);
+    }
+    float state = 1.0f;                       // zi = ones
+    const int cr = lane >> 4, cc = (lane & 15) * 4;  // cooperative copy: 4 rows x 16 float4 per pass
+    const bool vec = (L % 4 == 0) && vec_ok(u) && vec_ok(y);
+    for (int64_t n0 = 0; n0 < L; n0 += BCOLS) {
+#pragma unroll 4
+        for (int pass = 0; pass < BROWS / 4; ++pass) {
+            const int row = pass * 4 + cr;
+            const int64_t rr = r0 + row;
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (rr < R) load4(u + rr * L, n0 + cc, L, vec, v);
+            *reinterpret_cast<float4*>(&tile[row * BPAD + cc]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        float* mine = &tile[lane * BPAD];
+#pragma unroll 4
+        for (int j = 0; j < BCOLS; j += 4) {
+            float4 q = *reinterpret_cast<float4*>(mine + j);
+            float* qs = reinterpret_cast<float*>(&q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float c = qs[i] < state ? at : rt;
+                state = (1.0f - c) * state + c * qs[i];
+                qs[i] = state;
+            }
+            *reinterpret_cast<float4*>(mine + j) = q;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pass = 0; pass < BROWS / 4; ++pass) {
+            const int row = pass * 4 + cr;
+            const int64_t rr = r0 + row;
+            if (rr < R) {
+                const float4 q = *reinterpret_cast<const float4*>(&tile[row * BPAD + cc]);
+                const float v[4] = {q.x, q.y, q.z, q.w};
+                store4(y + rr * L, n0 + cc, L, vec, v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// env (R,L) -> gain (R,L):  g = log_gain(log(env + 1e-5));  out = exp(g) or g (log_out)
+__global__ void dyn_gain_kernel(const float* __restrict__ env, float* __restrict__ gain,
+                                const float* __restrict__ log_threshold, const float* __restrict__ log_ratio,
+                                const float* __restrict__ log_knee, int64_t R, int64_t L, int knee, int gate,
+                                int log_out) {
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y) {
+        Knee q;
+        knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, knee, gate);
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x) {
+            const float g = log_gain(q, logf(env[r * L + n] + 1e-5f));
+            gain[r * L + n] = log_out ? g : expf(g);
+        }
+    }
+}
+
+// y[r,c,n] = (exp_gain ? exp(g[r,n]) : g[r,n]) * x[r,c,n]
+__global__ void apply_gain_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, const float* __restrict__ g,
+                                  float* __restrict__ y, gfx_rowmap_t ymap, int64_t R, int64_t L, int C,
+                                  int exp_gain) {
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y)
+    for (int c = 0; c < C; ++c) {
+        const float* xr = x + drow_off(xmap, r, c);
+        float* yr = y + drow_off(ymap, r, c);
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x) {
+            const float gv = g[r * L + n];
+            yr[n] = (exp_gain ? expf(gv) : gv) * xr[n];
+        }
+    }
+}
+
+// StereoGain: y[r,c,n] = x[r,cx,n] * exp(log_gain[r,c])   (stereo.py:38-41; mono input broadcasts to 2 channels)
+__global__ void stereo_gain_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, const float* __restrict__ log_gain,
+                                   float* __restrict__ y, gfx_rowmap_t ymap, int64_t R, int64_t L, int Cin) {
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y)
+    for (int c = 0; c < 2; ++c) {
+        const float g = expf(log_gain[2 * r + c]);
+        const float* xr = x + drow_off(xmap, r, Cin == 2 ? c : 0);
+        float* yr = y + drow_off(ymap, r, c);
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x)
+            yr[n] = xr[n] * g;
+    }
+}
+
+static inline dim3 row_grid(int64_t R, int64_t L) {
+    int64_t bx = (L + 255) / 256;
+    if (bx > 64) bx = 64;
+    return dim3((unsigned)bx, (unsigned)(R > 65535 ? 65535 : R));
+}
+
+}  // namespace gfx
+
+using namespace gfx;
+
+#define GFX_LAUNCH_OK() (hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH)
+
+extern "C" {
+
+int gfx_dynamics_fused_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                           const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t R, int64_t C,
+                           int64_t L, int smoother, int64_t iir_len, int knee, int gate, void* stream) {
+    if (!x || !y || !log_threshold || !log_ratio || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
+    if (knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
+    if (smoother != 0 && smoother != 1) return GFX_EINVAL;
+    if (smoother == 1 && (!z_alpha || iir_len < 1)) return GFX_EINVAL;
+    if (R > 0x7fffffffLL) return GFX_EINVAL;
+    DynArgs a;
+    a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
+    a.smoother = smoother; a.knee = knee; a.gate = gate;
+    hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, x, y, log_threshold,
+                       log_ratio, log_knee, z_alpha, a);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream) {
+    if (!x || !e || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
+    hipLaunchKernelGGL(energy_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, e, R, L, (int)C);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
+                    int64_t iir_len, int relu, void* stream) {
+    if (!u || !z_alpha || !out || R <= 0 || L <= 0 || Lout <= 0 || iir_len < 1 || R > 0x7fffffffLL) return GFX_EINVAL;
+    hipLaunchKernelGGL(onepole_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, u, z_alpha, out, L, Lout,
+                       iir_len, relu);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_len, void* stream) {
+    if (!z_alpha || !h || R <= 0 || iir_len < 1) return GFX_EINVAL;
+    hipLaunchKernelGGL(onepole_fir_kernel, row_grid(R, iir_len), dim3(256), 0, (hipStream_t)stream, z_alpha, h, R, iir_len);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R, int64_t L, void* stream) {
+    if (!u || !z_alpha || !y || R <= 0 || L <= 0) return GFX_EINVAL;
+    hipLaunchKernelGGL(ballistics_kernel, dim3((unsigned)((R + BROWS - 1) / BROWS)), dim3(64), 0, (hipStream_t)stream,
+                       u, z_alpha, y, R, L);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_dyn_gain_f32(const float* env, float* gain, const float* log_threshold, const float* log_ratio,
+                     const float* log_knee, int64_t R, int64_t L, int knee, int gate, int log_out, void* stream) {
+    if (!env || !gain || !log_threshold || !log_ratio || R <= 0 || L <= 0) return GFX_EINVAL;
+    if (knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
+    hipLaunchKernelGGL(dyn_gain_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, env, gain, log_threshold,
+                       log_ratio, log_knee, R, L, knee, gate, log_out);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float* y, gfx_rowmap_t ymap, int64_t R,
+                       int64_t C, int64_t L, int exp_gain, void* stream) {
+    if (!x || !g || !y || R <= 0 || L <= 0 || C < 1) return GFX_EINVAL;
+    hipLaunchKernelGGL(apply_gain_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, g, y, ymap, R, L,
+                       (int)C, exp_gain);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_stereo_gain_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
+                        int64_t R, int64_t C_in, int64_t L, void* stream) {
+    if (!x || !log_gain || !y || R <= 0 || L <= 0 || (C_in != 1 && C_in != 2)) return GFX_EINVAL;
+    hipLaunchKernelGGL(stereo_gain_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, log_gain, y,
+                       ymap, R, L, (int)C_in);
+    return GFX_LAUNCH_OK();
+}
+
+}  // extern "C"

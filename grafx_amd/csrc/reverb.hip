@@ -1,0 +1,214 @@
+// STFT-masked noise reverb: impulse-response synthesis.
+//
+// Replaces STFTMaskedNoiseReverb.compute_stft_mask / compute_ir (reverb.py:161-200, torch.istft),
+// ms_to_lr (core/midside.py:4-8) and normalize_impulse (core/utils.py:14-18):
+//   M[r,c,k,m] = exp((H0[r,c,k] - softplus(Hd[r,c,k]) * m [+ G[r,c,m]]) / 8)
+//   ir[r,c]    = istft(V[c] * M[r,c])             (n_fft, hop, window; centred, trimmed to ir_len)
+//   [ir = (mid+side, mid-side)]                   ("pseudo_midside")
+//   gain[r]    = 1 / sqrt(mean_c sum_t ir^2 + 1e-12)   (applied when the taps are turned into spectra)
+//
+// The per-frame inverse real DFT (n_fft = 384 = 2^7*3 by default) is GEMM-shaped:
+//   frames[(r,c,m), n] = sum_kk A[(r,c,m), kk] * Basis[kk, n],   kk = (bin, re|im)
+// with the window and the 1/n_fft, Hermitian weights folded into Basis.  It runs on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains); the A operand (masked noise
+// spectrum) is generated in registers, never stored.  A second kernel overlap-adds the frames,
+// divides by the window envelope, applies mid/side -> left/right and accumulates the energy.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/grafx_amd.h"
+
+namespace gfx {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__host__ __device__ inline int64_t kpad_of(int64_t n_fft) { return ((2 * (n_fft / 2 + 1)) + 3) / 4 * 4; }
+
+// Basis[kk][n]: kk = 2k -> coefficient of Re S[k], kk = 2k+1 -> coefficient of Im S[k]; window folded in.
+__global__ void istft_basis_kernel(const float* __restrict__ window, float* __restrict__ basis, int n_fft, int kpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)kpad * n_fft) return;
+    const int kk = (int)(i / n_fft), n = (int)(i % n_fft);
+    const int k = kk >> 1, half = n_fft / 2;
+    float v = 0.0f;
+    if (k <= half) {
+        const bool edge = (k == 0 || k == half);
+        const int r = (int)(((int64_t)k * n) % n_fft);
+        float s, c;
+        sincospif(2.0f * (float)r / (float)n_fft, &s, &c);
+        const float wgt = (edge ? 1.0f : 2.0f) / (float)n_fft;
+        v = (kk & 1) ? (edge ? 0.0f : -wgt * s) : wgt * c;   // c2r ignores Im of DC / Nyquist
+        v *= window[n];
+    }
+    basis[i] = v;
+}
+
+__device__ __forceinline__ float softplus_t(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+
+struct IstftArgs {
+    int64_t R;
+    int n_fft, hop, T, K, kpad;   // K = n_fft/2+1 bins, T frames
+    int64_t ir_len;
+};
+
+// grid: (column chunks of 128, frame tiles of 64, R*2); 4 waves, each 16 frames x 128 columns.
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ noise_stft,  // (2,K,T,2)
+                                                           const float* __restrict__ init_lm,     // (R,2,K)
+                                                           const float* __restrict__ delta_lm,    // (R,2,K)
+                                                           const float* __restrict__ gain_env,    // (R,2,T) or null
+                                                           const float* __restrict__ basis,       // (kpad,n_fft)
+                                                           float* __restrict__ frames,            // (R*2,T,n_fft)
+                                                           IstftArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rc = blockIdx.z;
+    const int c = (int)(rc & 1);
+    const int col0 = blockIdx.x * 128;
+    const int m = blockIdx.y * 64 + wave * 16 + (lane & 15);   // this lane's A row (frame)
+    const int kq = lane >> 4;
+    const bool m_ok = m < a.T;
+    const float* H0 = init_lm + rc * a.K;
+    const float* Hd = delta_lm + rc * a.K;
+    const float genv = (gain_env && m_ok) ? gain_env[rc * a.T + m] : 0.0f;
+    const float mf = (float)m;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int ncol = (a.n_fft - col0 + 15) / 16;  // live column tiles in this chunk (<= 8)
+
+    for (int kk0 = 0; kk0 < a.kpad; kk0 += 4) {
+        const int kk = kk0 + kq, k = kk >> 1;
+        float av = 0.0f;
+        if (m_ok && k < a.K) {
+            // reverb.py:192-199: mask = exp((init + (-softplus(delta)) * m [+ gain_env]) / 8)
+            const float slope = -softplus_t(Hd[k]);
+            float lm = __fadd_rn(H0[k], __fmul_rn(slope, mf));
+            if (gain_env) lm = __fadd_rn(lm, genv);
+            const float mask = expf(lm / 8.0f);
+            av = noise_stft[(((int64_t)c * a.K + k) * a.T + m) * 2 + (kk & 1)] * mask;
+        }
+        const float* brow = basis + (int64_t)kk * a.n_fft + col0 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < ncol) {
+                const int col = col0 + 16 * j + (lane & 15);
+                const float bv = col < a.n_fft ? brow[16 * j] : 0.0f;
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // C layout: row = (lane >> 4) * 4 + reg, col = lane & 15
+    const int mrow0 = blockIdx.y * 64 + wave * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = col0 + 16 * j + (lane & 15);
+        if (j < ncol && col < a.n_fft) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mm = mrow0 + q;
+                if (mm < a.T) frames[(rc * a.T + mm) * a.n_fft + col] = acc[j][q];
+            }
+        }
+    }
+}
+
+// overlap-add + envelope division + trim (centre) + optional ms->lr + energy.
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
+                                                        float* __restrict__ ir, float* __restrict__ energy, IstftArgs a,
+                                                        int ms_to_lr) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.y;
+    const int64_t tp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output index after trimming
+    float e = 0.0f;
+    if (tp < a.ir_len) {
+        const int64_t t = tp + a.n_fft / 2;
+        int64_t m_hi = t / a.hop;
+        if (m_hi > a.T - 1) m_hi = a.T - 1;
+        int64_t m_lo = (t - a.n_fft + a.hop) / a.hop;  // ceil((t - n_fft + 1) / hop)
+        if (m_lo < 0) m_lo = 0;
+        float v0 = 0.0f, v1 = 0.0f, env = 0.0f;
+        for (int64_t m = m_lo; m <= m_hi; ++m) {
+            const int n = (int)(t - m * a.hop);
+            const float w = window[n];
+            env = fmaf(w, w, env);
+            v0 += frames[((r * 2 + 0) * a.T + m) * a.n_fft + n];
+            v1 += frames[((r * 2 + 1) * a.T + m) * a.n_fft + n];
+        }
+        v0 /= env;
+        v1 /= env;
+        if (ms_to_lr) {
+            const float l = v0 + v1, rr = v0 - v1;
+            v0 = l;
+            v1 = rr;
+        }
+        ir[(r * 2 + 0) * a.ir_len + tp] = v0;
+        ir[(r * 2 + 1) * a.ir_len + tp] = v1;
+        e = v0 * v0 + v1 * v1;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) e += __shfl_down(e, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&energy[r], 0.5f * (red[0] + red[1] + red[2] + red[3]));  // mean over 2 channels
+}
+
+__global__ void energy_to_gain_kernel(float* __restrict__ e, int64_t R) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) e[i] = 1.0f / sqrtf(e[i] + 1e-12f);  // core/utils.py:16-17
+}
+
+}  // namespace gfx
+
+using namespace gfx;
+
+extern "C" {
+
+size_t gfx_istft_basis_bytes(int64_t n_fft) {
+    if (n_fft < 2 || (n_fft & 1)) return 0;
+    return (size_t)kpad_of(n_fft) * n_fft * sizeof(float);
+}
+
+int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* stream) {
+    if (!window || !basis || n_fft < 2 || (n_fft & 1) || n_fft > 65536) return GFX_EINVAL;
+    const int64_t total = kpad_of(n_fft) * n_fft;
+    hipLaunchKernelGGL(istft_basis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       window, basis, (int)n_fft, (int)kpad_of(n_fft));
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+size_t gfx_stft_reverb_workspace_bytes(int64_t R, int64_t n_fft, int64_t num_frames) {
+    if (R <= 0 || n_fft <= 0 || num_frames <= 0) return 0;
+    return (size_t)R * 2 * num_frames * n_fft * sizeof(float);
+}
+
+int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnitude, const float* delta_log_magnitude,
+                           const float* gain_env_log_magnitude, const float* window, const float* basis, float* ir,
+                           float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
+                           int ms_to_lr, void* ws, size_t ws_bytes, void* stream) {
+    if (!noise_stft || !init_log_magnitude || !delta_log_magnitude || !window || !basis || !ir || !row_gain)
+        return GFX_EINVAL;
+    if (R <= 0 || ir_len <= 0 || n_fft < 2 || (n_fft & 1) || hop < 1 || hop > n_fft || num_frames < 1) return GFX_EINVAL;
+    if (R * 2 > 65535) return GFX_EINVAL;
+    const size_t need = gfx_stft_reverb_workspace_bytes(R, n_fft, num_frames);
+    if (!ws || ws_bytes < need) return GFX_ENOSPC;
+    IstftArgs a;
+    a.R = R;
+    a.n_fft = (int)n_fft;
+    a.hop = (int)hop;
+    a.T = (int)num_frames;
+    a.K = (int)(n_fft / 2 + 1);
+    a.kpad = (int)kpad_of(n_fft);
+    a.ir_len = ir_len;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(row_gain, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
+    dim3 g1((unsigned)((n_fft + 127) / 128), (unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
+    hipLaunchKernelGGL(istft_frames_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude, delta_log_magnitude,
+                       gain_env_log_magnitude, basis, (float*)ws, a);
+    dim3 g2((unsigned)((ir_len + 255) / 256), (unsigned)R);
+    hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, (const float*)ws, window, ir, row_gain, a, ms_to_lr);
+    hipLaunchKernelGGL(energy_to_gain_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, row_gain, R);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+}  // extern "C"

@@ -80,3 +80,174 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None):
         "gfx_fftconv_f32",
     )
     return out
+
+
+# ----------------------------------------------------------------------------------------- IIR (FSM)
+def iir_fsm_plan(N, device):
+    nbytes = lib().gfx_iir_fsm_plan_bytes(N)
+    if nbytes == 0:
+        raise NotImplementedError(f"fsm_fir_len={N}: the HIP FSM kernel supports 1 <= fsm_fir_len <= 4096")
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    check(lib().gfx_iir_fsm_plan_f32(_ptr(plan), N, _stream()), "gfx_iir_fsm_plan_f32")
+    return plan
+
+
+def iir_fsm_fir(Bs, As, N, plan):
+    """(R, Cf, K, 3) biquad coefficients -> (R*Cf, N) frequency-sampled FIR taps."""
+    _require_gpu(Bs, As)
+    Bs, As = Bs.contiguous(), As.contiguous()
+    K = Bs.shape[-2]
+    RC = Bs.numel() // (K * 3)
+    h = torch.empty((RC, N), dtype=torch.float32, device=Bs.device)
+    check(lib().gfx_iir_fsm_fir_f32(_ptr(Bs), _ptr(As), _ptr(plan), _ptr(h), RC, K, N, _stream()), "gfx_iir_fsm_fir_f32")
+    return h
+
+
+def peq_coeffs(w0, q_inv, log_gain, use_shelving=True):
+    _require_gpu(w0, q_inv, log_gain)
+    w0, q_inv, log_gain = w0.contiguous(), q_inv.contiguous(), log_gain.contiguous()
+    K = w0.shape[-1]
+    n = w0.numel() // K
+    Bs = torch.empty((*w0.shape, 3), dtype=torch.float32, device=w0.device)
+    As = torch.empty_like(Bs)
+    check(lib().gfx_peq_coeffs_f32(_ptr(w0), _ptr(q_inv), _ptr(log_gain), _ptr(Bs), _ptr(As), n, K, int(use_shelving), _stream()),
+          "gfx_peq_coeffs_f32")
+    return Bs, As
+
+
+def biquad_coeffs(Bs_in, A1_pre, A2_pre, A0=None):
+    _require_gpu(Bs_in, A1_pre, A2_pre, A0)
+    Bs_in, A1_pre, A2_pre = Bs_in.contiguous(), A1_pre.contiguous(), A2_pre.contiguous()
+    A0 = None if A0 is None else A0.contiguous()
+    Bs = torch.empty_like(Bs_in)
+    As = torch.empty_like(Bs_in)
+    check(lib().gfx_biquad_coeffs_f32(_ptr(Bs_in), _ptr(A1_pre), _ptr(A2_pre), _ptr(A0), _ptr(Bs), _ptr(As), A1_pre.numel(), _stream()),
+          "gfx_biquad_coeffs_f32")
+    return Bs, As
+
+
+# ----------------------------------------------------------------------------------------- dynamics
+KNEES = {"hard": 0, "quadratic": 1, "exponential": 2}
+
+
+def _rowvec(p, R):
+    if p is None:
+        return None
+    _require_gpu(p)
+    p = p.contiguous()
+    if p.numel() != R:
+        raise ValueError(f"per-row parameter has {p.numel()} elements for {R} rows")
+    return p
+
+
+def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None):
+    _require_gpu(x, out)
+    xmap, R, C, L = rowmap(x)
+    if out is None:
+        out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    ymap = rowmap(out)[0]
+    check(
+        lib().gfx_dynamics_fused_f32(
+            _ptr(x), xmap, _ptr(out), ymap, _ptr(_rowvec(log_threshold, R)), _ptr(_rowvec(log_ratio, R)),
+            _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)), R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream()),
+        "gfx_dynamics_fused_f32",
+    )
+    return out
+
+
+def energy(x):
+    _require_gpu(x)
+    xmap, R, C, L = rowmap(x)
+    e = torch.empty((R, L), dtype=torch.float32, device=x.device)
+    check(lib().gfx_energy_f32(_ptr(x), xmap, _ptr(e), R, C, L, _stream()), "gfx_energy_f32")
+    return e
+
+
+def onepole(u, z_alpha, iir_len, Lout=None, relu=True):
+    _require_gpu(u, z_alpha)
+    u = u.contiguous()
+    R, L = u.shape
+    Lout = L if Lout is None else Lout
+    out = torch.empty((R, Lout), dtype=torch.float32, device=u.device)
+    check(lib().gfx_onepole_f32(_ptr(u), _ptr(_rowvec(z_alpha, R)), _ptr(out), R, L, Lout, iir_len, int(relu), _stream()), "gfx_onepole_f32")
+    return out
+
+
+def onepole_fir(z_alpha, iir_len):
+    _require_gpu(z_alpha)
+    R = z_alpha.numel()
+    h = torch.empty((R, iir_len), dtype=torch.float32, device=z_alpha.device)
+    check(lib().gfx_onepole_fir_f32(_ptr(z_alpha.contiguous()), _ptr(h), R, iir_len, _stream()), "gfx_onepole_fir_f32")
+    return h
+
+
+def ballistics(u, z_alpha):
+    _require_gpu(u, z_alpha)
+    u, z_alpha = u.contiguous(), z_alpha.contiguous()
+    R, L = u.shape
+    if z_alpha.shape != (R, 2):
+        raise ValueError(f"z_alpha must be ({R}, 2), got {tuple(z_alpha.shape)}")
+    y = torch.empty_like(u)
+    check(lib().gfx_ballistics_f32(_ptr(u), _ptr(z_alpha), _ptr(y), R, L, _stream()), "gfx_ballistics_f32")
+    return y
+
+
+def dyn_gain(env, log_threshold, log_ratio, log_knee, knee, gate, log_out):
+    _require_gpu(env)
+    env = env.contiguous()
+    R, L = env.shape
+    g = torch.empty_like(env)
+    check(
+        lib().gfx_dyn_gain_f32(_ptr(env), _ptr(g), _ptr(_rowvec(log_threshold, R)), _ptr(_rowvec(log_ratio, R)),
+                               _ptr(_rowvec(log_knee, R)), R, L, KNEES[knee], int(gate), int(log_out), _stream()),
+        "gfx_dyn_gain_f32",
+    )
+    return g
+
+
+def apply_gain(x, g, exp_gain=False, out=None):
+    _require_gpu(x, g, out)
+    xmap, R, C, L = rowmap(x)
+    g = g.contiguous()
+    if out is None:
+        out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    check(lib().gfx_apply_gain_f32(_ptr(x), xmap, _ptr(g), _ptr(out), rowmap(out)[0], R, C, L, int(exp_gain), _stream()), "gfx_apply_gain_f32")
+    return out
+
+
+def stereo_gain(x, log_gain, out=None):
+    _require_gpu(x, log_gain, out)
+    xmap, R, C, L = rowmap(x)
+    if out is None:
+        out = torch.empty((R, 2, L), dtype=torch.float32, device=x.device)
+    check(lib().gfx_stereo_gain_f32(_ptr(x), xmap, _ptr(log_gain.contiguous()), _ptr(out), rowmap(out)[0], R, C, L, _stream()), "gfx_stereo_gain_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- reverb IR
+def istft_basis(window):
+    _require_gpu(window)
+    n_fft = window.numel()
+    basis = torch.empty(lib().gfx_istft_basis_bytes(n_fft) // 4, dtype=torch.float32, device=window.device)
+    check(lib().gfx_istft_basis_f32(_ptr(window.contiguous()), _ptr(basis), n_fft, _stream()), "gfx_istft_basis_f32")
+    return basis
+
+
+def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_len, hop, ms_to_lr):
+    """-> (ir (R,2,ir_len) un-normalised, row_gain (R) = 1/sqrt(mean_c sum_t ir^2 + 1e-12))."""
+    _require_gpu(init_lm, delta_lm, gain_env, window, basis)
+    R = init_lm.shape[0]
+    n_fft = window.numel()
+    T = noise_stft.shape[-1]
+    nz = torch.view_as_real(noise_stft.contiguous())  # (…,2,K,T,2) float32 view of the complex64 buffer
+    ir = torch.empty((R, 2, ir_len), dtype=torch.float32, device=init_lm.device)
+    row_gain = torch.empty((R,), dtype=torch.float32, device=init_lm.device)
+    nbytes = lib().gfx_stft_reverb_workspace_bytes(R, n_fft, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=init_lm.device)
+    check(
+        lib().gfx_stft_reverb_ir_f32(_ptr(nz), _ptr(init_lm.contiguous()), _ptr(delta_lm.contiguous()),
+                                     _ptr(None if gain_env is None else gain_env.contiguous()), _ptr(window), _ptr(basis),
+                                     _ptr(ir), _ptr(row_gain), R, ir_len, n_fft, hop, T, int(ms_to_lr), _ptr(ws), nbytes, _stream()),
+        "gfx_stft_reverb_ir_f32",
+    )
+    return ir, row_gain

@@ -1,0 +1,99 @@
+"""FIR convolution backend (mirrors grafx.processors.core.convolution —
+reference src/grafx/processors/core/convolution.py:17-134) on the HIP overlap-save kernels.
+
+Semantics are the reference's, including its length-parity quirk: `convolve`
+pads to P = Lx + Lh - 1, multiplies rffts and calls ``irfft`` *without* ``n``, so
+for odd P it inverts a P-point spectrum on a (P-1)-point grid
+(convolution.py:120-126).  Here
+
+* even P  -> the result IS the linear convolution: one pass of the HIP
+  overlap-save kernels (gfx_fftconv_f32), reading x once and writing y once;
+* odd P   -> the HIP kernels produce the full linear convolution z (length P) and
+  the reference's aliasing ``irfft(rfft(z))`` is applied on top with the device
+  FFT library (compatibility path, library FFT — see DESIGN.md §quirk).
+
+``set_exact_convolution(True)`` opts out of the quirk (true linear convolution
+for every length; deviates from the reference when P is odd).
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._grad import forward_only
+
+_EXACT = False
+
+
+def set_exact_convolution(flag=True):
+    """Force true linear convolution even where the reference aliases (odd Lx+Lh-1)."""
+    global _EXACT
+    _EXACT = bool(flag)
+
+
+def exact_convolution():
+    return _EXACT
+
+
+def reference_aliases(lx, lh):
+    """True when the reference's convolve() is NOT a linear convolution for these lengths."""
+    return (lx + lh - 1) % 2 == 1 and not _EXACT
+
+
+def odd_length_alias(z):
+    """irfft_{P-1}(rfft_P(z)) for a full linear convolution z of odd length P (convolution.py:123-126)."""
+    return torch.fft.irfft(torch.fft.rfft(z))
+
+
+def compute_pad_len(x, y, pad_mode="min"):
+    if pad_mode != "min":
+        # the reference's "pow2" branch never returns (convolution.py:111-114), so it cannot be relied on
+        raise ValueError(f"pad_mode={pad_mode!r} is not supported (only 'min', the reference default)")
+    return x.shape[-1] + y.shape[-1] - 1
+
+
+def convolve_taps(x, Hs, N, Cf, mode):
+    """convolve() given precomputed tile spectra of the taps."""
+    L = x.shape[-1]
+    if not reference_aliases(L, N):
+        if mode == "causal":
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0)
+        if mode == "zerophase":
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2)
+        return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0)
+    y_pad = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0))
+    if mode == "causal":
+        return y_pad[..., :L].contiguous()
+    if mode == "zerophase":
+        return y_pad[..., N // 2 : N // 2 + L].contiguous()
+    return y_pad
+
+
+def convolve(x, h, mode="zerophase", pad_mode="min"):
+    """Reference-compatible convolve(): x (R,C,L) or (R,L); h (R,Cf,N) or (R,N)."""
+    forward_only(x, h)
+    compute_pad_len(x, h, pad_mode)
+    flat = x.ndim == 2
+    if flat:
+        x, h = x.unsqueeze(1), h.unsqueeze(1)
+    R, Cf, N = h.shape
+    Hs = ops.fir_spectrum(h.reshape(R * Cf, N))
+    y = convolve_taps(x, Hs, N, Cf, mode)
+    return y.squeeze(1) if flat else y
+
+
+class FIRConvolution(nn.Module):
+    """Same constructor as the reference (convolution.py:38-65).  ``flashfftconv`` and
+    ``max_input_len`` are accepted and ignored: FlashFFTConv is a CUDA-only bf16 library; the
+    fp32 HIP overlap-save kernels are its MI355X counterpart and have no length cap."""
+
+    def __init__(self, mode="causal", flashfftconv=True, max_input_len=2**17):
+        super().__init__()
+        self.mode = mode
+        self.flashfftconv = False
+        if flashfftconv and mode == "zerophase":
+            warnings.warn("flashfftconv is ignored by grafx_amd (fp32 HIP FFT convolution is always used).")
+
+    def forward(self, input_signals, fir):
+        return convolve(input_signals, fir, mode=self.mode)

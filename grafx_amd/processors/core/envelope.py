@@ -1,0 +1,38 @@
+"""Envelope smoothers (mirrors grafx.processors.core.envelope — reference core/envelope.py:10-101)."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._grad import forward_only
+from .convolution import odd_length_alias, reference_aliases
+
+
+class TruncatedOnePoleIIRFilter(nn.Module):
+    """y = relu(u * h), h[n] = (1-a) a^n for n < iir_len, a = min(sigmoid(z), 1-1e-5).
+
+    Runs as the exact recursive form of that FIR (prefix scan) instead of an FFT convolution;
+    when the reference's convolve() would alias (odd L + iir_len - 1) the full-length result is
+    produced first and aliased the same way."""
+
+    def __init__(self, iir_len=16384, **backend_kwargs):
+        super().__init__()
+        self.iir_len = iir_len
+
+    def forward(self, input_signals, z_alpha):
+        forward_only(input_signals, z_alpha)
+        L = input_signals.shape[-1]
+        if not reference_aliases(L, self.iir_len):
+            return ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L, relu=True)
+        full = ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L + self.iir_len - 1, relu=False)
+        return torch.relu(odd_length_alias(full)[..., :L]).contiguous()
+
+    def compute_impulse(self, z_alpha):
+        return ops.onepole_fir(z_alpha, self.iir_len)
+
+
+class Ballistics(nn.Module):
+    """Attack/release one-pole recursion (torchcomp.compressor_core semantics as recalled)."""
+
+    def forward(self, input_signals, z_alpha):
+        forward_only(input_signals, z_alpha)
+        return ops.ballistics(input_signals, z_alpha)

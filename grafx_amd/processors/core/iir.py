@@ -1,0 +1,52 @@
+"""Biquad-cascade IIR filter (mirrors grafx.processors.core.iir.IIRFilter —
+reference core/iir.py:25-152, 263-276), frequency-sampling ("fsm") backend on HIP."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._grad import forward_only
+from .convolution import FIRConvolution, convolve_taps
+
+
+class IIRFilter(nn.Module):
+    def __init__(self, order=2, backend="fsm", flashfftconv=True, fsm_fir_len=4000,
+                 fsm_max_input_len=2**17, fsm_regularization=False):
+        super().__init__()
+        self.backend = backend
+        self.fsm_fir_len = fsm_fir_len
+        self.fsm_regularization = fsm_regularization
+        if flashfftconv:  # same precondition as upstream (iir.py:110-112)
+            assert fsm_fir_len % 2 == 0
+            assert fsm_max_input_len % 2 == 0
+        if backend == "fsm":
+            if order != 2:
+                raise NotImplementedError("the HIP FSM kernel evaluates second-order sections (order=2)")
+            if fsm_regularization:
+                assert False  # upstream: iir.py:122-123
+            self.conv = FIRConvolution(mode="causal", flashfftconv=flashfftconv, max_input_len=fsm_max_input_len)
+            self._plans = {}
+        elif backend in ("lfilter", "ssm"):
+            raise NotImplementedError(
+                f"backend={backend!r} (exact recursive filtering via torchaudio/torchlpc upstream) is not part of "
+                "this release; use backend='fsm' (the reference default)."
+            )
+        else:
+            raise ValueError(f"Unsupported backend: {backend}")
+
+    def _plan(self, device):
+        key = (device.type, device.index)
+        if key not in self._plans:
+            self._plans[key] = ops.iir_fsm_plan(self.fsm_fir_len, device)
+        return self._plans[key]
+
+    def fsm_fir(self, Bs, As):
+        """(R,Cf,K,3) coefficients -> (R,Cf,N) FIR the FSM backend convolves with (iir.py:148-150)."""
+        R, Cf = Bs.shape[0], Bs.shape[1]
+        return ops.iir_fsm_fir(Bs, As, self.fsm_fir_len, self._plan(Bs.device)).view(R, Cf, self.fsm_fir_len)
+
+    def forward(self, input_signal, Bs, As):
+        forward_only(input_signal, Bs, As)
+        R, Cf = Bs.shape[0], Bs.shape[1]
+        N = self.fsm_fir_len
+        h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
+        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal")

@@ -1,0 +1,82 @@
+"""Dynamic range processors (mirrors grafx.processors.dynamics — reference dynamics.py:213-721)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .core._grad import forward_only
+from .core.convolution import reference_aliases
+from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
+
+
+class _Dynamics(nn.Module):
+    _gate = False
+
+    def __init__(self, energy_smoother="iir", gain_smoother=None, gain_smooth_in_log=False, knee="quadratic",
+                 iir_len=16384, flashfftconv=True, max_input_len=2**17):
+        super().__init__()
+        self.iir_len = iir_len
+        self.energy_smoother = energy_smoother
+        if energy_smoother == "iir":
+            self.energy_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len)
+        elif energy_smoother == "ballistics":
+            self.energy_smoother_module = Ballistics()
+        elif energy_smoother is not None:
+            raise ValueError(f"Unknown energy_smoother: {self.energy_smoother}")
+        self.gain_smoother = gain_smoother
+        if gain_smoother == "iir":
+            self.gain_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len)
+        elif gain_smoother == "ballistics":
+            self.gain_smoother_module = Ballistics()
+        elif gain_smoother is not None:
+            raise ValueError(f"Unknown gain_smoother: {self.gain_smoother}")
+        if knee not in ("hard", "quadratic", "exponential"):
+            raise ValueError(f"Unknown knee: {knee}")
+        self.knee = knee
+        self.gain_smooth_in_log = gain_smooth_in_log
+
+    def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None):
+        forward_only(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post)
+        L = input_signals.shape[-1]
+        if self.knee == "hard":
+            log_knee = None
+        fusable = self.gain_smoother is None and (
+            self.energy_smoother is None or (self.energy_smoother == "iir" and not reference_aliases(L, self.iir_len))
+        )
+        if fusable:  # one pass: energy -> one-pole -> log -> knee -> exp -> multiply
+            return ops.dynamics_fused(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
+                                      smoother=int(self.energy_smoother == "iir"), iir_len=self.iir_len,
+                                      knee=self.knee, gate=self._gate)
+        energy = ops.energy(input_signals)
+        if self.energy_smoother is not None:
+            energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)
+        if self.gain_smoother is None:
+            gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
+            return ops.apply_gain(input_signals, gain)
+        if self.gain_smooth_in_log:  # dynamics.py:411-414
+            g = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=True)
+            return ops.apply_gain(input_signals, self.gain_smoother_module(g, z_alpha=z_alpha_post), exp_gain=True)
+        gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
+        return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post))
+
+    def parameter_size(self):
+        size = {"log_threshold": 1, "log_ratio": 1}
+        if self.knee != "hard":
+            size["log_knee"] = 1
+        for key, kind in (("z_alpha_pre", self.energy_smoother), ("z_alpha_post", self.gain_smoother)):
+            if kind == "iir":
+                size[key] = 1
+            elif kind == "ballistics":
+                size[key] = 2
+        return size
+
+
+class Compressor(_Dynamics):
+    """Feed-forward compressor (reference dynamics.py:213-489)."""
+
+    _gate = False
+
+
+class NoiseGate(_Dynamics):
+    """Feed-forward noise gate (reference dynamics.py:492-721)."""
+
+    _gate = True

@@ -1,0 +1,30 @@
+"""Equalizers (mirrors grafx.processors.eq — reference eq.py:217-336 for ParametricEqualizer)."""
+import torch.nn as nn
+
+from .. import ops
+from .core._grad import forward_only
+from .core.iir import IIRFilter
+from .core.midside import lr_to_ms, ms_to_lr
+
+
+class ParametricEqualizer(nn.Module):
+    def __init__(self, num_filters=10, processor_channel="mono", use_shelving_filters=True, **backend_kwargs):
+        super().__init__()
+        self.num_filters = num_filters
+        self.use_shelving_filters = use_shelving_filters
+        self.biquad = IIRFilter(order=2, **backend_kwargs)
+        self.processor_channel = processor_channel
+        if processor_channel not in ("mono", "stereo", "midside"):
+            raise ValueError(f"Invalid processor_channel: {self.processor_channel}")
+
+    def forward(self, input_signals, w0, q_inv, log_gain):
+        forward_only(input_signals, w0, q_inv, log_gain)
+        Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
+        if self.processor_channel == "midside":
+            return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
+        return self.biquad(input_signals, Bs, As)
+
+    def parameter_size(self):
+        n_channels = 1 if self.processor_channel == "mono" else 2
+        size = (n_channels, self.num_filters)
+        return {k: size for k in ["w0", "q_inv", "log_gain"]}

@@ -1,0 +1,71 @@
+"""Reverbs (mirrors grafx.processors.reverb.STFTMaskedNoiseReverb — reference reverb.py:15-228)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .core._grad import forward_only
+from .core.convolution import convolve_taps
+from .core.midside import lr_to_ms, ms_to_lr
+
+
+class STFTMaskedNoiseReverb(nn.Module):
+    def __init__(self, ir_len=60000, processor_channel="pseudo_midside", n_fft=384, hop_length=192,
+                 fixed_noise=True, gain_envelope=False, flashfftconv=True, max_input_len=2**17):
+        super().__init__()
+        self.ir_len, self.n_fft, self.hop_length = ir_len, n_fft, hop_length
+        self.num_frames = 1 + (ir_len // hop_length)
+        self.num_bins = 1 + n_fft // 2
+        self.register_buffer("window", torch.hann_window(n_fft))
+        self.register_buffer("arange", torch.arange(self.num_frames).view(1, 1, 1, -1))
+        self.fixed_noise = fixed_noise
+        if not fixed_noise:
+            raise NotImplementedError("fixed_noise=False (fresh noise every forward) is not part of this release")
+        self.get_fixed_noise()
+        self.gain_envelope = gain_envelope
+        self.processor_channel = processor_channel
+        if processor_channel not in ("mono", "stereo", "midside", "pseudo_midside"):
+            raise ValueError(f"Invalid processor_channel: {processor_channel}")
+        self._basis = {}
+
+    def get_fixed_noise(self):
+        """One-time constant, built exactly like upstream (reverb.py:101-114): RandomState(0) uniform
+        noise in [-1,1) -> float32 -> centred STFT.  Init-time only; the buffer then lives on the GPU."""
+        noise = np.random.RandomState(0).uniform(size=(2, self.ir_len)) * 2 - 1
+        noise = torch.tensor(noise).float()
+        spec = torch.stft(noise, n_fft=self.n_fft, hop_length=self.hop_length, window=self.window.cpu(),
+                          return_complex=True)
+        self.register_buffer("noise_stft", spec[None].contiguous())
+
+    def _istft_basis(self, device):
+        key = (device.type, device.index)
+        if key not in self._basis:
+            self._basis[key] = ops.istft_basis(self.window)
+        return self._basis[key]
+
+    def _ir_and_gain(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, ms_lr):
+        genv = gain_env_log_magnitude if self.gain_envelope else None
+        return ops.stft_reverb_ir(self.noise_stft, init_log_magnitude, delta_log_magnitude, genv, self.window,
+                                  self._istft_basis(init_log_magnitude.device), self.ir_len, self.hop_length, ms_lr)
+
+    def compute_ir(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
+        """Un-normalised mid/side impulse responses (R,2,ir_len) (reverb.py:161-187)."""
+        forward_only(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
+        return self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, False)[0]
+
+    def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
+        forward_only(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
+        pseudo = self.processor_channel == "pseudo_midside"
+        ir, gain = self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, pseudo)
+        R = ir.shape[0]
+        # normalize_impulse (core/utils.py:14-18) is folded into the tap -> spectrum step
+        Hs = ops.fir_spectrum(ir.view(R * 2, self.ir_len), gain=gain, gain_div=2)
+        if self.processor_channel == "midside":  # reverb.py:219-223
+            return ms_to_lr(convolve_taps(lr_to_ms(input_signals), Hs, self.ir_len, 2, "causal"))
+        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal")
+
+    def parameter_size(self):
+        size = {"init_log_magnitude": (2, self.num_bins), "delta_log_magnitude": (2, self.num_bins)}
+        if self.gain_envelope:
+            size["gain_env_log_magnitude"] = (2, self.num_frames)
+        return size

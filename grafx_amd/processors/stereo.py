@@ -1,0 +1,14 @@
+"""Stereo utilities (mirrors grafx.processors.stereo.StereoGain — reference stereo.py:9-48)."""
+import torch.nn as nn
+
+from .. import ops
+from .core._grad import forward_only
+
+
+class StereoGain(nn.Module):
+    def forward(self, input_signals, log_gain):
+        forward_only(input_signals, log_gain)
+        return ops.stereo_gain(input_signals, log_gain)
+
+    def parameter_size(self):
+        return {"log_gain": 2}

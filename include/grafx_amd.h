@@ -74,6 +74,80 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
                     int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* ---- frequency-sampled IIR -------------------------------------------------------------
+ * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276
+ * (complex64 response of the biquad cascade on the N-point grid, then torch.fft.irfft(n=N)).
+ * Bs, As: (RC, K, 3) contiguous; h: (RC, N) taps out.  N <= 4096 (Bluestein on the LDS tile).
+ * `plan` is a per-N constant (gfx_iir_fsm_plan_bytes bytes) filled once by gfx_iir_fsm_plan_f32.
+ */
+size_t gfx_iir_fsm_plan_bytes(int64_t N);
+int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream);
+int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h,
+                        int64_t RC, int64_t K, int64_t N, void* stream);
+
+/* coefficient front-ends (elementwise over n = rows*channels items of K biquads)
+ * gfx_peq_coeffs_f32    replaces ParametricEqualizer.forward's activations + RBJ formulas:
+ *                       eq.py:291-314, filter.py:593-604, 645-656, 687-705, 736-754
+ * gfx_biquad_coeffs_f32 replaces BiquadFilter.forward's stability activations: filter.py:144-153
+ *                       (A0 nullable = "normalized" off)
+ */
+int gfx_peq_coeffs_f32(const float* w0, const float* q_inv, const float* log_gain, float* Bs, float* As,
+                       int64_t n, int64_t K, int use_shelving, void* stream);
+int gfx_biquad_coeffs_f32(const float* Bin, const float* A1_pre, const float* A2_pre, const float* A0,
+                          float* Bs, float* As, int64_t n, void* stream);
+
+/* ---- dynamics ---------------------------------------------------------------------------
+ * gfx_dynamics_fused_f32 replaces Compressor.forward / NoiseGate.forward (dynamics.py:361-409,
+ *   598-641) for energy_smoother in {None (smoother=0), "iir" (smoother=1)} and no gain
+ *   smoother: energy -> truncated one-pole (exact recursive form, iir_len taps) -> log ->
+ *   knee (0 hard, 1 quadratic, 2 exponential; gate=1 selects NoiseGate's curves) -> exp -> y.
+ *   Per-row parameters are (R) arrays (the reference's (R,1) tensors).
+ * The remaining entry points are the same stages as separate launches, for configurations
+ * the fused kernel does not cover (ballistics, gain smoothing, odd-P compatibility):
+ *   gfx_energy_f32       e = mean_c x^2                                   dynamics.py:390
+ *   gfx_onepole_f32      TruncatedOnePoleIIRFilter on (R,L) rows -> (R,Lout), optional relu
+ *                        core/envelope.py:34-60 (Lout = L + iir_len - 1 gives the full convolution)
+ *   gfx_onepole_fir_f32  its taps h[n] = (1-a) exp(n log a)              core/envelope.py:51-60
+ *   gfx_ballistics_f32   Ballistics / torchcomp.compressor_core          core/envelope.py:84-101
+ *                        (z_alpha: (R,2); recursion recalled — parity unpinned)
+ *   gfx_dyn_gain_f32     env -> gain: log(env+1e-5) -> knee [-> exp unless log_out]
+ *   gfx_apply_gain_f32   y = (exp_gain ? exp(g) : g)[:,None,:] * x        dynamics.py:405
+ *   gfx_stereo_gain_f32  StereoGain.forward                               stereo.py:38-41
+ */
+int gfx_dynamics_fused_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
+                           const float* log_threshold, const float* log_ratio, const float* log_knee,
+                           const float* z_alpha, int64_t R, int64_t C, int64_t L, int smoother,
+                           int64_t iir_len, int knee, int gate, void* stream);
+int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
+int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
+                    int64_t iir_len, int relu, void* stream);
+int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_len, void* stream);
+int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R, int64_t L, void* stream);
+int gfx_dyn_gain_f32(const float* env, float* gain, const float* log_threshold, const float* log_ratio,
+                     const float* log_knee, int64_t R, int64_t L, int knee, int gate, int log_out, void* stream);
+int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float* y, gfx_rowmap_t ymap,
+                       int64_t R, int64_t C, int64_t L, int exp_gain, void* stream);
+int gfx_stereo_gain_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
+                        int64_t R, int64_t C_in, int64_t L, void* stream);
+
+/* ---- STFT-masked noise reverb: impulse response ------------------------------------------
+ * replaces STFTMaskedNoiseReverb.compute_stft_mask + compute_ir (reverb.py:161-200: mask, torch.istft),
+ * ms_to_lr (core/midside.py:4-8) and the energy of normalize_impulse (core/utils.py:14-18).
+ * noise_stft: (2, n_fft/2+1, num_frames) complex64 as interleaved floats (the module's buffer);
+ * init/delta: (R, 2, n_fft/2+1); gain_env (nullable): (R, 2, num_frames); window: (n_fft).
+ * Outputs ir (R, 2, ir_len), un-normalised, and row_gain (R) = 1/sqrt(mean_c sum_t ir^2 + 1e-12),
+ * to be passed as `gain` (gain_div = 2) to gfx_fir_spectrum_f32.
+ * `basis` is a per-(n_fft, window) constant from gfx_istft_basis_f32.
+ */
+size_t gfx_istft_basis_bytes(int64_t n_fft);
+int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* stream);
+size_t gfx_stft_reverb_workspace_bytes(int64_t R, int64_t n_fft, int64_t num_frames);
+int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnitude,
+                           const float* delta_log_magnitude, const float* gain_env_log_magnitude,
+                           const float* window, const float* basis, float* ir, float* row_gain,
+                           int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
+                           int ms_to_lr, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

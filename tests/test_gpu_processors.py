@@ -1,0 +1,184 @@
+"""GPU parity of the HIP processors against outputs of the reference itself
+(tests/golden/*.npz) — every case goes nn.Module -> ops -> C ABI -> HIP kernels.
+
+Tolerance: 1e-5 on max|y-ref|/max|ref| and on relative L2 (north star: 1e-5 relative fp32;
+metric per SURVEY.md H6).  Cases with pre-activation std=1 can place poles close to the unit
+circle where the reference's own complex64 response is only ~1e-5 accurate (H6); those use
+the stated looser bound and are additionally checked against a float64 evaluation.
+"""
+import pytest
+import torch
+
+import oracle
+from conftest import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def cu(t):
+    return t.cuda() if isinstance(t, torch.Tensor) else t
+
+
+def run(module, x, params):
+    module = module.cuda()
+    with torch.no_grad():
+        return module(cu(x), **{k: cu(v) for k, v in params.items()}).cpu()
+
+
+@pytest.mark.parametrize("N", [256, 257, 500])
+@pytest.mark.parametrize("K", [1, 6])
+def test_iir_fsm(golden, N, K):
+    from grafx_amd.processors import IIRFilter
+
+    g = golden("g2_iir_fsm")
+    tag = f"N{N}_K{K}"
+    flt = IIRFilter(order=2, backend="fsm", flashfftconv=False, fsm_fir_len=N)
+    with torch.no_grad():
+        fir = flt.fsm_fir(g[f"Bs_{tag}"].cuda(), g[f"As_{tag}"].cuda()).cpu()
+    assert_close(fir, g[f"fir_{tag}"], TOL, "fsm fir")
+    y = run(flt, g[f"x_{tag}"], {"Bs": g[f"Bs_{tag}"], "As": g[f"As_{tag}"]})
+    assert_close(y, g[f"y_{tag}"], TOL, "fsm y")
+
+
+@pytest.mark.parametrize("ch", ["mono", "stereo", "midside"])
+@pytest.mark.parametrize("N", [256, 257])
+@pytest.mark.parametrize("std", [0.01, 1.0])
+def test_peq(golden, ch, N, std):
+    from grafx_amd.processors import ParametricEqualizer
+
+    g = golden("g3_peq")
+    tag = f"{ch}_N{N}_std{std}"
+    m = ParametricEqualizer(num_filters=6, processor_channel=ch, flashfftconv=False, fsm_fir_len=N)
+    p = {k: g[f"{k}_{tag}"] for k in ("w0", "q_inv", "log_gain")}
+    y = run(m, g[f"x_{tag}"], p)
+    assert_close(y, g[f"y_{tag}"], TOL if std < 1 else 3e-5, "peq")
+    if std == 1.0:  # tie-breaker: float64 evaluation of the same formulas
+        m64 = oracle.OracleParametricEqualizer(num_filters=6, processor_channel=ch, fsm_fir_len=N)
+        y64 = m64(g[f"x_{tag}"].double(), **{k: v.double() for k, v in p.items()})
+        ours, ref = rel_err(y, y64)[0], rel_err(g[f"y_{tag}"], y64)[0]
+        assert ours <= max(3 * ref, TOL), f"vs float64: ours {ours:.2e}, reference {ref:.2e}"
+
+
+@pytest.mark.parametrize("K", [1, 4])
+@pytest.mark.parametrize("N", [256, 257])
+@pytest.mark.parametrize("normalized", [False, True])
+def test_biquad(golden, K, N, normalized):
+    from grafx_amd.processors import BiquadFilter
+
+    g = golden("g4_biquad_gain")
+    tag = f"K{K}_N{N}_norm{int(normalized)}"
+    m = BiquadFilter(num_filters=K, normalized=normalized, flashfftconv=False, fsm_fir_len=N)
+    p = {k: g[f"{k}_{tag}"] for k in m.parameter_size()}
+    assert_close(run(m, g[f"x_{tag}"], p), g[f"y_{tag}"], 3e-5, "biquad")
+
+
+def test_stereo_gain(golden):
+    from grafx_amd.processors import StereoGain
+
+    g = golden("g4_biquad_gain")
+    y = run(StereoGain(), g["gain_x"], {"log_gain": g["gain_log_gain"]})
+    assert_close(y, g["gain_y"], 1e-6, "gain")
+
+
+@pytest.mark.parametrize("ir_len", [3000, 3001])
+@pytest.mark.parametrize("ch", ["pseudo_midside", "midside", "stereo"])
+def test_reverb(golden, ir_len, ch):
+    from grafx_amd.processors import STFTMaskedNoiseReverb
+
+    g = golden("g5_reverb")
+    tag = f"ir{ir_len}_{ch}"
+    m = STFTMaskedNoiseReverb(ir_len=ir_len, processor_channel=ch, flashfftconv=False)
+    p = {k: g[f"{k}_{tag}"] for k in ("init_log_magnitude", "delta_log_magnitude")}
+    assert_close(run(m, g[f"x_{tag}"], p), g[f"y_{tag}"], TOL, "reverb y")
+    if ch == "pseudo_midside":
+        with torch.no_grad():
+            ir = m.cuda().compute_ir(**{k: v.cuda() for k, v in p.items()}).cpu()
+        assert_close(ir, g[f"ir_{tag}"], TOL, "reverb ir")
+
+
+def test_reverb_gain_envelope(golden):
+    from grafx_amd.processors import STFTMaskedNoiseReverb
+
+    g = golden("g5_reverb")
+    m = STFTMaskedNoiseReverb(ir_len=3001, gain_envelope=True, flashfftconv=False)
+    p = {k: g[f"{k}_genv"] for k in m.parameter_size()}
+    assert_close(run(m, g["x_genv"], p), g["y_genv"], TOL, "reverb genv")
+
+
+@pytest.mark.parametrize("cls", ["Compressor", "NoiseGate"])
+@pytest.mark.parametrize("knee", ["hard", "quadratic", "exponential"])
+@pytest.mark.parametrize("sm,iir_len", [("iir", 512), ("iir", 511), (None, 0), ("ballistics", 0)])
+def test_dynamics(golden, cls, knee, sm, iir_len):
+    import grafx_amd.processors as P
+
+    g = golden("g6_dynamics")
+    tag = f"{cls}_{knee}_{sm}_{iir_len}"
+    kw = dict(energy_smoother=sm, knee=knee, flashfftconv=False)
+    if sm == "iir":
+        kw["iir_len"] = iir_len
+    m = getattr(P, cls)(**kw)
+    p = {k: g[f"{k}_{tag}"] for k in m.parameter_size()}
+    assert_close(run(m, g["x_shared"], p), g[f"y_{tag}"], TOL, tag)
+
+
+@pytest.mark.parametrize("gs,in_log", [("iir", False), ("iir", True), ("ballistics", False)])
+def test_gain_smoothers(golden, gs, in_log):
+    from grafx_amd.processors import Compressor
+
+    g = golden("g6_dynamics")
+    tag = f"gs_{gs}_{int(in_log)}"
+    m = Compressor(energy_smoother="iir", gain_smoother=gs, gain_smooth_in_log=in_log, iir_len=511, flashfftconv=False)
+    p = {k: g[f"{k}_{tag}"] for k in m.parameter_size()}
+    assert_close(run(m, g[f"x_{tag}"], p), g[f"y_{tag}"], TOL, tag)
+
+
+@pytest.mark.parametrize("n", [512, 511])
+def test_one_pole(golden, n):
+    from grafx_amd.processors import TruncatedOnePoleIIRFilter
+
+    g = golden("g7_g9_smoothers")
+    f = TruncatedOnePoleIIRFilter(iir_len=n, flashfftconv=False)
+    with torch.no_grad():
+        h = f.compute_impulse(g["onepole_z"].cuda()).cpu()
+        y = f(g[f"onepole_u_{n}"].cuda(), g["onepole_z"].cuda()).cpu()
+    assert_close(h, g[f"onepole_h_{n}"], 1e-6, "one-pole taps")
+    assert_close(y, g[f"onepole_y_{n}"], TOL, "one-pole y")
+
+
+def test_ballistics_provisional(golden):
+    from grafx_amd.processors import Ballistics
+
+    g = golden("g7_g9_smoothers")
+    with torch.no_grad():
+        y = Ballistics()(g["ball_u"].cuda(), g["ball_z"].cuda()).cpu()
+    assert_close(y, g["ball_y"], TOL, "ballistics (recalled torchcomp semantics)")
+
+
+@pytest.mark.parametrize("L,N", [(1024, 128), (1025, 128), (1024, 127), (1000, 301)])
+@pytest.mark.parametrize("mode", ["causal", "zerophase"])
+def test_convolve_reference_semantics_both_parities(golden, L, N, mode):
+    from grafx_amd.processors import convolve
+
+    g = golden("g1_convolve")
+    for C, Cf in [(1, 1), (2, 1), (1, 2), (2, 2)]:
+        x, h = g[f"x_L{L}_N{N}"][:, :C].contiguous(), g[f"h_L{L}_N{N}"][:, :Cf].contiguous()
+        with torch.no_grad():
+            y = convolve(x.cuda(), h.cuda(), mode=mode).cpu()
+        assert_close(y, g[f"y_{mode}_L{L}_N{N}_C{C}_Cf{Cf}"], TOL, f"convolve C{C} Cf{Cf}")
+
+
+def test_loud_failures():
+    import grafx_amd.processors as P
+
+    m = P.StereoGain()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 8), torch.zeros(1, 2))  # CPU tensors are refused
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 2, 8).cuda(), torch.zeros(1, 2, requires_grad=True).cuda())  # forward-only, loud
+    with pytest.raises(NotImplementedError):
+        P.IIRFilter(backend="lfilter", flashfftconv=False)
+    with pytest.raises(ValueError):
+        P.IIRFilter(backend="nope", flashfftconv=False)
+    with pytest.raises(ValueError):
+        P.Compressor(knee="soft")
