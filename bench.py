@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward render of the 32-channel mixing-console graph
+(111 nodes: 36 EQ, 36 compressor, 1 reverb, 5 mix, 32 in, 1 out — BASELINE.json configs[3])
+at batch 256 per GPU, L = 131072 samples, stereo, fp32.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one render_grafx pass over one resident batch.  The batch axis shards over GPUs
+(weak scaling: 256 graphs per GPU, no data-path collective for the forward render).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def console_graph(n_ch=32, n_bus=4):
+    from grafx_amd.data import GRAFX, NodeConfigs
+
+    G = GRAFX(config=NodeConfigs(["eq", "compressor", "reverb"]))
+    out_id = G.add("out")
+    buses = [G.add("mix") for _ in range(n_bus)]
+    send = G.add("mix")
+    for ch in range(n_ch):
+        _, last = G.add_serial_chain(["in", "eq", "compressor"])
+        G.connect(last, buses[ch // (n_ch // n_bus)])
+        G.connect(last, send)
+    for b in buses:
+        e, c = G.add("eq"), G.add("compressor")
+        G.connect(b, e)
+        G.connect(e, c)
+        G.connect(c, out_id)
+    r = G.add("reverb")
+    G.connect(send, r)
+    G.connect(r, out_id)
+    return G
+
+
+# filter lengths: odd, so that L + N - 1 is even and the reference's convolve() IS the linear
+# convolution (see DESIGN.md "length-parity quirk"); all are legal reference constructor arguments.
+LENS = dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001)
+
+
+def hip_processors():
+    from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
+
+    return {
+        "eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=LENS["fsm_fir_len"]),
+        "compressor": Compressor(energy_smoother="iir", iir_len=LENS["iir_len"], flashfftconv=False),
+        "reverb": STFTMaskedNoiseReverb(ir_len=LENS["ir_len"], flashfftconv=False),
+    }
+
+
+def oracle_processors():
+    import oracle
+
+    return {
+        "eq": oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=LENS["fsm_fir_len"]),
+        "compressor": oracle.OracleCompressor(energy_smoother="iir", iir_len=LENS["iir_len"]),
+        "reverb": oracle.OracleSTFTMaskedNoiseReverb(ir_len=LENS["ir_len"]),
+    }
+
+
+def cpu_baseline(G, render_data, params_cpu, L, budget_s=20.0):
+    """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample."""
+    from grafx_amd.render import render_grafx
+
+    procs = oracle_processors()
+    B = 2
+    x = torch.randn(B, 32, 2, L)
+    torch.set_num_threads(os.cpu_count() or 1)
+    times = []
+    with torch.no_grad():
+        t_all = time.perf_counter()
+        for i in range(4):
+            t0 = time.perf_counter()
+            render_grafx(procs, x, params_cpu, render_data, parameters_grad=False)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget_s:
+                break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {
+        "value": B * L / best,
+        "unit": "audio samples/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"same 111-node console graph and lengths, batch {B} (of 256), L={L}, best of {len(times)} runs "
+                  f"after warm-up, torch CPU oracle",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
+    ap.add_argument("--length", type=int, default=131072)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from grafx_amd import ops
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    B, L = args.batch, args.length
+    G = console_graph()
+    render_data = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    procs = {k: v.to(dev) for k, v in hip_processors().items()}
+    torch.manual_seed(1234)  # identical parameters on every rank (a shared mixing console)
+    params_cpu = {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    params = {t: {k: v.to(dev) for k, v in d.items()} for t, d in params_cpu.items()}
+    torch.manual_seed(1000 + rank)  # each rank renders its own shard of the batch
+    x = torch.randn(B, 32, 2, L, device=dev)
+    rd_dev = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return render_grafx(procs, x, params, rd_dev, parameters_grad=False)[0]
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(y).all(), "render produced non-finite samples"
+
+    # dominant kernel, timed live with stream events on extra (untimed) steps
+    ops.PROFILE = {}
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    roof = None
+    prof, ops.PROFILE = ops.PROFILE, None
+    if prof:
+        stats = {}
+        for name, recs in prof.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            stats[name] = (sum(ms), sum(ms) / len(ms), sum(r[2] for r in recs) / len(recs), len(ms))
+        name = max(stats, key=lambda k: stats[k][0])
+        total_ms, avg_ms, avg_bytes, n = stats[name]
+        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": avg_bytes, "launches_per_step": n // 2,
+                "share_of_step": total_ms / 2 / (elapsed / args.steps * 1e3)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "audio samples/sec (rendered output frames of the 32-channel console graph, all GPUs)",
+            "value": world * B * L * args.steps / elapsed,
+            "unit": "audio samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (randn signals, randn*0.1 parameters, random-phase noise IRs)",
+            "config": {"workload": "BASELINE configs[3]: 32-channel mixing console, 111 nodes / 142 edges, "
+                                   "ParametricEqualizer(6) + Compressor(iir) + STFTMaskedNoiseReverb + bus sums",
+                       "batch_per_gpu": B, "global_batch": B * world, "audio_len": L, "channels": 2,
+                       "fsm_fir_len": LENS["fsm_fir_len"], "iir_len": LENS["iir_len"], "ir_len": LENS["ir_len"],
+                       "mode": "forward render, reference-exact lengths (even L+N-1)", "parallelism": f"batch-shard x{world}"},
+            "per_gpu_value": B * L * args.steps / elapsed,
+            "roofline": roof,
+        }
+        # whole-graph view of the same roofline: 285 row transfers per graph
+        graph_bytes = 285 * B * 2 * L * 4
+        out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
+                                 "achieved_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9,
+                                 "frac_of_hbm_peak": graph_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(G, render_data, params_cpu, L)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

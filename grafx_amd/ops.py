@@ -10,6 +10,26 @@ import torch
 from ._lib import RowMap, check, lib
 
 
+# bench.py sets PROFILE = {} to collect (start_event, end_event, algorithmic_bytes) per kernel launch
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.b.record()
+            PROFILE.setdefault(self.name, []).append((self.a, self.b, self.nbytes))
+
+
 def _require_gpu(*tensors):
     for t in tensors:
         if t is None:
@@ -75,10 +95,12 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None):
         raise ValueError(f"output shape {tuple(out.shape)} does not match rows={R}, channels={Cout}, length>={Lout}")
     nbytes = lib().gfx_fftconv_workspace_bytes(R, Cin, L, Lout, off, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    check(
-        lib().gfx_fftconv_f32(_ptr(x), xmap, _ptr(Hs), _ptr(out), ymap, R, Cin, Cf, L, Lout, off, N, _ptr(ws), nbytes, _stream()),
-        "gfx_fftconv_f32",
-    )
+    name = "fftconv1_kernel" if nbytes == 0 else "xspec+macinv_kernels"
+    with _timed(name, 4 * R * (Cin * L + Cout * Lout)):
+        check(
+            lib().gfx_fftconv_f32(_ptr(x), xmap, _ptr(Hs), _ptr(out), ymap, R, Cin, Cf, L, Lout, off, N, _ptr(ws), nbytes, _stream()),
+            "gfx_fftconv_f32",
+        )
     return out
 
 
@@ -146,12 +168,10 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
     if out is None:
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     ymap = rowmap(out)[0]
-    check(
-        lib().gfx_dynamics_fused_f32(
-            _ptr(x), xmap, _ptr(out), ymap, _ptr(_rowvec(log_threshold, R)), _ptr(_rowvec(log_ratio, R)),
-            _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)), R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream()),
-        "gfx_dynamics_fused_f32",
-    )
+    args = (_ptr(x), xmap, _ptr(out), ymap, _ptr(_rowvec(log_threshold, R)), _ptr(_rowvec(log_ratio, R)),
+            _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)), R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
+    with _timed("dyn_fused_kernel", 8 * R * C * L):
+        check(lib().gfx_dynamics_fused_f32(*args), "gfx_dynamics_fused_f32")
     return out
 
 

@@ -1,0 +1,45 @@
+"""Multi-GPU use of the render path: one process per GPU, batch-of-graphs axis sharded.
+
+The forward render needs no collective (graphs in a batch never exchange signals —
+reference src/grafx/data/batch.py:34 builds a disconnected union).  For the training path the
+only exchange is the sum of the (tiny, ~6 KB) shared-parameter gradients: one flat all-reduce
+on RCCL over xGMI ("nccl" backend on ROCm), latency-bound.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(x, rank=None, world_size=None):
+    """Contiguous shard of the leading (batch-of-graphs) axis for this rank."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    B = x.shape[0]
+    per = (B + world_size - 1) // world_size
+    return x[rank * per : min(B, (rank + 1) * per)]
+
+
+def all_reduce_gradients(parameters, average=True):
+    """Sum (or average) the gradients of shared parameters across ranks with ONE flat all-reduce."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    offset = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[offset : offset + n].view_as(g))
+        offset += n
+
+
+def gather_outputs(y, dst=0):
+    """Concatenate per-rank output shards on ``dst`` (None elsewhere)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return y
+    bucket = [torch.empty_like(y) for _ in range(dist.get_world_size())] if dist.get_rank() == dst else None
+    dist.gather(y, bucket, dst=dst)
+    return torch.cat(bucket) if bucket is not None else None

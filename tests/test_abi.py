@@ -1,0 +1,59 @@
+"""The C-ABI library builds, loads and exports exactly what include/grafx_amd.h declares (CPU only:
+no compute call is made here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "grafx_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gfx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_header_symbol():
+    from grafx_amd import _lib
+    from grafx_amd.build import LIB, build
+
+    build()
+    handle = _lib.lib()
+    declared = header_symbols()
+    assert declared, "no symbols parsed from the header"
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/grafx_amd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table and header disagree"
+    exported = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True).stdout
+    assert set(re.findall(r"\b(gfx_[a-z0-9_]+)\b", exported)) >= set(declared)
+
+
+def test_size_queries_need_no_gpu():
+    from grafx_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.gfx_abi_version() == 1
+    assert lib.gfx_fftconv_nparts(4001) == 1 and lib.gfx_fftconv_nparts(8193) == 1
+    assert lib.gfx_fftconv_nparts(8194) == 2 and lib.gfx_fftconv_nparts(60001) == 8
+    assert lib.gfx_fir_spectrum_bytes(3, 4001) == 3 * 17 * 256 * 16
+    assert lib.gfx_fftconv_workspace_bytes(2, 2, 131072, 131072, 0, 4001) == 0
+    assert lib.gfx_fftconv_workspace_bytes(2, 2, 131072, 131072, 0, 60001) == 2 * 2 * (16 + 7) * 8192 * 8
+    assert lib.gfx_iir_fsm_plan_bytes(4001) == 8192 * 8 and lib.gfx_iir_fsm_plan_bytes(5000) == 0
+    assert lib.gfx_istft_basis_bytes(384) == 388 * 384 * 4
+
+
+def test_processors_refuse_cpu_tensors_and_missing_library(monkeypatch):
+    import torch
+
+    import grafx_amd.processors as P
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.StereoGain()(torch.zeros(1, 2, 8), torch.zeros(1, 2))
+    from grafx_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB", "/nonexistent/libgrafx_amd.so")
+    with pytest.raises(ImportError, match="not built"):
+        _lib.lib()
