@@ -71,31 +71,43 @@ def oracle_processors():
     }
 
 
-def cpu_baseline(G, render_data, params_cpu, L, budget_s=20.0):
-    """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample."""
+def cpu_baseline(G, render_data, params_cpu, L, budget_s=25.0):
+    """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample.
+
+    torch's CPU FFT does not scale to every core of a large host (oversubscription makes it slower),
+    so a few thread counts are tried and the best one is reported with the count actually used."""
     from grafx_amd.render import render_grafx
 
     procs = oracle_processors()
-    B = 2
+    B = 8
     x = torch.randn(B, 32, 2, L)
-    torch.set_num_threads(os.cpu_count() or 1)
-    times = []
+    ncpu = os.cpu_count() or 1
+    best, best_threads, runs = None, None, 0
+    t_all = time.perf_counter()
     with torch.no_grad():
-        t_all = time.perf_counter()
-        for i in range(4):
-            t0 = time.perf_counter()
-            render_grafx(procs, x, params_cpu, render_data, parameters_grad=False)
-            times.append(time.perf_counter() - t0)
+        for threads in sorted({min(ncpu, t) for t in (16, 32, 64)}):
+            torch.set_num_threads(threads)
+            for i in range(3):
+                t0 = time.perf_counter()
+                render_grafx(procs, x, params_cpu, render_data, parameters_grad=False)
+                dt = time.perf_counter() - t0
+                runs += 1
+                if i > 0 and (best is None or dt < best):
+                    best, best_threads = dt, threads
+                if time.perf_counter() - t_all > budget_s:
+                    break
             if time.perf_counter() - t_all > budget_s:
                 break
-    best = min(times[1:]) if len(times) > 1 else times[0]
+    if best is None:
+        best, best_threads = dt, threads
     return {
         "value": B * L / best,
         "unit": "audio samples/s",
-        "cores": torch.get_num_threads(),
+        "cores": best_threads,
+        "host_cpus": ncpu,
         "kind": "port",
-        "sample": f"same 111-node console graph and lengths, batch {B} (of 256), L={L}, best of {len(times)} runs "
-                  f"after warm-up, torch CPU oracle",
+        "sample": f"same 111-node console graph and filter lengths, batch {B} (of 256), L={L}; best of {runs} timed "
+                  f"renders over thread counts 16/32/64 (torch CPU oracle, fp32)",
     }
 
 

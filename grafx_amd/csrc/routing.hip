@@ -1,0 +1,64 @@
+// Signal routing for render_grafx: gather rows of the signal buffer and sum them per destination.
+//
+// Replaces, in one pass over HBM, the reference's read -> aggregate -> write chain for `mix`/`out`
+// nodes and for any node with indexed or multiple inputs:
+//   read_single_tensor ("index": index_select)            render/core.py:36-50
+//   aggregate_tensor   ("sum" / "scatter" via PyG scatter) render/core.py:101-112
+//   inplace_write_tensor                                    render/core.py:80-98
+//   out[b, j, c, n] = sum_{e in [seg[j], seg[j+1])} buf[b, src[e], c, n]
+// Edges arrive sorted by (destination, source) (prepare.py:115-119), so every destination's
+// sources are one contiguous run and are added in that order.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/grafx_amd.h"
+
+namespace gfx {
+
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ buf, int64_t buf_sb, int64_t buf_sv,
+                                                         int64_t buf_sc, const int64_t* __restrict__ src,
+                                                         const int64_t* __restrict__ seg, float* __restrict__ out,
+                                                         int64_t out_sb, int64_t out_sv, int64_t out_sc, int C,
+                                                         int64_t L, int vec) {
+    const int j = blockIdx.y / C, c = blockIdx.y % C;
+    const int64_t b = blockIdx.z;
+    const int64_t e0 = seg[j], e1 = seg[j + 1];
+    const float* base = buf + b * buf_sb + (int64_t)c * buf_sc;
+    float* dst = out + b * out_sb + (int64_t)j * out_sv + (int64_t)c * out_sc;
+    if (vec) {
+        const int64_t L4 = L >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L4; i += (int64_t)gridDim.x * blockDim.x) {
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int64_t e = e0; e < e1; ++e) {
+                const float4 v = reinterpret_cast<const float4*>(base + src[e] * buf_sv)[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            reinterpret_cast<float4*>(dst)[i] = acc;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+            float acc = 0.0f;
+            for (int64_t e = e0; e < e1; ++e) acc += base[src[e] * buf_sv + i];
+            dst[i] = acc;
+        }
+    }
+}
+
+}  // namespace gfx
+
+extern "C" int gfx_gather_sum_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t buf_sc, const int64_t* src_idx,
+                                  const int64_t* seg_ptr, float* out, int64_t out_sb, int64_t out_sv, int64_t out_sc,
+                                  int64_t B, int64_t J, int64_t C, int64_t L, void* stream) {
+    if (!buf || !src_idx || !seg_ptr || !out || B <= 0 || J <= 0 || C <= 0 || L <= 0) return GFX_EINVAL;
+    if (B > 65535 || J * C > 65535) return GFX_EINVAL;
+    const bool aligned = (((uintptr_t)buf | (uintptr_t)out) & 15) == 0 && (L % 4 == 0) &&
+                         ((buf_sb | buf_sv | buf_sc | out_sb | out_sv | out_sc) % 4 == 0);
+    const int64_t work = aligned ? L / 4 : L;
+    int64_t bx = (work + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(gfx::gather_sum_kernel, dim3((unsigned)bx, (unsigned)(J * C), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, buf, buf_sb, buf_sv, buf_sc, src_idx, seg_ptr, out, out_sb, out_sv, out_sc,
+                       (int)C, L, aligned ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}

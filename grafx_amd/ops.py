@@ -271,3 +271,20 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
         "gfx_stft_reverb_ir_f32",
     )
     return ir, row_gain
+
+
+# ----------------------------------------------------------------------------------------- routing
+def gather_sum(buf, src_idx, seg_ptr, out):
+    """out[b,j] = sum of buf[b, src_idx[e]] over e in [seg_ptr[j], seg_ptr[j+1]); buf/out are (B,V,C,L) views."""
+    _require_gpu(buf, out)
+    if buf.stride(-1) != 1 or out.stride(-1) != 1:
+        raise ValueError("last dimension must be contiguous")
+    B, _, C, L = buf.shape
+    J = out.shape[1]
+    with _timed("gather_sum_kernel", 4 * B * C * L * (src_idx.numel() + J)):
+        check(
+            lib().gfx_gather_sum_f32(_ptr(buf), buf.stride(0), buf.stride(1), buf.stride(2), _ptr(src_idx), _ptr(seg_ptr),
+                                     _ptr(out), out.stride(0), out.stride(1), out.stride(2), B, J, C, L, _stream()),
+            "gfx_gather_sum_f32",
+        )
+    return out

@@ -53,21 +53,29 @@ def compute_pad_len(x, y, pad_mode="min"):
     return x.shape[-1] + y.shape[-1] - 1
 
 
-def convolve_taps(x, Hs, N, Cf, mode):
-    """convolve() given precomputed tile spectra of the taps."""
+def convolve_taps(x, Hs, N, Cf, mode, out=None):
+    """convolve() given precomputed tile spectra of the taps.
+
+    ``x`` is (R,C,L) or a strided (B,n,C,L) view of the signal buffer; with ``out`` (same kind of
+    view) the kernels write the result in place and ``out`` is returned."""
     L = x.shape[-1]
     if not reference_aliases(L, N):
         if mode == "causal":
-            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0)
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out)
         if mode == "zerophase":
-            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2)
-        return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0)
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2, out=out)
+        return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, out=out)
     y_pad = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0))
     if mode == "causal":
-        return y_pad[..., :L].contiguous()
-    if mode == "zerophase":
-        return y_pad[..., N // 2 : N // 2 + L].contiguous()
-    return y_pad
+        y = y_pad[..., :L]
+    elif mode == "zerophase":
+        y = y_pad[..., N // 2 : N // 2 + L]
+    else:
+        y = y_pad
+    if out is None:
+        return y.contiguous()
+    out.copy_(y.reshape(out.shape))
+    return out
 
 
 def convolve(x, h, mode="zerophase", pad_mode="min"):

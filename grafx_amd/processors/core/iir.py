@@ -44,9 +44,9 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         return ops.iir_fsm_fir(Bs, As, self.fsm_fir_len, self._plan(Bs.device)).view(R, Cf, self.fsm_fir_len)
 
-    def forward(self, input_signal, Bs, As):
+    def forward(self, input_signal, Bs, As, out=None):
         forward_only(input_signal, Bs, As)
         R, Cf = Bs.shape[0], Bs.shape[1]
         N = self.fsm_fir_len
         h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
-        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal")
+        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out)

@@ -3,12 +3,13 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .core._buffer_io import BufferIO
 from .core._grad import forward_only
 from .core.convolution import reference_aliases
 from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
 
 
-class _Dynamics(nn.Module):
+class _Dynamics(BufferIO, nn.Module):
     _gate = False
 
     def __init__(self, energy_smoother="iir", gain_smoother=None, gain_smooth_in_log=False, knee="quadratic",
@@ -34,7 +35,11 @@ class _Dynamics(nn.Module):
         self.knee = knee
         self.gain_smooth_in_log = gain_smooth_in_log
 
-    def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None):
+    def render_into(self, x4, out4, **params):
+        return self.forward(x4, _out=out4, **params)
+
+    def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None,
+                _out=None):
         forward_only(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post)
         L = input_signals.shape[-1]
         if self.knee == "hard":
@@ -45,7 +50,12 @@ class _Dynamics(nn.Module):
         if fusable:  # one pass: energy -> one-pole -> log -> knee -> exp -> multiply
             return ops.dynamics_fused(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                       smoother=int(self.energy_smoother == "iir"), iir_len=self.iir_len,
-                                      knee=self.knee, gate=self._gate)
+                                      knee=self.knee, gate=self._gate, out=_out)
+        if _out is not None:  # unfused configurations: run on flattened rows, then copy into the buffer slice
+            y = self.forward(input_signals.reshape(-1, *input_signals.shape[2:]), log_threshold, log_ratio, log_knee,
+                             z_alpha_pre, z_alpha_post)
+            _out.copy_(y.view(_out.shape))
+            return _out
         energy = ops.energy(input_signals)
         if self.energy_smoother is not None:
             energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)

@@ -2,12 +2,13 @@
 import torch.nn as nn
 
 from .. import ops
+from .core._buffer_io import BufferIO
 from .core._grad import forward_only
 from .core.iir import IIRFilter
 from .core.midside import lr_to_ms, ms_to_lr
 
 
-class ParametricEqualizer(nn.Module):
+class ParametricEqualizer(BufferIO, nn.Module):
     def __init__(self, num_filters=10, processor_channel="mono", use_shelving_filters=True, **backend_kwargs):
         super().__init__()
         self.num_filters = num_filters
@@ -17,12 +18,17 @@ class ParametricEqualizer(nn.Module):
         if processor_channel not in ("mono", "stereo", "midside"):
             raise ValueError(f"Invalid processor_channel: {self.processor_channel}")
 
-    def forward(self, input_signals, w0, q_inv, log_gain):
+    def forward(self, input_signals, w0, q_inv, log_gain, _out=None):
         forward_only(input_signals, w0, q_inv, log_gain)
         Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
-        return self.biquad(input_signals, Bs, As)
+        return self.biquad(input_signals, Bs, As, out=_out)
+
+    def render_into(self, x4, out4, **params):
+        if self.processor_channel == "midside":
+            return super().render_into(x4, out4, **params)
+        return self.forward(x4, _out=out4, **params)
 
     def parameter_size(self):
         n_channels = 1 if self.processor_channel == "mono" else 2

@@ -2,21 +2,25 @@
 import torch.nn as nn
 
 from .. import ops
+from .core._buffer_io import BufferIO
 from .core._grad import forward_only
 from .core.iir import IIRFilter
 
 
-class BiquadFilter(nn.Module):
+class BiquadFilter(BufferIO, nn.Module):
     def __init__(self, num_filters=1, normalized=False, **backend_kwargs):
         super().__init__()
         self.num_filters = num_filters
         self.normalized = normalized
         self.biquad = IIRFilter(order=2, **backend_kwargs)
 
-    def forward(self, input_signals, Bs, A1_pre, A2_pre, A0=None):
+    def forward(self, input_signals, Bs, A1_pre, A2_pre, A0=None, _out=None):
         forward_only(input_signals, Bs, A1_pre, A2_pre, A0)
         Bs, As = ops.biquad_coeffs(Bs, A1_pre, A2_pre, A0 if self.normalized else None)
-        return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1))
+        return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1), out=_out)
+
+    def render_into(self, x4, out4, **params):
+        return self.forward(x4, _out=out4, **params)
 
     def parameter_size(self):
         size = {"Bs": (self.num_filters, 3), "A1_pre": self.num_filters, "A2_pre": self.num_filters}

@@ -4,12 +4,13 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .core._buffer_io import BufferIO
 from .core._grad import forward_only
 from .core.convolution import convolve_taps
 from .core.midside import lr_to_ms, ms_to_lr
 
 
-class STFTMaskedNoiseReverb(nn.Module):
+class STFTMaskedNoiseReverb(BufferIO, nn.Module):
     def __init__(self, ir_len=60000, processor_channel="pseudo_midside", n_fft=384, hop_length=192,
                  fixed_noise=True, gain_envelope=False, flashfftconv=True, max_input_len=2**17):
         super().__init__()
@@ -53,7 +54,12 @@ class STFTMaskedNoiseReverb(nn.Module):
         forward_only(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         return self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, False)[0]
 
-    def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
+    def render_into(self, x4, out4, **params):
+        if self.processor_channel == "midside":
+            return super().render_into(x4, out4, **params)
+        return self.forward(x4, _out=out4, **params)
+
+    def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _out=None):
         forward_only(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         pseudo = self.processor_channel == "pseudo_midside"
         ir, gain = self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, pseudo)
@@ -62,7 +68,7 @@ class STFTMaskedNoiseReverb(nn.Module):
         Hs = ops.fir_spectrum(ir.view(R * 2, self.ir_len), gain=gain, gain_div=2)
         if self.processor_channel == "midside":  # reverb.py:219-223
             return ms_to_lr(convolve_taps(lr_to_ms(input_signals), Hs, self.ir_len, 2, "causal"))
-        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal")
+        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal", out=_out)
 
     def parameter_size(self):
         size = {"init_log_magnitude": (2, self.num_bins), "delta_log_magnitude": (2, self.num_bins)}

@@ -21,6 +21,112 @@ from .core import (
 )
 
 
+def _gather_plan(step, device):
+    """(src_idx, seg_ptr, n_out) for gfx_gather_sum_f32, or None when the step is a plain slice read.
+
+    Built once per (step, device) from the reference's own descriptors: ``source_reads[0]`` says which
+    buffer rows feed the step, ``aggregations[0]`` how they collapse onto its nodes."""
+    cache = step.__dict__.setdefault("_plans", {})
+    key = (device.type, device.index)
+    if key in cache:
+        return cache[key]
+    read, agg = step.source_reads[0], step.aggregations[0]
+    plan = None
+    if read.method == "slice" and agg.method == "none":
+        cache[key] = None
+        return None
+    if read.method == "slice":
+        sources = list(range(read.idx[0], read.idx[1]))
+    else:
+        sources = read.idx.tolist()
+    E = len(sources)
+    if agg.method == "none":
+        seg = list(range(E + 1))
+    elif agg.method == "sum":
+        seg = [0, E]
+    else:
+        slots = agg.idx.tolist()
+        if any(b < a for a, b in zip(slots, slots[1:])):
+            cache[key] = False  # unsorted scatter: leave it to the generic path
+            return False
+        n_out = max(slots) + 1
+        seg = [0] * (n_out + 1)
+        for j in slots:
+            seg[j + 1] += 1
+        for j in range(n_out):
+            seg[j + 1] += seg[j]
+    plan = (torch.tensor(sources, dtype=torch.long, device=device), torch.tensor(seg, dtype=torch.long, device=device),
+            len(seg) - 1)
+    cache[key] = plan
+    return plan
+
+
+def _buffer_io_ok(processors, input_signals, render_data):
+    if not input_signals.is_cuda or render_data.method == "one-by-one" or not render_data.siso_only:
+        return False
+    if torch.is_grad_enabled() and input_signals.requires_grad:
+        return False
+    for step in render_data.iter_list[1:]:
+        if step.node_type in processors:
+            if not hasattr(processors[step.node_type], "render_into"):
+                return False
+        elif step.node_type not in UTILITY_TYPES:
+            return False
+        if step.dest_write.method != "slice" or len(step.source_reads) != 1 or step.source_reads[0].method == "none":
+            return False
+        if _gather_plan(step, input_signals.device) is False:
+            return False
+    return True
+
+
+def _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters):
+    """render_grafx for HIP processors: every stage reads and writes the (B, V, C, L) signal buffer in place
+    (no clone / index_select / reshape copies), routing sums run as one gather-sum kernel."""
+    from .. import ops
+
+    squeeze = input_signals.ndim == 3
+    x = input_signals.unsqueeze(0) if squeeze else input_signals
+    B, n_src, C, L = x.shape
+    if not squeeze:
+        per_type_parameters = expand_tensor_or_tensor_dict(per_type_parameters, expand=B, dim=0)
+        if common_parameters is not None:
+            common_parameters = expand_tensor_or_tensor_dict(common_parameters, expand=B, dim=0)
+    node_dim = 0 if squeeze else 1
+    postprocess = None if squeeze else flatten_batch_and_node
+
+    buf = torch.empty(B, render_data.num_nodes, C, L, device=x.device)
+    buf[:, :n_src] = x
+    out_view = None
+    for i in range(1, render_data.max_order + 1):
+        step = render_data.iter_list[i]
+        d0, d1 = step.dest_write.idx
+        out_view = buf.narrow(1, d0, d1 - d0)
+        plan = _gather_plan(step, x.device)
+        node_type = step.node_type
+        if node_type not in processors:  # in / out / mix: the (summed) input is the output
+            if plan is None:
+                a, b = step.source_reads[0].idx
+                out_view.copy_(buf.narrow(1, a, b - a))
+            else:
+                ops.gather_sum(buf, plan[0], plan[1], out_view)
+            continue
+        if plan is None:
+            a, b = step.source_reads[0].idx
+            x_view = buf.narrow(1, a, b - a)
+        else:
+            x_view = ops.gather_sum(buf, plan[0], plan[1], torch.empty(B, plan[2], C, L, device=x.device))
+        params = read_tensor_or_tensor_dict(per_type_parameters[node_type], step.parameter_read, dim=node_dim,
+                                            postprocess=postprocess)
+        common_i = {}
+        if common_parameters is not None:
+            common_i = read_tensor_or_tensor_dict(common_parameters, step.dest_write, dim=node_dim,
+                                                  postprocess=postprocess)
+        processors[node_type].render_into(x_view, out_view, **params, **common_i)
+    if squeeze:
+        return out_view[0], [], buf[0]
+    return out_view, [], buf
+
+
 def render_grafx(
     processors,
     input_signals,
@@ -32,6 +138,8 @@ def render_grafx(
 ):
     method = render_data.method
     ndim = input_signals.ndim
+    if ndim in (3, 4) and _buffer_io_ok(processors, input_signals, render_data):
+        return _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters)
     if ndim == 3:
         node_dim, postprocess = 0, None
     elif ndim == 4:

@@ -148,6 +148,18 @@ int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnit
                            int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
                            int ms_to_lr, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- routing ----------------------------------------------------------------------------
+ * replaces read_single_tensor("index") + aggregate_tensor("sum"/"scatter") + inplace_write_tensor
+ * (reference src/grafx/render/core.py:36-50, 101-112, 80-98) for the (B, V, C, L) signal buffer:
+ *   out[b, j, c, n] = sum_{e in [seg_ptr[j], seg_ptr[j+1])} buf[b, src_idx[e], c, n]
+ * buf/out are addressed by (batch, node, channel) strides in floats; src_idx (E) and
+ * seg_ptr (J+1) are int64 device arrays (edges sorted by destination).
+ */
+int gfx_gather_sum_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t buf_sc,
+                       const int64_t* src_idx, const int64_t* seg_ptr,
+                       float* out, int64_t out_sb, int64_t out_sv, int64_t out_sc,
+                       int64_t B, int64_t J, int64_t C, int64_t L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
