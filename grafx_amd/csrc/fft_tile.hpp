@@ -115,17 +115,25 @@ __device__ __forceinline__ float2 unit_root(int num, float inv_half_den) {
     return make_float2(c, -s);
 }
 
-__device__ __forceinline__ void tile_twiddles(TileTw& tw, int t) {
+// Twiddle table: TW_ROWS x 256 float2, row-major [row][t]; rows 0-3 lo1, 4-11 hi1, 12-15 lo2, 16-19 hi2.
+// Filled once per device by tile_twiddle_table_kernel in common.hip (double precision, rounded once); every tile
+// then fetches its 20 values with coalesced 8-byte loads instead of 20 sincos evaluations.
+constexpr int TW_ROWS = 20;
+
+__device__ __forceinline__ void tile_twiddles(TileTw& tw, const float2* __restrict__ table, int t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tw.lo1[i] = unit_root(t * i, 1.0f / 4096.0f);
+    for (int i = 0; i < 4; ++i) tw.lo1[i] = table[i * TILE_T + t];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tw.hi1[i] = unit_root(t * 4 * i, 1.0f / 4096.0f);
-    const int d = t & 15;
+    for (int i = 0; i < 8; ++i) tw.hi1[i] = table[(4 + i) * TILE_T + t];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tw.lo2[i] = unit_root(d * i, 1.0f / 128.0f);
+    for (int i = 0; i < 4; ++i) tw.lo2[i] = table[(12 + i) * TILE_T + t];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tw.hi2[i] = unit_root(d * 4 * i, 1.0f / 128.0f);
+    for (int i = 0; i < 4; ++i) tw.hi2[i] = table[(16 + i) * TILE_T + t];
 }
+
+// Host side: one table per device, created on first use (the only allocation the library makes;
+// 40 KB, lives for the process).  Returns nullptr on failure.
+const float2* tile_twiddle_table(hipStream_t stream);
 
 __device__ __forceinline__ int s1_at(int k1, int b) { return k1 * S1_ROW + b; }
 __device__ __forceinline__ int s2_row(int k2, int k1) { return (k2 * 32 + k1) * S2_ROW; }

@@ -109,7 +109,8 @@ __device__ __forceinline__ void store_valid(const float2 (&v)[32], float* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restrict__ h, const float* __restrict__ gain,
                                                           int64_t gain_div, float4* __restrict__ Hs, int64_t N,
-                                                          int nparts, int64_t part_len) {
+                                                          int nparts, int64_t part_len,
+                                                          const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int64_t b = blockIdx.x;
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
     const float g = gain ? gain[rc / gain_div] : 1.0f;
 
     TileTw tw;
-    tile_twiddles(tw, t);
     float2 v[32], w[2][16];
     load_window(v, h + rc * N + start, 0, len, t, g);
+    tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
 
     float4* out = Hs + b * H_TILE_F4;
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
-                                                             float* __restrict__ y, ConvArgs a) {
+                                                             float* __restrict__ y, ConvArgs a,
+                                                             const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int64_t lb = xcd_logical_block();
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     const float4* H = Hs + (r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4;
 
     TileTw tw;
-    tile_twiddles(tw, t);
     float2 v[32], w[2][16];
     load_window(v, xrow, a.off + tile * a.V - a.O, a.L, t, 1.0f);
+    tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
 
     for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, float2 wk, bool self) {
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
 __device__ __forceinline__ bool window_live(int64_t s, int64_t L) { return s + TILE_F > 0 && s < L; }
 
 __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restrict__ x, float2* __restrict__ Zs,
-                                                          ConvArgs a, int64_t nwin) {
+                                                          ConvArgs a, int64_t nwin,
+                                                          const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int64_t lb = xcd_logical_block();
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
     if (!window_live(s, a.L)) return;
     const float* xrow = x + row_off(a.xmap, rcx / a.Cin, (int)(rcx % a.Cin));
     TileTw tw;
-    tile_twiddles(tw, t);
     float2 v[32], w[2][16];
     load_window(v, xrow, s, a.L, t, 1.0f);
+    tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
     float2* out = Zs + lb * TILE_M;
 #pragma unroll
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restrict__ Zs, const float4* __restrict__ Hs,
-                                                           float* __restrict__ y, ConvArgs a, int64_t nwin) {
+                                                           float* __restrict__ y, ConvArgs a, int64_t nwin,
+                                                           const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int64_t lb = xcd_logical_block();
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     float2 ye[H_SLOTS], yo[H_SLOTS];
 #pragma unroll
     for (int s = 0; s < H_SLOTS; ++s) ye[s] = yo[s] = make_float2(0.0f, 0.0f);
-    const float2 wj = unit_root(t, 1.0f / 4096.0f);
+    const float2 wj = twtab[TILE_T + t];  // W_8192^t
 
     for (int p = 0; p < a.nparts; ++p) {
         const int64_t j = tile - p;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
         if (!self) NAT(pz, ib) = zb;
     });
     TileTw tw;
-    tile_twiddles(tw, t);
+    tile_twiddles(tw, twtab, t);
     tile_inverse(pz, v, tw, lds, t);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
 }
@@ -277,8 +281,10 @@ int gfx_fir_spectrum_f32(const float* h, const float* gain, int64_t gain_div, vo
     const ConvGeom g = conv_geom(N, 1);
     if (RCf * g.nparts > 0x7fffffffLL) return GFX_EINVAL;
     if (allow_lds(hspec_kernel)) return GFX_ELAUNCH;
+    const float2* tw = tile_twiddle_table((hipStream_t)stream);
+    if (!tw) return GFX_ELAUNCH;
     hipLaunchKernelGGL(hspec_kernel, dim3((unsigned)(RCf * g.nparts)), dim3(TILE_T), TILE_LDS_BYTES,
-                       (hipStream_t)stream, h, gain, gain_div, (float4*)Hs, N, (int)g.nparts, g.part_len);
+                       (hipStream_t)stream, h, gain, gain_div, (float4*)Hs, N, (int)g.nparts, g.part_len, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
@@ -305,11 +311,13 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
     a.nblocks = R * a.Cout * g.ntiles;
     if (a.nblocks > 0x7ffffff0LL) return GFX_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const float2* tw = tile_twiddle_table(st);
+    if (!tw) return GFX_ELAUNCH;
 
     if (g.nparts == 1) {
         if (allow_lds(fftconv1_kernel)) return GFX_ELAUNCH;
         hipLaunchKernelGGL(fftconv1_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
-                           (const float4*)Hs, y, a);
+                           (const float4*)Hs, y, a, tw);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     const int64_t nwin = g.ntiles + g.nparts - 1;
@@ -320,9 +328,9 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
     ax.nblocks = R * C_in * nwin;
     if (ax.nblocks > 0x7ffffff0LL) return GFX_EINVAL;
     hipLaunchKernelGGL(xspec_kernel, dim3(pad8(ax.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, (float2*)ws, ax,
-                       nwin);
+                       nwin, tw);
     hipLaunchKernelGGL(macinv_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, (const float2*)ws,
-                       (const float4*)Hs, y, a, nwin);
+                       (const float4*)Hs, y, a, nwin, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

@@ -29,11 +29,12 @@ __device__ __forceinline__ float2 chirp(int k, int N, float sign) {
     return make_float2(c, sign * s);
 }
 
-__global__ __launch_bounds__(TILE_T, 2) void bluestein_plan_kernel(float2* __restrict__ plan, int N) {
+__global__ __launch_bounds__(TILE_T, 2) void bluestein_plan_kernel(float2* __restrict__ plan, int N,
+                                                                   const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     TileTw tw;
-    tile_twiddles(tw, t);
+    tile_twiddles(tw, twtab, t);
     float2 v[32], w[2][16];
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
@@ -78,7 +79,7 @@ __device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, 
 
 __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
                                                             const float2* __restrict__ plan, float* __restrict__ h,
-                                                            int K, int N) {
+                                                            int K, int N, const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int64_t rc = blockIdx.x;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
     const bool even = (N & 1) == 0;
 
     TileTw tw;
-    tile_twiddles(tw, t);
+    tile_twiddles(tw, twtab, t);
     float2 v[32], w[2][16];
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
@@ -203,8 +204,10 @@ size_t gfx_iir_fsm_plan_bytes(int64_t N) { return (N < 1 || N > FSM_MAX_N) ? 0 :
 int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream) {
     if (!plan || N < 1 || N > FSM_MAX_N) return GFX_EINVAL;
     if (allow_lds(bluestein_plan_kernel)) return GFX_ELAUNCH;
+    const float2* tw = tile_twiddle_table((hipStream_t)stream);
+    if (!tw) return GFX_ELAUNCH;
     hipLaunchKernelGGL(bluestein_plan_kernel, dim3(1), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream,
-                       (float2*)plan, (int)N);
+                       (float2*)plan, (int)N, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
@@ -213,8 +216,10 @@ int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, floa
     if (!Bs || !As || !plan || !h || RC <= 0 || K <= 0 || N < 1 || N > FSM_MAX_N || RC > 0x7fffffffLL)
         return GFX_EINVAL;
     if (allow_lds(iir_fsm_kernel)) return GFX_ELAUNCH;
+    const float2* tw = tile_twiddle_table((hipStream_t)stream);
+    if (!tw) return GFX_ELAUNCH;
     hipLaunchKernelGGL(iir_fsm_kernel, dim3((unsigned)RC), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream, Bs, As,
-                       (const float2*)plan, h, (int)K, (int)N);
+                       (const float2*)plan, h, (int)K, (int)N, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

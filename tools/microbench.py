@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-processor micro-benchmarks at headline shapes (run on the GPU box).
+
+    python tools/microbench.py [eq|comp|reverb|mix|all] [--rows 2048] [--length 131072] [--iters 5]
+Prints achieved algorithmic GB/s (4*(C_in+C_out)*R*L bytes per call) per processor call.
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--rows", type=int, default=2048)
+    ap.add_argument("--length", type=int, default=131072)
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    import grafx_amd.processors as P
+    from grafx_amd import ops
+
+    R, L = a.rows, a.length
+    dev = "cuda"
+    torch.manual_seed(0)
+    x = torch.randn(R, 2, L, device=dev)
+    y = torch.empty_like(x)
+    gb = 16 * R * L / 1e9
+    with torch.no_grad():
+        if a.what in ("eq", "all"):
+            eq = P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=4001).to(dev)
+            p = {k: 0.1 * torch.randn(R, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
+            ms = timeit(lambda: eq.render_into(x.view(1, R, 2, L), y.view(1, R, 2, L), **p), a.iters)
+            print(f"eq      R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            Bs, As = ops.peq_coeffs(p["w0"], p["q_inv"], p["log_gain"])
+            h = ops.iir_fsm_fir(Bs, As, 4001, eq.biquad._plan(x.device))
+            Hs = ops.fir_spectrum(h)
+            ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y), a.iters)
+            print(f"  fftconv1 only       {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            ms = timeit(lambda: ops.iir_fsm_fir(Bs, As, 4001, eq.biquad._plan(x.device)), a.iters)
+            print(f"  iir_fsm only        {ms:8.3f} ms")
+            ms = timeit(lambda: ops.fir_spectrum(h), a.iters)
+            print(f"  hspec only          {ms:8.3f} ms")
+        if a.what in ("comp", "all"):
+            cp = P.Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).to(dev)
+            p = {k: 0.1 * torch.randn(R, 1, device=dev) for k in cp.parameter_size()}
+            ms = timeit(lambda: cp.render_into(x.view(1, R, 2, L), y.view(1, R, 2, L), **p), a.iters)
+            print(f"comp    R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+        if a.what in ("reverb", "all"):
+            Rr = max(R // 8, 1)
+            rv = P.STFTMaskedNoiseReverb(ir_len=60001, flashfftconv=False).to(dev)
+            p = {k: 0.1 * torch.randn(Rr, 2, 193, device=dev) for k in rv.parameter_size()}
+            xr, yr = x[:Rr], y[:Rr]
+            ms = timeit(lambda: rv.render_into(xr.view(1, Rr, 2, L), yr.view(1, Rr, 2, L), **p), a.iters)
+            print(f"reverb  R={Rr} {ms:8.3f} ms  {16 * Rr * L / 1e9 / ms * 1e3:8.1f} GB/s")
+            ms = timeit(lambda: rv._ir_and_gain(p["init_log_magnitude"], p["delta_log_magnitude"], None, True), a.iters)
+            print(f"  ir synthesis        {ms:8.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
