@@ -23,7 +23,9 @@ constexpr int DE = 4;              // samples per thread per tile
 constexpr int DTILE = DT * DE;     // 1024 samples per tile
 
 __device__ __forceinline__ int64_t drow_off(const gfx_rowmap_t& m, int64_t r, int c) {
-    return (r / m.inner) * m.stride_outer + (r % m.inner) * m.stride_inner + (int64_t)c * m.stride_ch;
+    const unsigned inner = (unsigned)m.inner, rr = (unsigned)r;  // both fit 32 bits (launchers check)
+    const unsigned q = rr / inner, rem = rr - q * inner;
+    return (int64_t)q * m.stride_outer + (int64_t)rem * m.stride_inner + (int64_t)c * m.stride_ch;
 }
 
 __device__ __forceinline__ float sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }

@@ -50,15 +50,19 @@ struct ConvArgs {
     int Cin, Cf, Cout;
 };
 
-__device__ __forceinline__ int64_t row_off(const gfx_rowmap_t& m, int64_t r, int c) {
-    return (r / m.inner) * m.stride_outer + (r % m.inner) * m.stride_inner + (int64_t)c * m.stride_ch;
+// rows and row counts fit 32 bits (checked by the launchers): 32-bit division is ~5x cheaper than
+// the 64-bit software divide and stays on the scalar unit.
+__device__ __forceinline__ int64_t row_off(const gfx_rowmap_t& m, unsigned r, int c) {
+    const unsigned inner = (unsigned)m.inner;
+    const unsigned q = r / inner, rem = r - q * inner;
+    return (int64_t)q * m.stride_outer + (int64_t)rem * m.stride_inner + (int64_t)c * m.stride_ch;
 }
 
 // workgroup b runs on XCD b % 8 (observed): give each XCD a contiguous run of logical
 // indices so tiles of one row-channel (which share the filter spectrum) meet in one L2.
-__device__ __forceinline__ int64_t xcd_logical_block() {
-    const int64_t per_xcd = gridDim.x >> 3;
-    return (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+__device__ __forceinline__ unsigned xcd_logical_block() {
+    const unsigned per_xcd = gridDim.x >> 3;
+    return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 }
 
 // v[a] = (x[s + 2m], x[s + 2m + 1]), m = t + 256 a; x is zero outside [0, L)
@@ -113,20 +117,20 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
                                                           const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    const int64_t rc = b / nparts;
-    const int p = (int)(b % nparts);
+    const unsigned b = blockIdx.x;
+    const unsigned rc = b / (unsigned)nparts;
+    const int p = (int)(b - rc * (unsigned)nparts);
     const int64_t start = (int64_t)p * part_len;
     const int64_t len = min(part_len, N - start);
-    const float g = gain ? gain[rc / gain_div] : 1.0f;
+    const float g = gain ? gain[rc / (unsigned)gain_div] : 1.0f;
 
     TileTw tw;
     float2 v[32], w[2][16];
-    load_window(v, h + rc * N + start, 0, len, t, g);
+    load_window(v, h + (int64_t)rc * N + start, 0, len, t, g);
     tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
 
-    float4* out = Hs + b * H_TILE_F4;
+    float4* out = Hs + (int64_t)b * H_TILE_F4;
     const float sc = 1.0f / (4.0f * TILE_M);
     for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, float2, bool) {
         const float2 A = NAT(w, ia), B = cconj(NAT(w, ib));
@@ -141,14 +145,16 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
                                                              const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
-    const int64_t lb = xcd_logical_block();
-    if (lb >= a.nblocks) return;
-    const int64_t rco = lb / a.ntiles, tile = lb % a.ntiles;
-    const int64_t r = rco / a.Cout;
-    const int c = (int)(rco % a.Cout);
+    const unsigned lb = xcd_logical_block();
+    if (lb >= (unsigned)a.nblocks) return;
+    const unsigned ntiles = (unsigned)a.ntiles;
+    const unsigned rco = lb / ntiles;
+    const int64_t tile = lb - rco * ntiles;
+    const unsigned r = rco / (unsigned)a.Cout;
+    const int c = (int)(rco - r * (unsigned)a.Cout);
     const float* xrow = x + row_off(a.xmap, r, a.Cin == 1 ? 0 : c);
     float* yrow = y + row_off(a.ymap, r, c);
-    const float4* H = Hs + (r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4;
+    const float4* H = Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4;
 
     TileTw tw;
     float2 v[32], w[2][16];
@@ -178,18 +184,20 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
                                                           const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
-    const int64_t lb = xcd_logical_block();
-    if (lb >= a.nblocks) return;
-    const int64_t rcx = lb / nwin, jj = lb % nwin;
+    const unsigned lb = xcd_logical_block();
+    if (lb >= (unsigned)a.nblocks) return;
+    const unsigned rcx = lb / (unsigned)nwin;
+    const int64_t jj = lb - rcx * (unsigned)nwin;
     const int64_t s = a.off - a.O + (jj - (a.nparts - 1)) * a.V;
     if (!window_live(s, a.L)) return;
-    const float* xrow = x + row_off(a.xmap, rcx / a.Cin, (int)(rcx % a.Cin));
+    const unsigned xr = rcx / (unsigned)a.Cin;
+    const float* xrow = x + row_off(a.xmap, xr, (int)(rcx - xr * (unsigned)a.Cin));
     TileTw tw;
     float2 v[32], w[2][16];
     load_window(v, xrow, s, a.L, t, 1.0f);
     tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
-    float2* out = Zs + lb * TILE_M;
+    float2* out = Zs + (int64_t)lb * TILE_M;
 #pragma unroll
     for (int q = 0; q < 32; ++q) out[q * TILE_T + t] = w[q >> 4][q & 15];
 }
@@ -199,14 +207,16 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
                                                            const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
-    const int64_t lb = xcd_logical_block();
-    if (lb >= a.nblocks) return;
-    const int64_t rco = lb / a.ntiles, tile = lb % a.ntiles;
-    const int64_t r = rco / a.Cout;
-    const int c = (int)(rco % a.Cout);
+    const unsigned lb = xcd_logical_block();
+    if (lb >= (unsigned)a.nblocks) return;
+    const unsigned ntiles = (unsigned)a.ntiles;
+    const unsigned rco = lb / ntiles;
+    const int64_t tile = lb - rco * ntiles;
+    const unsigned r = rco / (unsigned)a.Cout;
+    const int c = (int)(rco - r * (unsigned)a.Cout);
     float* yrow = y + row_off(a.ymap, r, c);
-    const float4* H = Hs + (r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
-    const float2* Z = Zs + (r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
+    const float4* H = Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
+    const float2* Z = Zs + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
 
     float2 ye[H_SLOTS], yo[H_SLOTS];
 #pragma unroll
@@ -293,7 +303,7 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
                     size_t ws_bytes, void* stream) {
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (C_in < 1 || C_f < 1 || (C_in != C_f && C_in != 1 && C_f != 1)) return GFX_EINVAL;
-    if (xmap.inner <= 0 || ymap.inner <= 0) return GFX_EINVAL;
+    if (xmap.inner <= 0 || ymap.inner <= 0 || xmap.inner > 0x7fffffffLL || ymap.inner > 0x7fffffffLL) return GFX_EINVAL;
     const ConvGeom g = conv_geom(N, Lout);
     ConvArgs a;
     a.xmap = xmap;
