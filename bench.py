@@ -197,8 +197,19 @@ def main():
         name = max(stats, key=lambda k: stats[k][0])
         total_ms, avg_ms, avg_bytes, n = stats[name]
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic.json")
+        if os.path.exists(pmc):  # PMC bytes come from a separate rocprofv3 --pmc pass of this same command
+            with open(pmc) as f:
+                rec = json.load(f)
+            cfg = rec.get("config", {})
+            if cfg.get("batch") == B and cfg.get("audio_len") == L and all(cfg.get(k) == v for k, v in LENS.items()):
+                k = rec["kernels"].get("gfx::" + name)
+                if k:
+                    traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r1/pmc_hbm_traffic.json"
         roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": avg_bytes, "launches_per_step": n // 2,
                 "share_of_step": total_ms / 2 / (elapsed / args.steps * 1e3)}
 
