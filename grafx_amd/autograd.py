@@ -1,0 +1,190 @@
+"""Differentiable path of the HIP processors (used only when a gradient is requested).
+
+Inference (``torch.no_grad()`` or nothing requires grad) runs the fused HIP kernels. When autograd
+needs a graph, every processor is expressed as
+
+    parameters --(small torch ops on the GPU: activations, RBJ formulas, sampled response,
+                  irfft / istft of tiny tensors)--> FIR taps h --LinearConvFn--> signal
+
+where :class:`LinearConvFn` is the native overlap-save convolution with a **native backward**:
+
+    y[n]      = sum_k h[k] x[n + off - k]                                  gfx_fftconv_f32
+    grad_x[m] = sum_k h[k] g[m - off + k]  = linconv(g, flip(h))[m + N-1-off]   (same kernel)
+    grad_h[k] = sum_n g[n] x[n + off - k]  = linconv(g, flip(x))[k + L-1-off]   (same kernel,
+                                              the reversed signal is the partitioned "filter")
+
+so the heavy O(R*L) work of both passes stays in the HIP kernels; only the light front-end math
+(R x K x N/2 complex, R x 193 x 313, elementwise gain curves) is left to torch's autograd.
+The formulas mirror the reference (file:line cited per function, relative to
+/root/reference/src/grafx/processors).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+class LinearConvFn(torch.autograd.Function):
+    """y[r,c,n] = sum_k h[r,cf,k] x[r,cx,n+off-k], n in [0,Lout); channels broadcast 1<->2."""
+
+    @staticmethod
+    def forward(ctx, x, h, Lout, off):
+        x, h = x.contiguous(), h.contiguous()
+        R, Cf, N = h.shape
+        ctx.save_for_backward(x, h)
+        ctx.off = off
+        return ops.fftconv(x, ops.fir_spectrum(h.reshape(R * Cf, N)), N, Cf, Lout=Lout, off=off)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h = ctx.saved_tensors
+        off = ctx.off
+        g = g.contiguous()
+        R, Cin, L = x.shape
+        _, Cf, N = h.shape
+        gx = gh = None
+        if ctx.needs_input_grad[0]:
+            hr = h.flip(-1).contiguous()
+            gx = ops.fftconv(g, ops.fir_spectrum(hr.reshape(R * Cf, N)), N, Cf, Lout=L, off=N - 1 - off)
+            if gx.shape[1] != Cin:  # x was broadcast over the output channels
+                gx = gx.sum(1, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            xr = x.flip(-1).contiguous()
+            gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L)), L, Cin, Lout=N, off=L - 1 - off)
+            if gh.shape[1] != Cf:  # one filter shared by both channels
+                gh = gh.sum(1, keepdim=True)
+        return gx, gh, None, None
+
+
+def convolve(x, h, mode="causal"):
+    """Differentiable twin of processors.core.convolution.convolve (reference core/convolution.py:119-134),
+    including the odd-P aliasing (which is plain torch.fft and differentiates itself)."""
+    from .processors.core.convolution import reference_aliases
+
+    flat = x.ndim == 2
+    if flat:
+        x, h = x.unsqueeze(1), h.unsqueeze(1)
+    L, N = x.shape[-1], h.shape[-1]
+    if not reference_aliases(L, N):
+        if mode == "causal":
+            y = LinearConvFn.apply(x, h, L, 0)
+        elif mode == "zerophase":
+            y = LinearConvFn.apply(x, h, L, N // 2)
+        else:
+            y = LinearConvFn.apply(x, h, L + N - 1, 0)
+    else:
+        y_pad = torch.fft.irfft(torch.fft.rfft(LinearConvFn.apply(x, h, L + N - 1, 0)))
+        if mode == "causal":
+            y = y_pad[..., :L]
+        elif mode == "zerophase":
+            y = y_pad[..., N // 2 : N // 2 + L]
+        else:
+            y = y_pad
+    return y.squeeze(1) if flat else y
+
+
+# ----------------------------------------------------------------------------------------- front-ends
+def fsm_fir(Bs, As, fir_len):
+    """core/iir.py:147-150, 263-276: sampled cascade response -> irfft(n=N)."""
+    d = torch.arange(Bs.shape[-1], device=Bs.device)
+    k = torch.arange(fir_len // 2 + 1, device=Bs.device)
+    phase = (d[:, None] * k[None, :]).to(Bs.dtype) / fir_len * 2 * math.pi
+    delays = torch.exp(-1j * phase)
+    resp = ((Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)).prod(-2)
+    return torch.fft.irfft(resp, dim=-1, n=fir_len)
+
+
+def peq_coefficients(w0, q_inv, log_gain, use_shelving_filters=True):
+    """eq.py:291-314 + filter.py:593-604, 645-656, 687-705, 736-754."""
+    w = math.pi * torch.sigmoid(w0)
+    A = torch.exp(log_gain)
+    cw = torch.cos(w)
+    alpha = torch.sin(w) * torch.exp(q_inv) * 0.5
+
+    def peaking(cw, al, A):
+        return (torch.stack([1 + al * A, -2 * cw, 1 - al * A], -1), torch.stack([1 + al / A, -2 * cw, 1 - al / A], -1))
+
+    def shelf(cw, al, A, sg):
+        ap1, am1 = A + 1, A - 1
+        s = 2 * A.sqrt() * al
+        b = torch.stack([A * (ap1 - sg * am1 * cw + s), sg * 2 * A * (am1 - sg * ap1 * cw), A * (ap1 - sg * am1 * cw - s)], -1)
+        a = torch.stack([ap1 + sg * am1 * cw + s, -sg * 2 * (am1 + sg * ap1 * cw), ap1 + sg * am1 * cw - s], -1)
+        return b, a
+
+    if not use_shelving_filters:
+        return peaking(cw, alpha, A)
+    K = w0.shape[-1]
+    parts = [shelf(cw[..., :1], alpha[..., :1], A[..., :1], 1.0),
+             peaking(cw[..., 1 : K - 1], alpha[..., 1 : K - 1], A[..., 1 : K - 1]),
+             shelf(cw[..., K - 1 :], alpha[..., K - 1 :], A[..., K - 1 :], -1.0)]
+    return torch.cat([p[0] for p in parts], -2), torch.cat([p[1] for p in parts], -2)
+
+
+def biquad_coefficients(Bs, A1_pre, A2_pre, A0=None):
+    """filter.py:144-153."""
+    a1 = 2 * torch.tanh(A1_pre)
+    a2 = ((2 - a1.abs()) * torch.tanh(A2_pre) + a1.abs()) / 2
+    As = torch.stack([torch.ones_like(a1), a1, a2], -1)
+    if A0 is not None:
+        As = As * A0.unsqueeze(-1)
+    Bs = torch.cat([Bs[..., :1] + 1, Bs[..., 1:]], -1)
+    return Bs.unsqueeze(1), As.unsqueeze(1)
+
+
+def one_pole_fir(z_alpha, iir_len):
+    """core/envelope.py:51-60."""
+    alpha = torch.sigmoid(z_alpha).clamp(max=1 - 1e-5)
+    n = torch.arange(iir_len, device=z_alpha.device)[None, :]
+    return (1 - alpha) * torch.exp(n * torch.log(alpha))
+
+
+def truncated_one_pole(u, z_alpha, iir_len):
+    """core/envelope.py:34-49."""
+    return torch.relu(convolve(u, one_pole_fir(z_alpha, iir_len), "causal"))
+
+
+class BallisticsFn(torch.autograd.Function):
+    """Native forward (gfx_ballistics_f32); the adjoint recursion is not implemented yet."""
+
+    @staticmethod
+    def forward(ctx, x, z_alpha):
+        return ops.ballistics(x.contiguous(), z_alpha.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError(
+            "backward of the ballistics smoother is not implemented yet (forward-only); use the 'iir' smoother "
+            "for training, as the reference recommends for speed (dynamics.py:227)."
+        )
+
+
+def log_gain(G, T, log_ratio, log_knee, knee, gate):
+    """dynamics.py:444-489 (compressor), 676-721 (gate)."""
+    R = 1 + torch.exp(log_ratio)
+    if not gate:
+        if knee == "hard":
+            return torch.minimum(G, T + (G - T) / R) - G
+        if knee == "quadratic":
+            W = torch.exp(log_knee) / 2
+            below, above = G < (T - W), G > (T + W)
+            mid = ~below & ~above
+            out = G * below + (T + (G - T) / R) * above + (G + (1 / R - 1) * (G - T + W).square() / (4 * W)) * mid
+            return out - G
+        k = torch.exp(log_knee)
+        return (1 / R - 1) * F.softplus(k * (G - T)) / k
+    if knee == "hard":
+        return torch.minimum(G, R * (G - T) + T) - G
+    if knee == "quadratic":
+        W = torch.exp(log_knee) / 2
+        below, above = G < (T - W), G > (T + W)
+        mid = ~below & ~above
+        out = (R * (G - T) + T) * below + G * above + (G + (1 - R) * (G - T - W).square() / (4 * W)) * mid
+        return out - G
+    k = torch.exp(log_knee)
+    return -torch.exp(log_ratio) * F.softplus(k * (T - G)) / k

@@ -20,8 +20,9 @@ import warnings
 import torch
 import torch.nn as nn
 
+from ... import autograd as diff
 from ... import ops
-from ._grad import forward_only
+from ...autograd import needs_grad
 
 _EXACT = False
 
@@ -80,8 +81,9 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None):
 
 def convolve(x, h, mode="zerophase", pad_mode="min"):
     """Reference-compatible convolve(): x (R,C,L) or (R,L); h (R,Cf,N) or (R,N)."""
-    forward_only(x, h)
     compute_pad_len(x, h, pad_mode)
+    if needs_grad(x, h):
+        return diff.convolve(x, h, mode)
     flat = x.ndim == 2
     if flat:
         x, h = x.unsqueeze(1), h.unsqueeze(1)

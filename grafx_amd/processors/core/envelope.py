@@ -2,8 +2,9 @@
 import torch
 import torch.nn as nn
 
+from ... import autograd as diff
 from ... import ops
-from ._grad import forward_only
+from ...autograd import needs_grad
 from .convolution import odd_length_alias, reference_aliases
 
 
@@ -19,7 +20,8 @@ class TruncatedOnePoleIIRFilter(nn.Module):
         self.iir_len = iir_len
 
     def forward(self, input_signals, z_alpha):
-        forward_only(input_signals, z_alpha)
+        if needs_grad(input_signals, z_alpha):
+            return diff.truncated_one_pole(input_signals, z_alpha, self.iir_len)
         L = input_signals.shape[-1]
         if not reference_aliases(L, self.iir_len):
             return ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L, relu=True)
@@ -27,6 +29,8 @@ class TruncatedOnePoleIIRFilter(nn.Module):
         return torch.relu(odd_length_alias(full)[..., :L]).contiguous()
 
     def compute_impulse(self, z_alpha):
+        if needs_grad(z_alpha):
+            return diff.one_pole_fir(z_alpha, self.iir_len)
         return ops.onepole_fir(z_alpha, self.iir_len)
 
 
@@ -34,5 +38,6 @@ class Ballistics(nn.Module):
     """Attack/release one-pole recursion (torchcomp.compressor_core semantics as recalled)."""
 
     def forward(self, input_signals, z_alpha):
-        forward_only(input_signals, z_alpha)
+        if needs_grad(input_signals, z_alpha):
+            return diff.BallisticsFn.apply(input_signals, z_alpha)
         return ops.ballistics(input_signals, z_alpha)

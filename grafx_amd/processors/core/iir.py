@@ -3,8 +3,9 @@ reference core/iir.py:25-152, 263-276), frequency-sampling ("fsm") backend on HI
 import torch
 import torch.nn as nn
 
+from ... import autograd as diff
 from ... import ops
-from ._grad import forward_only
+from ...autograd import needs_grad
 from .convolution import FIRConvolution, convolve_taps
 
 
@@ -45,7 +46,13 @@ class IIRFilter(nn.Module):
         return ops.iir_fsm_fir(Bs, As, self.fsm_fir_len, self._plan(Bs.device)).view(R, Cf, self.fsm_fir_len)
 
     def forward(self, input_signal, Bs, As, out=None):
-        forward_only(input_signal, Bs, As)
+        if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
+            x = input_signal.reshape(-1, *input_signal.shape[-2:])
+            y = diff.convolve(x, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal")
+            if out is None:
+                return y
+            out.copy_(y.view(out.shape))
+            return out
         R, Cf = Bs.shape[0], Bs.shape[1]
         N = self.fsm_fir_len
         h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))

@@ -2,9 +2,10 @@
 import torch
 import torch.nn as nn
 
+from .. import autograd as diff
 from .. import ops
+from ..autograd import needs_grad
 from .core._buffer_io import BufferIO
-from .core._grad import forward_only
 from .core.convolution import reference_aliases
 from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
 
@@ -40,7 +41,13 @@ class _Dynamics(BufferIO, nn.Module):
 
     def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None,
                 _out=None):
-        forward_only(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post)
+        if needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
+            y = self._forward_differentiable(input_signals.reshape(-1, *input_signals.shape[-2:]), log_threshold,
+                                             log_ratio, log_knee, z_alpha_pre, z_alpha_post)
+            if _out is None:
+                return y
+            _out.copy_(y.view(_out.shape))
+            return _out
         L = input_signals.shape[-1]
         if self.knee == "hard":
             log_knee = None
@@ -67,6 +74,20 @@ class _Dynamics(BufferIO, nn.Module):
             return ops.apply_gain(input_signals, self.gain_smoother_module(g, z_alpha=z_alpha_post), exp_gain=True)
         gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
         return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post))
+
+    def _forward_differentiable(self, x, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
+        """dynamics.py:390-405 as torch ops around the native (differentiable) smoothers."""
+        energy = x.square().mean(-2)
+        if self.energy_smoother is not None:
+            energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)
+        g = diff.log_gain(torch.log(energy + 1e-5), log_threshold - 6, log_ratio, log_knee, self.knee, self._gate)
+        if self.gain_smoother is None:
+            gain = torch.exp(g)
+        elif self.gain_smooth_in_log:
+            gain = torch.exp(self.gain_smoother_module(g, z_alpha=z_alpha_post))
+        else:
+            gain = self.gain_smoother_module(torch.exp(g), z_alpha=z_alpha_post)
+        return gain[:, None, :] * x
 
     def parameter_size(self):
         size = {"log_threshold": 1, "log_ratio": 1}

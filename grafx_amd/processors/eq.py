@@ -3,7 +3,8 @@ import torch.nn as nn
 
 from .. import ops
 from .core._buffer_io import BufferIO
-from .core._grad import forward_only
+from .. import autograd as diff
+from ..autograd import needs_grad
 from .core.iir import IIRFilter
 from .core.midside import lr_to_ms, ms_to_lr
 
@@ -19,8 +20,10 @@ class ParametricEqualizer(BufferIO, nn.Module):
             raise ValueError(f"Invalid processor_channel: {self.processor_channel}")
 
     def forward(self, input_signals, w0, q_inv, log_gain, _out=None):
-        forward_only(input_signals, w0, q_inv, log_gain)
-        Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
+        if needs_grad(input_signals, w0, q_inv, log_gain):
+            Bs, As = diff.peq_coefficients(w0, q_inv, log_gain, self.use_shelving_filters)
+        else:
+            Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
         return self.biquad(input_signals, Bs, As, out=_out)

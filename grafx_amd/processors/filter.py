@@ -3,7 +3,8 @@ import torch.nn as nn
 
 from .. import ops
 from .core._buffer_io import BufferIO
-from .core._grad import forward_only
+from .. import autograd as diff
+from ..autograd import needs_grad
 from .core.iir import IIRFilter
 
 
@@ -15,8 +16,10 @@ class BiquadFilter(BufferIO, nn.Module):
         self.biquad = IIRFilter(order=2, **backend_kwargs)
 
     def forward(self, input_signals, Bs, A1_pre, A2_pre, A0=None, _out=None):
-        forward_only(input_signals, Bs, A1_pre, A2_pre, A0)
-        Bs, As = ops.biquad_coeffs(Bs, A1_pre, A2_pre, A0 if self.normalized else None)
+        A0 = A0 if self.normalized else None
+        if needs_grad(input_signals, Bs, A1_pre, A2_pre, A0):
+            return self.biquad(input_signals, *diff.biquad_coefficients(Bs, A1_pre, A2_pre, A0), out=_out)
+        Bs, As = ops.biquad_coeffs(Bs, A1_pre, A2_pre, A0)
         return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1), out=_out)
 
     def render_into(self, x4, out4, **params):

@@ -3,9 +3,13 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import torch.nn.functional as F
+
+from .. import autograd as diff
 from .. import ops
+from ..autograd import needs_grad
 from .core._buffer_io import BufferIO
-from .core._grad import forward_only
+from .core.utils import normalize_impulse
 from .core.convolution import convolve_taps
 from .core.midside import lr_to_ms, ms_to_lr
 
@@ -51,8 +55,20 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
 
     def compute_ir(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
         """Un-normalised mid/side impulse responses (R,2,ir_len) (reverb.py:161-187)."""
-        forward_only(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
+        if needs_grad(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
+            return self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         return self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, False)[0]
+
+    def _compute_ir_differentiable(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
+        """reverb.py:161-200 with torch ops (mask, istft) for the training path."""
+        logmag = init_log_magnitude[..., None] - F.softplus(delta_log_magnitude)[..., None] * self.arange
+        if self.gain_envelope:
+            logmag = logmag + gain_env_log_magnitude[:, :, None, :]
+        spec = self.noise_stft * torch.exp(logmag / 8)
+        R = spec.shape[0]
+        ir = torch.istft(spec.reshape(R * 2, self.num_bins, self.num_frames), n_fft=self.n_fft,
+                         hop_length=self.hop_length, window=self.window, length=self.ir_len)
+        return ir.view(R, 2, self.ir_len)
 
     def render_into(self, x4, out4, **params):
         if self.processor_channel == "midside":
@@ -60,8 +76,20 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         return self.forward(x4, _out=out4, **params)
 
     def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _out=None):
-        forward_only(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         pseudo = self.processor_channel == "pseudo_midside"
+        if needs_grad(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
+            x = input_signals.reshape(-1, *input_signals.shape[-2:])
+            ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
+            if pseudo:
+                y = diff.convolve(x, normalize_impulse(ms_to_lr(ir)), "causal")
+            elif self.processor_channel == "midside":
+                y = ms_to_lr(diff.convolve(lr_to_ms(x), normalize_impulse(ir), "causal"))
+            else:
+                y = diff.convolve(x, normalize_impulse(ir), "causal")
+            if _out is None:
+                return y
+            _out.copy_(y.view(_out.shape))
+            return _out
         ir, gain = self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, pseudo)
         R = ir.shape[0]
         # normalize_impulse (core/utils.py:14-18) is folded into the tap -> spectrum step

@@ -61,11 +61,19 @@ def _gather_plan(step, device):
     return plan
 
 
-def _buffer_io_ok(processors, input_signals, render_data):
+def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
     if not input_signals.is_cuda or render_data.method == "one-by-one" or not render_data.siso_only:
         return False
-    if torch.is_grad_enabled() and input_signals.requires_grad:
-        return False
+    if torch.is_grad_enabled():
+        # training: saved views of a buffer that later stages keep writing would trip autograd's version
+        # check, so the reference's clone-on-read loop is used instead
+        def any_requires_grad(p):
+            if isinstance(p, torch.Tensor):
+                return p.requires_grad
+            return any(any_requires_grad(v) for v in p.values()) if hasattr(p, "values") else False
+
+        if input_signals.requires_grad or any_requires_grad(per_type_parameters):
+            return False
     for step in render_data.iter_list[1:]:
         if step.node_type in processors:
             if not hasattr(processors[step.node_type], "render_into"):
@@ -138,7 +146,7 @@ def render_grafx(
 ):
     method = render_data.method
     ndim = input_signals.ndim
-    if ndim in (3, 4) and _buffer_io_ok(processors, input_signals, render_data):
+    if ndim in (3, 4) and _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
         return _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters)
     if ndim == 3:
         node_dim, postprocess = 0, None

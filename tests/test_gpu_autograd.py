@@ -1,0 +1,115 @@
+"""GPU: the differentiable path (native conv forward/backward + torch front-ends) against parameter
+gradients computed by the reference itself (tests/golden) and against torch.fft autograd."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_linconv(x, h, Lout, off):
+    L, N = x.shape[-1], h.shape[-1]
+    n = 1 << (L + N).bit_length()
+    full = torch.fft.irfft(torch.fft.rfft(x.double(), n=n) * torch.fft.rfft(h.double(), n=n), n=n)[..., : L + N - 1]
+    return full[..., off : off + Lout]
+
+
+@pytest.mark.parametrize("L,N,C,Cf,off", [(3000, 257, 2, 1, 0), (3000, 257, 1, 2, 0), (2049, 128, 2, 2, 64),
+                                          (20000, 9001, 2, 1, 0), (1500, 301, 2, 2, 0)])
+def test_linear_conv_backward(L, N, C, Cf, off):
+    from grafx_amd.autograd import LinearConvFn
+
+    torch.manual_seed(L + N)
+    x = torch.randn(2, C, L, device="cuda", requires_grad=True)
+    h = (torch.randn(2, Cf, N, device="cuda") / N**0.5).requires_grad_()
+    w = torch.randn(2, max(C, Cf), L, device="cuda")
+    y = LinearConvFn.apply(x, h, L, off)
+    gx, gh = torch.autograd.grad((y * w).sum(), [x, h])
+    x2, h2 = x.detach().clone().requires_grad_(), h.detach().clone().requires_grad_()
+    y2 = _ref_linconv(x2, h2, L, off)
+    gx2, gh2 = torch.autograd.grad((y2 * w.double()).sum(), [x2, h2])
+    assert_close(y.detach().cpu(), y2.detach().float().cpu(), 1e-5, "y")
+    assert_close(gx.cpu(), gx2.float().cpu(), 1e-5, "grad_x")
+    assert_close(gh.cpu(), gh2.float().cpu(), 1e-5, "grad_h")
+
+
+@pytest.mark.parametrize("ch", ["mono", "stereo", "midside"])
+@pytest.mark.parametrize("N", [256, 257])
+def test_peq_parameter_gradients_vs_reference(golden, ch, N):
+    from grafx_amd.processors import ParametricEqualizer
+
+    g = golden("g3_peq")
+    tag = f"{ch}_N{N}_std0.01"
+    m = ParametricEqualizer(num_filters=6, processor_channel=ch, flashfftconv=False, fsm_fir_len=N).cuda()
+    p = {k: g[f"{k}_{tag}"].cuda().requires_grad_() for k in ("w0", "q_inv", "log_gain")}
+    y = m(g[f"x_{tag}"].cuda(), **p)
+    assert_close(y.detach().cpu(), g[f"y_{tag}"], 1e-5, "peq y (grad mode)")
+    grads = torch.autograd.grad((y * g[f"w_{tag}"].cuda()).sum(), list(p.values()))
+    for k, gr in zip(p, grads):
+        assert_close(gr.cpu(), g[f"grad_{k}_{tag}"], 2e-4, f"peq grad {k}")
+
+
+@pytest.mark.parametrize("ir_len", [3000, 3001])
+def test_reverb_parameter_gradients_vs_reference(golden, ir_len):
+    from grafx_amd.processors import STFTMaskedNoiseReverb
+
+    g = golden("g5_reverb")
+    tag = f"ir{ir_len}_pseudo_midside"
+    m = STFTMaskedNoiseReverb(ir_len=ir_len, flashfftconv=False).cuda()
+    p = {k: g[f"{k}_{tag}"].cuda().requires_grad_() for k in ("init_log_magnitude", "delta_log_magnitude")}
+    y = m(g[f"x_{tag}"].cuda(), **p)
+    assert_close(y.detach().cpu(), g[f"y_{tag}"], 1e-5, "reverb y (grad mode)")
+    grads = torch.autograd.grad((y * g[f"w_{tag}"].cuda()).sum(), list(p.values()))
+    for k, gr in zip(p, grads):
+        assert_close(gr.cpu(), g[f"grad_{k}_{tag}"], 2e-4, f"reverb grad {k}")
+
+
+def test_compressor_parameter_gradients_vs_reference(golden):
+    from grafx_amd.processors import Compressor
+
+    g = golden("g6_dynamics")
+    tag = "Compressor_quadratic_iir_511"
+    m = Compressor(energy_smoother="iir", knee="quadratic", iir_len=511, flashfftconv=False).cuda()
+    p = {k: g[f"{k}_{tag}"].cuda().requires_grad_() for k in m.parameter_size()}
+    y = m(g["x_shared"].cuda(), **p)
+    assert_close(y.detach().cpu(), g[f"y_{tag}"], 1e-5, "compressor y (grad mode)")
+    grads = torch.autograd.grad((y * g[f"w_{tag}"].cuda()).sum(), list(p.values()))
+    for k, gr in zip(p, grads):
+        assert_close(gr.cpu(), g[f"grad_{k}_{tag}"], 5e-4, f"compressor grad {k}")
+
+
+def test_training_step_through_render_grafx():
+    """Forward + backward through the whole console graph with shared parameters."""
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+    from test_routing_golden import build_console
+
+    import oracle
+
+    torch.manual_seed(0)
+    G = build_console(4, 2)
+    kw = dict(fsm_fir_len=129, iir_len=127, ir_len=1537)
+    hip = {"eq": ParametricEqualizer(num_filters=4, flashfftconv=False, fsm_fir_len=kw["fsm_fir_len"]).cuda(),
+           "compressor": Compressor(iir_len=kw["iir_len"], flashfftconv=False).cuda(),
+           "reverb": STFTMaskedNoiseReverb(ir_len=kw["ir_len"], flashfftconv=False).cuda()}
+    cpu = {"eq": oracle.OracleParametricEqualizer(num_filters=4, fsm_fir_len=kw["fsm_fir_len"]),
+           "compressor": oracle.OracleCompressor(iir_len=kw["iir_len"]),
+           "reverb": oracle.OracleSTFTMaskedNoiseReverb(ir_len=kw["ir_len"])}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    params = create_empty_parameters(hip, G, std=0.2)
+    x = torch.randn(2, 4, 2, 1024)
+    y_ref, _, _ = render_grafx(cpu, x, params, rd)
+    y_ref.square().mean().backward()
+    ref_grads = [p.grad.clone() for p in params.parameters()]
+    for p in params.parameters():
+        p.grad = None
+    params_gpu = params.cuda()
+    rd_gpu = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    y, _, _ = render_grafx(hip, x.cuda(), params_gpu, rd_gpu)
+    y.square().mean().backward()
+    assert_close(y.detach().cpu(), y_ref.detach(), 2e-5, "y")
+    for gp, rg in zip(params_gpu.parameters(), ref_grads):
+        assert_close(gp.grad.cpu(), rg, 1e-3, "parameter gradient")

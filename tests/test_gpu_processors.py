@@ -179,8 +179,11 @@ def test_loud_failures():
     m = P.StereoGain()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 2, 8), torch.zeros(1, 2))  # CPU tensors are refused
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 2, 8).cuda(), torch.zeros(1, 2, requires_grad=True).cuda())  # forward-only, loud
+    y = m(torch.ones(1, 2, 8).cuda(), torch.zeros(1, 2, device="cuda", requires_grad=True))
+    assert y.requires_grad  # gradient requested -> differentiable path
+    with pytest.raises(NotImplementedError):  # the one missing backward fails loudly, at backward time
+        b = P.Ballistics()(torch.rand(2, 64).cuda(), torch.zeros(2, 2, device="cuda", requires_grad=True))
+        b.sum().backward()
     with pytest.raises(NotImplementedError):
         P.IIRFilter(backend="lfilter", flashfftconv=False)
     with pytest.raises(ValueError):
