@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
     ap.add_argument("--length", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="also time forward+backward+gradient all-reduce (BASELINE configs[4]) at --train-batch per GPU")
+    ap.add_argument("--train-batch", type=int, default=32)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +216,44 @@ def main():
                 "algorithmic_bytes_per_launch": avg_bytes, "launches_per_step": n // 2,
                 "share_of_step": total_ms / 2 / (elapsed / args.steps * 1e3)}
 
+    train = None
+    if args.train:
+        # BASELINE configs[4]: shared parameters, batch sharded over the GPUs, one flat gradient all-reduce
+        import torch.nn as nn
+
+        from grafx_amd.parallel import all_reduce_gradients
+
+        del y
+        torch.cuda.empty_cache()
+        Bt = args.train_batch
+        tparams = nn.ParameterDict({t: nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in d.items()})
+                                    for t, d in params.items()})
+        plist = list(tparams.parameters())
+        xt = x[:Bt]
+
+        def train_step():
+            for p in plist:
+                p.grad = None
+            out = render_grafx(procs, xt, tparams, rd_dev)[0]
+            out.square().mean().backward()
+            all_reduce_gradients(plist)
+
+        train_step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            train_step()
+        fence()
+        dt = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        train = {"what": "forward + backward + flat all-reduce of shared-parameter gradients", "batch_per_gpu": Bt,
+                 "ms_per_step": dt / args.steps * 1e3, "value": world * Bt * L * args.steps / dt,
+                 "unit": "audio samples/s", "grad_floats": sum(p.numel() for p in plist),
+                 "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -241,6 +282,8 @@ def main():
         out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
                                  "achieved_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9,
                                  "frac_of_hbm_peak": graph_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if train is not None:
+            out["training"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, render_data, params_cpu, L)
         print(json.dumps(out))

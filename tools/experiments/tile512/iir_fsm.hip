@@ -1,0 +1,239 @@
+// Frequency-sampled IIR (biquad cascade) -> length-N FIR, plus the coefficient front-ends.
+//
+// Replaces IIRFilter._process_fsm / iir_fsm / delay — core/iir.py:147-150, 263-276:
+//   D[d,k] = exp(-j*phase), phase = fl32(fl32(fl32(d*k / N) * 2) * pi)      (d = 0,1,2; k = 0..N/2)
+//   H[k]   = prod_i (sum_d B[i,d] D[d,k]) / (sum_d A[i,d] D[d,k])           (complex64, in cascade order)
+//   h      = irfft(H, n = N)
+// The phase is rounded exactly like the reference's float32 tensor arithmetic so that
+// high-Q sections (denominator near zero) see the same perturbed sample points.
+//
+// The inverse real DFT has arbitrary length N <= 4096 (e.g. 4000 = 2^5*5^3, 4001 prime), so it
+// runs as a Bluestein chirp-z transform on the 8192-point LDS FFT tile: one workgroup per
+// (row, filter-channel), 2 tile FFTs each.  The chirp filter spectrum is a per-N "plan".
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/grafx_amd.h"
+#include "fft_tile.hpp"
+
+namespace gfx {
+
+constexpr int FSM_MAX_N = 4096;  // 2N-1 <= 8192
+
+// exp(+i*pi*k^2/N) (sign = +1) or exp(-i*pi*k^2/N) (sign = -1); k^2 reduced mod 2N in integers
+__device__ __forceinline__ float2 chirp(int k, int N, float sign) {
+    const int r = (int)(((int64_t)k * k) % (2 * (int64_t)N));
+    float s, c;
+    sincospif((float)r / (float)N, &s, &c);
+    return make_float2(c, sign * s);
+}
+
+__global__ __launch_bounds__(TILE_T, 4) void bluestein_plan_kernel(float2* __restrict__ plan, int N,
+                                                                   const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int t = threadIdx.x;
+    float2 v[16], w[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const int i = tile_point(t, a);
+        const int m = i < N ? i : (i > TILE_M - N ? TILE_M - i : -1);  // |m|; b[m] is even in m
+        v[a] = m >= 0 ? chirp(m, N, -1.0f) : make_float2(0.0f, 0.0f);
+    }
+    tile_forward(v, w, twtab, lds, t);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) plan[q * TILE_T + t] = w[q];
+}
+
+// complex division, scaled like torch's vectorised complex64 kernel (divide through by max(|c|,|d|))
+__device__ __forceinline__ float2 cdiv(float2 n, float2 d) {
+    const float sc = 1.0f / fmaxf(fabsf(d.x), fabsf(d.y));
+    const float a = n.x * sc, b = n.y * sc, c = d.x * sc, e = d.y * sc;
+    const float den = 1.0f / (c * c + e * e);
+    return make_float2((a * c + b * e) * den, (b * c - a * e) * den);
+}
+
+// cascade response at bin k (0 <= k <= N/2), reference arithmetic (see header)
+__device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, const float* __restrict__ A, int K,
+                                                   int k, int N) {
+    const float pi32 = 3.14159274101257324219f;
+    const float ph1 = ((float)k / (float)N) * 2.0f * pi32;
+    const float ph2 = ((float)(2 * k) / (float)N) * 2.0f * pi32;
+    float s1, c1, s2, c2;
+    sincosf(ph1, &s1, &c1);
+    sincosf(ph2, &s2, &c2);
+    const float2 d1 = make_float2(c1, -s1), d2 = make_float2(c2, -s2);
+    float2 H = make_float2(1.0f, 0.0f);
+    for (int i = 0; i < K; ++i) {
+        const float b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
+        const float a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
+        const float2 num = make_float2((b0 + b1 * d1.x) + b2 * d2.x, (b1 * d1.y) + b2 * d2.y);
+        const float2 den = make_float2((a0 + a1 * d1.x) + a2 * d2.x, (a1 * d1.y) + a2 * d2.y);
+        const float2 q = cdiv(num, den);
+        H = (i == 0) ? q : cmul(H, q);
+    }
+    return H;
+}
+
+__global__ __launch_bounds__(TILE_T, 4) void iir_fsm_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
+                                                            const float2* __restrict__ plan, float* __restrict__ h,
+                                                            int K, int N, const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int t = threadIdx.x;
+    const int64_t rc = blockIdx.x;
+    const float* B = Bs + rc * K * 3;
+    const float* A = As + rc * K * 3;
+    const int half = N / 2;
+    const bool even = (N & 1) == 0;
+
+    float2 v[16], w[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const int k = tile_point(t, a);
+        float2 e = make_float2(0.0f, 0.0f);
+        if (k < N) {  // Hermitian extension of the half spectrum, as a c2r transform reads it
+            const bool upper = k > half;
+            float2 Hk = cascade_response(B, A, K, upper ? N - k : k, N);
+            if (upper) Hk.y = -Hk.y;
+            if (k == 0 || (even && k == half)) Hk.y = 0.0f;
+            e = cmul(Hk, chirp(k, N, 1.0f));
+        }
+        v[a] = e;
+    }
+    tile_forward(v, w, twtab, lds, t);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = cmul(w[q], plan[q * TILE_T + t]);
+    __syncthreads();
+    tile_inverse(w, v, twtab, lds, t);
+    const float sc = 1.0f / ((float)N * (float)TILE_M);
+    float* out = h + rc * N;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const int n = tile_point(t, a);
+        if (n < N) {
+            const float2 c = chirp(n, N, 1.0f), e = v[a];
+            out[n] = (e.x * c.x - e.y * c.y) * sc;
+        }
+    }
+}
+
+// ---- coefficient front-ends (elementwise over rows x K) ------------------------------------------
+// ParametricEqualizer: eq.py:273-314 + filter.py:593-604 (activations), 645-656 (peaking),
+// 687-705 (low shelf), 736-754 (high shelf).  One thread per (row-channel, band).
+__global__ void peq_coeffs_kernel(const float* __restrict__ w0, const float* __restrict__ q_inv,
+                                  const float* __restrict__ log_gain, float* __restrict__ Bs, float* __restrict__ As,
+                                  int64_t n, int K, int shelving) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int band = (int)(i % K);
+    const float pi32 = 3.14159274101257324219f;
+    const float w = pi32 * (1.0f / (1.0f + expf(-w0[i])));
+    const float qi = expf(q_inv[i]);
+    const float A = expf(log_gain[i]);
+    float sw, cw;
+    sincosf(w, &sw, &cw);
+    const float alpha = sw * qi * 0.5f;
+    float b0, b1, b2, a0, a1, a2;
+    const bool low = shelving && band == 0, high = shelving && band == K - 1;
+    if (low || high) {
+        const float sg = low ? 1.0f : -1.0f;
+        const float ap1 = A + 1.0f, am1 = A - 1.0f;
+        const float ap1c = ap1 * cw, am1c = am1 * cw;
+        const float s = 2.0f * sqrtf(A) * alpha;
+        b0 = A * ((ap1 - sg * am1c) + s);
+        b1 = sg * 2.0f * A * (am1 - sg * ap1c);
+        b2 = A * ((ap1 - sg * am1c) - s);
+        a0 = (ap1 + sg * am1c) + s;
+        a1 = -sg * 2.0f * (am1 + sg * ap1c);
+        a2 = (ap1 + sg * am1c) - s;
+    } else {
+        const float aA = alpha * A, adA = alpha / A;
+        b0 = 1.0f + aA;
+        b1 = -2.0f * cw;
+        b2 = 1.0f - aA;
+        a0 = 1.0f + adA;
+        a1 = b1;
+        a2 = 1.0f - adA;
+    }
+    Bs[3 * i] = b0;
+    Bs[3 * i + 1] = b1;
+    Bs[3 * i + 2] = b2;
+    As[3 * i] = a0;
+    As[3 * i + 1] = a1;
+    As[3 * i + 2] = a2;
+}
+
+// BiquadFilter: filter.py:144-153.
+__global__ void biquad_coeffs_kernel(const float* __restrict__ Bin, const float* __restrict__ A1_pre,
+                                     const float* __restrict__ A2_pre, const float* __restrict__ A0,
+                                     float* __restrict__ Bs, float* __restrict__ As, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a1 = 2.0f * tanhf(A1_pre[i]);
+    const float a1a = fabsf(a1);
+    const float a2 = ((2.0f - a1a) * tanhf(A2_pre[i]) + a1a) / 2.0f;
+    const float g = A0 ? A0[i] : 1.0f;
+    As[3 * i] = g;
+    As[3 * i + 1] = a1 * g;
+    As[3 * i + 2] = a2 * g;
+    Bs[3 * i] = Bin[3 * i] + 1.0f;
+    Bs[3 * i + 1] = Bin[3 * i + 1];
+    Bs[3 * i + 2] = Bin[3 * i + 2];
+}
+
+template <typename K>
+static int allow_lds(K kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               TILE_LDS_BYTES) == hipSuccess
+               ? 0
+               : GFX_ELAUNCH;
+}
+
+}  // namespace gfx
+
+using namespace gfx;
+
+extern "C" {
+
+size_t gfx_iir_fsm_plan_bytes(int64_t N) { return (N < 1 || N > FSM_MAX_N) ? 0 : (size_t)TILE_M * sizeof(float2); }
+
+int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream) {
+    if (!plan || N < 1 || N > FSM_MAX_N) return GFX_EINVAL;
+    if (allow_lds(bluestein_plan_kernel)) return GFX_ELAUNCH;
+    const float2* tw = tile_twiddle_table((hipStream_t)stream);
+    if (!tw) return GFX_ELAUNCH;
+    hipLaunchKernelGGL(bluestein_plan_kernel, dim3(1), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream,
+                       (float2*)plan, (int)N, tw);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h, int64_t RC, int64_t K,
+                        int64_t N, void* stream) {
+    if (!Bs || !As || !plan || !h || RC <= 0 || K <= 0 || N < 1 || N > FSM_MAX_N || RC > 0x7fffffffLL)
+        return GFX_EINVAL;
+    if (allow_lds(iir_fsm_kernel)) return GFX_ELAUNCH;
+    const float2* tw = tile_twiddle_table((hipStream_t)stream);
+    if (!tw) return GFX_ELAUNCH;
+    hipLaunchKernelGGL(iir_fsm_kernel, dim3((unsigned)RC), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream, Bs, As,
+                       (const float2*)plan, h, (int)K, (int)N, tw);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_peq_coeffs_f32(const float* w0, const float* q_inv, const float* log_gain, float* Bs, float* As, int64_t n,
+                       int64_t K, int use_shelving, void* stream) {
+    if (!w0 || !q_inv || !log_gain || !Bs || !As || n <= 0 || K <= 0) return GFX_EINVAL;
+    const int64_t total = n * K;
+    hipLaunchKernelGGL(peq_coeffs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w0,
+                       q_inv, log_gain, Bs, As, n, (int)K, use_shelving);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_biquad_coeffs_f32(const float* Bin, const float* A1_pre, const float* A2_pre, const float* A0, float* Bs,
+                          float* As, int64_t n, void* stream) {
+    if (!Bin || !A1_pre || !A2_pre || !Bs || !As || n <= 0) return GFX_EINVAL;
+    hipLaunchKernelGGL(biquad_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Bin,
+                       A1_pre, A2_pre, A0, Bs, As, n);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+}  // extern "C"
