@@ -4,8 +4,20 @@ from . import core
 from .core.convolution import FIRConvolution, convolve, set_exact_convolution
 from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
 from .core.iir import IIRFilter
-from .dynamics import Compressor, NoiseGate
-from .eq import ParametricEqualizer
-from .filter import BiquadFilter
+from .container import DryWet, GainStagingRegularization, ParallelMix, SerialChain
+from .dynamics import ApproxCompressor, ApproxNoiseGate, Compressor, NoiseGate
+from .eq import ParametricEqualizer, ZeroPhaseFIREqualizer
+from .filter import (
+    AllPassFilter,
+    BandPassFilter,
+    BandRejectFilter,
+    BiquadFilter,
+    HighPassFilter,
+    HighShelf,
+    LowPassFilter,
+    LowShelf,
+    PeakingFilter,
+    StateVariableFilter,
+)
 from .reverb import STFTMaskedNoiseReverb
-from .stereo import StereoGain
+from .stereo import MidSideToStereo, MonoToStereo, SideGainImager, StereoGain, StereoToMidSide

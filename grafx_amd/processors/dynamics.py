@@ -111,3 +111,43 @@ class NoiseGate(_Dynamics):
     """Feed-forward noise gate (reference dynamics.py:492-721)."""
 
     _gate = True
+
+
+class ApproxCompressor(Compressor):
+    """Reference dynamics.py:8-120: Compressor(energy "iir", quadratic knee) under its older parameter
+    names (``z_alpha`` instead of ``z_alpha_pre``)."""
+
+    def __init__(self, iir_len=16384, flashfftconv=True, max_input_len=2**17):
+        super().__init__(energy_smoother="iir", gain_smoother=None, knee="quadratic", iir_len=iir_len)
+
+    def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None):
+        return super().forward(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre=z_alpha, _out=_out)
+
+    def parameter_size(self):
+        return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}
+
+
+class ApproxNoiseGate(nn.Module):
+    """Reference dynamics.py:123-210.  Its knee differs from NoiseGate's (ratio = exp(r), full-width knee,
+    +1e-3 in the denominator), so the gain curve is evaluated with elementwise torch ops on the smoothed
+    log-energy produced by the HIP one-pole kernel."""
+
+    def __init__(self, freq_sample_n=16384, flashfftconv=True, max_input_len=2**17):
+        super().__init__()
+        self.smoother = TruncatedOnePoleIIRFilter(iir_len=freq_sample_n)
+
+    def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None):
+        if needs_grad(input_signals, z_alpha, log_threshold, log_ratio, log_knee):
+            energy = input_signals.square().mean(-2)
+        else:
+            energy = ops.energy(input_signals)
+        G = torch.log(self.smoother(energy, z_alpha) + 1e-5)
+        T = log_threshold - 6
+        ratio, W = torch.exp(log_ratio), torch.exp(log_knee)
+        below, above = G < (T - W / 2), G > (T + W / 2)
+        middle = (~below) * (~above)
+        out = (ratio * (G - T) + T) * below + G * above + (G + (1 - ratio) * (G - T - W / 2) ** 2 / 2 / (W + 1e-3)) * middle
+        return torch.exp(out - G)[:, None, :] * input_signals
+
+    def parameter_size(self):
+        return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}

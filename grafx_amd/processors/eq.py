@@ -3,6 +3,8 @@ import torch.nn as nn
 
 from .. import ops
 from .core._buffer_io import BufferIO
+from .core.convolution import convolve
+from .core.fir import ZeroPhaseFIR
 from .. import autograd as diff
 from ..autograd import needs_grad
 from .core.iir import IIRFilter
@@ -37,3 +39,21 @@ class ParametricEqualizer(BufferIO, nn.Module):
         n_channels = 1 if self.processor_channel == "mono" else 2
         size = (n_channels, self.num_filters)
         return {k: size for k in ["w0", "q_inv", "log_gain"]}
+
+
+class ZeroPhaseFIREqualizer(nn.Module):
+    """Single-channel zero-phase FIR equaliser (reference eq.py:25-79): log-magnitude -> windowed
+    zero-phase FIR of 2*bins-1 taps (odd, so the reference's convolve is an exact linear convolution for
+    even audio lengths) -> HIP overlap-save convolution in "zerophase" mode."""
+
+    def __init__(self, num_magnitude_bins=1024):
+        super().__init__()
+        self.num_magnitude_bins = num_magnitude_bins
+        self.fir = ZeroPhaseFIR(num_magnitude_bins)
+
+    def forward(self, input_signals, log_magnitude):
+        fir = self.fir(log_magnitude)[:, None, :]
+        return convolve(input_signals, fir, mode="zerophase")
+
+    def parameter_size(self):
+        return {"log_magnitude": self.num_magnitude_bins}

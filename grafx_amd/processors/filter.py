@@ -1,5 +1,9 @@
 """Filters (mirrors grafx.processors.filter — reference filter.py:87-168 for BiquadFilter)."""
+import math
+
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from .core._buffer_io import BufferIO
@@ -30,3 +34,139 @@ class BiquadFilter(BufferIO, nn.Module):
         if self.normalized:
             size["A0"] = self.num_filters
         return size
+
+
+# ---- single-biquad parametric filters (reference filter.py:263-560) ----------------------------------
+# Coefficient formulas are a few elementwise ops on (R, 1) tensors (torch, on the GPU); the filtering is
+# the HIP frequency-sampling path of IIRFilter.
+class BaseParametricFilter(nn.Module):
+    def __init__(self, **backend_kwargs):
+        super().__init__()
+        self.biquad = IIRFilter(order=2, **backend_kwargs)
+
+    def forward(self, input_signals, w0, q_inv):
+        w0, q = self.filter_parameter_activations(w0, q_inv)
+        cos_w0, alpha = self.compute_common_filter_parameters(w0, q)
+        Bs, As = self.get_biquad_coefficients(cos_w0, alpha)
+        return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1))
+
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha):
+        raise NotImplementedError
+
+    @staticmethod
+    def filter_parameter_activations(w0, q_inv):
+        return math.pi * torch.sigmoid(w0), torch.exp(q_inv)
+
+    @staticmethod
+    def compute_common_filter_parameters(w0, q_inv):
+        return torch.cos(w0), torch.sin(w0) * q_inv * 0.5
+
+    def parameter_size(self):
+        return {"w0": 1, "q_inv": 1}
+
+
+def _den(cos_w0, alpha):
+    return torch.stack([1 + alpha, -2 * cos_w0, 1 - alpha], -1)
+
+
+class LowPassFilter(BaseParametricFilter):
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha):  # filter.py:416-426 (sign as in the code, not the docstring)
+        c = cos_w0 - 1
+        return torch.stack([c / 2, c, c / 2], -1), _den(cos_w0, alpha)
+
+
+class HighPassFilter(BaseParametricFilter):
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha):
+        c = 1 + cos_w0
+        return torch.stack([c / 2, -c, c / 2], -1), _den(cos_w0, alpha)
+
+
+class BandPassFilter(BaseParametricFilter):
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha):
+        return torch.stack([alpha, torch.zeros_like(alpha), -alpha], -1), _den(cos_w0, alpha)
+
+
+class BandRejectFilter(BaseParametricFilter):
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha):
+        one = torch.ones_like(cos_w0)
+        return torch.stack([one, -2 * cos_w0, one], -1), _den(cos_w0, alpha)
+
+
+class AllPassFilter(BaseParametricFilter):
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha):
+        den = _den(cos_w0, alpha)
+        return den.flip(-1), den
+
+
+class BaseParametricEqualizerFilter(nn.Module):
+    """Stack of `num_filters` equaliser sections of one kind (filter.py:563-617)."""
+
+    _kind = None
+
+    def __init__(self, num_filters=1, **backend_kwargs):
+        super().__init__()
+        self.num_filters = num_filters
+        self.biquad = IIRFilter(order=2, **backend_kwargs)
+
+    def forward(self, input_signals, w0, q_inv, log_gain):
+        Bs, As = self._coefficients(w0, q_inv, log_gain)
+        return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1))
+
+    def _coefficients(self, w0, q_inv, log_gain):
+        w = math.pi * torch.sigmoid(w0)
+        A = torch.exp(log_gain)
+        cw, alpha = torch.cos(w), torch.sin(w) * torch.exp(q_inv) * 0.5
+        if self._kind == "peak":  # filter.py:645-656
+            return (torch.stack([1 + alpha * A, -2 * cw, 1 - alpha * A], -1),
+                    torch.stack([1 + alpha / A, -2 * cw, 1 - alpha / A], -1))
+        sg = 1.0 if self._kind == "low" else -1.0  # filter.py:687-705 / 736-754
+        ap1, am1, s = A + 1, A - 1, 2 * A.sqrt() * alpha
+        Bs = torch.stack([A * (ap1 - sg * am1 * cw + s), sg * 2 * A * (am1 - sg * ap1 * cw), A * (ap1 - sg * am1 * cw - s)], -1)
+        As = torch.stack([ap1 + sg * am1 * cw + s, -sg * 2 * (am1 + sg * ap1 * cw), ap1 + sg * am1 * cw - s], -1)
+        return Bs, As
+
+    def parameter_size(self):
+        return {"w0": self.num_filters, "q_inv": self.num_filters, "log_gain": self.num_filters}
+
+
+class PeakingFilter(BaseParametricEqualizerFilter):
+    _kind = "peak"
+
+
+class LowShelf(BaseParametricEqualizerFilter):
+    _kind = "low"
+
+
+class HighShelf(BaseParametricEqualizerFilter):
+    _kind = "high"
+
+
+class StateVariableFilter(nn.Module):
+    """SVF-parameterised biquads (filter.py:223-300)."""
+
+    def __init__(self, num_filters=1, **backend_kwargs):
+        super().__init__()
+        self.num_filters = num_filters
+        self.biquad = IIRFilter(order=2, **backend_kwargs)
+
+    def forward(self, input_signals, twoR, G, c_hp, c_bp, c_lp):
+        G = torch.tan(math.pi / 2 * torch.sigmoid(G))
+        twoR = F.softplus(twoR) / math.log(2) + 1e-2
+        Bs, As = self.get_biquad_coefficients(twoR, G, c_hp, c_bp, c_lp)
+        return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1))
+
+    @staticmethod
+    def get_biquad_coefficients(twoR, G, c_hp, c_bp, c_lp):
+        G2 = G.square()
+        Bs = torch.stack([c_hp + c_bp * G + c_lp * G2, -c_hp * 2 + c_lp * 2 * G2, c_hp - c_bp * G + c_lp * G2], -1)
+        As = torch.stack([1 + G2 + twoR * G, 2 * G2 - 2, 1 + G2 - twoR * G], -1)
+        return Bs, As
+
+    def parameter_size(self):
+        return {k: self.num_filters for k in ("twoR", "G", "c_hp", "c_bp", "c_lp")}

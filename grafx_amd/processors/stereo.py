@@ -21,3 +21,57 @@ class StereoGain(BufferIO, nn.Module):
 
     def parameter_size(self):
         return {"log_gain": 2}
+
+
+INV_SQRT_2 = 1 / 2**0.5
+
+
+class SideGainImager(nn.Module):
+    """Stereo width via side-channel gain (stereo.py:51-100); elementwise."""
+
+    def forward(self, input_signals, log_gain):
+        assert input_signals.shape[1] == 2
+        left, right = input_signals[:, 0, :], input_signals[:, 1, :]
+        mid, side = left + right, (left - right) * torch.exp(log_gain)
+        return torch.stack([(mid + side) / 2, (mid - side) / 2], 1)
+
+    def parameter_size(self):
+        return {"log_gain": 1}
+
+
+class MonoToStereo(nn.Module):
+    def forward(self, input_signals):
+        assert input_signals.shape[1] == 1
+        return input_signals.repeat(1, 2, 1)
+
+    def parameter_size(self):
+        return {}
+
+
+class StereoToMidSide(nn.Module):
+    def __init__(self, normalize=True):
+        super().__init__()
+        self.normalize = normalize
+
+    def forward(self, input_signals):
+        assert input_signals.shape[1] == 2
+        if self.normalize:
+            input_signals = input_signals * INV_SQRT_2
+        left, right = input_signals[:, :1, :], input_signals[:, 1:, :]
+        return left + right, left - right
+
+    def parameter_size(self):
+        return {}
+
+
+class MidSideToStereo(nn.Module):
+    def __init__(self, normalize=True):
+        super().__init__()
+        self.normalization_const = INV_SQRT_2 if normalize else 0.5
+
+    def forward(self, mid, side):
+        assert mid.shape[1] == 1
+        return torch.cat([mid + side, mid - side], 1) * self.normalization_const
+
+    def parameter_size(self):
+        return {}

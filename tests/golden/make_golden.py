@@ -321,6 +321,65 @@ def g8():
     save("g8_render", **arrays)
 
 
+# ----------------------------------------------------------------------------- G10 "next row" processors
+def g10():
+    import grafx.processors as P
+
+    out = {}
+    torch.manual_seed(10)
+    x = torch.randn(3, 2, 1023)
+    out["x"] = x
+    for name in ("LowPassFilter", "HighPassFilter", "BandPassFilter", "BandRejectFilter", "AllPassFilter"):
+        for N in (256, 257):
+            m = getattr(P, name)(flashfftconv=False, fsm_fir_len=N)
+            p = {k: torch.randn(3, 1) for k in m.parameter_size()}
+            out[f"y_{name}_N{N}"] = m(x, **p)
+            for k, v in p.items():
+                out[f"{k}_{name}_N{N}"] = v
+    for name in ("PeakingFilter", "LowShelf", "HighShelf"):
+        m = getattr(P, name)(num_filters=2, flashfftconv=False, fsm_fir_len=257)
+        p = {k: 0.5 * torch.randn(3, 2) for k in m.parameter_size()}
+        out[f"y_{name}"] = m(x, **p)
+        for k, v in p.items():
+            out[f"{k}_{name}"] = v
+    m = P.StateVariableFilter(num_filters=2, flashfftconv=False, fsm_fir_len=257)
+    p = {k: 0.5 * torch.randn(3, 2) for k in m.parameter_size()}
+    out["y_svf"] = m(x, **p)
+    for k, v in p.items():
+        out[f"{k}_svf"] = v
+    for L in (1024, 1023):
+        m = P.ZeroPhaseFIREqualizer(num_magnitude_bins=128)
+        xl = torch.randn(3, 2, L)
+        lm = 0.5 * torch.randn(3, 128)
+        out[f"x_zpfir_L{L}"], out[f"lm_zpfir_L{L}"], out[f"y_zpfir_L{L}"] = xl, lm, m(xl, log_magnitude=lm)
+    for cls, kw in ((P.ApproxCompressor, "iir_len"), (P.ApproxNoiseGate, "freq_sample_n")):
+        m = cls(**{kw: 255}, flashfftconv=False)
+        p = {k: torch.randn(3, 1) for k in m.parameter_size()}
+        out[f"y_{cls.__name__}"] = m(x, **p)
+        for k, v in p.items():
+            out[f"{k}_{cls.__name__}"] = v
+    # containers around simple processors
+    gain, lp = P.StereoGain(), P.LowPassFilter(flashfftconv=False, fsm_fir_len=257)
+    pg, pl = {"log_gain": torch.randn(3, 2)}, {"w0": torch.randn(3, 1), "q_inv": torch.randn(3, 1)}
+    w = torch.rand(3, 1)
+    out["dw_w"], out["dw_lg"] = w, pg["log_gain"]
+    out["y_drywet"] = P.DryWet(gain)(x, drywet_weight=w, **pg)
+    out["lp_w0"], out["lp_q_inv"] = pl["w0"], pl["q_inv"]
+    y, _ = P.SerialChain({"g": gain, "lp": lp})(x, g=pg, lp=pl)
+    out["y_serial"] = y
+    pw = torch.randn(3, 2)
+    out["pm_w"] = pw
+    y, _ = P.ParallelMix({"g": gain, "lp": lp})(x, parallel_weights=pw, g=pg, lp=pl)
+    out["y_parallel"] = y
+    y, inter = P.GainStagingRegularization(gain)(x, **pg)
+    out["y_gsr"], out["gsr_reg"] = y, inter["gain_reg"]
+    sg = torch.randn(3, 1)
+    out["side_lg"], out["y_side"] = sg, P.SideGainImager()(x, sg)
+    mid, side = P.StereoToMidSide()(x)
+    out["ms_mid"], out["ms_side"], out["y_ms2lr"] = mid, side, P.MidSideToStereo()(mid, side)
+    save("g10_next_rows", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8()
+    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8(); g10()
