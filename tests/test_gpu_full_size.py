@@ -1,0 +1,109 @@
+"""GPU parity at BASELINE's full sizes (L = 131072, default-scale filter lengths).
+
+The oracle renders a couple of graphs of the headline console in well under a second, so the
+headline configuration itself (111 nodes, fsm_fir_len 4001 / iir_len 16383 / ir_len 60001) is compared
+sample by sample at batch 2; per-processor checks cover cfg2 / cfg3 shapes on a few rows, both length
+parities (reference-default even lengths exercise the odd-P aliasing path end to end)."""
+import pytest
+import torch
+
+import oracle
+from conftest import assert_close, assert_parity, rel_err
+from test_routing_golden import build_console
+
+pytestmark = pytest.mark.gpu
+L = 131072
+
+
+def _params(procs, G, std, seed):
+    from grafx_amd.utils import create_empty_parameters
+
+    torch.manual_seed(seed)
+    return {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=std).items()}
+
+
+@pytest.mark.parametrize("lens", [dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001),
+                                  dict(fsm_fir_len=4000, iir_len=16384, ir_len=60000)])
+def test_headline_console_graph_batch2(lens):
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+
+    G = build_console(32, 4)
+    hip = {"eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=lens["fsm_fir_len"]).cuda(),
+           "compressor": Compressor(energy_smoother="iir", iir_len=lens["iir_len"], flashfftconv=False).cuda(),
+           "reverb": STFTMaskedNoiseReverb(ir_len=lens["ir_len"], flashfftconv=False).cuda()}
+    cpu = {"eq": oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=lens["fsm_fir_len"]),
+           "compressor": oracle.OracleCompressor(energy_smoother="iir", iir_len=lens["iir_len"]),
+           "reverb": oracle.OracleSTFTMaskedNoiseReverb(ir_len=lens["ir_len"])}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    params = _params(hip, G, 0.1, 7)
+    torch.manual_seed(8)
+    x = torch.randn(2, 32, 2, L)
+    with torch.no_grad():
+        want, _, wbuf = render_grafx(cpu, x, params, rd, parameters_grad=False)
+        dev = {t: {k: v.cuda() for k, v in d.items()} for t, d in params.items()}
+        got, _, gbuf = render_grafx(hip, x.cuda(), dev,
+                                    prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda"))
+    if lens["fsm_fir_len"] % 2 == 1:  # reference == linear convolution: plain tolerance
+        assert_close(got.cpu(), want, 2e-5, "console output")
+        # every intermediate node too (eq outputs, compressor outputs, buses, reverb)
+        for lo, hi, name in [(32, 64, "eq"), (64, 96, "compressor"), (96, 101, "mix"), (109, 110, "reverb")]:
+            assert_close(gbuf[:, lo:hi].cpu(), wbuf[:, lo:hi], 2e-5, name)
+        return
+    # reference-default (even) lengths: every convolve() inverts a ~135071-point spectrum on a 135070-point
+    # grid in fp32; five such stages in series leave the reference's own fp32 render a few 1e-5
+    # from a float64 evaluation, so the float64 tie-breaker applies (conftest.assert_parity)
+    with torch.no_grad():
+        p64 = {t: {k: v.double() for k, v in d.items()} for t, d in params.items()}
+        cpu64 = {k: m.double() for k, m in cpu.items()}
+        want64, _, _ = render_grafx(cpu64, x.double(), p64, rd, parameters_grad=False)
+    assert_parity(got.cpu(), want, want64.float(), 2e-5, "console output (odd-P aliasing path)")
+
+
+def test_cfg2_peq_rows_full_length():
+    from grafx_amd.processors import ParametricEqualizer
+
+    torch.manual_seed(2)
+    Lc = 480000  # BASELINE configs[1]: 10 s @ 48 kHz
+    x = torch.randn(4, 1, Lc)
+    p = {k: torch.randn(4, 1, 6) for k in ("w0", "q_inv", "log_gain")}
+    for N in (4001, 4000):
+        m = ParametricEqualizer(num_filters=6, processor_channel="mono", flashfftconv=False, fsm_fir_len=N)
+        with torch.no_grad():
+            y = m.cuda()(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+        ref = oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=N)(x, **p)
+        ref64 = oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=N)(x.double(), **{k: v.double() for k, v in p.items()})
+        assert_parity(y, ref, ref64, 1e-5, f"cfg2 N={N}")
+
+
+def test_cfg3_reverb_rows_full_length():
+    from grafx_amd.processors import STFTMaskedNoiseReverb
+
+    torch.manual_seed(3)
+    Lc = 240000  # BASELINE configs[2]: 5 s stereo
+    x = torch.randn(2, 2, Lc)
+    p = {k: torch.randn(2, 2, 193) for k in ("init_log_magnitude", "delta_log_magnitude")}
+    for ir_len in (60001, 60000):
+        m = STFTMaskedNoiseReverb(ir_len=ir_len, flashfftconv=False)
+        with torch.no_grad():
+            y = m.cuda()(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+        ref = oracle.OracleSTFTMaskedNoiseReverb(ir_len=ir_len)(x, **p)
+        assert_close(y, ref, 1e-5, f"cfg3 ir_len={ir_len}")
+
+
+def test_compressor_extreme_poles_full_length():
+    """One-pole coefficients from very fast to the clamp (a = 1 - 1e-5, where the a^N term matters)."""
+    from grafx_amd.processors import Compressor
+
+    torch.manual_seed(4)
+    z = torch.tensor([[-6.0], [0.0], [4.0], [8.0], [20.0]])
+    x = torch.randn(5, 2, L) * torch.tensor([1.0, 0.3, 0.1, 1.0, 0.5])[:, None, None]
+    p = {"log_threshold": torch.randn(5, 1), "log_ratio": torch.randn(5, 1), "log_knee": torch.randn(5, 1), "z_alpha_pre": z}
+    for iir_len in (16383, 16384):
+        m = Compressor(energy_smoother="iir", iir_len=iir_len, flashfftconv=False)
+        with torch.no_grad():
+            y = m.cuda()(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+        ref = oracle.OracleCompressor(iir_len=iir_len)(x, **p)
+        ref64 = oracle.OracleCompressor(iir_len=iir_len)(x.double(), **{k: v.double() for k, v in p.items()})
+        assert_parity(y, ref, ref64, 1e-5, f"compressor iir_len={iir_len}")
