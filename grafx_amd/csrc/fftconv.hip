@@ -65,46 +65,66 @@ __device__ __forceinline__ unsigned xcd_logical_block() {
     return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 }
 
-// v[a] = (x[s + 2m], x[s + 2m + 1]), m = t + 256 a; x is zero outside [0, L)
+// ---- raw buffer access (SRSRC descriptor in SGPRs + one 32-bit lane offset) --------------------------
+// All per-tile traffic goes through buffer instructions: the row base and the per-`a` strides live in
+// SGPRs, every lane carries ONE 32-bit byte offset, and the hardware range check supplies the zeros
+// outside [0, L) / drops the stores past the row end — no 64-bit per-lane addresses, no bounds code.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    // descriptor inputs must be provably wave-uniform (else hipcc wraps every access in a waterfall loop)
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    const int64_t nb = bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes);
+    const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)nb);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load_f2(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+__device__ __forceinline__ float4 buf_load_f4(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff, uint32_t soff, float2 e) {
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    const u32x2 v = {__float_as_uint(e.x), __float_as_uint(e.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+constexpr uint32_t OOB = 0xffffffffu;  // lane offset that the range check always rejects
+
+// v[a] = (x[s + 2m], x[s + 2m + 1]), m = t + 256 a; x is zero outside [0, L).  `row` = start of the signal row.
 __device__ __forceinline__ void load_window(float2 (&v)[32], const float* __restrict__ row, int64_t s, int64_t L,
                                             int t, float gain) {
-    const bool inside = s >= 0 && s + TILE_F <= L;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(row + s)) & 7) == 0;
-    if (inside && aligned) {
-        const float2* p = reinterpret_cast<const float2*>(row + s);
+    // descriptor starts at the window (possibly before the row for the first tile: those lanes are masked)
+    const rsrc_t r = make_rsrc(row + s, (L - s) * 4);
+    const bool clip = s < 0;                                   // uniform; only a first tile can start before the row
+    const int s32 = clip ? (int)s : 0;                         // |s| <= 16384 there
 #pragma unroll
-        for (int a = 0; a < 32; ++a) {
-            const float2 e = p[t + 256 * a];
-            v[a] = make_float2(e.x * gain, e.y * gain);
-        }
-    } else {
-#pragma unroll
-        for (int a = 0; a < 32; ++a) {
-            const int64_t n = s + 2 * (t + 256 * a);
-            const float e0 = (n >= 0 && n < L) ? row[n] : 0.0f;
-            const float e1 = (n + 1 >= 0 && n + 1 < L) ? row[n + 1] : 0.0f;
-            v[a] = make_float2(e0 * gain, e1 * gain);
-        }
+    for (int a = 0; a < 32; ++a) {
+        const int n = s32 + 2 * (t + 256 * a);                 // sample index of the pair's first element (if clip)
+        const uint32_t voff = (clip && n < 0) ? OOB : 8u * (uint32_t)t;
+        float2 e = buf_load_f2(r, voff, 2048u * a);
+        if (clip && n == -1) e = make_float2(0.0f, row[0]);    // pair straddling n = 0 (odd window starts only)
+        v[a] = make_float2(e.x * gain, e.y * gain);
     }
 }
 
 // y[n0 + (2m - O)] for 2m >= O, n < Lout;  v[brev5(a)] = (z'[2m], z'[2m+1])
 __device__ __forceinline__ void store_valid(const float2 (&v)[32], float* __restrict__ row, int64_t n0, int64_t O,
                                             int64_t Lout, int t) {
-    const bool aligned = ((reinterpret_cast<uintptr_t>(row + n0)) & 7) == 0 && (O & 1) == 0;
-    const bool whole = n0 + (TILE_F - O) <= Lout;
+    const int64_t room = Lout - (n0 - O);                      // samples from the descriptor base to the row end
+    const rsrc_t r = make_rsrc(row + (n0 - O), room * 4);
+    const int o32 = (int)O;
+    const int tail = (room & 1) && room < TILE_F ? (int)room - 1 : -1;  // a pair straddling the row end starts here
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
-        const int64_t q = 2 * (t + 256 * a);
-        if (q < O) continue;
-        const int64_t n = n0 + q - O;
+        const int q = 2 * (t + 256 * a);
         const float2 e = v[brev(a, 5)];
-        if (whole && aligned) {
-            *reinterpret_cast<float2*>(row + n) = e;
-        } else {
-            if (n < Lout) row[n] = e.x;
-            if (n + 1 < Lout) row[n + 1] = e.y;
-        }
+        const uint32_t voff = (q < o32 || q == tail) ? OOB : 8u * (uint32_t)t;
+        buf_store_f2(r, voff, 2048u * a, e);
+        if (q == tail && q >= o32) row[n0 - O + q] = e.x;       // single trailing sample
     }
 }
 
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     const int c = (int)(rco - r * (unsigned)a.Cout);
     const float* xrow = x + row_off(a.xmap, r, a.Cin == 1 ? 0 : c);
     float* yrow = y + row_off(a.ymap, r, c);
-    const float4* H = Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4;
+    const rsrc_t H = make_rsrc(Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4, H_TILE_F4 * 16);
 
     TileTw tw;
     float2 v[32], w[2][16];
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, float2 wk, bool self) {
         float2 xe, xo, ye, yo, za, zb;
         pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
-        pair_product(xe, xo, H[slot * TILE_T + t], wk, ye, yo);
+        pair_product(xe, xo, buf_load_f4(H, 16u * (uint32_t)t, 4096u * slot), wk, ye, yo);
         pair_merge(ye, yo, za, zb);
         NAT(w, ia) = za;
         if (!self) NAT(w, ib) = zb;
