@@ -121,14 +121,23 @@ __device__ __forceinline__ float2 unit_root(int num, float inv_half_den) {
 constexpr int TW_ROWS = 20;
 
 __device__ __forceinline__ void tile_twiddles(TileTw& tw, const float2* __restrict__ table, int t) {
+    // buffer loads: descriptor in SGPRs, one lane offset, row stride as the scalar offset
+    const uint64_t p = reinterpret_cast<uint64_t>(table);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, TW_ROWS * TILE_T * 8, 0x00020000);
+    auto row = [&](int i) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, 8u * (uint32_t)t, (uint32_t)(i * TILE_T * 8), 0);
+        return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+    };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tw.lo1[i] = table[i * TILE_T + t];
+    for (int i = 0; i < 4; ++i) tw.lo1[i] = row(i);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tw.hi1[i] = table[(4 + i) * TILE_T + t];
+    for (int i = 0; i < 8; ++i) tw.hi1[i] = row(4 + i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tw.lo2[i] = table[(12 + i) * TILE_T + t];
+    for (int i = 0; i < 4; ++i) tw.lo2[i] = row(12 + i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tw.hi2[i] = table[(16 + i) * TILE_T + t];
+    for (int i = 0; i < 4; ++i) tw.hi2[i] = row(16 + i);
 }
 
 // Host side: one table per device, created on first use (the only allocation the library makes;
