@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
     ap.add_argument("--length", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-default-lengths", action="store_true",
+                    help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
+                         "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
     ap.add_argument("--train", action="store_true",
                     help="also time forward+backward+gradient all-reduce (BASELINE configs[4]) at --train-batch per GPU")
     ap.add_argument("--train-batch", type=int, default=32)
@@ -138,6 +141,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.reference_default_lengths:
+        LENS.update(fsm_fir_len=4000, iir_len=16384, ir_len=60000)
     from grafx_amd import ops
     from grafx_amd.data import convert_to_tensor
     from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
@@ -273,7 +278,8 @@ def main():
                                    "ParametricEqualizer(6) + Compressor(iir) + STFTMaskedNoiseReverb + bus sums",
                        "batch_per_gpu": B, "global_batch": B * world, "audio_len": L, "channels": 2,
                        "fsm_fir_len": LENS["fsm_fir_len"], "iir_len": LENS["iir_len"], "ir_len": LENS["ir_len"],
-                       "mode": "forward render, reference-exact lengths (even L+N-1)", "parallelism": f"batch-shard x{world}"},
+                       "mode": ("forward render, reference-default even lengths (odd L+N-1: aliasing compatibility path)"
+                                if args.reference_default_lengths else "forward render, reference-exact lengths (even L+N-1)"), "parallelism": f"batch-shard x{world}"},
             "per_gpu_value": B * L * args.steps / elapsed,
             "roofline": roof,
         }
