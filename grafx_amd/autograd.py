@@ -79,7 +79,8 @@ def convolve(x, h, mode="causal"):
         else:
             y = LinearConvFn.apply(x, h, L + N - 1, 0)
     else:
-        y_pad = torch.fft.irfft(torch.fft.rfft(LinearConvFn.apply(x, h, L + N - 1, 0)))
+        z = LinearConvFn.apply(x, h, L + N - 1, 0)
+        y_pad = torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)  # float64 aliasing, see odd_length_alias
         if mode == "causal":
             y = y_pad[..., :L]
         elif mode == "zerophase":

@@ -1,0 +1,119 @@
+"""GPU parity on ragged / tiny / awkward shapes (edge cases of the hot path)."""
+import pytest
+import torch
+
+import oracle
+from conftest import assert_close, assert_parity
+from oracle import lti
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("L,N", [(1, 2), (1, 4), (2, 3), (3, 2), (5, 8), (17, 17), (100, 4097), (16385, 16385),
+                                  (12384, 4001), (12385, 4001), (24768, 4001), (8192, 8194), (33, 60001)])
+def test_convolve_ragged_shapes(L, N):
+    from grafx_amd.processors import convolve
+
+    torch.manual_seed(L * 7 + N)
+    x, h = torch.randn(2, 2, L), torch.randn(2, 1, N) / N**0.5
+    for mode in ("causal", "zerophase"):
+        with torch.no_grad():
+            y = convolve(x.cuda(), h.cuda(), mode=mode).cpu()
+        ref = oracle.convolve(x.double(), h.double(), mode).float()  # reference semantics (both parities)
+        assert y.shape == ref.shape
+        assert_close(y, ref, 2e-5, f"convolve L={L} N={N} {mode}")
+
+
+@pytest.mark.parametrize("L", [1, 3, 4, 5, 1023, 1024, 1025, 4099])
+@pytest.mark.parametrize("C", [1, 2])
+def test_compressor_ragged_lengths(L, C):
+    from grafx_amd.processors import Compressor
+
+    torch.manual_seed(L + C)
+    x = torch.randn(3, C, L)
+    p = {"log_threshold": torch.randn(3, 1), "log_ratio": torch.randn(3, 1), "log_knee": torch.randn(3, 1),
+         "z_alpha_pre": torch.randn(3, 1)}
+    for iir_len in (63, 64):
+        m = Compressor(energy_smoother="iir", iir_len=iir_len, flashfftconv=False)
+        with torch.no_grad():
+            y = m.cuda()(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+        ref64 = oracle.OracleCompressor(iir_len=iir_len)(x.double(), **{k: v.double() for k, v in p.items()}).float()
+        ref32 = oracle.OracleCompressor(iir_len=iir_len)(x, **p)
+        assert_parity(y, ref32, ref64, 2e-5, f"compressor L={L} C={C} iir_len={iir_len}")
+
+
+def test_degenerate_length_fails_like_the_reference():
+    """L = N = 1 gives P = 1: the reference's irfft has nothing to invert and raises; so do we."""
+    from grafx_amd.processors import convolve
+
+    x, h = torch.randn(1, 1, 1), torch.randn(1, 1, 1)
+    with pytest.raises(RuntimeError):
+        oracle.convolve(x, h, "causal")
+    with pytest.raises(RuntimeError):
+        convolve(x.cuda(), h.cuda(), mode="causal")
+
+
+@pytest.mark.parametrize("R,L", [(1, 7), (65, 130), (3, 1), (130, 63)])
+def test_ballistics_ragged(R, L):
+    from grafx_amd.processors import Ballistics
+
+    torch.manual_seed(R + L)
+    u, z = torch.rand(R, L) * 2, torch.randn(R, 2)
+    with torch.no_grad():
+        y = Ballistics()(u.cuda(), z.cuda()).cpu()
+    assert_close(y, oracle.ballistics(u, z), 1e-5, "ballistics")
+
+
+def test_single_row_mono_eq_and_gain():
+    from grafx_amd.processors import ParametricEqualizer, StereoGain
+
+    torch.manual_seed(1)
+    x = torch.randn(1, 1, 777)
+    p = {k: torch.randn(1, 1, 3) for k in ("w0", "q_inv", "log_gain")}
+    m = ParametricEqualizer(num_filters=3, flashfftconv=False, fsm_fir_len=65)
+    with torch.no_grad():
+        y = m.cuda()(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+        g = StereoGain()(x.cuda(), torch.randn(1, 2).cuda())
+    assert_close(y, oracle.OracleParametricEqualizer(num_filters=3, fsm_fir_len=65)(x, **p), 2e-5, "mono eq")
+    assert g.shape == (1, 2, 777)  # mono input broadcasts to stereo, as upstream
+
+
+def test_fsm_fir_lengths_and_limits():
+    from grafx_amd.processors import IIRFilter
+
+    torch.manual_seed(2)
+    Bs = torch.randn(2, 1, 2, 3) * 0.2 + torch.tensor([1.0, 0, 0])
+    As = torch.tensor([1.0, -1.2, 0.5]).expand(2, 1, 2, 3).contiguous()
+    for N in (2, 3, 64, 1000, 4095, 4096):
+        f = IIRFilter(flashfftconv=False, fsm_fir_len=N)
+        with torch.no_grad():
+            fir = f.fsm_fir(Bs.cuda(), As.cuda()).cpu()
+        assert_close(fir, lti.iir_fsm_fir(Bs, As, N), 1e-5, f"fsm N={N}")
+    with pytest.raises(NotImplementedError):
+        IIRFilter(flashfftconv=False, fsm_fir_len=8192).fsm_fir(Bs.cuda(), As.cuda())
+
+
+def test_render_3d_input_and_index_reads():
+    """3-D (unbatched) input and a graph whose reads are index-based (no reordering applied)."""
+    from grafx_amd.data import GRAFX, NodeConfigs, convert_to_tensor
+    from grafx_amd.processors import StereoGain
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+
+    G = GRAFX(config=NodeConfigs(["gain"]))
+    ins = [G.add("in") for _ in range(3)]
+    gains = [G.add("gain") for _ in range(3)]
+    out = G.add("out")
+    for i, g in zip(ins, gains[::-1]):  # crossed wiring -> index reads
+        G.connect(i, g)
+    for g in gains:
+        G.connect(g, out)
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    torch.manual_seed(3)
+    x = torch.randn(3, 2, 500)
+    lg = torch.randn(3, 2)
+    want, _, _ = render_grafx({"gain": oracle.OracleStereoGain()}, x, {"gain": {"log_gain": lg}}, rd)
+    rd_gpu = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    with torch.no_grad():
+        got, _, buf = render_grafx({"gain": StereoGain()}, x.cuda(), {"gain": {"log_gain": lg.cuda()}}, rd_gpu)
+    assert got.shape == want.shape
+    assert_close(got.cpu(), want, 1e-6, "3-D render")
