@@ -113,6 +113,93 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
     }
 }
 
+// Block-tiled variant for n_fft <= 384: one workgroup = 64 frames x all columns.  The A operand (masked
+// noise spectrum, one exp per bin) is generated ONCE per 32-deep k-chunk into LDS and shared by the 4
+// waves; each wave owns a 96-column slab (6 column tiles) for all 4 row tiles -> 24 MFMAs per k-step
+// against 4 LDS reads + 6 basis loads (the per-wave kernel above does 8 MFMAs per 9 loads and
+// regenerates A three times).
+constexpr int IST_KC = 32;           // k-depth per LDS chunk (8 MFMA k-steps)
+constexpr int IST_AROW = 80;         // floats per kk row of the A chunk (64 frames + pad: rows 16 banks apart)
+__global__ __launch_bounds__(256) void istft_frames_tiled_kernel(const float* __restrict__ noise_stft,
+                                                                 const float* __restrict__ init_lm,
+                                                                 const float* __restrict__ delta_lm,
+                                                                 const float* __restrict__ gain_env,
+                                                                 const float* __restrict__ basis,
+                                                                 float* __restrict__ frames, IstftArgs a) {
+    __shared__ float As[2][IST_KC * IST_AROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rc = blockIdx.y;
+    const int c = (int)(rc & 1);
+    const int m0 = blockIdx.x * 64;
+    const float* H0 = init_lm + rc * a.K;
+    const float* Hd = delta_lm + rc * a.K;
+    // A generation role: frame fm = tid & 63, bins kb = (tid >> 6) * 4 .. +3 of the chunk's 16 bins
+    const int fm = tid & 63, m = m0 + fm;
+    const bool m_ok = m < a.T;
+    const float mf = (float)m;
+    const float genv = (gain_env && m_ok) ? gain_env[rc * a.T + m] : 0.0f;
+
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int kq = lane >> 4, li = lane & 15;
+    const int colw = wave * 96 + li;
+    const int nchunks = (a.kpad + IST_KC - 1) / IST_KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        float* A = As[ch & 1];
+        const int kk0 = ch * IST_KC;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = (kk0 >> 1) + (tid >> 6) * 4 + q;
+            float re = 0.0f, im = 0.0f;
+            if (m_ok && k < a.K) {
+                const float slope = -softplus_t(Hd[k]);
+                float lm = __fadd_rn(H0[k], __fmul_rn(slope, mf));
+                if (gain_env) lm = __fadd_rn(lm, genv);
+                const float mask = expf(lm / 8.0f);
+                const float2 nz = *reinterpret_cast<const float2*>(noise_stft + (((int64_t)c * a.K + k) * a.T + m) * 2);
+                re = nz.x * mask;
+                im = nz.y * mask;
+            }
+            const int kkl = 2 * ((tid >> 6) * 4 + q);
+            A[kkl * IST_AROW + fm] = re;
+            A[(kkl + 1) * IST_AROW + fm] = im;
+        }
+        __syncthreads();  // chunk ch visible; the other buffer is free again two barriers later
+#pragma unroll
+        for (int ks = 0; ks < IST_KC / 4; ++ks) {
+            const int kk = kk0 + ks * 4 + kq;
+            float av[4], bv[6];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) av[rt] = A[(ks * 4 + kq) * IST_AROW + 16 * rt + li];
+            const float* brow = basis + (int64_t)kk * a.n_fft + colw;
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) bv[ct] = (kk < a.kpad && colw + 16 * ct < a.n_fft) ? brow[16 * ct] : 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 6; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) {
+            const int col = colw + 16 * ct;
+            if (col < a.n_fft) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mm = m0 + 16 * rt + kq * 4 + q;
+                    if (mm < a.T) frames[(rc * a.T + mm) * a.n_fft + col] = acc[rt][ct][q];
+                }
+            }
+        }
+}
+
 // overlap-add + envelope division + trim (centre) + optional ms->lr + energy.
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
                                                         float* __restrict__ ir, float* __restrict__ energy, IstftArgs a,
@@ -202,9 +289,15 @@ int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnit
     a.ir_len = ir_len;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(row_gain, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
-    dim3 g1((unsigned)((n_fft + 127) / 128), (unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
-    hipLaunchKernelGGL(istft_frames_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude, delta_log_magnitude,
-                       gain_env_log_magnitude, basis, (float*)ws, a);
+    if (n_fft <= 384) {
+        dim3 g1((unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
+        hipLaunchKernelGGL(istft_frames_tiled_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude,
+                           delta_log_magnitude, gain_env_log_magnitude, basis, (float*)ws, a);
+    } else {
+        dim3 g1((unsigned)((n_fft + 127) / 128), (unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
+        hipLaunchKernelGGL(istft_frames_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude,
+                           delta_log_magnitude, gain_env_log_magnitude, basis, (float*)ws, a);
+    }
     dim3 g2((unsigned)((ir_len + 255) / 256), (unsigned)R);
     hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, (const float*)ws, window, ir, row_gain, a, ms_to_lr);
     hipLaunchKernelGGL(energy_to_gain_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, row_gain, R);
