@@ -91,19 +91,28 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
     TileTw tw;
     tile_twiddles(tw, twtab, t);
     float2 v[32], w[2][16];
+    // the cascade response is evaluated once per bin of the half spectrum (k <= N/2 <= 2048) and shared
+    // through LDS; the Hermitian extension a c2r transform implies is read back from there
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        const int k = t + 256 * a;
+        if (k <= half) lds[k] = cascade_response(B, A, K, k, N);
+    }
+    __syncthreads();
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         const int k = t + 256 * a;
         float2 e = make_float2(0.0f, 0.0f);
-        if (k < N) {  // Hermitian extension of the half spectrum, as a c2r transform reads it
+        if (a < 17 && k < N) {
             const bool upper = k > half;
-            float2 Hk = cascade_response(B, A, K, upper ? N - k : k, N);
+            float2 Hk = lds[upper ? N - k : k];
             if (upper) Hk.y = -Hk.y;
             if (k == 0 || (even && k == half)) Hk.y = 0.0f;
             e = cmul(Hk, chirp(k, N, 1.0f));
         }
         v[a] = e;
     }
+    __syncthreads();  // the response table is dead; the tile passes reuse this LDS
     tile_forward(v, w, tw, lds, t);
 #pragma unroll
     for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], plan[q * TILE_T + t]);
