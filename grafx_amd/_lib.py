@@ -39,6 +39,7 @@ SIGNATURES = {
     "gfx_apply_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, ctypes.c_int, vp]),
     "gfx_stereo_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, vp]),
     "gfx_gather_sum_f32": (ctypes.c_int, [f32p, i64, i64, i64, vp, vp, f32p, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "gfx_gather_sum_fanout_f32": (ctypes.c_int, [f32p, i64, i64, i64, vp, vp, i64, f32p, i64, i64, i64, i64, i64, i64, i64, vp]),
     "gfx_istft_basis_bytes": (sz, [i64]),
     "gfx_istft_basis_f32": (ctypes.c_int, [f32p, f32p, i64, vp]),
     "gfx_stft_reverb_workspace_bytes": (sz, [i64, i64, i64]),

@@ -45,7 +45,59 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
     }
 }
 
+// Source-major variant for fan-out routing (a source feeding several destinations, e.g. every channel
+// strip -> its bus AND the send): each source row is read ONCE and added to up to NJ destination
+// accumulators selected by a per-source bit mask.  Per destination the sources still arrive in
+// increasing order, i.e. the same summation order as the destination-major kernel.
+template <int NJ>
+__global__ __launch_bounds__(256) void gather_sum_fanout_kernel(const float* __restrict__ buf, int64_t buf_sb,
+                                                                int64_t buf_sv, int64_t buf_sc,
+                                                                const int64_t* __restrict__ usrc,
+                                                                const int64_t* __restrict__ dmask, int U,
+                                                                float* __restrict__ out, int64_t out_sb,
+                                                                int64_t out_sv, int64_t out_sc, int J, int64_t L4) {
+    const int c = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const float* base = buf + b * buf_sb + (int64_t)c * buf_sc;
+    float* dst = out + b * out_sb + (int64_t)c * out_sc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int u = 0; u < U; ++u) {
+            const float4 v = reinterpret_cast<const float4*>(base + usrc[u] * buf_sv)[i];
+            const unsigned mask = (unsigned)dmask[u];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if ((mask >> j) & 1u) {
+                    acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (j < J) reinterpret_cast<float4*>(dst + (int64_t)j * out_sv)[i] = acc[j];
+    }
+}
+
 }  // namespace gfx
+
+extern "C" int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t buf_sc,
+                                         const int64_t* unique_src, const int64_t* dest_mask, int64_t U, float* out,
+                                         int64_t out_sb, int64_t out_sv, int64_t out_sc, int64_t B, int64_t J,
+                                         int64_t C, int64_t L, void* stream) {
+    if (!buf || !unique_src || !dest_mask || !out || B <= 0 || J <= 0 || J > 8 || C <= 0 || L <= 0 || U <= 0)
+        return GFX_EINVAL;
+    if (B > 65535 || C > 65535) return GFX_EINVAL;
+    const bool aligned = (((uintptr_t)buf | (uintptr_t)out) & 15) == 0 && (L % 4 == 0) &&
+                         ((buf_sb | buf_sv | buf_sc | out_sb | out_sv | out_sc) % 4 == 0);
+    if (!aligned) return GFX_EINVAL;  // callers fall back to gfx_gather_sum_f32
+    int64_t bx = (L / 4 + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(gfx::gather_sum_fanout_kernel<8>, dim3((unsigned)bx, (unsigned)C, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, buf, buf_sb, buf_sv, buf_sc, unique_src, dest_mask, (int)U, out, out_sb,
+                       out_sv, out_sc, (int)J, L / 4);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
 
 extern "C" int gfx_gather_sum_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t buf_sc, const int64_t* src_idx,
                                   const int64_t* seg_ptr, float* out, int64_t out_sb, int64_t out_sv, int64_t out_sc,

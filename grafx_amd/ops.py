@@ -288,3 +288,15 @@ def gather_sum(buf, src_idx, seg_ptr, out):
             "gfx_gather_sum_f32",
         )
     return out
+
+
+def gather_sum_fanout(buf, unique_src, dest_mask, out):
+    """Fan-out form of :func:`gather_sum`: source rows read once, up to 8 destinations (bit mask per source)."""
+    _require_gpu(buf, out)
+    B, _, C, L = buf.shape
+    J = out.shape[1]
+    with _timed("gather_sum_kernel", 4 * B * C * L * (unique_src.numel() + J)):
+        code = lib().gfx_gather_sum_fanout_f32(_ptr(buf), buf.stride(0), buf.stride(1), buf.stride(2), _ptr(unique_src),
+                                               _ptr(dest_mask), unique_src.numel(), _ptr(out), out.stride(0),
+                                               out.stride(1), out.stride(2), B, J, C, L, _stream())
+    return code == 0

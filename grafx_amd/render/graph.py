@@ -55,10 +55,26 @@ def _gather_plan(step, device):
             seg[j + 1] += 1
         for j in range(n_out):
             seg[j + 1] += seg[j]
+    n_out = len(seg) - 1
+    fan = None
+    uniq = sorted(set(sources))
+    if n_out <= 8 and len(uniq) < E:  # some source feeds several destinations: read each source once
+        masks = {u: 0 for u in uniq}
+        for j in range(n_out):
+            for e in range(seg[j], seg[j + 1]):
+                masks[sources[e]] |= 1 << j
+        fan = (torch.tensor(uniq, dtype=torch.long, device=device),
+               torch.tensor([masks[u] for u in uniq], dtype=torch.long, device=device))
     plan = (torch.tensor(sources, dtype=torch.long, device=device), torch.tensor(seg, dtype=torch.long, device=device),
-            len(seg) - 1)
+            n_out, fan)
     cache[key] = plan
     return plan
+
+
+def _gather(ops, buf, plan, out):
+    if plan[3] is not None and ops.gather_sum_fanout(buf, plan[3][0], plan[3][1], out):
+        return out
+    return ops.gather_sum(buf, plan[0], plan[1], out)
 
 
 def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
@@ -116,13 +132,13 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
                 a, b = step.source_reads[0].idx
                 out_view.copy_(buf.narrow(1, a, b - a))
             else:
-                ops.gather_sum(buf, plan[0], plan[1], out_view)
+                _gather(ops, buf, plan, out_view)
             continue
         if plan is None:
             a, b = step.source_reads[0].idx
             x_view = buf.narrow(1, a, b - a)
         else:
-            x_view = ops.gather_sum(buf, plan[0], plan[1], torch.empty(B, plan[2], C, L, device=x.device))
+            x_view = _gather(ops, buf, plan, torch.empty(B, plan[2], C, L, device=x.device))
         params = read_tensor_or_tensor_dict(per_type_parameters[node_type], step.parameter_read, dim=node_dim,
                                             postprocess=postprocess)
         common_i = {}
