@@ -178,11 +178,23 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
     const float invC = 1.0f / (float)a.C;
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    // software prefetch: the next tile's samples are requested before the current tile is scanned, so the
+    // HBM round trip overlaps the scan / log / exp work (the barrier inside scan_tile would otherwise fence it)
+    float na[DE], nb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+    load4(x0, (int64_t)DE * t, a.L, vx, na);
+    if (a.C == 2) load4(x1, (int64_t)DE * t, a.L, vx, nb);
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         const int64_t n = tile * DTILE + DE * t;
-        float xa[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, e[DE], env[DE];
-        load4(x0, n, a.L, vx, xa);
-        if (a.C == 2) load4(x1, n, a.L, vx, xb);
+        float xa[DE], xb[DE], e[DE], env[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            xa[i] = na[i];
+            xb[i] = nb[i];
+        }
+        if (tile + 1 < ntiles) {
+            load4(x0, n + DTILE, a.L, vx, na);
+            if (a.C == 2) load4(x1, n + DTILE, a.L, vx, nb);
+        }
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
             const float sq = a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i];
