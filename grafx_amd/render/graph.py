@@ -77,6 +77,24 @@ def _gather(ops, buf, plan, out):
     return ops.gather_sum(buf, plan[0], plan[1], out)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _touches_inputs(read, n_src):
+    if read.method == "slice":
+        return read.idx[0] < n_src
+    if read.method == "index":
+        return bool((read.idx < n_src).any()) if isinstance(read.idx, torch.Tensor) else any(i < n_src for i in read.idx)
+    return False
+
+
 def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
     if not input_signals.is_cuda or render_data.method == "one-by-one" or not render_data.siso_only:
         return False
@@ -119,7 +137,17 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
     postprocess = None if squeeze else flatten_batch_and_node
 
     buf = torch.empty(B, render_data.num_nodes, C, L, device=x.device)
-    buf[:, :n_src] = x
+    # The sources must end up in the buffer's first slots (the buffer is returned with every node's signal),
+    # but nothing has to wait for that copy: stages that read source rows read them from `x` itself, and the
+    # copy runs on a side stream underneath the first (compute-bound) stages.
+    main = torch.cuda.current_stream(x.device)
+    side = _side_stream(x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        buf[:, :n_src].copy_(x, non_blocking=True)
+    x.record_stream(side)
+    buf.record_stream(side)
+    copied = False  # has the main stream joined the copy yet?
     out_view = None
     for i in range(1, render_data.max_order + 1):
         step = render_data.iter_list[i]
@@ -127,16 +155,21 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         out_view = buf.narrow(1, d0, d1 - d0)
         plan = _gather_plan(step, x.device)
         node_type = step.node_type
+        src_read = step.source_reads[0]
+        from_inputs = plan is None and src_read.idx[1] <= n_src  # plain slice of source rows
+        if not from_inputs and not copied and _touches_inputs(src_read, n_src):
+            main.wait_stream(side)
+            copied = True
         if node_type not in processors:  # in / out / mix: the (summed) input is the output
             if plan is None:
                 a, b = step.source_reads[0].idx
-                out_view.copy_(buf.narrow(1, a, b - a))
+                out_view.copy_((x if from_inputs else buf).narrow(1, a, b - a))
             else:
                 _gather(ops, buf, plan, out_view)
             continue
         if plan is None:
             a, b = step.source_reads[0].idx
-            x_view = buf.narrow(1, a, b - a)
+            x_view = (x if from_inputs else buf).narrow(1, a, b - a)
         else:
             x_view = _gather(ops, buf, plan, torch.empty(B, plan[2], C, L, device=x.device))
         params = read_tensor_or_tensor_dict(per_type_parameters[node_type], step.parameter_read, dim=node_dim,
@@ -146,6 +179,8 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             common_i = read_tensor_or_tensor_dict(common_parameters, step.dest_write, dim=node_dim,
                                                   postprocess=postprocess)
         processors[node_type].render_into(x_view, out_view, **params, **common_i)
+    if not copied:
+        main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:
         return out_view[0], [], buf[0]
     return out_view, [], buf
