@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgrafx_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"] + os.environ.get("GRAFX_HIPCC_FLAGS", "").split()
+# -pragma-unroll-threshold: the FFT tile passes are `#pragma unroll` loop nests around inline packed-FP32
+# instructions; the default size cap stops unrolling them (and then every twiddle index is a run-time value).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
+         "-mllvm", "-pragma-unroll-threshold=1048576"] + os.environ.get("GRAFX_HIPCC_FLAGS", "").split()
 
 
 def sources():

@@ -31,17 +31,66 @@ constexpr int TILE_LDS_BYTES = TILE_LDS_F2 * 8;       // 73,728 B
 constexpr int H_SLOTS = 17;          // (He,Ho) pair slots per thread (slot 16: thread 0 only)
 constexpr int H_TILE_F4 = H_SLOTS * TILE_T;           // float4 per (row-channel, partition)
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+// ---- complex arithmetic on packed FP32 (v_pk_*_f32) ---------------------------------------------
+// A complex value is one even-aligned VGPR pair (re, im).  CDNA3/4 execute v_pk_add/mul/fma_f32 on
+// both halves at the rate of one scalar op, and their op_sel / neg modifiers pick and negate halves for
+// free, so a complex add is ONE instruction, a complex multiply TWO, and multiplications by +-i or a
+// conjugation fold into the neighbouring add.  The compiler maps plain vector expressions (a + b,
+// a * const) to the packed forms by itself; the forms that need a half-swap plus a one-sided negation
+// it does not find, so those are spelled out below.  (Build with -fno-slp-vectorize: the automatic
+// packing of the *scalar* code is slower than scalar code.)
+using cx = float __attribute__((ext_vector_type(2)));
+using f4v = float __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ cx to_cx(float2 a) { return cx{a.x, a.y}; }
+__device__ __forceinline__ cx cadd(cx a, cx b) { return a + b; }
+__device__ __forceinline__ cx csub(cx a, cx b) { return a - b; }
+__device__ __forceinline__ cx cswap(cx a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cx cconj(cx a) { return a * cx{1.0f, -1.0f}; }
+__device__ __forceinline__ cx mul_neg_i(cx a) { return cswap(a) * cx{1.0f, -1.0f}; }  // a * (-i)
+__device__ __forceinline__ cx mul_pos_i(cx a) { return cswap(a) * cx{-1.0f, 1.0f}; }  // a * (+i)
+
+#define GFX_PK2(name, insn)                                                  \
+    __device__ __forceinline__ cx name(cx a, cx b) {                         \
+        cx r;                                                                \
+        asm(insn : "=v"(r) : "v"(a), "v"(b));                                \
+        return r;                                                            \
+    }
+// (a - b) * (-i) = (a.y - b.y, b.x - a.x)
+GFX_PK2(sub_mul_neg_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]")
+// (a - b) * (+i) = (b.y - a.y, a.x - b.x)
+GFX_PK2(sub_mul_pos_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]")
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+GFX_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")
+// (a - conj(b)) * (-i) = (a.y + b.y, b.x - a.x)
+GFX_PK2(sub_conj_mul_neg_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]")
+// a + i*b = (a.x - b.y, a.y + b.x)
+GFX_PK2(add_mul_pos_i, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+// conj(a - i*b) = (a.x + b.y, b.x - a.y)
+GFX_PK2(conj_sub_mul_pos_i, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]")
+#undef GFX_PK2
+
+// a * w:  t = (a.x w.x, a.y w.x);  r = (a.y * -w.y + t.x, a.x * w.y + t.y)
+__device__ __forceinline__ cx cmul(cx a, cx w) {
+    cx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
-    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+// a * conj(w)
+__device__ __forceinline__ cx cmulc(cx a, cx w) {
+    cx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-__device__ __forceinline__ float2 mul_pos_i(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+// acc + a * w
+__device__ __forceinline__ cx cmac(cx acc, cx a, cx w) {
+    cx t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
 
 // W_32^j = exp(-2*pi*i*j/32), j = 0..15 (cos, sin magnitudes)
 __device__ constexpr float kCos32[16] = {
@@ -55,13 +104,23 @@ __device__ constexpr float kSin32[16] = {
     1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
     0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
 
-// d * W_32^(+-idx32): forward uses exp(-i..), INV uses exp(+i..)
+// d * W_32^(+-idx32), idx32 in [0, 32): forward uses exp(-i..), INV uses exp(+i..).  idx32 is a compile-time
+// constant at every call site, so the factors become scalar-register constants of two packed instructions.
 template <bool INV>
-__device__ __forceinline__ float2 tw32(float2 d, int idx32) {
+__device__ __forceinline__ cx tw32(cx d, int idx32) {
     if (idx32 == 0) return d;
+    if (idx32 == 16) return d * cx{-1.0f, -1.0f};
     if (idx32 == 8) return INV ? mul_pos_i(d) : mul_neg_i(d);
-    const float c = kCos32[idx32], s = INV ? kSin32[idx32] : -kSin32[idx32];  // w = c + i*s
-    return make_float2(fmaf(d.x, c, -d.y * s), fmaf(d.x, s, d.y * c));
+    if (idx32 == 24) return INV ? mul_neg_i(d) : mul_pos_i(d);
+    const float sg = idx32 >= 16 ? -1.0f : 1.0f;
+    const float c = sg * kCos32[idx32 & 15], s = sg * (INV ? kSin32[idx32 & 15] : -kSin32[idx32 & 15]);  // w = c + i*s
+    return d * cx{c, c} + cswap(d) * cx{-s, s};
+}
+// (a - b) * W_32^(+-idx32), idx32 in [0, 16)
+template <bool INV>
+__device__ __forceinline__ cx tw32_sub(cx a, cx b, int idx32) {
+    if (idx32 == 8) return INV ? sub_mul_pos_i(a, b) : sub_mul_neg_i(a, b);
+    return tw32<INV>(a - b, idx32);
 }
 
 constexpr __host__ __device__ int brev(int v, int bits) {
@@ -72,7 +131,7 @@ constexpr __host__ __device__ int brev(int v, int bits) {
 
 // In-register radix-2 DIF DFT of N (16 or 32) points; result for frequency k is at v[brev(k)].
 template <int N, bool INV>
-__device__ __forceinline__ void dif(float2 (&v)[N]) {
+__device__ __forceinline__ void dif(cx (&v)[N]) {
 #pragma unroll
     for (int len = N; len >= 2; len >>= 1) {
         const int half = len >> 1;
@@ -80,9 +139,9 @@ __device__ __forceinline__ void dif(float2 (&v)[N]) {
         for (int base = 0; base < N; base += len) {
 #pragma unroll
             for (int j = 0; j < half; ++j) {
-                const float2 a = v[base + j], b = v[base + j + half];
+                const cx a = v[base + j], b = v[base + j + half];
                 v[base + j] = cadd(a, b);
-                v[base + j + half] = tw32<INV>(csub(a, b), j * (32 / len));
+                v[base + j + half] = tw32_sub<INV>(a, b, j * (32 / len));
             }
         }
     }
@@ -91,19 +150,19 @@ __device__ __forceinline__ void dif(float2 (&v)[N]) {
 // Per-thread twiddles, kept two-level to save VGPRs: W^(t*k1) = lo[k1 & 3] * hi[k1 >> 2]
 // (one extra complex multiply per use, one extra rounding ~6e-8).
 struct TileTw {
-    float2 lo1[4], hi1[8];  // W_8192^(t*i), W_8192^(t*4i)
-    float2 lo2[4], hi2[4];  // W_256^(d*i),  W_256^(d*4i), d = t & 15
+    cx lo1[4], hi1[8];  // W_8192^(t*i), W_8192^(t*4i)
+    cx lo2[4], hi2[4];  // W_256^(d*i),  W_256^(d*4i), d = t & 15
 
-    __device__ __forceinline__ float2 fwd1(float2 e, int k1) const { return apply<false>(e, lo1[k1 & 3], hi1[k1 >> 2], k1 & 3, k1 >> 2); }
-    __device__ __forceinline__ float2 inv1(float2 e, int k1) const { return apply<true>(e, lo1[k1 & 3], hi1[k1 >> 2], k1 & 3, k1 >> 2); }
-    __device__ __forceinline__ float2 fwd2(float2 e, int k2) const { return apply<false>(e, lo2[k2 & 3], hi2[k2 >> 2], k2 & 3, k2 >> 2); }
-    __device__ __forceinline__ float2 inv2(float2 e, int k2) const { return apply<true>(e, lo2[k2 & 3], hi2[k2 >> 2], k2 & 3, k2 >> 2); }
-    __device__ __forceinline__ float2 base() const { return lo1[1]; }  // W_8192^t
+    __device__ __forceinline__ cx fwd1(cx e, int k1) const { return apply<false>(e, lo1[k1 & 3], hi1[k1 >> 2], k1 & 3, k1 >> 2); }
+    __device__ __forceinline__ cx inv1(cx e, int k1) const { return apply<true>(e, lo1[k1 & 3], hi1[k1 >> 2], k1 & 3, k1 >> 2); }
+    __device__ __forceinline__ cx fwd2(cx e, int k2) const { return apply<false>(e, lo2[k2 & 3], hi2[k2 >> 2], k2 & 3, k2 >> 2); }
+    __device__ __forceinline__ cx inv2(cx e, int k2) const { return apply<true>(e, lo2[k2 & 3], hi2[k2 >> 2], k2 & 3, k2 >> 2); }
+    __device__ __forceinline__ cx base() const { return lo1[1]; }  // W_8192^t
 
     template <bool CONJ>
-    static __device__ __forceinline__ float2 apply(float2 e, float2 lo, float2 hi, int il, int ih) {
+    static __device__ __forceinline__ cx apply(cx e, cx lo, cx hi, int il, int ih) {
         if (il == 0 && ih == 0) return e;
-        const float2 w = il == 0 ? hi : (ih == 0 ? lo : cmul(lo, hi));
+        const cx w = il == 0 ? hi : (ih == 0 ? lo : cmul(lo, hi));
         return CONJ ? cmulc(e, w) : cmul(e, w);
     }
 };
@@ -128,7 +187,7 @@ __device__ __forceinline__ void tile_twiddles(TileTw& tw, const float2* __restri
         reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, TW_ROWS * TILE_T * 8, 0x00020000);
     auto row = [&](int i) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, 8u * (uint32_t)t, (uint32_t)(i * TILE_T * 8), 0);
-        return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+        return __builtin_bit_cast(cx, v);
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i) tw.lo1[i] = row(i);
@@ -153,7 +212,7 @@ __device__ __forceinline__ int bf_b(int t) { return t == 0 ? 256 : 512 - t; }
 
 // Forward: v[a] = z[t + 256*a] (natural order)  ->  w[bf][brev4(k3)] = Z[j_bf + 512*k3].
 // Uses 3 barriers; on return other threads may still be reading S2.
-__device__ __forceinline__ void tile_forward(float2 (&v)[32], float2 (&w)[2][16], const TileTw& tw, float2* lds, int t) {
+__device__ __forceinline__ void tile_forward(cx (&v)[32], cx (&w)[2][16], const TileTw& tw, cx* lds, int t) {
     dif<32, false>(v);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -162,7 +221,7 @@ __device__ __forceinline__ void tile_forward(float2 (&v)[32], float2 (&w)[2][16]
     }
     __syncthreads();
     const int kk = t >> 4, d = t & 15;
-    float2 u[2][16];
+    cx u[2][16];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -181,12 +240,12 @@ __device__ __forceinline__ void tile_forward(float2 (&v)[32], float2 (&w)[2][16]
 #pragma unroll
     for (int bf = 0; bf < 2; ++bf) {
         const int j = bf ? bf_b(t) : bf_a(t);
-        const float4* row = reinterpret_cast<const float4*>(lds + s2_row(j >> 5, j & 31));
+        const f4v* row = reinterpret_cast<const f4v*>(lds + s2_row(j >> 5, j & 31));
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float4 p = row[q];
-            w[bf][2 * q] = make_float2(p.x, p.y);
-            w[bf][2 * q + 1] = make_float2(p.z, p.w);
+            const f4v p = row[q];
+            w[bf][2 * q] = p.lo;
+            w[bf][2 * q + 1] = p.hi;
         }
         dif<16, false>(w[bf]);
     }
@@ -195,24 +254,21 @@ __device__ __forceinline__ void tile_forward(float2 (&v)[32], float2 (&w)[2][16]
 // Inverse (unnormalised): w[bf][brev4(k3)] = Z'[j_bf + 512*k3] (the layout tile_forward leaves)
 //   ->  v[brev5(a)] = z'[t + 256*a].
 // The caller must have a barrier between the last S2 read of tile_forward and this call.
-__device__ __forceinline__ void tile_inverse(float2 (&w)[2][16], float2 (&v)[32], const TileTw& tw, float2* lds, int t) {
+__device__ __forceinline__ void tile_inverse(cx (&w)[2][16], cx (&v)[32], const TileTw& tw, cx* lds, int t) {
 #pragma unroll
     for (int bf = 0; bf < 2; ++bf) {
-        float2 p[16];
+        cx p[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) p[k] = w[bf][brev(k, 4)];  // register renaming only
         dif<16, true>(p);
         const int j = bf ? bf_b(t) : bf_a(t);
-        float4* row = reinterpret_cast<float4*>(lds + s2_row(j >> 5, j & 31));
+        f4v* row = reinterpret_cast<f4v*>(lds + s2_row(j >> 5, j & 31));
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float2 e0 = p[brev(2 * q, 4)], e1 = p[brev(2 * q + 1, 4)];
-            row[q] = make_float4(e0.x, e0.y, e1.x, e1.y);
-        }
+        for (int q = 0; q < 8; ++q) row[q] = __builtin_shufflevector(p[brev(2 * q, 4)], p[brev(2 * q + 1, 4)], 0, 1, 2, 3);
     }
     __syncthreads();
     const int kk = t >> 4, d = t & 15;
-    float2 u[2][16];
+    cx u[2][16];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -240,44 +296,46 @@ __device__ __forceinline__ void tile_inverse(float2 (&w)[2][16], float2 (&v)[32]
 //   Ye = He*Xe + W_M^k*Ho*Xo,  Yo = Ho*Xe + He*Xo
 //   Z'[k] = Ye + i*Yo,  Z'[M-k] = conj(Ye - i*Yo)
 // where (He, Ho) are the spectra of the even / odd filter taps scaled by 1/(4M).
-__device__ __forceinline__ void pair_split(float2 za, float2 zb, float2& xe, float2& xo) {
-    const float2 b = cconj(zb);
-    xe = cadd(za, b);
-    xo = mul_neg_i(csub(za, b));
+__device__ __forceinline__ void pair_split(cx za, cx zb, cx& xe, cx& xo) {
+    xe = add_conj(za, zb);
+    xo = sub_conj_mul_neg_i(za, zb);
 }
-__device__ __forceinline__ void pair_product(float2 xe, float2 xo, float4 h, float2 wk, float2& ye, float2& yo) {
-    const float2 he = make_float2(h.x, h.y), ho = make_float2(h.z, h.w);
-    const float2 who = cmul(wk, ho);
-    ye = cadd(cmul(he, xe), cmul(who, xo));
-    yo = cadd(cmul(ho, xe), cmul(he, xo));
+__device__ __forceinline__ void pair_product(cx xe, cx xo, f4v h, cx wk, cx& ye, cx& yo) {
+    const cx he = h.lo, ho = h.hi;
+    const cx who = cmul(wk, ho);
+    ye = cmac(cmul(he, xe), who, xo);
+    yo = cmac(cmul(ho, xe), he, xo);
 }
-__device__ __forceinline__ void pair_merge(float2 ye, float2 yo, float2& za, float2& zb) {
-    const float2 iyo = mul_pos_i(yo);
-    za = cadd(ye, iyo);
-    zb = cconj(csub(ye, iyo));
+// (ye, yo) += the product (partitioned convolution accumulates over partitions)
+__device__ __forceinline__ void pair_product_acc(cx xe, cx xo, f4v h, cx wk, cx& ye, cx& yo) {
+    const cx he = h.lo, ho = h.hi;
+    const cx who = cmul(wk, ho);
+    ye = cmac(cmac(ye, he, xe), who, xo);
+    yo = cmac(cmac(yo, ho, xe), he, xo);
+}
+__device__ __forceinline__ void pair_merge(cx ye, cx yo, cx& za, cx& zb) {
+    za = add_mul_pos_i(ye, yo);
+    zb = conj_sub_mul_pos_i(ye, yo);
 }
 
-// W_16^k3 (forward sign) as a compile-time-foldable constant
-__device__ __forceinline__ float2 w16(int k3) {
-    const float2 w = tw32<false>(make_float2(1.0f, 0.0f), 2 * (k3 & 7));
-    return (k3 & 8) ? make_float2(-w.x, -w.y) : w;
-}
+// a * W_16^k3 (forward sign), k3 a compile-time constant
+__device__ __forceinline__ cx mul_w16(cx a, int k3) { return tw32<false>(a, 2 * k3); }
 
 // Visit every mirrored pair held by thread t.  fn(slot, ia, ib, wk, self): ia/ib index into the
 // flattened [2][16] natural-order arrays (bf*16 + k3); wk = W_M^k for k = bin of ia.
 template <typename Fn>
-__device__ __forceinline__ void for_each_pair(int t, float2 wj, Fn&& fn) {
+__device__ __forceinline__ void for_each_pair(int t, cx wj, Fn&& fn) {
     if (t != 0) {
 #pragma unroll
-        for (int k3 = 0; k3 < 16; ++k3) fn(k3, k3, 16 + (15 - k3), cmul(wj, w16(k3)), false);
+        for (int k3 = 0; k3 < 16; ++k3) fn(k3, k3, 16 + (15 - k3), mul_w16(wj, k3), false);
     } else {
-        fn(0, 0, 0, make_float2(1.0f, 0.0f), true);    // k = 0
-        fn(8, 8, 8, make_float2(-1.0f, 0.0f), true);   // k = M/2
+        const cx one = {1.0f, 0.0f};
+        fn(0, 0, 0, one, true);               // k = 0
+        fn(8, 8, 8, mul_w16(one, 8), true);   // k = M/2
 #pragma unroll
-        for (int k3 = 1; k3 < 8; ++k3) fn(k3, k3, 16 - k3, w16(k3), false);
-        const float2 w256 = tw32<false>(make_float2(1.0f, 0.0f), 1);  // W_8192^256 = W_32^1
+        for (int k3 = 1; k3 < 8; ++k3) fn(k3, k3, 16 - k3, mul_w16(one, k3), false);
 #pragma unroll
-        for (int k3 = 0; k3 < 8; ++k3) fn(9 + k3, 16 + k3, 16 + (15 - k3), cmul(w256, w16(k3)), false);
+        for (int k3 = 0; k3 < 8; ++k3) fn(9 + k3, 16 + k3, 16 + (15 - k3), tw32<false>(one, 1 + 2 * k3), false);  // W_8192^256 = W_32^1
     }
 }
 

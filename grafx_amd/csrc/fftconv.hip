@@ -79,23 +79,22 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
     const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)nb);
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
 }
-__device__ __forceinline__ float2 buf_load_f2(rsrc_t r, uint32_t voff, uint32_t soff) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+__device__ __forceinline__ cx buf_load_f2(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(cx, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
-__device__ __forceinline__ float4 buf_load_f4(rsrc_t r, uint32_t voff, uint32_t soff) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+__device__ __forceinline__ f4v buf_load_f4(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff, uint32_t soff, float2 e) {
+__device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff, uint32_t soff, cx e) {
     using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-    const u32x2 v = {__float_as_uint(e.x), __float_as_uint(e.y)};
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e), r, voff, soff, 0);
 }
 constexpr uint32_t OOB = 0xffffffffu;  // lane offset that the range check always rejects
 
 // v[a] = (x[s + 2m], x[s + 2m + 1]), m = t + 256 a; x is zero outside [0, L).  `row` = start of the signal row.
-__device__ __forceinline__ void load_window(float2 (&v)[32], const float* __restrict__ row, int64_t s, int64_t L,
+// Straight-line in the common case: the two special cases (a window starting before the row, a pair straddling
+// sample 0) sit behind one wave-uniform branch after all 32 loads have been issued.
+__device__ __forceinline__ void load_window(cx (&v)[32], const float* __restrict__ row, int64_t s, int64_t L,
                                             int t, float gain) {
     // descriptor starts at the window (possibly before the row for the first tile: those lanes are masked)
     const rsrc_t r = make_rsrc(row + s, (L - s) * 4);
@@ -105,14 +104,22 @@ __device__ __forceinline__ void load_window(float2 (&v)[32], const float* __rest
     for (int a = 0; a < 32; ++a) {
         const int n = s32 + 2 * (t + 256 * a);                 // sample index of the pair's first element (if clip)
         const uint32_t voff = (clip && n < 0) ? OOB : 8u * (uint32_t)t;
-        float2 e = buf_load_f2(r, voff, 2048u * a);
-        if (clip && n == -1) e = make_float2(0.0f, row[0]);    // pair straddling n = 0 (odd window starts only)
-        v[a] = make_float2(e.x * gain, e.y * gain);
+        v[a] = buf_load_f2(r, voff, 2048u * a);
+    }
+    if (clip && (s32 & 1)) {                                   // odd start: the pair (x[-1], x[0]) was masked as a whole
+        const float x0 = row[0];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            if (s32 + 2 * (t + 256 * a) == -1) v[a] = cx{0.0f, x0};
+    }
+    if (gain != 1.0f) {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) v[a] *= gain;
     }
 }
 
 // y[n0 + (2m - O)] for 2m >= O, n < Lout;  v[brev5(a)] = (z'[2m], z'[2m+1])
-__device__ __forceinline__ void store_valid(const float2 (&v)[32], float* __restrict__ row, int64_t n0, int64_t O,
+__device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict__ row, int64_t n0, int64_t O,
                                             int64_t Lout, int t) {
     const int64_t room = Lout - (n0 - O);                      // samples from the descriptor base to the row end
     const rsrc_t r = make_rsrc(row + (n0 - O), room * 4);
@@ -121,10 +128,19 @@ __device__ __forceinline__ void store_valid(const float2 (&v)[32], float* __rest
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         const int q = 2 * (t + 256 * a);
-        const float2 e = v[brev(a, 5)];
         const uint32_t voff = (q < o32 || q == tail) ? OOB : 8u * (uint32_t)t;
-        buf_store_f2(r, voff, 2048u * a, e);
-        if (q == tail && q >= o32) row[n0 - O + q] = e.x;       // single trailing sample
+        buf_store_f2(r, voff, 2048u * a, v[brev(a, 5)]);
+    }
+    if (tail >= o32) {                                         // uniform: single trailing sample of an odd-length row
+        float last = 0.0f;
+        bool mine = false;
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            if (2 * (t + 256 * a) == tail) {
+                last = v[brev(a, 5)].x;
+                mine = true;
+            }
+        if (mine) row[n0 - O + tail] = last;
     }
 }
 
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
                                                           int64_t gain_div, float4* __restrict__ Hs, int64_t N,
                                                           int nparts, int64_t part_len,
                                                           const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned b = blockIdx.x;
     const unsigned rc = b / (unsigned)nparts;
@@ -145,17 +161,17 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
     const float g = gain ? gain[rc / (unsigned)gain_div] : 1.0f;
 
     TileTw tw;
-    float2 v[32], w[2][16];
+    cx v[32], w[2][16];
     load_window(v, h + (int64_t)rc * N + start, 0, len, t, g);
     tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
 
-    float4* out = Hs + (int64_t)b * H_TILE_F4;
+    f4v* out = reinterpret_cast<f4v*>(Hs) + (int64_t)b * H_TILE_F4;
     const float sc = 1.0f / (4.0f * TILE_M);
-    for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, float2, bool) {
-        const float2 A = NAT(w, ia), B = cconj(NAT(w, ib));
-        const float2 he = cadd(A, B), ho = mul_neg_i(csub(A, B));
-        out[slot * TILE_T + t] = make_float4(he.x * sc, he.y * sc, ho.x * sc, ho.y * sc);
+    for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx, bool) {
+        cx he, ho;
+        pair_split(NAT(w, ia), NAT(w, ib), he, ho);
+        out[slot * TILE_T + t] = __builtin_shufflevector(he * sc, ho * sc, 0, 1, 2, 3);
     });
 }
 
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
 __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
                                                              float* __restrict__ y, ConvArgs a,
                                                              const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
     if (lb >= (unsigned)a.nblocks) return;
@@ -176,16 +192,22 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     float* yrow = y + row_off(a.ymap, r, c);
     const rsrc_t H = make_rsrc(Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4, H_TILE_F4 * 16);
 
+    // Every global load of the tile is issued up front: the window, the twiddles, and the filter spectrum
+    // (needed only after the forward transform, by which time it has long arrived).  Left to itself the
+    // compiler issues each spectrum load right before its use and waits for it: 16 serialised L2 round trips.
     TileTw tw;
-    float2 v[32], w[2][16];
+    cx v[32], w[2][16];
+    f4v hreg[H_SLOTS];
     load_window(v, xrow, a.off + tile * a.V - a.O, a.L, t, 1.0f);
     tile_twiddles(tw, twtab, t);
+#pragma unroll
+    for (int q = 0; q < H_SLOTS; ++q) hreg[q] = buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
+    __builtin_amdgcn_sched_barrier(0);
     tile_forward(v, w, tw, lds, t);
-
-    for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, float2 wk, bool self) {
-        float2 xe, xo, ye, yo, za, zb;
+    for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool self) {
+        cx xe, xo, ye, yo, za, zb;
         pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
-        pair_product(xe, xo, buf_load_f4(H, 16u * (uint32_t)t, 4096u * slot), wk, ye, yo);
+        pair_product(xe, xo, hreg[slot], wk, ye, yo);
         pair_merge(ye, yo, za, zb);
         NAT(w, ia) = za;
         if (!self) NAT(w, ib) = zb;
@@ -202,7 +224,7 @@ __device__ __forceinline__ bool window_live(int64_t s, int64_t L) { return s + T
 __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restrict__ x, float2* __restrict__ Zs,
                                                           ConvArgs a, int64_t nwin,
                                                           const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
     if (lb >= (unsigned)a.nblocks) return;
@@ -213,11 +235,11 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
     const unsigned xr = rcx / (unsigned)a.Cin;
     const float* xrow = x + row_off(a.xmap, xr, (int)(rcx - xr * (unsigned)a.Cin));
     TileTw tw;
-    float2 v[32], w[2][16];
+    cx v[32], w[2][16];
     load_window(v, xrow, s, a.L, t, 1.0f);
     tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
-    float2* out = Zs + (int64_t)lb * TILE_M;
+    cx* out = reinterpret_cast<cx*>(Zs) + (int64_t)lb * TILE_M;
 #pragma unroll
     for (int q = 0; q < 32; ++q) out[q * TILE_T + t] = w[q >> 4][q & 15];
 }
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
 __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restrict__ Zs, const float4* __restrict__ Hs,
                                                            float* __restrict__ y, ConvArgs a, int64_t nwin,
                                                            const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
     if (lb >= (unsigned)a.nblocks) return;
@@ -235,34 +257,32 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     const unsigned r = rco / (unsigned)a.Cout;
     const int c = (int)(rco - r * (unsigned)a.Cout);
     float* yrow = y + row_off(a.ymap, r, c);
-    const float4* H = Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
-    const float2* Z = Zs + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
+    const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
+    const cx* Z = reinterpret_cast<const cx*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
 
-    float2 ye[H_SLOTS], yo[H_SLOTS];
+    cx ye[H_SLOTS], yo[H_SLOTS];
 #pragma unroll
-    for (int s = 0; s < H_SLOTS; ++s) ye[s] = yo[s] = make_float2(0.0f, 0.0f);
-    const float2 wj = twtab[TILE_T + t];  // W_8192^t
+    for (int s = 0; s < H_SLOTS; ++s) ye[s] = yo[s] = cx{0.0f, 0.0f};
+    const cx wj = to_cx(twtab[TILE_T + t]);  // W_8192^t
 
     for (int p = 0; p < a.nparts; ++p) {
         const int64_t j = tile - p;
         if (!window_live(a.off - a.O + j * a.V, a.L)) continue;
-        const float2* Zj = Z + (j + a.nparts - 1) * TILE_M;
-        const float4* Hp = H + (int64_t)p * H_TILE_F4;
-        float2 w[2][16];
+        const cx* Zj = Z + (j + a.nparts - 1) * TILE_M;
+        const f4v* Hp = H + (int64_t)p * H_TILE_F4;
+        cx w[2][16];
 #pragma unroll
         for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = Zj[q * TILE_T + t];
-        for_each_pair(t, wj, [&](int slot, int ia, int ib, float2 wk, bool) {
-            float2 xe, xo, de, dn;
+        for_each_pair(t, wj, [&](int slot, int ia, int ib, cx wk, bool) {
+            cx xe, xo;
             pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
-            pair_product(xe, xo, Hp[slot * TILE_T + t], wk, de, dn);
-            ye[slot] = cadd(ye[slot], de);
-            yo[slot] = cadd(yo[slot], dn);
+            pair_product_acc(xe, xo, Hp[slot * TILE_T + t], wk, ye[slot], yo[slot]);
         });
     }
 
-    float2 pz[2][16], v[32];
-    for_each_pair(t, wj, [&](int slot, int ia, int ib, float2, bool self) {
-        float2 za, zb;
+    cx pz[2][16], v[32];
+    for_each_pair(t, wj, [&](int slot, int ia, int ib, cx, bool self) {
+        cx za, zb;
         pair_merge(ye[slot], yo[slot], za, zb);
         NAT(pz, ia) = za;
         if (!self) NAT(pz, ib) = zb;

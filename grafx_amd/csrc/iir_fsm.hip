@@ -31,20 +31,20 @@ __device__ __forceinline__ float2 chirp(int k, int N, float sign) {
 
 __global__ __launch_bounds__(TILE_T, 2) void bluestein_plan_kernel(float2* __restrict__ plan, int N,
                                                                    const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     TileTw tw;
     tile_twiddles(tw, twtab, t);
-    float2 v[32], w[2][16];
+    cx v[32], w[2][16];
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         const int i = t + 256 * a;
         const int m = i < N ? i : (i > TILE_M - N ? TILE_M - i : -1);  // |m|; b[m] is even in m
-        v[a] = m >= 0 ? chirp(m, N, -1.0f) : make_float2(0.0f, 0.0f);
+        v[a] = m >= 0 ? to_cx(chirp(m, N, -1.0f)) : cx{0.0f, 0.0f};
     }
     tile_forward(v, w, tw, lds, t);
 #pragma unroll
-    for (int q = 0; q < 32; ++q) plan[q * TILE_T + t] = w[q >> 4][q & 15];
+    for (int q = 0; q < 32; ++q) reinterpret_cast<cx*>(plan)[q * TILE_T + t] = w[q >> 4][q & 15];
 }
 
 // complex division, scaled like torch's vectorised complex64 kernel (divide through by max(|c|,|d|))
@@ -72,7 +72,7 @@ __device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, 
         const float2 num = make_float2((b0 + b1 * d1.x) + b2 * d2.x, (b1 * d1.y) + b2 * d2.y);
         const float2 den = make_float2((a0 + a1 * d1.x) + a2 * d2.x, (a1 * d1.y) + a2 * d2.y);
         const float2 q = cdiv(num, den);
-        H = (i == 0) ? q : cmul(H, q);
+        H = (i == 0) ? q : make_float2(fmaf(H.x, q.x, -H.y * q.y), fmaf(H.x, q.y, H.y * q.x));
     }
     return H;
 }
@@ -80,7 +80,7 @@ __device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, 
 __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
                                                             const float2* __restrict__ plan, float* __restrict__ h,
                                                             int K, int N, const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const int64_t rc = blockIdx.x;
     const float* B = Bs + rc * K * 3;
@@ -90,32 +90,32 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
 
     TileTw tw;
     tile_twiddles(tw, twtab, t);
-    float2 v[32], w[2][16];
+    cx v[32], w[2][16];
     // the cascade response is evaluated once per bin of the half spectrum (k <= N/2 <= 2048) and shared
     // through LDS; the Hermitian extension a c2r transform implies is read back from there
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         const int k = t + 256 * a;
-        if (k <= half) lds[k] = cascade_response(B, A, K, k, N);
+        if (k <= half) lds[k] = to_cx(cascade_response(B, A, K, k, N));
     }
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         const int k = t + 256 * a;
-        float2 e = make_float2(0.0f, 0.0f);
+        cx e = {0.0f, 0.0f};
         if (a < 17 && k < N) {
             const bool upper = k > half;
-            float2 Hk = lds[upper ? N - k : k];
+            cx Hk = lds[upper ? N - k : k];
             if (upper) Hk.y = -Hk.y;
             if (k == 0 || (even && k == half)) Hk.y = 0.0f;
-            e = cmul(Hk, chirp(k, N, 1.0f));
+            e = cmul(Hk, to_cx(chirp(k, N, 1.0f)));
         }
         v[a] = e;
     }
     __syncthreads();  // the response table is dead; the tile passes reuse this LDS
     tile_forward(v, w, tw, lds, t);
 #pragma unroll
-    for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], plan[q * TILE_T + t]);
+    for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], reinterpret_cast<const cx*>(plan)[q * TILE_T + t]);
     __syncthreads();
     tile_inverse(w, v, tw, lds, t);
     const float sc = 1.0f / ((float)N * (float)TILE_M);
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
     for (int a = 0; a < 32; ++a) {
         const int n = t + 256 * a;
         if (n < N) {
-            const float2 c = chirp(n, N, 1.0f), e = v[brev(a, 5)];
+            const float2 c = chirp(n, N, 1.0f);
+            const cx e = v[brev(a, 5)];
             out[n] = (e.x * c.x - e.y * c.y) * sc;
         }
     }
