@@ -42,7 +42,7 @@ static inline ConvGeom conv_geom(int64_t N, int64_t Lout) {
 }
 
 struct ConvArgs {
-    gfx_rowmap_t xmap, ymap;
+    gfx_rowmap_t xmap, ymap, cmap;  // cmap: rows of the optional input copy (fftconv1 only)
     int64_t L, Lout, off;    // signal length, outputs per row, output offset into the full convolution
     int64_t O, V;            // overlap and valid samples per tile
     int64_t ntiles, nblocks; // tiles per row-channel, total workgroups of real work
@@ -118,7 +118,8 @@ __device__ __forceinline__ void load_window(cx (&v)[32], const float* __restrict
     }
 }
 
-// y[n0 + (2m - O)] for 2m >= O, n < Lout;  v[brev5(a)] = (z'[2m], z'[2m+1])
+// y[n0 + (2m - O)] for 2m >= O, n < Lout;  v[brev5(a)] = (z'[2m], z'[2m+1])  (NATURAL: v[a] instead)
+template <bool NATURAL = false>
 __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict__ row, int64_t n0, int64_t O,
                                             int64_t Lout, int t) {
     const int64_t room = Lout - (n0 - O);                      // samples from the descriptor base to the row end
@@ -129,7 +130,7 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
     for (int a = 0; a < 32; ++a) {
         const int q = 2 * (t + 256 * a);
         const uint32_t voff = (q < o32 || q == tail) ? OOB : 8u * (uint32_t)t;
-        buf_store_f2(r, voff, 2048u * a, v[brev(a, 5)]);
+        buf_store_f2(r, voff, 2048u * a, v[NATURAL ? a : brev(a, 5)]);
     }
     if (tail >= o32) {                                         // uniform: single trailing sample of an odd-length row
         float last = 0.0f;
@@ -137,7 +138,7 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
 #pragma unroll
         for (int a = 0; a < 32; ++a)
             if (2 * (t + 256 * a) == tail) {
-                last = v[brev(a, 5)].x;
+                last = v[NATURAL ? a : brev(a, 5)].x;
                 mine = true;
             }
         if (mine) row[n0 - O + tail] = last;
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool TEE>
 __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
-                                                             float* __restrict__ y, ConvArgs a,
-                                                             const float2* __restrict__ twtab) {
+                                                             float* __restrict__ y, float* __restrict__ xcopy,
+                                                             ConvArgs a, const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
 #pragma unroll
     for (int q = 0; q < H_SLOTS; ++q) hreg[q] = buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
     __builtin_amdgcn_sched_barrier(0);
+    // off == 0 here: the window's valid part is x[tile*V, tile*V + V) itself
+    if (TEE) store_valid<true>(v, xcopy + row_off(a.cmap, r, c), tile * a.V, a.O, a.L, t);
     tile_forward(v, w, tw, lds, t);
     for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool self) {
         cx xe, xo, ye, yo, za, zb;
@@ -341,13 +345,23 @@ int gfx_fir_spectrum_f32(const float* h, const float* gain, int64_t gain_div, vo
 int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap, int64_t R,
                     int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws,
                     size_t ws_bytes, void* stream) {
+    const gfx_rowmap_t none = {1, 0, 0, 0};
+    return gfx_fftconv_tee_f32(x, xmap, Hs, y, ymap, nullptr, none, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes, stream);
+}
+
+int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap, float* xcopy,
+                        gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off,
+                        int64_t N, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
+    if (xcopy && (off != 0 || Lout != L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
+        return GFX_EINVAL;
     if (C_in < 1 || C_f < 1 || (C_in != C_f && C_in != 1 && C_f != 1)) return GFX_EINVAL;
     if (xmap.inner <= 0 || ymap.inner <= 0 || xmap.inner > 0x7fffffffLL || ymap.inner > 0x7fffffffLL) return GFX_EINVAL;
     const ConvGeom g = conv_geom(N, Lout);
     ConvArgs a;
     a.xmap = xmap;
     a.ymap = ymap;
+    a.cmap = cmap;
     a.L = L;
     a.Lout = Lout;
     a.off = off;
@@ -365,9 +379,13 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
     if (!tw) return GFX_ELAUNCH;
 
     if (g.nparts == 1) {
-        if (allow_lds(fftconv1_kernel)) return GFX_ELAUNCH;
-        hipLaunchKernelGGL(fftconv1_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
-                           (const float4*)Hs, y, a, tw);
+        if (allow_lds(fftconv1_kernel<false>) || allow_lds(fftconv1_kernel<true>)) return GFX_ELAUNCH;
+        if (xcopy)
+            hipLaunchKernelGGL(fftconv1_kernel<true>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
+                               (const float4*)Hs, y, xcopy, a, tw);
+        else
+            hipLaunchKernelGGL(fftconv1_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
+                               (const float4*)Hs, y, xcopy, a, tw);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     const int64_t nwin = g.ntiles + g.nparts - 1;

@@ -79,12 +79,18 @@ def fir_spectrum(h, gain=None, gain_div=1):
     return Hs
 
 
-def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None):
+def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
+    """Whether :func:`fftconv` can also write a copy of its input (gfx_fftconv_tee_f32's conditions)."""
+    return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
+
+
+def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None):
     """y[r,c,n] = sum_k h[r,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
 
     ``x`` / ``out`` may be (R,C,L) tensors or strided (B,n,C,L) views (see :func:`rowmap`).
+    ``tee``: optional tensor shaped like ``x`` that receives a copy of ``x`` from the same kernel.
     """
-    _require_gpu(x, out)
+    _require_gpu(x, out, tee)
     xmap, R, Cin, L = rowmap(x)
     Lout = L if Lout is None else Lout
     Cout = max(Cin, Cf)
@@ -96,6 +102,17 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None):
     nbytes = lib().gfx_fftconv_workspace_bytes(R, Cin, L, Lout, off, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     name = "fftconv1_kernel" if nbytes == 0 else "xspec+macinv_kernels"
+    if tee is not None:
+        cmap, Rc, Cc, Lc = rowmap(tee)
+        if (Rc, Cc, Lc) != (R, Cin, L):
+            raise ValueError(f"tee shape {tuple(tee.shape)} does not match the input {tuple(x.shape)}")
+        with _timed(name, 4 * R * (2 * Cin * L + Cout * Lout)):
+            check(
+                lib().gfx_fftconv_tee_f32(_ptr(x), xmap, _ptr(Hs), _ptr(out), ymap, _ptr(tee), cmap, R, Cin, Cf, L, Lout,
+                                          off, N, _ptr(ws), nbytes, _stream()),
+                "gfx_fftconv_tee_f32",
+            )
+        return out
     with _timed(name, 4 * R * (Cin * L + Cout * Lout)):
         check(
             lib().gfx_fftconv_f32(_ptr(x), xmap, _ptr(Hs), _ptr(out), ymap, R, Cin, Cf, L, Lout, off, N, _ptr(ws), nbytes, _stream()),

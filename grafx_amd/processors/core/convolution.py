@@ -64,12 +64,17 @@ def compute_pad_len(x, y, pad_mode="min"):
     return x.shape[-1] + y.shape[-1] - 1
 
 
-def convolve_taps(x, Hs, N, Cf, mode, out=None):
+def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None):
     """convolve() given precomputed tile spectra of the taps.
 
     ``x`` is (R,C,L) or a strided (B,n,C,L) view of the signal buffer; with ``out`` (same kind of
-    view) the kernels write the result in place and ``out`` is returned."""
+    view) the kernels write the result in place and ``out`` is returned.  ``tee`` (a view shaped like
+    ``x``) additionally receives a copy of ``x`` -- from the convolution kernel itself when it can."""
     L = x.shape[-1]
+    if tee is not None:
+        if mode == "causal" and not reference_aliases(L, N) and ops.fftconv_can_tee(x.shape[-2], Cf, L, L, 0, N):
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, tee=tee)
+        tee.copy_(x)
     if not reference_aliases(L, N):
         if mode == "causal":
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out)

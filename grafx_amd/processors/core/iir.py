@@ -45,7 +45,10 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         return ops.iir_fsm_fir(Bs, As, self.fsm_fir_len, self._plan(Bs.device)).view(R, Cf, self.fsm_fir_len)
 
-    def forward(self, input_signal, Bs, As, out=None):
+    def forward(self, input_signal, Bs, As, out=None, tee=None):
+        if tee is not None and needs_grad(input_signal, Bs, As):
+            tee.copy_(input_signal)
+            tee = None
         if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
             x = input_signal.reshape(-1, *input_signal.shape[-2:])
             y = diff.convolve(x, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal")
@@ -56,4 +59,4 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         N = self.fsm_fir_len
         h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
-        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out)
+        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out, tee=tee)

@@ -21,19 +21,23 @@ class ParametricEqualizer(BufferIO, nn.Module):
         if processor_channel not in ("mono", "stereo", "midside"):
             raise ValueError(f"Invalid processor_channel: {self.processor_channel}")
 
-    def forward(self, input_signals, w0, q_inv, log_gain, _out=None):
+    accepts_tee = True  # render_into(..., tee=view) also leaves a copy of the input in `view`
+
+    def forward(self, input_signals, w0, q_inv, log_gain, _out=None, _tee=None):
         if needs_grad(input_signals, w0, q_inv, log_gain):
             Bs, As = diff.peq_coefficients(w0, q_inv, log_gain, self.use_shelving_filters)
         else:
             Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
-        return self.biquad(input_signals, Bs, As, out=_out)
+        return self.biquad(input_signals, Bs, As, out=_out, tee=_tee)
 
-    def render_into(self, x4, out4, **params):
+    def render_into(self, x4, out4, tee=None, **params):
         if self.processor_channel == "midside":
+            if tee is not None:
+                tee.copy_(x4)
             return super().render_into(x4, out4, **params)
-        return self.forward(x4, _out=out4, **params)
+        return self.forward(x4, _out=out4, _tee=tee, **params)
 
     def parameter_size(self):
         n_channels = 1 if self.processor_channel == "mono" else 2

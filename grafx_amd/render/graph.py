@@ -87,6 +87,31 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+def _first_order(render_data):
+    return 1
+
+
+def _tee_range(render_data, processors, n_src, device):
+    """Source rows [a, b) that the first stage reads as a plain slice through a tee-capable processor, or None."""
+    if render_data.max_order < 1:
+        return None
+    step = render_data.iter_list[_first_order(render_data)]
+    read = step.source_reads[0]
+    proc = processors[step.node_type] if step.node_type in processors else None
+    if proc is None or not getattr(proc, "accepts_tee", False):
+        return None
+    if read.method != "slice" or read.idx[1] > n_src or _gather_plan(step, device) is not None:
+        return None
+    return tuple(read.idx)
+
+
+def _complement(rng, n):
+    if rng is None:
+        return [(0, n)]
+    a, b = rng
+    return [(lo, hi) for lo, hi in ((0, a), (b, n)) if hi > lo]
+
+
 def _touches_inputs(read, n_src):
     if read.method == "slice":
         return read.idx[0] < n_src
@@ -140,11 +165,15 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
     # The sources must end up in the buffer's first slots (the buffer is returned with every node's signal),
     # but nothing has to wait for that copy: stages that read source rows read them from `x` itself, and the
     # copy runs on a side stream underneath the first (compute-bound) stages.
+    # ... and a stage whose processor can "tee" (write its input through to a second destination from the
+    # registers that hold it anyway) makes the copy of the rows it reads free.
+    teed = _tee_range(render_data, processors, n_src, x.device)
     main = torch.cuda.current_stream(x.device)
     side = _side_stream(x.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        buf[:, :n_src].copy_(x, non_blocking=True)
+        for a, b in _complement(teed, n_src):
+            buf[:, a:b].copy_(x[:, a:b], non_blocking=True)
     x.record_stream(side)
     buf.record_stream(side)
     copied = False  # has the main stream joined the copy yet?
@@ -178,7 +207,11 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         if common_parameters is not None:
             common_i = read_tensor_or_tensor_dict(common_parameters, step.dest_write, dim=node_dim,
                                                   postprocess=postprocess)
-        processors[node_type].render_into(x_view, out_view, **params, **common_i)
+        if teed is not None and i == _first_order(render_data):
+            a, b = teed
+            processors[node_type].render_into(x_view, out_view, tee=buf.narrow(1, a, b - a), **params, **common_i)
+        else:
+            processors[node_type].render_into(x_view, out_view, **params, **common_i)
     if not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:

@@ -73,6 +73,15 @@ int gfx_fir_spectrum_f32(const float* h, const float* gain, int64_t gain_div, vo
 int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap,
                     int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                     void* ws, size_t ws_bytes, void* stream);
+/* Same, and additionally copies the input rows to `xcopy` (rows addressed by `cmap`, same R x C_in x L) from
+ * the registers that already hold them.  render_grafx keeps every node's signal in one buffer
+ * (render/graph.py:104-106: `signal_buffer[:, :num_sources] = input_signals`); when the first stage is a
+ * convolution this folds that copy into the stage's kernel.  Only for the causal single-partition case
+ * (off == 0, Lout == L, C_in == max(C_in, C_f), N <= 8193); anything else returns GFX_EINVAL. */
+int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap,
+                        float* xcopy, gfx_rowmap_t cmap,
+                        int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---- frequency-sampled IIR -------------------------------------------------------------
  * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276

@@ -83,3 +83,26 @@ def test_linearity_and_shift_at_full_size():
     d = torch.zeros(4, 2, L)
     d[..., 5] = 1.0
     assert_close(_run(d, h, 0, L)[..., 5 : 5 + N], h.expand(4, 2, N), 2e-6, "impulse response")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,N,Cin,Cf", [(40000, 4001, 2, 1), (16385, 8193, 2, 2), (5000, 33, 1, 1)])
+def test_fftconv_tee_copies_the_input_and_leaves_the_output_unchanged(L, N, Cin, Cf):
+    """gfx_fftconv_tee_f32: same y as gfx_fftconv_f32, plus a bit-exact copy of x (strided destination rows)."""
+    import torch
+
+    from grafx_amd import ops
+
+    torch.manual_seed(3)
+    x = torch.randn(6, Cin, L, device="cuda")
+    h = torch.randn(6, Cf, N, device="cuda") / N**0.5
+    Hs = ops.fir_spectrum(h.view(-1, N))
+    assert ops.fftconv_can_tee(Cin, Cf, L, L, 0, N)
+    y0 = ops.fftconv(x, Hs, N, Cf)
+    big = torch.full((2, 5, Cin, L), float("nan"), device="cuda")  # tee into rows 1..3 of a (B, n, C, L) buffer
+    tee = big.narrow(1, 1, 3)
+    y1 = ops.fftconv(x.view(2, 3, Cin, L), Hs, N, Cf, tee=tee)
+    assert torch.equal(y0, y1)
+    assert torch.equal(tee.reshape(6, Cin, L), x)
+    assert torch.isnan(big[:, 0]).all() and torch.isnan(big[:, 4]).all()
+    assert not ops.fftconv_can_tee(Cin, Cf, L, L, 1, N) and not ops.fftconv_can_tee(1, 2, L, L, 0, N)
