@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Distil gpurun_out/profiles_raw (see tools/collect_profiles.sh) into profiles/r1/.
+
+HBM bytes per launch = FETCH_SIZE (KB, x2 on gfx950: the counter tallies 128-byte requests as 64 bytes --
+MI355X_MICROARCH.md, HBM / rocprofv3 section) + WRITE_SIZE (KB), averaged over the launches of a kernel.
+Template instances of one kernel (fftconv1_kernel<true>/<false>) are pooled under the bare name, which is
+what bench.py's live timing hook keys on.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
+DST = os.path.join(ROOT, "profiles", "r1")
+
+
+def bare(name):
+    name = re.sub(r"^void\s+", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return re.sub(r"<.*$", "", name)
+
+
+def counter(dirname, cname):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(RAW, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cname:
+                agg[bare(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    bench = json.loads(open(os.path.join(RAW, "bench.json")).read().strip().splitlines()[-1])
+    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, "bench_r1.json"))
+    shutil.copy(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(DST, "bench_under_rocprof.json"))
+    stats = glob.glob(os.path.join(RAW, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    shutil.copy(stats[0], os.path.join(DST, "rocprofv3_kernel_stats.csv"))
+    fetch, write = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("gfx::"):
+            continue
+        f = sum(fetch[k]) / max(len(fetch[k]), 1)
+        w = sum(write[k]) / max(len(write[k]), 1)
+        kernels[k] = {
+            "launches": len(fetch[k]),
+            "FETCH_SIZE_KB_avg_per_launch": f,
+            "WRITE_SIZE_KB_avg_per_launch": w,
+            "hbm_read_bytes_per_launch_corrected": 2 * f * 1024,
+            "hbm_write_bytes_per_launch": w * 1024,
+            "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+        }
+    cfg = bench["config"]
+    rec = {
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); sanity check: "
+                "dyn_fused_kernel streams exactly 4*R*C*L bytes each way",
+        "config": {"batch": cfg["batch_per_gpu"], "audio_len": cfg["audio_len"], "fsm_fir_len": cfg["fsm_fir_len"],
+                   "iir_len": cfg["iir_len"], "ir_len": cfg["ir_len"]},
+        "kernels": kernels,
+    }
+    json.dump(rec, open(os.path.join(DST, "pmc_hbm_traffic.json"), "w"), indent=1)
+    k = kernels.get("gfx::fftconv1_kernel")
+    print("bench:", bench["ms_per_step"], "ms/step", bench["value"], bench["unit"])
+    print("fftconv1 HBM bytes/launch:", k and k["hbm_bytes_per_launch"])
+    d = kernels.get("gfx::dyn_fused_kernel")
+    print("dyn_fused HBM bytes/launch:", d and (d["hbm_read_bytes_per_launch_corrected"], d["hbm_write_bytes_per_launch"]))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
