@@ -16,6 +16,13 @@
 
 #include "../../include/grafx_amd.h"
 
+#ifdef GFX_NT_OFF
+#define GFX_NT_STORE(...) gfx_plain_store(__VA_ARGS__)
+template <typename T> __device__ __forceinline__ void gfx_plain_store(T v, T* p) { *p = v; }
+#else
+#define GFX_NT_STORE(...) __builtin_nontemporal_store(__VA_ARGS__)
+#endif
+
 namespace gfx {
 
 constexpr int DT = 256;            // threads per workgroup
@@ -152,7 +159,8 @@ __device__ __forceinline__ void load4(const float* __restrict__ row, int64_t n, 
 }
 __device__ __forceinline__ void store4(float* __restrict__ row, int64_t n, int64_t L, bool vec, const float (&v)[DE]) {
     if (vec && n + DE <= L) {
-        *reinterpret_cast<float4*>(row + n) = make_float4(v[0], v[1], v[2], v[3]);
+        using f4 = float __attribute__((ext_vector_type(4)));
+        GFX_NT_STORE(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(row + n));  // streamed output
     } else {
 #pragma unroll
         for (int i = 0; i < DE; ++i)

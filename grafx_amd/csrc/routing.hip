@@ -14,7 +14,20 @@
 
 #include "../../include/grafx_amd.h"
 
+#ifdef GFX_NT_OFF
+#define GFX_NT_STORE(...) gfx_plain_store(__VA_ARGS__)
+template <typename T> __device__ __forceinline__ void gfx_plain_store(T v, T* p) { *p = v; }
+#else
+#define GFX_NT_STORE(...) __builtin_nontemporal_store(__VA_ARGS__)
+#endif
+
 namespace gfx {
+
+// streamed outputs: non-temporal, so they do not push the rows still being read out of L2
+__device__ __forceinline__ void nt_store(float4* p, float4 v) {
+    using f4 = float __attribute__((ext_vector_type(4)));
+    GFX_NT_STORE(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+}
 
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ buf, int64_t buf_sb, int64_t buf_sv,
                                                          int64_t buf_sc, const int64_t* __restrict__ src,
@@ -34,7 +47,7 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
                 const float4 v = reinterpret_cast<const float4*>(base + src[e] * buf_sv)[i];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            reinterpret_cast<float4*>(dst)[i] = acc;
+            nt_store(reinterpret_cast<float4*>(dst) + i, acc);
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(256) void gather_sum_fanout_kernel(const float* __r
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (j < J) reinterpret_cast<float4*>(dst + (int64_t)j * out_sv)[i] = acc[j];
+            if (j < J) nt_store(reinterpret_cast<float4*>(dst + (int64_t)j * out_sv) + i, acc[j]);
     }
 }
 
