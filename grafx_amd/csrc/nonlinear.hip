@@ -1,0 +1,199 @@
+// Memoryless waveshapers (gfx950): one streaming pass, 8 B per channel-sample, HBM-bound.
+//
+// Replaces the forward() bodies of grafx.processors.nonlinear (reference nonlinear.py):
+//   TanhDistortion           46-79    y = post * (tanh(pre*(x-dc) + b) - tanh(b))
+//   PiecewiseTanhDistortion  120-175  tanh in the middle, rescaled tanh branches beyond +kp / -kn
+//   PowerDistortion          210-233  y = sum_k tanh(w_k) * f((pre*(x-dc))^k)
+//   ChebyshevDistortion      270-307  y = sum_k tanh(w_k) * f(T_k(pre*(x-dc)))
+// where f = tanh or identity, dc = the row-channel mean when remove_dc is set (row_mean_kernel),
+// pre = exp(log_pre_gain), post = exp(log_post_gain) or 1/pre.  The upstream torch code materialises
+// K full-size tensors for the two polynomial shapers; here the K terms live in registers.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/grafx_amd.h"
+
+namespace gfx {
+
+constexpr int WS_MAX_K = 32;
+
+__device__ __forceinline__ int64_t nrow_off(const gfx_rowmap_t& m, int64_t r, int c) {
+    const unsigned inner = (unsigned)m.inner, rr = (unsigned)r;
+    const unsigned q = rr / inner, rem = rr - q * inner;
+    return (int64_t)q * m.stride_outer + (int64_t)rem * m.stride_inner + (int64_t)c * m.stride_ch;
+}
+
+struct WsArgs {
+    gfx_rowmap_t xmap, ymap;
+    int64_t R, L;
+    int C, mode, K;
+    int use_tanh, inverse_post;
+};
+
+struct WsRow {
+    float pre, post, dc;
+    float b, tb;                    // tanh: bias, tanh(bias)
+    float kp, kn, gp, gn, ap, an, bp, bn;  // piecewise
+    float w[WS_MAX_K];              // polynomial weights (already tanh'ed)
+};
+
+template <int MODE>
+__device__ __forceinline__ float shape(float x, const WsRow& q, int K, bool use_tanh) {
+    const float u = (x - q.dc) * q.pre;
+    float y;
+    if (MODE == GFX_WS_TANH) {
+        y = tanhf(u + q.b) - q.tb;
+    } else if (MODE == GFX_WS_PIECEWISE) {
+        if (u > q.kp)
+            y = q.ap * tanhf(q.gp * (u - q.kp)) + q.bp;
+        else if (u < -q.kn)
+            y = q.an * tanhf(q.gn * (u + q.kn)) + q.bn;
+        else
+            y = tanhf(u);
+    } else if (MODE == GFX_WS_POWER) {
+        float p = 1.0f;
+        y = q.w[0] * (use_tanh ? tanhf(1.0f) : 1.0f);
+        for (int k = 1; k < K; ++k) {
+            p *= u;
+            y += q.w[k] * (use_tanh ? tanhf(p) : p);
+        }
+    } else {  // Chebyshev
+        float t0 = 1.0f, t1 = u;
+        y = q.w[0] * (use_tanh ? tanhf(1.0f) : 1.0f);
+        if (K > 1) y += q.w[1] * (use_tanh ? tanhf(u) : u);
+        for (int k = 2; k < K; ++k) {
+            const float t2 = 2.0f * u * t1 - t0;
+            y += q.w[k] * (use_tanh ? tanhf(t2) : t2);
+            t0 = t1;
+            t1 = t2;
+        }
+    }
+    return y * q.post;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void waveshaper_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ log_pre,
+                                                         const float* __restrict__ log_post,
+                                                         const float* __restrict__ p0, const float* __restrict__ p1,
+                                                         const float* __restrict__ dc, WsArgs a, int vec) {
+    for (int64_t r = blockIdx.y; r < a.R; r += gridDim.y) {
+        WsRow q;
+        q.pre = log_pre ? expf(log_pre[r]) : 1.0f;
+        q.post = a.inverse_post ? 1.0f / q.pre : (log_post ? expf(log_post[r]) : 1.0f);
+        q.b = q.tb = 0.0f;
+        if (MODE == GFX_WS_TANH && p0) {
+            q.b = p0[r];
+            q.tb = tanhf(q.b);
+        }
+        if (MODE == GFX_WS_PIECEWISE) {
+            // nonlinear.py:163-166: threshold splits as (kn, kp), hardness as (gp, gn)
+            q.gp = expf(p0[2 * r]);
+            q.gn = expf(p0[2 * r + 1]);
+            q.kn = 1.0f / (1.0f + expf(-p1[2 * r]));
+            q.kp = 1.0f / (1.0f + expf(-p1[2 * r + 1]));
+            q.bp = tanhf(q.kp);
+            q.bn = -tanhf(q.kn);
+            q.ap = (1.0f - q.bp) / q.gp;
+            q.an = (1.0f + q.bn) / q.gn;
+        }
+        if (MODE == GFX_WS_POWER || MODE == GFX_WS_CHEBYSHEV) {
+            for (int k = 0; k < a.K; ++k) q.w[k] = tanhf(p0[r * a.K + k]);
+        }
+        for (int c = 0; c < a.C; ++c) {
+            q.dc = dc ? dc[r * a.C + c] : 0.0f;
+            const float* xr = x + nrow_off(a.xmap, r, c);
+            float* yr = y + nrow_off(a.ymap, r, c);
+            const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+            if (vec) {
+                using f4 = float __attribute__((ext_vector_type(4)));
+                for (int64_t i = tid; i < a.L / 4; i += nthr) {
+                    const f4 v = reinterpret_cast<const f4*>(xr)[i];
+                    f4 o;
+                    o.x = shape<MODE>(v.x, q, a.K, a.use_tanh);
+                    o.y = shape<MODE>(v.y, q, a.K, a.use_tanh);
+                    o.z = shape<MODE>(v.z, q, a.K, a.use_tanh);
+                    o.w = shape<MODE>(v.w, q, a.K, a.use_tanh);
+                    __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yr) + i);
+                }
+                for (int64_t n = (a.L & ~int64_t(3)) + tid; n < a.L; n += nthr) yr[n] = shape<MODE>(xr[n], q, a.K, a.use_tanh);
+            } else {
+                for (int64_t n = tid; n < a.L; n += nthr) yr[n] = shape<MODE>(xr[n], q, a.K, a.use_tanh);
+            }
+        }
+    }
+}
+
+// mean over time of every row-channel (the remove_dc option): one workgroup per row-channel
+__global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ x, gfx_rowmap_t xmap,
+                                                       float* __restrict__ mean, int64_t R, int C, int64_t L) {
+    __shared__ float part[4];
+    for (int64_t rc = blockIdx.x; rc < R * C; rc += gridDim.x) {
+        const int64_t r = rc / C;
+        const float* xr = x + nrow_off(xmap, r, (int)(rc - r * C));
+        float s = 0.0f;
+        for (int64_t n = threadIdx.x; n < L; n += 256) s += xr[n];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) mean[rc] = (part[0] + part[1] + part[2] + part[3]) / (float)L;
+        __syncthreads();
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool map_vec(const gfx_rowmap_t& m) {
+    return m.stride_outer % 4 == 0 && m.stride_inner % 4 == 0 && m.stride_ch % 4 == 0;
+}
+
+}  // namespace gfx
+
+using namespace gfx;
+
+extern "C" {
+
+int gfx_row_mean_f32(const float* x, gfx_rowmap_t xmap, float* mean, int64_t R, int64_t C, int64_t L, void* stream) {
+    if (!x || !mean || R <= 0 || C <= 0 || L <= 0 || xmap.inner <= 0 || R > 0x7fffffffLL) return GFX_EINVAL;
+    const int64_t n = R * C;
+    hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)(n > 65535 * 16 ? 65535 * 16 : n)), dim3(256), 0,
+                       (hipStream_t)stream, x, xmap, mean, R, (int)C, L);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_waveshaper_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, int64_t R, int64_t C, int64_t L,
+                       int mode, int use_tanh, int inverse_post_gain, const float* log_pre_gain,
+                       const float* log_post_gain, const float* p0, const float* p1, int64_t K, const float* dc,
+                       void* stream) {
+    if (!x || !y || R <= 0 || C <= 0 || L <= 0 || R > 0x7fffffffLL || xmap.inner <= 0 || ymap.inner <= 0) return GFX_EINVAL;
+    if (mode < GFX_WS_TANH || mode > GFX_WS_CHEBYSHEV) return GFX_EINVAL;
+    if (inverse_post_gain && !log_pre_gain) return GFX_EINVAL;
+    if (mode == GFX_WS_PIECEWISE && (!p0 || !p1)) return GFX_EINVAL;
+    if ((mode == GFX_WS_POWER || mode == GFX_WS_CHEBYSHEV) && (!p0 || K < 1 || K > WS_MAX_K)) return GFX_EINVAL;
+    WsArgs a;
+    a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.C = (int)C; a.mode = mode; a.K = (int)K;
+    a.use_tanh = use_tanh; a.inverse_post = inverse_post_gain;
+    const int vec = aligned16(x) && aligned16(y) && map_vec(xmap) && map_vec(ymap);
+    int64_t bx = (L / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    const dim3 grid((unsigned)bx, (unsigned)(R > 65535 ? 65535 : R));
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode) {
+        case GFX_WS_TANH:
+            hipLaunchKernelGGL(waveshaper_kernel<GFX_WS_TANH>, grid, dim3(256), 0, st, x, y, log_pre_gain, log_post_gain, p0, p1, dc, a, vec);
+            break;
+        case GFX_WS_PIECEWISE:
+            hipLaunchKernelGGL(waveshaper_kernel<GFX_WS_PIECEWISE>, grid, dim3(256), 0, st, x, y, log_pre_gain, log_post_gain, p0, p1, dc, a, vec);
+            break;
+        case GFX_WS_POWER:
+            hipLaunchKernelGGL(waveshaper_kernel<GFX_WS_POWER>, grid, dim3(256), 0, st, x, y, log_pre_gain, log_post_gain, p0, p1, dc, a, vec);
+            break;
+        default:
+            hipLaunchKernelGGL(waveshaper_kernel<GFX_WS_CHEBYSHEV>, grid, dim3(256), 0, st, x, y, log_pre_gain, log_post_gain, p0, p1, dc, a, vec);
+            break;
+    }
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+}  // extern "C"

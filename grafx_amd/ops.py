@@ -261,6 +261,56 @@ def stereo_gain(x, log_gain, out=None):
     return out
 
 
+def noise_shaping_ir(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain, ir_len, min_decay, max_decay):
+    """noise (C,K,>=ir_len) view with unit last stride; parameters (R,C,K) -> ir (R,C,ir_len), un-normalised."""
+    _require_gpu(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain)
+    R, C, K = log_decay.shape
+    if noise.shape[:2] != (C, K) or noise.stride(-1) != 1 or noise.stride(1) != noise.stride(0) // K:
+        raise ValueError("noise must be a (C, K, T) view of a contiguous band-split noise buffer")
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    ir = torch.empty((R, C, ir_len), dtype=torch.float32, device=log_decay.device)
+    check(
+        lib().gfx_noise_shaping_ir_f32(_ptr(noise), noise.stride(1), _ptr(c(log_decay)), _ptr(c(log_gain)), _ptr(c(log_fade_in)),
+                                       _ptr(c(z_fade_in_gain)), _ptr(ir), R, C, K, ir_len, float(min_decay), float(max_decay), _stream()),
+        "gfx_noise_shaping_ir_f32",
+    )
+    return ir
+
+
+# ----------------------------------------------------------------------------------------- waveshapers
+WS_TANH, WS_PIECEWISE, WS_POWER, WS_CHEBYSHEV = 0, 1, 2, 3
+
+
+def row_mean(x):
+    """Mean over time of every row-channel: (R,C,L) or (B,n,C,L) view -> (R*C,)."""
+    _require_gpu(x)
+    xmap, R, C, L = rowmap(x)
+    mean = torch.empty(R * C, dtype=torch.float32, device=x.device)
+    check(lib().gfx_row_mean_f32(_ptr(x), xmap, _ptr(mean), R, C, L, _stream()), "gfx_row_mean_f32")
+    return mean
+
+
+def waveshaper(x, mode, log_pre_gain=None, log_post_gain=None, p0=None, p1=None, use_tanh=False,
+               inverse_post_gain=False, remove_dc=False, out=None):
+    """Memoryless distortion of every row (see gfx_waveshaper_f32 in the header for the modes)."""
+    _require_gpu(x, log_pre_gain, log_post_gain, p0, p1, out)
+    xmap, R, C, L = rowmap(x)
+    if out is None:
+        out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    ymap = rowmap(out)[0]
+    c = lambda t: None if t is None else t.contiguous().view(R, -1)  # noqa: E731
+    log_pre_gain, log_post_gain, p0, p1 = c(log_pre_gain), c(log_post_gain), c(p0), c(p1)
+    K = p0.shape[1] if (p0 is not None and mode in (WS_POWER, WS_CHEBYSHEV)) else 0
+    dc = row_mean(x) if remove_dc else None
+    with _timed("waveshaper_kernel", 8 * R * C * L):
+        check(
+            lib().gfx_waveshaper_f32(_ptr(x), xmap, _ptr(out), ymap, R, C, L, mode, int(use_tanh), int(inverse_post_gain),
+                                     _ptr(log_pre_gain), _ptr(log_post_gain), _ptr(p0), _ptr(p1), K, _ptr(dc), _stream()),
+            "gfx_waveshaper_f32",
+        )
+    return out
+
+
 # ----------------------------------------------------------------------------------------- reverb IR
 def istft_basis(window):
     _require_gpu(window)

@@ -5,13 +5,24 @@ from .core.convolution import FIRConvolution, convolve, set_exact_convolution
 from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
 from .core.iir import IIRFilter
 from .container import DryWet, GainStagingRegularization, ParallelMix, SerialChain
-from .dynamics import ApproxCompressor, ApproxNoiseGate, Compressor, NoiseGate
-from .eq import ParametricEqualizer, ZeroPhaseFIREqualizer
+from .delay import MultitapDelay
+from .dynamics import (
+    ApproxCompressor,
+    ApproxNoiseGate,
+    BallisticsEnvelopeFollower,
+    BaseEnvelopeFollower,
+    Compressor,
+    IIREnvelopeFollower,
+    NoiseGate,
+)
+from .eq import GraphicEqualizer, NewZeroPhaseFIREqualizer, ParametricEqualizer, ZeroPhaseFIREqualizer
 from .filter import (
     AllPassFilter,
     BandPassFilter,
     BandRejectFilter,
     BiquadFilter,
+    FIRFilter,
+    PoleZeroFilter,
     HighPassFilter,
     HighShelf,
     LowPassFilter,
@@ -19,5 +30,6 @@ from .filter import (
     PeakingFilter,
     StateVariableFilter,
 )
-from .reverb import STFTMaskedNoiseReverb
+from .nonlinear import ChebyshevDistortion, PiecewiseTanhDistortion, PowerDistortion, TanhDistortion
+from .reverb import FilteredNoiseShapingReverb, STFTMaskedNoiseReverb
 from .stereo import MidSideToStereo, MonoToStereo, SideGainImager, StereoGain, StereoToMidSide

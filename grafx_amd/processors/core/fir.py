@@ -1,8 +1,10 @@
 """Zero-phase FIR design from a log-magnitude response (mirrors grafx.processors.core.fir —
-reference core/fir.py:7-74).  A tiny front-end (R x 1024 bins): exp -> irfft(n = 2*bins-1) ->
+reference core/fir.py:7-74; filterbank variant 77-127).  A tiny front-end (R x 1024 bins): exp -> irfft(n = 2*bins-1) ->
 roll -> window, left to torch on the GPU; the heavy part is the zero-phase convolution that follows."""
 import torch
 import torch.nn as nn
+
+from .fft_filterbank import TriangularFilterBank
 
 
 def get_window(window_type, window_length, **kwargs):
@@ -40,3 +42,30 @@ class ZeroPhaseFIR(nn.Module):
 
     def forward(self, log_magnitude):
         return log_magnitude_to_zerophase_fir(log_magnitude, fir_len=self.fir_len, window=self.window)
+
+
+class ZeroPhaseFilterBankFIR(nn.Module):
+    """ZeroPhaseFIR whose parameter may live on a perceptual band grid: band log-magnitudes -> energies ->
+    triangular synthesis filterbank -> sqrt -> the same irfft / roll / window front-end."""
+
+    def __init__(self, num_frequency_bins=1024, use_filterbank=False, filterbank_kwargs={}, window="hann",
+                 window_kwargs={}, eps=1e-7):
+        super().__init__()
+        self.num_frequency_bins = num_frequency_bins
+        self.fir_len = 2 * num_frequency_bins - 1
+        self.eps = eps
+        self.use_filterbank = use_filterbank
+        if use_filterbank:
+            self.filterbank = TriangularFilterBank(num_frequency_bins=num_frequency_bins, **filterbank_kwargs)
+        w = window if isinstance(window, torch.Tensor) else get_window(window, self.fir_len, **window_kwargs)
+        self.register_buffer("window", w)
+
+    def forward(self, log_magnitude):
+        lead, bins = log_magnitude.shape[:-1], log_magnitude.shape[-1]
+        magnitude = torch.exp(log_magnitude.reshape(-1, bins))
+        if self.use_filterbank:
+            magnitude = torch.sqrt(self.filterbank(magnitude.square()) + self.eps)
+        ir = torch.roll(torch.fft.irfft(magnitude, n=self.fir_len), shifts=self.fir_len // 2, dims=-1)
+        if self.window is not None:
+            ir = ir * self.window[None, :]
+        return ir.view(*lead, -1)

@@ -151,3 +151,40 @@ class ApproxNoiseGate(nn.Module):
 
     def parameter_size(self):
         return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}
+
+
+# ---- envelope followers (reference dynamics.py:1053-1117) ----------------------------------------------
+class BaseEnvelopeFollower(nn.Module):
+    """log(smoother(loudness) + 1e-5) with loudness = channel-mean energy or amplitude; the smoother is one of
+    the HIP smoothers (truncated one-pole scan / attack-release recursion)."""
+
+    def __init__(self, smoother, detect_with="energy"):
+        super().__init__()
+        if detect_with not in ("energy", "amplitude", "rms_channel"):
+            raise ValueError(f"Invalid detect_with: {detect_with}")
+        self.detect_with = detect_with
+        self.smoother = smoother
+
+    def forward(self, signal, *args, **kwargs):
+        if self.detect_with == "energy":
+            loudness = signal.square().mean(-2) if needs_grad(signal) else ops.energy(signal)
+        elif self.detect_with == "amplitude":
+            loudness = signal.abs().mean(-2)
+        else:
+            raise AttributeError('detect_with="rms_channel" reads an attribute (eps) that upstream never defines '
+                                 "(dynamics.py:1071); it cannot be used there either")
+        return torch.log(self.smoother(loudness, *args, **kwargs) + 1e-5)
+
+    def parameter_size(self):
+        return self.smoother.parameter_size()
+
+
+class IIREnvelopeFollower(BaseEnvelopeFollower):
+    def __init__(self, detect_with="energy", iir_len=16384, flashfftconv=True, max_input_len=2**17):
+        super().__init__(TruncatedOnePoleIIRFilter(iir_len=iir_len, flashfftconv=flashfftconv,
+                                                   max_input_len=max_input_len), detect_with=detect_with)
+
+
+class BallisticsEnvelopeFollower(BaseEnvelopeFollower):
+    def __init__(self, detect_with="energy"):
+        super().__init__(Ballistics(), detect_with=detect_with)

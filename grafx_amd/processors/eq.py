@@ -4,7 +4,8 @@ import torch.nn as nn
 from .. import ops
 from .core._buffer_io import BufferIO
 from .core.convolution import convolve
-from .core.fir import ZeroPhaseFIR
+from .core.fir import ZeroPhaseFilterBankFIR, ZeroPhaseFIR
+from .core.geq import GraphicEqualizerBiquad
 from .. import autograd as diff
 from ..autograd import needs_grad
 from .core.iir import IIRFilter
@@ -61,3 +62,53 @@ class ZeroPhaseFIREqualizer(nn.Module):
 
     def parameter_size(self):
         return {"log_magnitude": self.num_magnitude_bins}
+
+
+class NewZeroPhaseFIREqualizer(nn.Module):
+    """Zero-phase FIR equaliser with optional perceptual filterbank parameterisation (reference eq.py:80-214).
+    Taps = 2*bins-1 (odd), so for even audio lengths the reference's convolve() is an exact linear convolution
+    and the whole signal path is the HIP overlap-save kernel in "zerophase" mode."""
+
+    def __init__(self, num_frequency_bins=1024, processor_channel="mono", use_filterbank=False, filterbank_kwargs={},
+                 window="hann", window_kwargs={}, eps=1e-7, flashfftconv=False):
+        super().__init__()
+        if processor_channel not in ("mono", "stereo", "midside"):
+            raise ValueError(f"Invalid processor_channel: {processor_channel}")
+        self.num_frequency_bins = num_frequency_bins
+        self.processor_channel = processor_channel
+        self.use_filterbank = use_filterbank
+        self.fir = ZeroPhaseFilterBankFIR(num_frequency_bins=num_frequency_bins, use_filterbank=use_filterbank,
+                                          filterbank_kwargs=filterbank_kwargs, window=window,
+                                          window_kwargs=window_kwargs, eps=eps)
+
+    def forward(self, input_signals, log_magnitude):
+        fir = self.fir(log_magnitude)
+        if self.processor_channel == "midside":
+            return ms_to_lr(convolve(lr_to_ms(input_signals), fir, mode="zerophase"))
+        return convolve(input_signals, fir, mode="zerophase")
+
+    def parameter_size(self):
+        n_bins = self.fir.filterbank.num_filters if self.use_filterbank else self.num_frequency_bins
+        return {"log_magnitude": (1 if self.processor_channel == "mono" else 2, n_bins)}
+
+
+class GraphicEqualizer(nn.Module):
+    """Cascade of fixed-frequency peaking biquads (24 Bark or 31 third-octave bands; reference eq.py:339-436):
+    band design on the GPU (core/geq.py), then the native frequency-sampling kernels."""
+
+    def __init__(self, processor_channel="mono", scale="bark", sr=44100, **backend_kwargs):
+        super().__init__()
+        if processor_channel not in ("mono", "stereo", "midside"):
+            raise ValueError(f"Invalid processor_channel: {processor_channel}")
+        self.geq = GraphicEqualizerBiquad(scale=scale, sr=sr)
+        self.biquad = IIRFilter(**backend_kwargs)
+        self.processor_channel = processor_channel
+
+    def forward(self, input_signals, log_gains):
+        Bs, As = self.geq(log_gains)
+        if self.processor_channel == "midside":
+            return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
+        return self.biquad(input_signals, Bs, As)
+
+    def parameter_size(self):
+        return {"log_gains": (1 if self.processor_channel == "mono" else 2, self.geq.num_bands)}

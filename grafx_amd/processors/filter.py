@@ -9,7 +9,59 @@ from .. import ops
 from .core._buffer_io import BufferIO
 from .. import autograd as diff
 from ..autograd import needs_grad
+from .core.convolution import FIRConvolution
 from .core.iir import IIRFilter
+from .core.midside import lr_to_ms, ms_to_lr
+from .core.utils import normalize_impulse
+
+
+class FIRFilter(nn.Module):
+    """Learnable FIR taps: tanh -> energy normalisation -> causal convolution (reference filter.py:20-84).
+    Upstream's constructor reads ``self.processor_channel`` before assigning it (filter.py:39) and therefore
+    cannot be instantiated; this class implements what the rest of that code plainly intends."""
+
+    def __init__(self, fir_len=1023, processor_channel="mono", **backend_kwargs):
+        super().__init__()
+        if processor_channel not in ("mono", "stereo", "midside"):
+            raise ValueError(f"Unknown channel type: {processor_channel}")
+        self.fir_len = fir_len
+        self.processor_channel = processor_channel
+        self.num_channels = 1 if processor_channel == "mono" else 2
+        backend_kwargs.pop("fir_len", None)
+        self.conv = FIRConvolution(**backend_kwargs)
+
+    def forward(self, input_signals, fir):
+        fir = normalize_impulse(torch.tanh(fir))
+        if self.processor_channel == "midside":
+            return ms_to_lr(self.conv(lr_to_ms(input_signals), fir))
+        return self.conv(input_signals, fir)
+
+    def parameter_size(self):
+        return {"fir": (self.num_channels, self.fir_len)}
+
+
+class PoleZeroFilter(nn.Module):
+    """Biquad cascade parameterised by complex zeros and (tanh-radius-limited) poles (reference filter.py:171-239).
+    Two upstream details are kept because they change the numbers: the denominator's z^-2 coefficient uses the
+    *unlimited* pole radius (filter.py:224), and one coefficient set is shared by all channels."""
+
+    def __init__(self, num_filters=1, **backend_kwargs):
+        super().__init__()
+        self.num_filters = num_filters
+        self.biquad = IIRFilter(order=2, **backend_kwargs)
+
+    def forward(self, input_signals, log_gain, poles, zeros):
+        p, z = torch.view_as_complex(poles.contiguous()), torch.view_as_complex(zeros.contiguous())
+        p_radius, z_radius = p.abs(), z.abs()
+        p = p * torch.tanh(p_radius) / (p_radius + 1e-5)
+        one = torch.ones_like(p_radius)
+        Bs = torch.stack([one, -2 * z.real, z_radius.square()], -1)
+        As = torch.stack([one, -2 * p.real, p_radius.square()], -1)
+        y = self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1))
+        return torch.exp(log_gain).unsqueeze(-1) * y
+
+    def parameter_size(self):
+        return {"log_gain": 1, "poles": (self.num_filters, 2), "zeros": (self.num_filters, 2)}
 
 
 class BiquadFilter(BufferIO, nn.Module):

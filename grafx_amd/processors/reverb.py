@@ -103,3 +103,74 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         if self.gain_envelope:
             size["gain_env_log_magnitude"] = (2, self.num_frames)
         return size
+
+
+class FilteredNoiseShapingReverb(nn.Module):
+    """Band-wise exponentially decaying filtered noise (mirrors reference reverb.py:231-401).
+
+    Init: uniform noise split into `num_bands` bands by a Linkwitz-Riley crossover (host side, scipy).
+    Forward: `gfx_noise_shaping_ir_f32` sums the K decaying bands into the impulse response (the reference
+    materialises a (B, C, K, ir_len) envelope tensor for this), the response is energy-normalised and the
+    HIP overlap-save convolution applies it (uniformly partitioned for the default 60 000 taps)."""
+
+    def __init__(self, ir_len=60000, num_bands=12, processor_channel="midside", f_min=31.5, f_max=15000, scale="log",
+                 sr=30000, zerophase=True, order=2, noise_randomness="pseudo-random", use_fade_in=False,
+                 min_decay_ms=50, max_decay_ms=2000, flashfftconv=True, max_input_len=2**17):
+        super().__init__()
+        from .core.convolution import FIRConvolution
+        from .core.noise import get_filtered_noise
+
+        if processor_channel not in ("midside", "stereo", "mono"):
+            raise ValueError(f"Unknown channel type: {processor_channel}")
+        if noise_randomness not in ("pseudo-random", "fixed"):
+            if noise_randomness == "random":
+                raise NotImplementedError('noise_randomness="random" is an unfinished option upstream (assert False)')
+            raise ValueError(f"Invalid filtered_noise argument: {noise_randomness}")
+        self.num_bands = num_bands
+        self.processor_channel = processor_channel
+        self.num_channels = 1 if processor_channel == "mono" else 2
+        self.ir_len = ir_len
+        self.noise_randomness = noise_randomness
+        noise_len = ir_len if noise_randomness == "fixed" else 5 * ir_len
+        noise = get_filtered_noise(noise_len, num_channels=self.num_channels, num_bands=num_bands, f_min=f_min,
+                                   f_max=f_max, scale=scale, sr=sr, zerophase=zerophase, order=order)
+        self.register_buffer("filtered_noise", noise.unsqueeze(0))      # (1, C, K, noise_len)
+        self.conv = FIRConvolution(mode="causal", flashfftconv=flashfftconv, max_input_len=max_input_len)
+        ln10_20 = np.log(10) / 20
+        self.min_decay = -60 / (min_decay_ms * sr / 1000) * ln10_20      # log-amplitude slope per sample
+        self.max_decay = -60 / (max_decay_ms * sr / 1000) * ln10_20
+        self.use_fade_in = use_fade_in
+        self.register_buffer("arange", torch.arange(ir_len)[None, None, None, :])
+
+    def get_filtered_noise(self):
+        if self.noise_randomness == "fixed":
+            return self.filtered_noise
+        start = int(torch.randint(0, self.filtered_noise.shape[-1] - self.ir_len, (1,)))
+        return self.filtered_noise[..., start : start + self.ir_len]
+
+    def compute_ir(self, log_decay, log_gain, log_fade_in=None, z_fade_in_gain=None):
+        noise = self.get_filtered_noise()
+        fade = (log_fade_in, z_fade_in_gain) if self.use_fade_in else (None, None)
+        if needs_grad(log_decay, log_gain, *fade):
+            d = torch.sigmoid(log_decay) * (self.max_decay - self.min_decay) + self.min_decay
+            env = torch.exp(self.arange * d.unsqueeze(-1))
+            if self.use_fade_in:
+                f = torch.sigmoid(fade[0]) * (d - self.min_decay) + self.min_decay
+                env = env - torch.exp(self.arange * f.unsqueeze(-1)) * torch.sigmoid(fade[1]).unsqueeze(-1)
+            return (noise * (env * log_gain.unsqueeze(-1))).sum(2)
+        return ops.noise_shaping_ir(noise[0], log_decay, log_gain, fade[0], fade[1], self.ir_len, self.min_decay,
+                                    self.max_decay)
+
+    def forward(self, input_signals, log_decay, log_gain, log_fade_in=None, z_fade_in_gain=None):
+        ir = normalize_impulse(self.compute_ir(log_decay, log_gain, log_fade_in, z_fade_in_gain))
+        if self.processor_channel == "midside":
+            return ms_to_lr(self.conv(lr_to_ms(input_signals), ir))
+        return self.conv(input_signals, ir)
+
+    def parameter_size(self):
+        shape = (self.num_channels, self.num_bands)
+        size = {"log_decay": shape, "log_gain": shape}
+        if self.use_fade_in:
+            size["log_fade_in"] = shape
+            size["z_fade_in_gain"] = shape
+        return size

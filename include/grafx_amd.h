@@ -176,6 +176,37 @@ int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, 
                               float* out, int64_t out_sb, int64_t out_sv, int64_t out_sc,
                               int64_t B, int64_t J, int64_t C, int64_t L, void* stream);
 
+/* ---- noise-shaping reverb impulse response ------------------------------------------------
+ * replaces the envelope synthesis of FilteredNoiseShapingReverb.forward (reverb.py:343-366):
+ *   ir[r,c,t] = sum_k noise[c,k,t] * log_gain[r,c,k] * (exp(t*d) - sigmoid(z_fade_in_gain)*exp(t*f))
+ *   d = sigmoid(log_decay)*(max_decay-min_decay)+min_decay,  f = sigmoid(log_fade_in)*(d-min_decay)+min_decay
+ * (the fade-in term only when both fade pointers are non-null; the gain is the raw parameter, as upstream).
+ * noise: (C, K, noise_stride) band-split noise, the first ir_len samples of every band row are used (pass an
+ * offset pointer for the "pseudo-random" start).  Parameters (R, C, K) contiguous; ir (R, C, ir_len).  K <= 64. */
+int gfx_noise_shaping_ir_f32(const float* noise, int64_t noise_stride, const float* log_decay, const float* log_gain,
+                             const float* log_fade_in, const float* z_fade_in_gain, float* ir, int64_t R, int64_t C,
+                             int64_t K, int64_t ir_len, float min_decay, float max_decay, void* stream);
+
+/* ---- memoryless waveshapers --------------------------------------------------------------
+ * replaces the forward() of TanhDistortion (nonlinear.py:46-79), PiecewiseTanhDistortion (120-175),
+ * PowerDistortion (210-233) and ChebyshevDistortion (270-307): one streaming pass.
+ *   u = pre * (x - dc),  pre = exp(log_pre_gain[r]) (1 if null),  dc = dc[r*C + c] (0 if null)
+ *   GFX_WS_TANH       y = tanh(u + b) - tanh(b),            b = p0[r] (0 if null)
+ *   GFX_WS_PIECEWISE  p0 = log_hardness (R,2), p1 = z_threshold (R,2)  (upstream's split order is kept)
+ *   GFX_WS_POWER      y = sum_k tanh(p0[r,k]) f(u^k),       k < K <= 32, f = tanh if use_tanh
+ *   GFX_WS_CHEBYSHEV  y = sum_k tanh(p0[r,k]) f(T_k(u))
+ * then y *= post, post = 1/pre if inverse_post_gain else exp(log_post_gain[r]) (1 if null).
+ * gfx_row_mean_f32 computes the per-row-channel means the remove_dc option subtracts. */
+#define GFX_WS_TANH 0
+#define GFX_WS_PIECEWISE 1
+#define GFX_WS_POWER 2
+#define GFX_WS_CHEBYSHEV 3
+int gfx_row_mean_f32(const float* x, gfx_rowmap_t xmap, float* mean, int64_t R, int64_t C, int64_t L, void* stream);
+int gfx_waveshaper_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, int64_t R, int64_t C, int64_t L,
+                       int mode, int use_tanh, int inverse_post_gain, const float* log_pre_gain,
+                       const float* log_post_gain, const float* p0, const float* p1, int64_t K, const float* dc,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,6 +380,115 @@ def g10():
     save("g10_next_rows", **out)
 
 
+def g11():
+    """Second batch of "next" rows: graphic / filterbank equalisers, pole-zero filter, memoryless distortions,
+    multitap delay, noise-shaping reverb, envelope followers."""
+    import grafx.processors as P
+    from grafx.processors.core.delay import SurrogateDelay
+    from grafx.processors.core.fft_filterbank import TriangularFilterBank
+    from grafx.processors.dynamics import BallisticsEnvelopeFollower, IIREnvelopeFollower
+
+    out = {}
+    torch.manual_seed(11)
+    x = torch.randn(3, 2, 2048)
+    out["x"] = x
+    for scale in ("bark", "third_octave"):
+        for ch in ("mono", "stereo", "midside"):
+            m = P.GraphicEqualizer(processor_channel=ch, scale=scale, sr=44100, flashfftconv=False, fsm_fir_len=1025)
+            (k, shp), = m.parameter_size().items()
+            lg = 0.5 * torch.randn(3, *shp)
+            lg[0, 0, :3] = 0.0  # exercise the |log gain| < 1e-3 branch
+            out[f"geq_lg_{scale}_{ch}"], out[f"geq_y_{scale}_{ch}"] = lg, m(x, log_gains=lg)
+    for scale in ("bark_traunmuller", "bark_schroeder", "bark_wang", "mel_htk", "mel_slaney", "linear", "log"):
+        fb = TriangularFilterBank(num_frequency_bins=128, num_filters=20, scale=scale, f_min=40, f_max=16000, sr=44100)
+        out[f"fbank_{scale}"] = fb.filterbank
+    fb = TriangularFilterBank(num_frequency_bins=128, num_filters=20, scale="mel_htk", f_min=40, f_max=16000, sr=44100,
+                              low_half_triangle=False)
+    out["fbank_mel_htk_nolow"] = fb.filterbank
+    e = torch.rand(3, 128)
+    out["fbank_e"], out["fbank_analysis"] = e, fb(e, mode="analysis")
+    for tag, kw in (("plain", dict()), ("fb", dict(use_filterbank=True, filterbank_kwargs=dict(
+            num_filters=24, scale="bark_traunmuller", f_min=40, f_max=16000, sr=44100)))):
+        for ch in ("mono", "stereo", "midside"):
+            m = P.NewZeroPhaseFIREqualizer(num_frequency_bins=128, processor_channel=ch, **kw)
+            (k, shp), = m.parameter_size().items()
+            lm = 0.5 * torch.randn(3, *shp)
+            out[f"nzp_lm_{tag}_{ch}"], out[f"nzp_y_{tag}_{ch}"] = lm, m(x, log_magnitude=lm)
+    # PoleZeroFilter: the reference passes 3-D coefficients to IIRFilter, which only broadcasts for one row
+    m = P.PoleZeroFilter(num_filters=3, flashfftconv=False, fsm_fir_len=513)
+    pz = dict(log_gain=0.3 * torch.randn(1, 1), poles=torch.randn(1, 3, 2), zeros=torch.randn(1, 3, 2))
+    out["pz_x"] = x[:1]
+    for k, v in pz.items():
+        out[f"pz_{k}"] = v
+    out["pz_y"] = m(x[:1], **pz)
+    # memoryless distortions
+    cfgs = {
+        "tanh_a": (P.TanhDistortion, dict(pre_post_gain=True, inverse_post_gain=True, remove_dc=False, use_bias=False)),
+        "tanh_b": (P.TanhDistortion, dict(pre_post_gain=True, inverse_post_gain=False, remove_dc=True, use_bias=True)),
+        "tanh_c": (P.TanhDistortion, dict(pre_post_gain=False, inverse_post_gain=False, remove_dc=False, use_bias=True)),
+        "pw_a": (P.PiecewiseTanhDistortion, dict(pre_post_gain=True, inverse_post_gain=True, remove_dc=False)),
+        "pw_b": (P.PiecewiseTanhDistortion, dict(pre_post_gain=True, inverse_post_gain=False, remove_dc=True)),
+        "pow_a": (P.PowerDistortion, dict(max_order=10, pre_gain=True, remove_dc=False, use_tanh=False)),
+        "pow_b": (P.PowerDistortion, dict(max_order=6, pre_gain=False, remove_dc=True, use_tanh=True)),
+        "cheb_a": (P.ChebyshevDistortion, dict(max_order=10, pre_gain=True, remove_dc=False, use_tanh=False)),
+        "cheb_b": (P.ChebyshevDistortion, dict(max_order=6, pre_gain=False, remove_dc=True, use_tanh=True)),
+    }
+    xs = 0.7 * x
+    out["nl_x"] = xs
+    for tag, (cls, kw) in cfgs.items():
+        m = cls(**kw)
+        ps = {}
+        for k, shp in m.parameter_size().items():
+            ps[k] = 0.5 * torch.randn(3, shp)
+            out[f"nl_{tag}_{k}"] = ps[k]
+        out[f"nl_{tag}_y"] = m(xs, **ps)
+    # surrogate delay + multitap delay
+    for st in (True, False):
+        d = SurrogateDelay(N=256, straight_through=st)
+        z = torch.view_as_complex(torch.randn(5, 2))
+        irs, loss = d(z)
+        out[f"sd_z_{int(st)}"], out[f"sd_ir_{int(st)}"], out[f"sd_loss_{int(st)}"] = torch.view_as_real(z), irs, loss
+    for tag, kw in (("zp", dict(zp_filter_per_tap=True, zp_filter_bins=8)), ("nozp", dict(zp_filter_per_tap=False))):
+        for ch in ("stereo", "mono"):
+            m = P.MultitapDelay(segment_len=101, num_segments=5, num_delay_per_segment=2, processor_channel=ch,
+                                flashfftconv=False, pre_delay=7 if ch == "stereo" else 0, **kw)
+            ps = {k: torch.randn(3, *shp) for k, shp in m.parameter_size().items()}
+            y, reg = m(x, **ps)
+            for k, v in ps.items():
+                out[f"mtd_{tag}_{ch}_{k}"] = v
+            out[f"mtd_{tag}_{ch}_y"], out[f"mtd_{tag}_{ch}_reg"] = y, reg["radii_reg"]
+            out[f"mtd_{tag}_{ch}_ir"] = m.get_ir(ps["delay_z"], ps.get("log_fir_magnitude"))[0]
+    # noise-shaping reverb (fixed noise so that the forward is deterministic given the buffer)
+    for ch in ("midside", "stereo", "mono"):
+        for fade in (False, True):
+            m = P.FilteredNoiseShapingReverb(ir_len=1501, num_bands=4, processor_channel=ch, f_min=100, f_max=8000,
+                                             scale="log", sr=30000, noise_randomness="fixed", use_fade_in=fade,
+                                             flashfftconv=False)
+            ps = {k: torch.randn(3, *shp) for k, shp in m.parameter_size().items()}
+            tag = f"{ch}_{int(fade)}"
+            out[f"fnr_noise_{tag}"] = m.filtered_noise
+            for k, v in ps.items():
+                out[f"fnr_{tag}_{k}"] = v
+            out[f"fnr_{tag}_y"] = m(x, **ps)
+    # the Linkwitz-Riley band split itself (deterministic input)
+    from grafx.processors.core.noise import apply_linkwitz_riley
+    import numpy as np
+    sig = np.random.RandomState(5).rand(2, 4000) * 2 - 1
+    out["lr_in"] = torch.from_numpy(sig)
+    for zp in (True, False):
+        out[f"lr_out_{int(zp)}"] = torch.from_numpy(apply_linkwitz_riley(sig, num_bands=4, f_min=100, f_max=8000,
+                                                                         scale="log", sr=30000, zerophase=zp, order=2))
+    # envelope followers
+    for det in ("energy", "amplitude"):
+        m = IIREnvelopeFollower(detect_with=det, iir_len=255, flashfftconv=False)
+        za = torch.randn(3, 1)
+        out[f"envf_iir_{det}_z"], out[f"envf_iir_{det}_y"] = za, m(x, za)
+        m = BallisticsEnvelopeFollower(detect_with=det)
+        zb = torch.randn(3, 2)
+        out[f"envf_bal_{det}_z"], out[f"envf_bal_{det}_y"] = zb, m(x, zb)
+    save("g11_next_rows2", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8(); g10()
+    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8(); g10(); g11()
