@@ -261,6 +261,24 @@ def stereo_gain(x, log_gain, out=None):
     return out
 
 
+def biquad_cascade(x, Bs, As, ssm_quirk=False, out=None):
+    """Exact time-domain cascade of the K biquads in Bs/As (R,Cf,K,3) over x (R,C,L) or a (B,n,C,L) view."""
+    _require_gpu(x, Bs, As, out)
+    xmap, R, Cin, L = rowmap(x)
+    Rb, Cf, K, three = Bs.shape
+    if Rb != R or three != 3 or As.shape != Bs.shape:
+        raise ValueError(f"coefficients {tuple(Bs.shape)} / {tuple(As.shape)} do not match {R} rows")
+    Cout = max(Cin, Cf)
+    if out is None:
+        out = torch.empty((R, Cout, L), dtype=torch.float32, device=x.device)
+    ymap = rowmap(out)[0]
+    Bs, As = Bs.contiguous(), As.contiguous()
+    with _timed("biquad_cascade_kernel", 4 * R * (Cin + Cout) * L):
+        check(lib().gfx_biquad_cascade_f32(_ptr(x), xmap, _ptr(out), ymap, _ptr(Bs), _ptr(As), R, Cin, Cf, K, L,
+                                           int(ssm_quirk), _stream()), "gfx_biquad_cascade_f32")
+    return out
+
+
 def noise_shaping_ir(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain, ir_len, min_decay, max_decay):
     """noise (C,K,>=ir_len) view with unit last stride; parameters (R,C,K) -> ir (R,C,ir_len), un-normalised."""
     _require_gpu(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain)

@@ -1,5 +1,6 @@
 """Biquad-cascade IIR filter (mirrors grafx.processors.core.iir.IIRFilter —
-reference core/iir.py:25-152, 263-276), frequency-sampling ("fsm") backend on HIP."""
+reference core/iir.py:25-276): the frequency-sampling ("fsm") backend and the exact recursive backends
+("lfilter", "ssm") on HIP."""
 import torch
 import torch.nn as nn
 
@@ -27,10 +28,10 @@ class IIRFilter(nn.Module):
             self.conv = FIRConvolution(mode="causal", flashfftconv=flashfftconv, max_input_len=fsm_max_input_len)
             self._plans = {}
         elif backend in ("lfilter", "ssm"):
-            raise NotImplementedError(
-                f"backend={backend!r} (exact recursive filtering via torchaudio/torchlpc upstream) is not part of "
-                "this release; use backend='fsm' (the reference default)."
-            )
+            # upstream: torchaudio.functional.lfilter per section / a state-space form on torchlpc (iir.py:154-261).
+            # Here both are the exact recursive cascade as one parallel-scan HIP kernel (gfx_biquad_cascade_f32).
+            if order != 2:
+                raise NotImplementedError("the HIP recursive kernel runs second-order sections (order=2)")
         else:
             raise ValueError(f"Unsupported backend: {backend}")
 
@@ -45,7 +46,20 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         return ops.iir_fsm_fir(Bs, As, self.fsm_fir_len, self._plan(Bs.device)).view(R, Cf, self.fsm_fir_len)
 
+    def _process_recursive(self, input_signal, Bs, As, out=None):
+        if needs_grad(input_signal, Bs, As):
+            raise NotImplementedError(f"backend={self.backend!r}: the exact recursive kernel is forward-only; "
+                                      "train with backend='fsm' (the reference default)")
+        if self.backend == "ssm":
+            assert Bs.shape[-1] == As.shape[-1] == 3, "The filter order must be 2."
+        # "ssm" with K > 1: upstream drives every section's recursion with the original input (iir.py:226-246)
+        return ops.biquad_cascade(input_signal, Bs, As, ssm_quirk=self.backend == "ssm", out=out)
+
     def forward(self, input_signal, Bs, As, out=None, tee=None):
+        if self.backend != "fsm":
+            if tee is not None:
+                tee.copy_(input_signal)
+            return self._process_recursive(input_signal, Bs, As, out=out)
         if tee is not None and needs_grad(input_signal, Bs, As):
             tee.copy_(input_signal)
             tee = None

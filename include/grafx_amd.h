@@ -176,6 +176,18 @@ int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, 
                               float* out, int64_t out_sb, int64_t out_sv, int64_t out_sc,
                               int64_t B, int64_t J, int64_t C, int64_t L, void* stream);
 
+/* ---- exact recursive biquad cascade -------------------------------------------------------
+ * replaces IIRFilter._process_lfilter / _process_ssm: core/iir.py:154-261 (torchaudio.functional.lfilter per
+ * section / the state-space form on torchlpc).  K second-order sections in series per row-channel, zero initial
+ * state, coefficients normalised by a0:  y = b0 w[n] + b1 w[n-1] + b2 w[n-2],  w[n] = x[n] - a1 w[n-1] - a2 w[n-2].
+ * A parallel scan over time (matrix powers of the 2x2 transition matrix), no FFT.
+ * Bs, As: (R, C_f, K, 3) contiguous; channels broadcast 1<->C like gfx_fftconv_f32; K <= 36.
+ * ssm_quirk != 0 reproduces upstream's "ssm" backend for K > 1, which feeds the ORIGINAL input to the
+ * recursive part of every section (core/iir.py:226-246); for K == 1 both settings are the same filter. */
+int gfx_biquad_cascade_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* Bs,
+                           const float* As, int64_t R, int64_t C_in, int64_t C_f, int64_t K, int64_t L, int ssm_quirk,
+                           void* stream);
+
 /* ---- noise-shaping reverb impulse response ------------------------------------------------
  * replaces the envelope synthesis of FilteredNoiseShapingReverb.forward (reverb.py:343-366):
  *   ir[r,c,t] = sum_k noise[c,k,t] * log_gain[r,c,k] * (exp(t*d) - sigmoid(z_fade_in_gain)*exp(t*f))

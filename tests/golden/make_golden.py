@@ -489,6 +489,29 @@ def g11():
     save("g11_next_rows2", **out)
 
 
+def g12():
+    """Exact recursive IIR backends.  torchaudio / torchlpc are not installed; the stand-ins in _shims implement
+    their documented recursions (scipy.signal.lfilter per row; y_t = x_t - sum_k A[t,k] y_{t-k-1}), everything else
+    (section loop, channel broadcasting, the state-space decomposition of "ssm") is the reference's own code."""
+    out = {}
+    torch.manual_seed(12)
+    for K in (1, 3):
+        for (C, Cf) in ((2, 1), (1, 2), (2, 2)):
+            tag = f"K{K}_C{C}_F{Cf}"
+            x = torch.randn(2, C, 3000)
+            a1 = 2 * torch.tanh(0.7 * torch.randn(2, Cf, K))
+            a2 = ((2 - a1.abs()) * torch.tanh(0.7 * torch.randn(2, Cf, K) + 0.5) + a1.abs()) / 2
+            a0 = 1 + 0.3 * torch.rand(2, Cf, K)
+            As = torch.stack([a0, a0 * a1, a0 * a2], -1)
+            Bs = torch.randn(2, Cf, K, 3)
+            out[f"x_{tag}"], out[f"Bs_{tag}"], out[f"As_{tag}"] = x, Bs, As
+            for backend in ("lfilter", "ssm"):
+                m = IIRFilter(order=2, backend=backend, flashfftconv=False)
+                out[f"y_{backend}_{tag}"] = m(x, Bs, As)
+                out[f"y64_{backend}_{tag}"] = m(x.double(), Bs.double(), As.double()).float()  # f64 result, stored rounded
+    save("g12_recursive_iir", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8(); g10(); g11()
+    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8(); g10(); g11(); g12()

@@ -61,6 +61,15 @@ def main():
             print(f"  iir_fsm only        {ms:8.3f} ms")
             ms = timeit(lambda: ops.fir_spectrum(h), a.iters)
             print(f"  hspec only          {ms:8.3f} ms")
+        if a.what in ("eqx", "all"):
+            eqx = P.ParametricEqualizer(num_filters=6, backend="lfilter", flashfftconv=False).to(dev)
+            p = {k: 0.1 * torch.randn(R, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
+            ms = timeit(lambda: eqx(x, **p), a.iters)
+            print(f"eq exact recursion (K=6) R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            Bs, As = ops.peq_coeffs(p["w0"], p["q_inv"], p["log_gain"])
+            for K in (1, 2, 6):
+                ms = timeit(lambda: ops.biquad_cascade(x, Bs[:, :, :K].contiguous(), As[:, :, :K].contiguous(), out=y), a.iters)
+                print(f"  biquad_cascade K={K}   {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
         if a.what in ("comp", "all"):
             cp = P.Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).to(dev)
             p = {k: 0.1 * torch.randn(R, 1, device=dev) for k in cp.parameter_size()}
