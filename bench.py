@@ -51,9 +51,12 @@ def console_graph(n_ch=32, n_bus=4):
 LENS = dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001)
 
 
-def hip_processors():
+def hip_processors(default_args=False):
     from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
 
+    if default_args:  # upstream's constructor defaults: flashfftconv=True, 4000 / 16384 / 60000 taps
+        return {"eq": ParametricEqualizer(num_filters=6), "compressor": Compressor(energy_smoother="iir"),
+                "reverb": STFTMaskedNoiseReverb()}
     return {
         "eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=LENS["fsm_fir_len"]),
         "compressor": Compressor(energy_smoother="iir", iir_len=LENS["iir_len"], flashfftconv=False),
@@ -122,6 +125,9 @@ def main():
     ap.add_argument("--reference-default-lengths", action="store_true",
                     help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
                          "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
+    ap.add_argument("--reference-default-args", action="store_true",
+                    help="build the processors with upstream's constructor defaults (flashfftconv=True, 4000/16384/60000 taps): "
+                         "the FlashFFTConv flavour, i.e. plain causal convolutions; not the headline configuration")
     ap.add_argument("--train", action="store_true",
                     help="also time forward+backward+gradient all-reduce (BASELINE configs[4]) at --train-batch per GPU")
     ap.add_argument("--train-batch", type=int, default=32)
@@ -141,7 +147,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if args.reference_default_lengths:
+    if args.reference_default_lengths or args.reference_default_args:
         LENS.update(fsm_fir_len=4000, iir_len=16384, ir_len=60000)
     from grafx_amd import ops
     from grafx_amd.data import convert_to_tensor
@@ -151,7 +157,7 @@ def main():
     B, L = args.batch, args.length
     G = console_graph()
     render_data = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
-    procs = {k: v.to(dev) for k, v in hip_processors().items()}
+    procs = {k: v.to(dev) for k, v in hip_processors(args.reference_default_args).items()}
     torch.manual_seed(1234)  # identical parameters on every rank (a shared mixing console)
     params_cpu = {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
     params = {t: {k: v.to(dev) for k, v in d.items()} for t, d in params_cpu.items()}
@@ -279,7 +285,9 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "audio_len": L, "channels": 2,
                        "fsm_fir_len": LENS["fsm_fir_len"], "iir_len": LENS["iir_len"], "ir_len": LENS["ir_len"],
                        "mode": ("forward render, reference-default even lengths (odd L+N-1: aliasing compatibility path)"
-                                if args.reference_default_lengths else "forward render, reference-exact lengths (even L+N-1)"), "parallelism": f"batch-shard x{world}"},
+                                if args.reference_default_lengths else
+                                "forward render, upstream default constructor arguments (flashfftconv=True: plain causal convolutions)"
+                                if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"), "parallelism": f"batch-shard x{world}"},
             "per_gpu_value": B * L * args.steps / elapsed,
             "roofline": roof,
         }

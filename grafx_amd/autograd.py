@@ -62,7 +62,7 @@ class LinearConvFn(torch.autograd.Function):
         return gx, gh, None, None
 
 
-def convolve(x, h, mode="causal"):
+def convolve(x, h, mode="causal", exact=False):
     """Differentiable twin of processors.core.convolution.convolve (reference core/convolution.py:119-134),
     including the odd-P aliasing (which is plain torch.fft and differentiates itself)."""
     from .processors.core.convolution import reference_aliases
@@ -71,7 +71,7 @@ def convolve(x, h, mode="causal"):
     if flat:
         x, h = x.unsqueeze(1), h.unsqueeze(1)
     L, N = x.shape[-1], h.shape[-1]
-    if not reference_aliases(L, N):
+    if not reference_aliases(L, N, exact):
         if mode == "causal":
             y = LinearConvFn.apply(x, h, L, 0)
         elif mode == "zerophase":
@@ -145,9 +145,9 @@ def one_pole_fir(z_alpha, iir_len):
     return (1 - alpha) * torch.exp(n * torch.log(alpha))
 
 
-def truncated_one_pole(u, z_alpha, iir_len):
+def truncated_one_pole(u, z_alpha, iir_len, exact=False):
     """core/envelope.py:34-49."""
-    return torch.relu(convolve(u, one_pole_fir(z_alpha, iir_len), "causal"))
+    return torch.relu(convolve(u, one_pole_fir(z_alpha, iir_len), "causal", exact=exact))
 
 
 class BallisticsFn(torch.autograd.Function):

@@ -37,9 +37,14 @@ def exact_convolution():
     return _EXACT
 
 
-def reference_aliases(lx, lh):
-    """True when the reference's convolve() is NOT a linear convolution for these lengths."""
-    return (lx + lh - 1) % 2 == 1 and not _EXACT
+def reference_aliases(lx, lh, exact=False):
+    """True when the reference's *native* convolve() is NOT a linear convolution for these lengths.
+
+    ``exact`` is a call site's own request for the true linear convolution: the processors pass their
+    ``flashfftconv`` constructor flag here, because that is what the flag selects upstream — FlashFFTConv computes
+    the plain causal convolution (convolution.py:85-106), only the native torch.fft path has the odd-length
+    aliasing (convolution.py:119-134)."""
+    return (lx + lh - 1) % 2 == 1 and not (_EXACT or exact)
 
 
 def odd_length_alias(z, rows_per_chunk=2048):
@@ -64,7 +69,7 @@ def compute_pad_len(x, y, pad_mode="min"):
     return x.shape[-1] + y.shape[-1] - 1
 
 
-def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None):
+def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False):
     """convolve() given precomputed tile spectra of the taps.
 
     ``x`` is (R,C,L) or a strided (B,n,C,L) view of the signal buffer; with ``out`` (same kind of
@@ -72,10 +77,10 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None):
     ``x``) additionally receives a copy of ``x`` -- from the convolution kernel itself when it can."""
     L = x.shape[-1]
     if tee is not None:
-        if mode == "causal" and not reference_aliases(L, N) and ops.fftconv_can_tee(x.shape[-2], Cf, L, L, 0, N):
+        if mode == "causal" and not reference_aliases(L, N, exact) and ops.fftconv_can_tee(x.shape[-2], Cf, L, L, 0, N):
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, tee=tee)
         tee.copy_(x)
-    if not reference_aliases(L, N):
+    if not reference_aliases(L, N, exact):
         if mode == "causal":
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out)
         if mode == "zerophase":
@@ -94,31 +99,38 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None):
     return out
 
 
-def convolve(x, h, mode="zerophase", pad_mode="min"):
-    """Reference-compatible convolve(): x (R,C,L) or (R,L); h (R,Cf,N) or (R,N)."""
+def convolve(x, h, mode="zerophase", pad_mode="min", exact=False):
+    """Reference-compatible convolve(): x (R,C,L) or (R,L); h (R,Cf,N) or (R,N).  ``exact``: see reference_aliases."""
     compute_pad_len(x, h, pad_mode)
     if needs_grad(x, h):
-        return diff.convolve(x, h, mode)
+        return diff.convolve(x, h, mode, exact=exact)
     flat = x.ndim == 2
     if flat:
         x, h = x.unsqueeze(1), h.unsqueeze(1)
     R, Cf, N = h.shape
     Hs = ops.fir_spectrum(h.reshape(R * Cf, N))
-    y = convolve_taps(x, Hs, N, Cf, mode)
+    y = convolve_taps(x, Hs, N, Cf, mode, exact=exact)
     return y.squeeze(1) if flat else y
 
 
 class FIRConvolution(nn.Module):
-    """Same constructor as the reference (convolution.py:38-65).  ``flashfftconv`` and
-    ``max_input_len`` are accepted and ignored: FlashFFTConv is a CUDA-only bf16 library; the
-    fp32 HIP overlap-save kernels are its MI355X counterpart and have no length cap."""
+    """Same constructor as the reference (convolution.py:38-65).
+
+    ``flashfftconv=True`` (the upstream default) selects, upstream, the FlashFFTConv CUDA library: a plain causal
+    convolution in bf16, capped at ``max_input_len``.  Its MI355X counterpart is the fp32 HIP overlap-save kernel
+    computing that same causal convolution (no length cap; ``max_input_len`` is accepted and unused).
+    ``flashfftconv=False`` selects upstream's native torch.fft path, whose odd-length aliasing is reproduced
+    (DESIGN.md section 2).  As upstream, the FlashFFTConv flavour has no zero-phase mode (convolution.py:86-89)."""
 
     def __init__(self, mode="causal", flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.mode = mode
-        self.flashfftconv = False
-        if flashfftconv and mode == "zerophase":
-            warnings.warn("flashfftconv is ignored by grafx_amd (fp32 HIP FFT convolution is always used).")
+        self.flashfftconv = bool(flashfftconv)
+        if self.flashfftconv and mode == "zerophase":
+            warnings.warn("When using FlashFFTConv with zerophase mode, make sure that the sum of the input and kernel "
+                          "lengths is less than or equal to max_input_len.")
 
     def forward(self, input_signals, fir):
-        return convolve(input_signals, fir, mode=self.mode)
+        if self.flashfftconv:
+            assert self.mode != "zerophase", "We currently do not support zerophase mode with FlashFFTConv."
+        return convolve(input_signals, fir, mode=self.mode, exact=self.flashfftconv)

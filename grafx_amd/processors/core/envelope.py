@@ -15,15 +15,16 @@ class TruncatedOnePoleIIRFilter(nn.Module):
     when the reference's convolve() would alias (odd L + iir_len - 1) the full-length result is
     produced first and aliased the same way."""
 
-    def __init__(self, iir_len=16384, **backend_kwargs):
+    def __init__(self, iir_len=16384, flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.iir_len = iir_len
+        self.flashfftconv = bool(flashfftconv)  # True: plain causal convolution, see FIRConvolution
 
     def forward(self, input_signals, z_alpha):
         if needs_grad(input_signals, z_alpha):
-            return diff.truncated_one_pole(input_signals, z_alpha, self.iir_len)
+            return diff.truncated_one_pole(input_signals, z_alpha, self.iir_len, exact=self.flashfftconv)
         L = input_signals.shape[-1]
-        if not reference_aliases(L, self.iir_len):
+        if not reference_aliases(L, self.iir_len, self.flashfftconv):
             return ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L, relu=True)
         full = ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L + self.iir_len - 1, relu=False)
         return torch.relu(odd_length_alias(full)[..., :L]).contiguous()

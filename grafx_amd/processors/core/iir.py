@@ -17,6 +17,7 @@ class IIRFilter(nn.Module):
         self.backend = backend
         self.fsm_fir_len = fsm_fir_len
         self.fsm_regularization = fsm_regularization
+        self.flashfftconv = bool(flashfftconv)  # True: plain causal convolution (FlashFFTConv's role), see FIRConvolution
         if flashfftconv:  # same precondition as upstream (iir.py:110-112)
             assert fsm_fir_len % 2 == 0
             assert fsm_max_input_len % 2 == 0
@@ -65,7 +66,7 @@ class IIRFilter(nn.Module):
             tee = None
         if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
             x = input_signal.reshape(-1, *input_signal.shape[-2:])
-            y = diff.convolve(x, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal")
+            y = diff.convolve(x, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal", exact=self.flashfftconv)
             if out is None:
                 return y
             out.copy_(y.view(out.shape))
@@ -73,4 +74,4 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         N = self.fsm_fir_len
         h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
-        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out, tee=tee)
+        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out, tee=tee, exact=self.flashfftconv)

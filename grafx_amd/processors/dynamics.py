@@ -17,16 +17,17 @@ class _Dynamics(BufferIO, nn.Module):
                  iir_len=16384, flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.iir_len = iir_len
+        self.flashfftconv = bool(flashfftconv)
         self.energy_smoother = energy_smoother
         if energy_smoother == "iir":
-            self.energy_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len)
+            self.energy_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len, flashfftconv=flashfftconv)
         elif energy_smoother == "ballistics":
             self.energy_smoother_module = Ballistics()
         elif energy_smoother is not None:
             raise ValueError(f"Unknown energy_smoother: {self.energy_smoother}")
         self.gain_smoother = gain_smoother
         if gain_smoother == "iir":
-            self.gain_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len)
+            self.gain_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len, flashfftconv=flashfftconv)
         elif gain_smoother == "ballistics":
             self.gain_smoother_module = Ballistics()
         elif gain_smoother is not None:
@@ -52,7 +53,7 @@ class _Dynamics(BufferIO, nn.Module):
         if self.knee == "hard":
             log_knee = None
         fusable = self.gain_smoother is None and (
-            self.energy_smoother is None or (self.energy_smoother == "iir" and not reference_aliases(L, self.iir_len))
+            self.energy_smoother is None or (self.energy_smoother == "iir" and not reference_aliases(L, self.iir_len, self.flashfftconv))
         )
         if fusable:  # one pass: energy -> one-pole -> log -> knee -> exp -> multiply
             return ops.dynamics_fused(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
@@ -118,7 +119,8 @@ class ApproxCompressor(Compressor):
     names (``z_alpha`` instead of ``z_alpha_pre``)."""
 
     def __init__(self, iir_len=16384, flashfftconv=True, max_input_len=2**17):
-        super().__init__(energy_smoother="iir", gain_smoother=None, knee="quadratic", iir_len=iir_len)
+        super().__init__(energy_smoother="iir", gain_smoother=None, knee="quadratic", iir_len=iir_len,
+                         flashfftconv=flashfftconv, max_input_len=max_input_len)
 
     def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None):
         return super().forward(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre=z_alpha, _out=_out)
@@ -134,7 +136,8 @@ class ApproxNoiseGate(nn.Module):
 
     def __init__(self, freq_sample_n=16384, flashfftconv=True, max_input_len=2**17):
         super().__init__()
-        self.smoother = TruncatedOnePoleIIRFilter(iir_len=freq_sample_n)
+        self.smoother = TruncatedOnePoleIIRFilter(iir_len=freq_sample_n, flashfftconv=flashfftconv,
+                                                  max_input_len=max_input_len)
 
     def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None):
         if needs_grad(input_signals, z_alpha, log_threshold, log_ratio, log_knee):

@@ -19,6 +19,7 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
                  fixed_noise=True, gain_envelope=False, flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.ir_len, self.n_fft, self.hop_length = ir_len, n_fft, hop_length
+        self.flashfftconv = bool(flashfftconv)  # True: plain causal convolution (FlashFFTConv's role), see FIRConvolution
         self.num_frames = 1 + (ir_len // hop_length)
         self.num_bins = 1 + n_fft // 2
         self.register_buffer("window", torch.hann_window(n_fft))
@@ -81,11 +82,11 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
             x = input_signals.reshape(-1, *input_signals.shape[-2:])
             ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
             if pseudo:
-                y = diff.convolve(x, normalize_impulse(ms_to_lr(ir)), "causal")
+                y = diff.convolve(x, normalize_impulse(ms_to_lr(ir)), "causal", exact=self.flashfftconv)
             elif self.processor_channel == "midside":
-                y = ms_to_lr(diff.convolve(lr_to_ms(x), normalize_impulse(ir), "causal"))
+                y = ms_to_lr(diff.convolve(lr_to_ms(x), normalize_impulse(ir), "causal", exact=self.flashfftconv))
             else:
-                y = diff.convolve(x, normalize_impulse(ir), "causal")
+                y = diff.convolve(x, normalize_impulse(ir), "causal", exact=self.flashfftconv)
             if _out is None:
                 return y
             _out.copy_(y.view(_out.shape))
@@ -95,8 +96,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         # normalize_impulse (core/utils.py:14-18) is folded into the tap -> spectrum step
         Hs = ops.fir_spectrum(ir.view(R * 2, self.ir_len), gain=gain, gain_div=2)
         if self.processor_channel == "midside":  # reverb.py:219-223
-            return ms_to_lr(convolve_taps(lr_to_ms(input_signals), Hs, self.ir_len, 2, "causal"))
-        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal", out=_out)
+            return ms_to_lr(convolve_taps(lr_to_ms(input_signals), Hs, self.ir_len, 2, "causal", exact=self.flashfftconv))
+        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal", out=_out, exact=self.flashfftconv)
 
     def parameter_size(self):
         size = {"init_log_magnitude": (2, self.num_bins), "delta_log_magnitude": (2, self.num_bins)}

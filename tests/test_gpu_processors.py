@@ -184,8 +184,8 @@ def test_loud_failures():
     with pytest.raises(NotImplementedError):  # the one missing backward fails loudly, at backward time
         b = P.Ballistics()(torch.rand(2, 64).cuda(), torch.zeros(2, 2, device="cuda", requires_grad=True))
         b.sum().backward()
-    with pytest.raises(NotImplementedError):
-        P.IIRFilter(backend="lfilter", flashfftconv=False)
+    with pytest.raises(NotImplementedError):  # the recursive kernel runs second-order sections only
+        P.IIRFilter(order=3, backend="lfilter", flashfftconv=False)
     with pytest.raises(ValueError):
         P.IIRFilter(backend="nope", flashfftconv=False)
     with pytest.raises(ValueError):
