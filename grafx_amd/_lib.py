@@ -24,6 +24,7 @@ SIGNATURES = {
     "gfx_fftconv_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64]),
     "gfx_fir_spectrum_f32": (ctypes.c_int, [f32p, f32p, i64, vp, i64, i64, vp]),
     "gfx_fftconv_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
+    "gfx_fftconv_ex_f32": (ctypes.c_int, [f32p, RowMap, vp, i64, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_fftconv_tee_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_iir_fsm_plan_bytes": (sz, [i64]),
     "gfx_iir_fsm_plan_f32": (ctypes.c_int, [vp, i64, vp]),
@@ -32,6 +33,8 @@ SIGNATURES = {
     "gfx_biquad_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, vp]),
     "gfx_dynamics_fused_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64,
                                               ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, vp]),
+    "gfx_dynamics_fused_ex_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                                 ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, vp]),
     "gfx_energy_f32": (ctypes.c_int, [f32p, RowMap, f32p, i64, i64, i64, vp]),
     "gfx_onepole_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, i64, i64, ctypes.c_int, vp]),
     "gfx_onepole_fir_f32": (ctypes.c_int, [f32p, f32p, i64, i64, vp]),

@@ -175,6 +175,7 @@ struct DynArgs {
     int C;                 // channels
     int smoother;          // 0 none, 1 truncated one-pole
     int knee, gate;
+    unsigned prows;        // parameter rows: row r uses parameters r % prows
 };
 
 // ---- fused compressor / gate: energy -> one-pole -> log -> knee -> exp -> multiply -----------------
@@ -251,9 +252,10 @@ __global__ __launch_bounds__(DT) void dyn_fused_kernel(const float* __restrict__
     const int64_t r = blockIdx.x;
     OnePole p;
     p.trunc = false;
-    if (a.smoother == 1) onepole_setup(p, z_alpha[r], a.N, t & 63);
+    const unsigned pr = (unsigned)r % a.prows;
+    if (a.smoother == 1) onepole_setup(p, z_alpha[pr], a.N, t & 63);
     Knee q;
-    knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, a.knee, a.gate);
+    knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
     const float* x0 = x + drow_off(a.xmap, r, 0);
     const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
     float* y0 = y + drow_off(a.ymap, r, 0);
@@ -449,6 +451,15 @@ extern "C" {
 int gfx_dynamics_fused_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
                            const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t R, int64_t C,
                            int64_t L, int smoother, int64_t iir_len, int knee, int gate, void* stream) {
+    return gfx_dynamics_fused_ex_f32(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, R, R, C, L, smoother,
+                                     iir_len, knee, gate, stream);
+}
+
+int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                              int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                              void* stream) {
+    if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
     if (!x || !y || !log_threshold || !log_ratio || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
     if (knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
     if (smoother != 0 && smoother != 1) return GFX_EINVAL;
@@ -457,6 +468,7 @@ int gfx_dynamics_fused_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowm
     DynArgs a;
     a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = smoother; a.knee = knee; a.gate = gate;
+    a.prows = (unsigned)param_rows;
     hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, x, y, log_threshold,
                        log_ratio, log_knee, z_alpha, a);
     return GFX_LAUNCH_OK();

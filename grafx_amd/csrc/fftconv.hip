@@ -48,6 +48,7 @@ struct ConvArgs {
     int64_t ntiles, nblocks; // tiles per row-channel, total workgroups of real work
     int nparts;
     int Cin, Cf, Cout;
+    unsigned hrows;          // filter rows: row r convolves with filter r % hrows (batch-major rows sharing filters)
 };
 
 // rows and row counts fit 32 bits (checked by the launchers): 32-bit division is ~5x cheaper than
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     const int c = (int)(rco - r * (unsigned)a.Cout);
     const float* xrow = x + row_off(a.xmap, r, a.Cin == 1 ? 0 : c);
     float* yrow = y + row_off(a.ymap, r, c);
-    const rsrc_t H = make_rsrc(Hs + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4, H_TILE_F4 * 16);
+    const rsrc_t H = make_rsrc(Hs + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4, H_TILE_F4 * 16);
 
     // Every global load of the tile is issued up front: the window, the twiddles, and the filter spectrum
     // (needed only after the forward transform, by which time it has long arrived).  Left to itself the
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     const unsigned r = rco / (unsigned)a.Cout;
     const int c = (int)(rco - r * (unsigned)a.Cout);
     float* yrow = y + row_off(a.ymap, r, c);
-    const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
+    const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
     const cx* Z = reinterpret_cast<const cx*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
 
     cx ye[H_SLOTS], yo[H_SLOTS];
@@ -352,13 +353,21 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
                     int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws,
                     size_t ws_bytes, void* stream) {
     const gfx_rowmap_t none = {1, 0, 0, 0};
-    return gfx_fftconv_tee_f32(x, xmap, Hs, y, ymap, nullptr, none, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes, stream);
+    return gfx_fftconv_ex_f32(x, xmap, Hs, R, y, ymap, nullptr, none, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes, stream);
 }
 
 int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap, float* xcopy,
                         gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off,
                         int64_t N, void* ws, size_t ws_bytes, void* stream) {
+    if (!xcopy) return GFX_EINVAL;
+    return gfx_fftconv_ex_f32(x, xmap, Hs, R, y, ymap, xcopy, cmap, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes, stream);
+}
+
+int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, float* y, gfx_rowmap_t ymap,
+                       float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout,
+                       int64_t off, int64_t N, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
+    if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
     if (xcopy && (off != 0 || Lout != L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
         return GFX_EINVAL;
     if (C_in < 1 || C_f < 1 || (C_in != C_f && C_in != 1 && C_f != 1)) return GFX_EINVAL;
@@ -368,6 +377,7 @@ int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float
     a.xmap = xmap;
     a.ymap = ymap;
     a.cmap = cmap;
+    a.hrows = (unsigned)h_rows;
     a.L = L;
     a.Lout = Lout;
     a.off = off;

@@ -84,39 +84,39 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
-def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None):
-    """y[r,c,n] = sum_k h[r,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
+def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None):
+    """y[r,c,n] = sum_k h[r % h_rows,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
 
     ``x`` / ``out`` may be (R,C,L) tensors or strided (B,n,C,L) views (see :func:`rowmap`).
     ``tee``: optional tensor shaped like ``x`` that receives a copy of ``x`` from the same kernel.
+    ``h_rows``: number of filters in ``Hs`` when fewer than the signal rows (rows are batch-major, so
+    ``h_rows = nodes`` shares one filter per node across the batch); default: one filter per row.
     """
     _require_gpu(x, out, tee)
     xmap, R, Cin, L = rowmap(x)
     Lout = L if Lout is None else Lout
     Cout = max(Cin, Cf)
+    h_rows = R if h_rows is None else h_rows
     if out is None:
         out = torch.empty((R, Cout, Lout), dtype=torch.float32, device=x.device)
     ymap, Ry, Cy, Ly = rowmap(out)
     if (Ry, Cy) != (R, Cout) or Ly < Lout:
         raise ValueError(f"output shape {tuple(out.shape)} does not match rows={R}, channels={Cout}, length>={Lout}")
+    if Hs.numel() != lib().gfx_fir_spectrum_bytes(h_rows * Cf, N):
+        raise ValueError(f"filter spectra hold {Hs.numel()} bytes, expected {h_rows} x {Cf} filters of {N} taps")
     nbytes = lib().gfx_fftconv_workspace_bytes(R, Cin, L, Lout, off, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     name = "fftconv1_kernel" if nbytes == 0 else "xspec+macinv_kernels"
+    cmap = RowMap(1, 0, 0, 0)
     if tee is not None:
         cmap, Rc, Cc, Lc = rowmap(tee)
         if (Rc, Cc, Lc) != (R, Cin, L):
             raise ValueError(f"tee shape {tuple(tee.shape)} does not match the input {tuple(x.shape)}")
-        with _timed(name, 4 * R * (2 * Cin * L + Cout * Lout)):
-            check(
-                lib().gfx_fftconv_tee_f32(_ptr(x), xmap, _ptr(Hs), _ptr(out), ymap, _ptr(tee), cmap, R, Cin, Cf, L, Lout,
-                                          off, N, _ptr(ws), nbytes, _stream()),
-                "gfx_fftconv_tee_f32",
-            )
-        return out
-    with _timed(name, 4 * R * (Cin * L + Cout * Lout)):
+    with _timed(name, 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)):
         check(
-            lib().gfx_fftconv_f32(_ptr(x), xmap, _ptr(Hs), _ptr(out), ymap, R, Cin, Cf, L, Lout, off, N, _ptr(ws), nbytes, _stream()),
-            "gfx_fftconv_f32",
+            lib().gfx_fftconv_ex_f32(_ptr(x), xmap, _ptr(Hs), h_rows, _ptr(out), ymap, _ptr(tee), cmap, R, Cin, Cf, L, Lout,
+                                     off, N, _ptr(ws), nbytes, _stream()),
+            "gfx_fftconv_ex_f32",
         )
     return out
 
@@ -179,16 +179,19 @@ def _rowvec(p, R):
     return p
 
 
-def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None):
+def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None,
+                   param_rows=None):
+    """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows)."""
     _require_gpu(x, out)
     xmap, R, C, L = rowmap(x)
+    P = R if param_rows is None else param_rows
     if out is None:
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     ymap = rowmap(out)[0]
-    args = (_ptr(x), xmap, _ptr(out), ymap, _ptr(_rowvec(log_threshold, R)), _ptr(_rowvec(log_ratio, R)),
-            _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)), R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
+    args = (_ptr(x), xmap, _ptr(out), ymap, _ptr(_rowvec(log_threshold, P)), _ptr(_rowvec(log_ratio, P)),
+            _ptr(_rowvec(log_knee, P)), _ptr(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
     with _timed("dyn_fused_kernel", 8 * R * C * L):
-        check(lib().gfx_dynamics_fused_f32(*args), "gfx_dynamics_fused_f32")
+        check(lib().gfx_dynamics_fused_ex_f32(*args), "gfx_dynamics_fused_ex_f32")
     return out
 
 

@@ -69,7 +69,7 @@ def compute_pad_len(x, y, pad_mode="min"):
     return x.shape[-1] + y.shape[-1] - 1
 
 
-def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False):
+def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False, h_rows=None):
     """convolve() given precomputed tile spectra of the taps.
 
     ``x`` is (R,C,L) or a strided (B,n,C,L) view of the signal buffer; with ``out`` (same kind of
@@ -78,15 +78,15 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False):
     L = x.shape[-1]
     if tee is not None:
         if mode == "causal" and not reference_aliases(L, N, exact) and ops.fftconv_can_tee(x.shape[-2], Cf, L, L, 0, N):
-            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, tee=tee)
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, tee=tee, h_rows=h_rows)
         tee.copy_(x)
     if not reference_aliases(L, N, exact):
         if mode == "causal":
-            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out)
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, h_rows=h_rows)
         if mode == "zerophase":
-            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2, out=out)
-        return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, out=out)
-    y_pad = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0))
+            return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2, out=out, h_rows=h_rows)
+        return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, out=out, h_rows=h_rows)
+    y_pad = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows))
     if mode == "causal":
         y = y_pad[..., :L]
     elif mode == "zerophase":

@@ -56,7 +56,12 @@ class IIRFilter(nn.Module):
         # "ssm" with K > 1: upstream drives every section's recursion with the original input (iir.py:226-246)
         return ops.biquad_cascade(input_signal, Bs, As, ssm_quirk=self.backend == "ssm", out=out)
 
-    def forward(self, input_signal, Bs, As, out=None, tee=None):
+    def forward(self, input_signal, Bs, As, out=None, tee=None, shared_rows=None):
+        """``shared_rows``: Bs/As hold that many rows, shared by the batch (signal row r uses r % shared_rows)."""
+        if shared_rows is not None and (self.backend != "fsm" or needs_grad(input_signal, Bs, As)):
+            reps = input_signal.shape[0] if input_signal.ndim == 4 else input_signal.shape[0] // shared_rows
+            Bs, As = Bs.repeat(reps, 1, 1, 1), As.repeat(reps, 1, 1, 1)  # paths without row sharing
+            shared_rows = None
         if self.backend != "fsm":
             if tee is not None:
                 tee.copy_(input_signal)
@@ -74,4 +79,5 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         N = self.fsm_fir_len
         h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
-        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out, tee=tee, exact=self.flashfftconv)
+        return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out, tee=tee, exact=self.flashfftconv,
+                             h_rows=shared_rows)

@@ -37,11 +37,13 @@ class _Dynamics(BufferIO, nn.Module):
         self.knee = knee
         self.gain_smooth_in_log = gain_smooth_in_log
 
-    def render_into(self, x4, out4, **params):
-        return self.forward(x4, _out=out4, **params)
+    accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
+
+    def render_into(self, x4, out4, _shared_rows=None, **params):
+        return self.forward(x4, _out=out4, _shared_rows=_shared_rows, **params)
 
     def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None,
-                _out=None):
+                _out=None, _shared_rows=None):
         if needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
             y = self._forward_differentiable(input_signals.reshape(-1, *input_signals.shape[-2:]), log_threshold,
                                              log_ratio, log_knee, z_alpha_pre, z_alpha_post)
@@ -52,13 +54,23 @@ class _Dynamics(BufferIO, nn.Module):
         L = input_signals.shape[-1]
         if self.knee == "hard":
             log_knee = None
+        if _shared_rows is not None and (needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
+                                                    z_alpha_post) or self.gain_smoother is not None
+                                         or self.energy_smoother == "ballistics"
+                                         or (self.energy_smoother == "iir" and reference_aliases(
+                                             input_signals.shape[-1], self.iir_len, self.flashfftconv))):
+            reps = input_signals.shape[0]  # paths without row sharing: expand to one parameter row per signal row
+            log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post = (
+                None if t is None else t.repeat(reps, *([1] * (t.ndim - 1)))
+                for t in (log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post))
+            _shared_rows = None
         fusable = self.gain_smoother is None and (
             self.energy_smoother is None or (self.energy_smoother == "iir" and not reference_aliases(L, self.iir_len, self.flashfftconv))
         )
         if fusable:  # one pass: energy -> one-pole -> log -> knee -> exp -> multiply
             return ops.dynamics_fused(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                       smoother=int(self.energy_smoother == "iir"), iir_len=self.iir_len,
-                                      knee=self.knee, gate=self._gate, out=_out)
+                                      knee=self.knee, gate=self._gate, out=_out, param_rows=_shared_rows)
         if _out is not None:  # unfused configurations: run on flattened rows, then copy into the buffer slice
             y = self.forward(input_signals.reshape(-1, *input_signals.shape[2:]), log_threshold, log_ratio, log_knee,
                              z_alpha_pre, z_alpha_post)

@@ -23,22 +23,25 @@ class ParametricEqualizer(BufferIO, nn.Module):
             raise ValueError(f"Invalid processor_channel: {self.processor_channel}")
 
     accepts_tee = True  # render_into(..., tee=view) also leaves a copy of the input in `view`
+    accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
 
-    def forward(self, input_signals, w0, q_inv, log_gain, _out=None, _tee=None):
+    def forward(self, input_signals, w0, q_inv, log_gain, _out=None, _tee=None, _shared_rows=None):
         if needs_grad(input_signals, w0, q_inv, log_gain):
             Bs, As = diff.peq_coefficients(w0, q_inv, log_gain, self.use_shelving_filters)
         else:
             Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
-        return self.biquad(input_signals, Bs, As, out=_out, tee=_tee)
+        return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows)
 
-    def render_into(self, x4, out4, tee=None, **params):
+    def render_into(self, x4, out4, tee=None, _shared_rows=None, **params):
         if self.processor_channel == "midside":
             if tee is not None:
                 tee.copy_(x4)
+            if _shared_rows is not None:
+                params = {k: v.repeat(x4.shape[0], *([1] * (v.ndim - 1))) for k, v in params.items()}
             return super().render_into(x4, out4, **params)
-        return self.forward(x4, _out=out4, _tee=tee, **params)
+        return self.forward(x4, _out=out4, _tee=tee, _shared_rows=_shared_rows, **params)
 
     def parameter_size(self):
         n_channels = 1 if self.processor_channel == "mono" else 2

@@ -71,13 +71,25 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
                          hop_length=self.hop_length, window=self.window, length=self.ir_len)
         return ir.view(R, 2, self.ir_len)
 
-    def render_into(self, x4, out4, **params):
-        if self.processor_channel == "midside":
-            return super().render_into(x4, out4, **params)
-        return self.forward(x4, _out=out4, **params)
+    accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
 
-    def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _out=None):
+    def render_into(self, x4, out4, _shared_rows=None, **params):
+        if self.processor_channel == "midside":
+            if _shared_rows is not None:
+                params = {k: v.repeat(x4.shape[0], *([1] * (v.ndim - 1))) for k, v in params.items()}
+            return super().render_into(x4, out4, **params)
+        return self.forward(x4, _out=out4, _shared_rows=_shared_rows, **params)
+
+    def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _out=None,
+                _shared_rows=None):
         pseudo = self.processor_channel == "pseudo_midside"
+        if _shared_rows is not None and needs_grad(input_signals, init_log_magnitude, delta_log_magnitude,
+                                                   gain_env_log_magnitude):
+            reps = input_signals.shape[0]
+            init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude = (
+                None if t is None else t.repeat(reps, 1, 1)
+                for t in (init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude))
+            _shared_rows = None
         if needs_grad(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
             x = input_signals.reshape(-1, *input_signals.shape[-2:])
             ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
@@ -97,7 +109,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         Hs = ops.fir_spectrum(ir.view(R * 2, self.ir_len), gain=gain, gain_div=2)
         if self.processor_channel == "midside":  # reverb.py:219-223
             return ms_to_lr(convolve_taps(lr_to_ms(input_signals), Hs, self.ir_len, 2, "causal", exact=self.flashfftconv))
-        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal", out=_out, exact=self.flashfftconv)
+        return convolve_taps(input_signals, Hs, self.ir_len, 2, "causal", out=_out, exact=self.flashfftconv,
+                             h_rows=_shared_rows)
 
     def parameter_size(self):
         size = {"init_log_magnitude": (2, self.num_bins), "delta_log_magnitude": (2, self.num_bins)}

@@ -120,19 +120,21 @@ def _touches_inputs(read, n_src):
     return False
 
 
+def _any_requires_grad(p):
+    if isinstance(p, torch.Tensor):
+        return p.requires_grad
+    return any(_any_requires_grad(v) for v in p.values()) if hasattr(p, "values") else False
+
+
+def _wants_grad(input_signals, per_type_parameters, common_parameters):
+    return torch.is_grad_enabled() and (input_signals.requires_grad or _any_requires_grad(per_type_parameters)
+                                        or (common_parameters is not None and _any_requires_grad(common_parameters)))
+
+
 def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
+    """Structural conditions of the in-place buffer path (gradients are handled by _BufferRenderFn around it)."""
     if not input_signals.is_cuda or render_data.method == "one-by-one" or not render_data.siso_only:
         return False
-    if torch.is_grad_enabled():
-        # training: saved views of a buffer that later stages keep writing would trip autograd's version
-        # check, so the reference's clone-on-read loop is used instead
-        def any_requires_grad(p):
-            if isinstance(p, torch.Tensor):
-                return p.requires_grad
-            return any(any_requires_grad(v) for v in p.values()) if hasattr(p, "values") else False
-
-        if input_signals.requires_grad or any_requires_grad(per_type_parameters):
-            return False
     for step in render_data.iter_list[1:]:
         if step.node_type in processors:
             if not hasattr(processors[step.node_type], "render_into"):
@@ -154,8 +156,12 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
     squeeze = input_signals.ndim == 3
     x = input_signals.unsqueeze(0) if squeeze else input_signals
     B, n_src, C, L = x.shape
+    # 4-D input: the parameters are per node and shared by the batch (upstream expands them B times,
+    # render/graph.py:68-75).  Processors that understand sharing get the un-expanded rows, build their filters
+    # once per node and let every batch row read them; the others get the expanded copies.
+    shared_tree = per_type_parameters if (not squeeze and common_parameters is None) else None
     if not squeeze:
-        per_type_parameters = expand_tensor_or_tensor_dict(per_type_parameters, expand=B, dim=0)
+        expanded_tree = None  # built on first use
         if common_parameters is not None:
             common_parameters = expand_tensor_or_tensor_dict(common_parameters, expand=B, dim=0)
     node_dim = 0 if squeeze else 1
@@ -201,22 +207,151 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             x_view = (x if from_inputs else buf).narrow(1, a, b - a)
         else:
             x_view = _gather(ops, buf, plan, torch.empty(B, plan[2], C, L, device=x.device))
-        params = read_tensor_or_tensor_dict(per_type_parameters[node_type], step.parameter_read, dim=node_dim,
-                                            postprocess=postprocess)
+        proc = processors[node_type]
+        extra = {}
+        if squeeze:
+            params = read_tensor_or_tensor_dict(per_type_parameters[node_type], step.parameter_read, dim=0)
+        elif shared_tree is not None and getattr(proc, "accepts_shared_params", False):
+            params = read_tensor_or_tensor_dict(shared_tree[node_type], step.parameter_read, dim=0)
+            extra["_shared_rows"] = d1 - d0
+        else:
+            if expanded_tree is None:
+                expanded_tree = expand_tensor_or_tensor_dict(per_type_parameters, expand=B, dim=0)
+            params = read_tensor_or_tensor_dict(expanded_tree[node_type], step.parameter_read, dim=1,
+                                                postprocess=flatten_batch_and_node)
         common_i = {}
         if common_parameters is not None:
             common_i = read_tensor_or_tensor_dict(common_parameters, step.dest_write, dim=node_dim,
                                                   postprocess=postprocess)
         if teed is not None and i == _first_order(render_data):
             a, b = teed
-            processors[node_type].render_into(x_view, out_view, tee=buf.narrow(1, a, b - a), **params, **common_i)
-        else:
-            processors[node_type].render_into(x_view, out_view, **params, **common_i)
+            extra["tee"] = buf.narrow(1, a, b - a)
+        proc.render_into(x_view, out_view, **extra, **params, **common_i)
     if not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:
         return out_view[0], [], buf[0]
     return out_view, [], buf
+
+
+# ---- training: the same in-place forward, with a stage-wise backward ------------------------------------
+def _flatten_tree(tree, leaves):
+    """Nested dict of tensors -> spec with leaf indices (tensors appended to `leaves`)."""
+    if isinstance(tree, torch.Tensor):
+        leaves.append(tree)
+        return len(leaves) - 1
+    if hasattr(tree, "items"):
+        return {k: _flatten_tree(v, leaves) for k, v in tree.items()}
+    return ("const", tree)
+
+
+def _unflatten_tree(spec, leaves):
+    if isinstance(spec, int):
+        return leaves[spec]
+    if isinstance(spec, dict):
+        return {k: _unflatten_tree(v, leaves) for k, v in spec.items()}
+    return spec[1]
+
+
+class _BufferRenderFn(torch.autograd.Function):
+    """render_grafx as ONE autograd node.
+
+    Forward is the in-place buffer render (the inference path, run without a tape).  The signal buffer it returns
+    holds every node's output, i.e. every activation the backward needs, so the backward walks the schedule in
+    reverse and, per stage, re-evaluates that stage alone on its (detached) input rows with a local tape,
+    back-propagates the stage's slice of the buffer gradient through it, and adds the input gradient onto the
+    rows the stage read.  Compared with taping the upstream loop (clone-on-read + in-place slice writes into
+    one (B, V, C, L) tensor) this never copies or zero-fills the whole buffer gradient per stage — at the console
+    graph that was most of the step — and keeps peak memory at two buffers plus one stage's tape."""
+
+    @staticmethod
+    def forward(ctx, meta, input_signals, *leaves):
+        processors, render_data, p_spec, c_spec = meta
+        params = _unflatten_tree(p_spec, leaves)
+        common = None if c_spec is None else _unflatten_tree(c_spec, leaves)
+        with torch.no_grad():
+            _, _, buf = _render_buffer_io(processors, input_signals, params, render_data, common)
+        ctx.meta = meta
+        ctx.squeeze = input_signals.ndim == 3
+        ctx.n_src = input_signals.shape[0 if ctx.squeeze else 1]
+        ctx.save_for_backward(buf, *leaves)
+        return buf
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gbuf):
+        from .. import ops
+
+        processors, render_data, p_spec, c_spec = ctx.meta
+        buf, *leaves = ctx.saved_tensors
+        squeeze = ctx.squeeze
+        if squeeze:
+            buf, gbuf = buf.unsqueeze(0), gbuf.unsqueeze(0)
+        gbuf = gbuf.clone()  # accumulated into below
+        B, V, C, L = buf.shape
+        dev = buf.device
+        node_dim = 0 if squeeze else 1
+        postprocess = None if squeeze else flatten_batch_and_node
+        leaf_grads = [None] * len(leaves)
+        live = [i for i, t in enumerate(leaves) if t.requires_grad]
+
+        for i in range(render_data.max_order, 0, -1):
+            step = render_data.iter_list[i]
+            d0, d1 = step.dest_write.idx
+            g_out = gbuf.narrow(1, d0, d1 - d0)
+            plan = _gather_plan(step, dev)
+            node_type = step.node_type
+            if node_type in processors:
+                if plan is None:
+                    a, b = step.source_reads[0].idx
+                    x_in = buf.narrow(1, a, b - a)
+                else:
+                    x_in = _gather(ops, buf, plan, torch.empty(B, plan[2], C, L, device=dev))
+                with torch.enable_grad():
+                    x_in = x_in.reshape(-1, C, L).detach().requires_grad_(True)
+                    local = [t.detach().requires_grad_(t.requires_grad) for t in leaves]
+                    params = _unflatten_tree(p_spec, local)[node_type]
+                    common = None if c_spec is None else _unflatten_tree(c_spec, local)
+                    if not squeeze:
+                        params = expand_tensor_or_tensor_dict(params, expand=B, dim=0)
+                        if common is not None:
+                            common = expand_tensor_or_tensor_dict(common, expand=B, dim=0)
+                    params = read_tensor_or_tensor_dict(params, step.parameter_read, dim=node_dim, postprocess=postprocess)
+                    common_i = {} if common is None else read_tensor_or_tensor_dict(
+                        common, step.dest_write, dim=node_dim, postprocess=postprocess)
+                    y = processors[node_type](x_in, **params, **common_i)
+                    y = y[0] if isinstance(y, tuple) else y
+                    wrt = [x_in] + [local[j] for j in live]
+                    grads = torch.autograd.grad(y, wrt, grad_outputs=g_out.reshape(y.shape), allow_unused=True)
+                g_in = grads[0].view(B, -1, C, L)
+                for j, g in zip(live, grads[1:]):
+                    if g is not None:
+                        leaf_grads[j] = g if leaf_grads[j] is None else leaf_grads[j] + g
+            else:  # in / out / mix: the (summed) input is the output
+                g_in = g_out
+            # add the stage's input gradient onto the rows it read
+            if plan is None:
+                a, b = step.source_reads[0].idx
+                gbuf.narrow(1, a, b - a).add_(g_in)
+            else:
+                src_idx, seg_ptr = plan[0], plan[1]
+                counts = (seg_ptr[1:] - seg_ptr[:-1])
+                dst_of_edge = torch.repeat_interleave(torch.arange(counts.numel(), device=dev), counts)
+                gbuf.index_add_(1, src_idx, g_in.index_select(1, dst_of_edge))
+        g_x = gbuf.narrow(1, 0, ctx.n_src)
+        g_x = g_x[0] if squeeze else g_x
+        return (None, g_x.contiguous() if ctx.needs_input_grad[1] else None, *leaf_grads)
+
+
+def _render_buffer_io_with_grad(processors, input_signals, per_type_parameters, render_data, common_parameters):
+    leaves = []
+    p_spec = _flatten_tree(per_type_parameters, leaves)
+    c_spec = None if common_parameters is None else _flatten_tree(common_parameters, leaves)
+    buf = _BufferRenderFn.apply((processors, render_data, p_spec, c_spec), input_signals, *leaves)
+    last = render_data.iter_list[render_data.max_order]
+    d0, d1 = last.dest_write.idx
+    out = buf.narrow(0 if input_signals.ndim == 3 else 1, d0, d1 - d0)
+    return out, [], buf
 
 
 def render_grafx(
@@ -231,6 +366,9 @@ def render_grafx(
     method = render_data.method
     ndim = input_signals.ndim
     if ndim in (3, 4) and _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
+        if _wants_grad(input_signals, per_type_parameters, common_parameters):
+            return _render_buffer_io_with_grad(processors, input_signals, per_type_parameters, render_data,
+                                               common_parameters)
         return _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters)
     if ndim == 3:
         node_dim, postprocess = 0, None

@@ -83,6 +83,15 @@ int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float
                         int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* The general form of the two above.  `h_rows` <= R: row r convolves with filter (r % h_rows) -- rows are
+ * batch-major (r = b * nodes + node), so h_rows = nodes shares one filter per node across the batch, which is
+ * what render_grafx's 4-D path means by un-batched parameters (render/graph.py:68-75 expands them B times;
+ * here the spectra are built once per node and every batch row reads them).  xcopy may be null (no tee). */
+int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, float* y, gfx_rowmap_t ymap,
+                       float* xcopy, gfx_rowmap_t cmap,
+                       int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---- frequency-sampled IIR -------------------------------------------------------------
  * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276
  * (complex64 response of the biquad cascade on the N-point grid, then torch.fft.irfft(n=N)).
@@ -127,6 +136,11 @@ int gfx_dynamics_fused_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowm
                            const float* log_threshold, const float* log_ratio, const float* log_knee,
                            const float* z_alpha, int64_t R, int64_t C, int64_t L, int smoother,
                            int64_t iir_len, int knee, int gate, void* stream);
+/* Same with parameters shared across the batch: row r reads parameter row (r % param_rows). */
+int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
+                              const float* log_threshold, const float* log_ratio, const float* log_knee,
+                              const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
+                              int smoother, int64_t iir_len, int knee, int gate, void* stream);
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);

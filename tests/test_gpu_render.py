@@ -43,3 +43,40 @@ def test_console8_batched_graph(golden):
         y, _, buf = render_grafx(procs, g["console8_x"].cuda(), params, rd)
     assert_close(y.cpu(), g["console8_y"], 2e-5, "console8 y")
     assert_close(buf[:, -8:].cpu(), g["console8_buf_last8"], 2e-5, "console8 buffer tail")
+
+
+@pytest.mark.gpu
+def test_batch_shared_parameters_equal_expanded_parameters():
+    """4-D input: processors that accept un-expanded (per-node) parameters must produce exactly what they produce
+    from the B-times expanded copies upstream feeds them (render/graph.py:68-75)."""
+    import torch
+
+    import grafx_amd.processors as P
+
+    torch.manual_seed(5)
+    B, n, L = 3, 4, 20000
+    x4 = torch.randn(B, n, 2, L, device="cuda")
+    cases = [
+        (P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=1025),
+         {k: 0.3 * torch.randn(n, 1, 6, device="cuda") for k in ("w0", "q_inv", "log_gain")}),
+        (P.Compressor(energy_smoother="iir", iir_len=1023, flashfftconv=False),
+         {"log_threshold": torch.randn(n, 1, device="cuda") - 2, "log_ratio": torch.randn(n, 1, device="cuda"),
+          "log_knee": torch.randn(n, 1, device="cuda"), "z_alpha_pre": torch.randn(n, 1, device="cuda") + 2}),
+        (P.Compressor(energy_smoother="ballistics", flashfftconv=False),   # a path without native row sharing
+         {"log_threshold": torch.randn(n, 1, device="cuda") - 2, "log_ratio": torch.randn(n, 1, device="cuda"),
+          "log_knee": torch.randn(n, 1, device="cuda"), "z_alpha_pre": torch.randn(n, 2, device="cuda")}),
+        (P.STFTMaskedNoiseReverb(ir_len=3001, flashfftconv=False),
+         {"init_log_magnitude": torch.randn(n, 2, 193, device="cuda"), "delta_log_magnitude": torch.randn(n, 2, 193, device="cuda")}),
+    ]
+    for m, p in cases:
+        m = m.cuda()
+        assert m.accepts_shared_params
+        expanded = {k: v.unsqueeze(0).expand(B, *v.shape).reshape(B * n, *v.shape[1:]).contiguous() for k, v in p.items()}
+        a, b = torch.empty_like(x4), torch.empty_like(x4)
+        with torch.no_grad():
+            m.render_into(x4, a, _shared_rows=n, **p)
+            m.render_into(x4, b, **expanded)
+        if isinstance(m, P.STFTMaskedNoiseReverb):  # its energy normalisation accumulates with atomics
+            assert (a - b).abs().max() <= 2e-6 * b.abs().max(), type(m).__name__
+        else:
+            assert torch.equal(a, b), type(m).__name__
