@@ -145,8 +145,100 @@ def one_pole_fir(z_alpha, iir_len):
     return (1 - alpha) * torch.exp(n * torch.log(alpha))
 
 
+class TruncatedOnePoleFn(torch.autograd.Function):
+    """y = relu(u * h), h[k] = (1-a) a^k, k < N, a = min(sigmoid(z), 1-1e-5)  (core/envelope.py:34-60), as the
+    native prefix scan in both directions instead of a 16384-tap FFT convolution and its two adjoint convolutions.
+
+    With U[n] = sum_{k<=n} a^k u[n-k] (the untruncated scan) the filter output is (1-a)(U[n] - a^N U[n-N]), so
+      grad_u[m] = sum_{k<N} h[k] g[m+k]                      -- the same scan run backwards in time
+      d/da      = -(U[n] - a^N U[n-N]) + (1-a)(D[n] - N a^(N-1) U[n-N] - a^N D[n-N]),
+                  D = dU/da = sum_k k a^(k-1) u[n-k],  D[n] = a D[n-1] + U[n-1]   -- one more scan
+    (g already masked by the relu)."""
+
+    @staticmethod
+    def forward(ctx, u, z_alpha, N):
+        u = u.contiguous()
+        y = ops.onepole(u, z_alpha, N, relu=True)
+        ctx.save_for_backward(u, z_alpha, y)
+        ctx.N = N
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        u, z_alpha, y = ctx.saved_tensors
+        gu, gz = one_pole_backward(u, z_alpha, y, ctx.N, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gu, gz, None
+
+
+def one_pole_backward(u, z_alpha, y, N, g, need_u=True, need_z=True):
+    """Adjoint of y = relu(truncated one-pole(u)) given g = dL/dy (see TruncatedOnePoleFn)."""
+    R, L = u.shape
+    g = (g * (y > 0)).contiguous()
+    gu = gz = None
+    if need_u:
+        gu = ops.onepole(g.flip(-1), z_alpha, N, relu=False).flip(-1)
+    if need_z:
+        sig = torch.sigmoid(z_alpha.reshape(R, 1))
+        a = sig.clamp(max=1 - 1e-5)
+        one_m_a = 1 - a
+        inf = L + 1  # longer than the signal: no truncation term
+        U = ops.onepole(u, z_alpha, inf, relu=False) / one_m_a
+        D = ops.onepole(F.pad(U, (1, 0))[:, :L], z_alpha, inf, relu=False) / one_m_a
+        dlin = -U + one_m_a * D
+        if N < L:
+            aN = torch.pow(a.double(), N).float()
+            aN1 = torch.pow(a.double(), N - 1).float()
+            Ud, Dd = F.pad(U, (N, 0))[:, :L], F.pad(D, (N, 0))[:, :L]
+            dlin = dlin + aN * Ud - one_m_a * (N * aN1 * Ud + aN * Dd)
+        da = (g * dlin).sum(-1, keepdim=True)
+        gz = (da * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
+    return gu, gz
+
+
+class DynamicsFn(torch.autograd.Function):
+    """Compressor / NoiseGate without gain smoother (dynamics.py:390-405, 625-640) as one autograd node.
+
+    Forward is the fused inference kernel.  Backward recomputes the (smoothed) energy with the native energy and
+    scan kernels, takes the gain computer's derivatives in one native pass (gfx_dyn_gain_bwd_f32), pushes the
+    energy gradient back through the one-pole smoother with the scan run backwards in time, and assembles the
+    input gradient in one more pass (gfx_dyn_dx_f32) -- instead of ~40 full-size elementwise torch kernels and
+    three 16384-tap FFT convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate):
+        x = x.contiguous()
+        y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
+                               smoother=int(smoother), iir_len=iir_len, knee=knee, gate=gate)
+        ctx.save_for_backward(x, log_threshold, log_ratio, log_knee, z_alpha)
+        ctx.cfg = (smoother, iir_len, knee, gate)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, log_threshold, log_ratio, log_knee, z_alpha = ctx.saved_tensors
+        smoother, iir_len, knee, gate = ctx.cfg
+        gy = gy.contiguous()
+        e = ops.energy(x)
+        env = ops.onepole(e, z_alpha, iir_len, relu=True) if smoother else e
+        gain, denv, gp = ops.dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee if knee != "hard" else None,
+                                          knee, gate)
+        gz = None
+        if smoother:
+            de, gz = one_pole_backward(e, z_alpha, env, iir_len, denv, True, ctx.needs_input_grad[4])
+        else:
+            de = denv
+        gx = ops.dyn_dx(x, gy, gain, de) if ctx.needs_input_grad[0] else None
+        like = lambda t, col: None if t is None else gp[:, col].reshape(t.shape)  # noqa: E731
+        return (gx, like(log_threshold, 0), like(log_ratio, 1), like(log_knee if knee != "hard" else None, 2), gz,
+                None, None, None, None)
+
+
 def truncated_one_pole(u, z_alpha, iir_len, exact=False):
     """core/envelope.py:34-49."""
+    from .processors.core.convolution import reference_aliases
+
+    if u.ndim == 2 and not reference_aliases(u.shape[-1], iir_len, exact):
+        return TruncatedOnePoleFn.apply(u, z_alpha, iir_len)
     return torch.relu(convolve(u, one_pole_fir(z_alpha, iir_len), "causal", exact=exact))
 
 

@@ -421,6 +421,132 @@ __global__ void apply_gain_kernel(const float* __restrict__ x, gfx_rowmap_t xmap
     }
 }
 
+// ---- backward of the gain computer (training path of Compressor / NoiseGate) --------------------------------
+// Partial derivatives of g = log_gain(G) (dynamics.py:444-489 compressor, 676-721 gate) w.r.t. G, the threshold T,
+// log_ratio and log_knee.  The region masks are piecewise constant, as in torch's autograd of the same expressions.
+struct KneeGrad {
+    float dG, dT, dlr, dlk;
+};
+__device__ __forceinline__ KneeGrad log_gain_grad(const Knee& q, float G) {
+    KneeGrad o = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float d = G - q.T;
+    if (!q.gate) {
+        const float c = q.invR - 1.0f;  // (1/R - 1)
+        if (q.kind == 0 || (q.kind == 1 && G > q.T + q.W)) {
+            if (q.kind == 1 || d > 0.0f) {  // above the threshold: g = (1/R - 1)(G - T)
+                o.dG = c;
+                o.dT = -c;
+                o.dlr = -d * q.invR * q.invR * q.er;
+            }
+        } else if (q.kind == 1) {
+            if (!(G < q.T - q.W)) {  // knee region: g = c s^2 / (4W), s = G - T + W
+                const float s = d + q.W, h = s / (2.0f * q.W);
+                o.dG = c * h;
+                o.dT = -c * h;
+                o.dlr = -q.invR * q.invR * s * s / (4.0f * q.W) * q.er;
+                o.dlk = c * (h - h * h) * q.W;  // dg/dW * dW/dlk,  W = exp(lk)/2
+            }
+        } else {  // exponential: g = c softplus(k d) / k
+            const float v = q.k * d;
+            const float sp = softplusf(v), sg = v > 20.0f ? 1.0f : sigmoidf(v);
+            o.dG = c * sg;
+            o.dT = -c * sg;
+            o.dlr = -q.invR * q.invR * sp / q.k * q.er;
+            o.dlk = c * (sg * v - sp) / q.k;  // dg/dk * k
+        }
+    } else {
+        const float c = 1.0f - q.R;  // (1 - R) = -exp(lr)
+        if (q.kind == 0 || (q.kind == 1 && G < q.T - q.W)) {
+            if (q.kind == 1 || d < 0.0f) {  // below the threshold: g = (R - 1)(G - T)
+                o.dG = -c;
+                o.dT = c;
+                o.dlr = d * q.er;
+            }
+        } else if (q.kind == 1) {
+            if (!(G > q.T + q.W)) {  // knee region: g = c s^2 / (4W), s = G - T - W
+                const float s = d - q.W, h = s / (2.0f * q.W);
+                o.dG = c * h;
+                o.dT = -c * h;
+                o.dlr = -s * s / (4.0f * q.W) * q.er;
+                o.dlk = c * (-h - h * h) * q.W;
+            }
+        } else {  // exponential: g = -er softplus(k (T - G)) / k
+            const float v = -q.k * d;
+            const float sp = softplusf(v), sg = v > 20.0f ? 1.0f : sigmoidf(v);
+            o.dG = q.er * sg;
+            o.dT = -q.er * sg;
+            o.dlr = -q.er * sp / q.k;
+            o.dlk = -q.er * (sg * v - sp) / q.k;
+        }
+    }
+    return o;
+}
+
+// One pass over (x, gy, env): gain = exp(g(log(env + 1e-5))),  dgain = sum_c gy x,  dg = dgain * gain,
+//   denv = dg * dg/dG / (env + 1e-5),   gparams[r] += sum_n dg * (dg/dT, dg/dlog_ratio, dg/dlog_knee).
+__global__ __launch_bounds__(256) void dyn_gain_bwd_kernel(const float* __restrict__ x, gfx_rowmap_t xmap,
+                                                           const float* __restrict__ gy, gfx_rowmap_t gmap,
+                                                           const float* __restrict__ env,
+                                                           const float* __restrict__ log_threshold,
+                                                           const float* __restrict__ log_ratio,
+                                                           const float* __restrict__ log_knee, int64_t R, int64_t L,
+                                                           int C, int knee, int gate, float* __restrict__ gain,
+                                                           float* __restrict__ denv, float* __restrict__ gparams) {
+    __shared__ float red[3][4];
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y) {
+        Knee q;
+        knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, knee, gate);
+        const float* x0 = x + drow_off(xmap, r, 0);
+        const float* x1 = x + drow_off(xmap, r, C == 2 ? 1 : 0);
+        const float* g0 = gy + drow_off(gmap, r, 0);
+        const float* g1 = gy + drow_off(gmap, r, C == 2 ? 1 : 0);
+        float sT = 0.0f, sR = 0.0f, sK = 0.0f;
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x) {
+            const float e = env[r * L + n];
+            const float G = logf(e + 1e-5f);
+            const float gn = expf(log_gain(q, G));
+            const float dgain = C == 2 ? (g0[n] * x0[n] + g1[n] * x1[n]) : g0[n] * x0[n];
+            const float dg = dgain * gn;
+            const KneeGrad k = log_gain_grad(q, G);
+            gain[r * L + n] = gn;
+            denv[r * L + n] = dg * k.dG / (e + 1e-5f);
+            sT += dg * k.dT;
+            sR += dg * k.dlr;
+            sK += dg * k.dlk;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sT += __shfl_down(sT, o, 64);
+            sR += __shfl_down(sR, o, 64);
+            sK += __shfl_down(sK, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = sT;
+            red[1][threadIdx.x >> 6] = sR;
+            red[2][threadIdx.x >> 6] = sK;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            atomicAdd(&gparams[3 * r + threadIdx.x],
+                      red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+        __syncthreads();
+    }
+}
+
+// gx[r,c,n] = gain[r,n] * gy[r,c,n] + (2/C) * de[r,n] * x[r,c,n]   (de = dL/d energy, energy = mean_c x^2)
+__global__ void dyn_dx_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, const float* __restrict__ gy,
+                              gfx_rowmap_t gmap, const float* __restrict__ gain, const float* __restrict__ de,
+                              float* __restrict__ gx, int64_t R, int64_t L, int C) {
+    const float k = 2.0f / (float)C;
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y)
+    for (int c = 0; c < C; ++c) {
+        const float* xr = x + drow_off(xmap, r, c);
+        const float* gr = gy + drow_off(gmap, r, c);
+        float* o = gx + (r * C + c) * L;
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x)
+            o[n] = fmaf(gain[r * L + n], gr[n], k * de[r * L + n] * xr[n]);
+    }
+}
+
 // StereoGain: y[r,c,n] = x[r,cx,n] * exp(log_gain[r,c])   (stereo.py:38-41; mono input broadcasts to 2 channels)
 __global__ void stereo_gain_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, const float* __restrict__ log_gain,
                                    float* __restrict__ y, gfx_rowmap_t ymap, int64_t R, int64_t L, int Cin) {
@@ -507,6 +633,24 @@ int gfx_dyn_gain_f32(const float* env, float* gain, const float* log_threshold, 
     if (knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_gain_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, env, gain, log_threshold,
                        log_ratio, log_knee, R, L, knee, gate, log_out);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap, const float* env,
+                         const float* log_threshold, const float* log_ratio, const float* log_knee, int64_t R, int64_t C,
+                         int64_t L, int knee, int gate, float* gain, float* denv, float* gparams, void* stream) {
+    if (!x || !gy || !env || !log_threshold || !log_ratio || !gain || !denv || !gparams) return GFX_EINVAL;
+    if (R <= 0 || L <= 0 || (C != 1 && C != 2) || knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
+    hipLaunchKernelGGL(dyn_gain_bwd_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, gy, gmap, env,
+                       log_threshold, log_ratio, log_knee, R, L, (int)C, knee, gate, gain, denv, gparams);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_dyn_dx_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap, const float* gain,
+                   const float* de, float* gx, int64_t R, int64_t C, int64_t L, void* stream) {
+    if (!x || !gy || !gain || !de || !gx || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
+    hipLaunchKernelGGL(dyn_dx_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, gy, gmap, gain, de, gx,
+                       R, L, (int)C);
     return GFX_LAUNCH_OK();
 }
 

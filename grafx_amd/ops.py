@@ -195,6 +195,29 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
     return out
 
 
+def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
+    """-> (gain (R,L), denv (R,L), gparams (R,3) = d/d(log_threshold, log_ratio, log_knee)); see the header."""
+    _require_gpu(x, gy, env)
+    xmap, R, C, L = rowmap(x)
+    gmap = rowmap(gy)[0]
+    env = env.contiguous()
+    gain, denv = torch.empty_like(env), torch.empty_like(env)
+    gp = torch.zeros((R, 3), dtype=torch.float32, device=x.device)
+    check(lib().gfx_dyn_gain_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(env), _ptr(_rowvec(log_threshold, R)),
+                                     _ptr(_rowvec(log_ratio, R)), _ptr(_rowvec(log_knee, R)), R, C, L, KNEES[knee],
+                                     int(gate), _ptr(gain), _ptr(denv), _ptr(gp), _stream()), "gfx_dyn_gain_bwd_f32")
+    return gain, denv, gp
+
+
+def dyn_dx(x, gy, gain, de):
+    _require_gpu(x, gy, gain, de)
+    xmap, R, C, L = rowmap(x)
+    gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    check(lib().gfx_dyn_dx_f32(_ptr(x), xmap, _ptr(gy), rowmap(gy)[0], _ptr(gain.contiguous()), _ptr(de.contiguous()),
+                               _ptr(gx), R, C, L, _stream()), "gfx_dyn_dx_f32")
+    return gx
+
+
 def energy(x):
     _require_gpu(x)
     xmap, R, C, L = rowmap(x)

@@ -89,7 +89,12 @@ class _Dynamics(BufferIO, nn.Module):
         return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post))
 
     def _forward_differentiable(self, x, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
-        """dynamics.py:390-405 as torch ops around the native (differentiable) smoothers."""
+        """dynamics.py:390-405: one native autograd node when there is no gain smoother and the energy smoother is
+        the (non-aliasing) one-pole or absent; otherwise torch ops around the native (differentiable) smoothers."""
+        if self.gain_smoother is None and (self.energy_smoother is None or (
+                self.energy_smoother == "iir" and not reference_aliases(x.shape[-1], self.iir_len, self.flashfftconv))):
+            return diff.DynamicsFn.apply(x, log_threshold, log_ratio, log_knee, z_alpha_pre,
+                                         self.energy_smoother == "iir", self.iir_len, self.knee, self._gate)
         energy = x.square().mean(-2)
         if self.energy_smoother is not None:
             energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)

@@ -148,6 +148,19 @@ int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_l
 int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R, int64_t L, void* stream);
 int gfx_dyn_gain_f32(const float* env, float* gain, const float* log_threshold, const float* log_ratio,
                      const float* log_knee, int64_t R, int64_t L, int knee, int gate, int log_out, void* stream);
+/* Backward of the gain computer, for the training path (forward: gfx_dynamics_fused_f32).
+ * gfx_dyn_gain_bwd_f32, one pass over x, the output gradient gy and the (smoothed) energy env (R, L):
+ *   gain = exp(g(log(env + 1e-5)))                       -> gain (R, L)
+ *   dg   = gain * sum_c gy[c] x[c];   denv = dg * dg/dG / (env + 1e-5)   -> denv (R, L)
+ *   gparams[r, 0..2] += sum_n dg * (dg/dlog_threshold, dg/dlog_ratio, dg/dlog_knee)   (caller zero-fills)
+ * with the partials of dynamics.py:444-489 / 676-721 (region masks piecewise constant, as in torch autograd).
+ * gfx_dyn_dx_f32: gx = gain * gy + (2/C) * de * x, de = dL/d(mean_c x^2) (denv pushed back through the smoother). */
+int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap, const float* env,
+                         const float* log_threshold, const float* log_ratio, const float* log_knee,
+                         int64_t R, int64_t C, int64_t L, int knee, int gate,
+                         float* gain, float* denv, float* gparams, void* stream);
+int gfx_dyn_dx_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap, const float* gain,
+                   const float* de, float* gx, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float* y, gfx_rowmap_t ymap,
                        int64_t R, int64_t C, int64_t L, int exp_gain, void* stream);
 int gfx_stereo_gain_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,

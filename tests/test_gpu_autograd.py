@@ -113,3 +113,42 @@ def test_training_step_through_render_grafx():
     assert_close(y.detach().cpu(), y_ref.detach(), 2e-5, "y")
     for gp, rg in zip(params_gpu.parameters(), ref_grads):
         assert_close(gp.grad.cpu(), rg, 1e-3, "parameter gradient")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gate", [False, True])
+@pytest.mark.parametrize("knee", ["hard", "quadratic", "exponential"])
+@pytest.mark.parametrize("smoother", [False, True])
+def test_native_dynamics_backward_matches_torch_autograd_of_the_same_formulas(gate, knee, smoother):
+    """DynamicsFn (native gain-computer backward + scans run backwards in time) against torch autograd of the
+    reference's expressions (dynamics.py:390-405 / 625-640) with the smoother written as the FIR convolution."""
+    import torch
+
+    from grafx_amd import autograd as diff
+
+    torch.manual_seed(7)
+    R, C, L, N = 4, 2, 3000, 257
+    x = (0.5 * torch.randn(R, C, L, device="cuda")).requires_grad_(True)
+    p = {"log_threshold": torch.randn(R, 1, device="cuda") - 3, "log_ratio": torch.randn(R, 1, device="cuda"),
+         "log_knee": torch.randn(R, 1, device="cuda"), "z": torch.randn(R, 1, device="cuda") + 2}
+    p["z"][0] = 20.0  # sigmoid saturates: the clamp at 1 - 1e-5 is active, a^N is far from negligible
+    for v in p.values():
+        v.requires_grad_(True)
+    w = torch.randn(R, C, L, device="cuda")
+
+    def grads(y):
+        gs = torch.autograd.grad((y * w).sum(), [x] + list(p.values()), allow_unused=True)
+        return [g for g in gs]
+
+    y_native = diff.DynamicsFn.apply(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z"], smoother, N, knee, gate)
+    e = x.square().mean(-2)
+    if smoother:
+        e = torch.relu(diff.convolve(e, diff.one_pole_fir(p["z"], N), "causal", exact=True))
+    g = diff.log_gain(torch.log(e + 1e-5), p["log_threshold"] - 6, p["log_ratio"], p["log_knee"], knee, gate)
+    y_torch = torch.exp(g)[:, None, :] * x
+    assert (y_native - y_torch).abs().max() <= 2e-5 * y_torch.abs().max()
+    for name, a, b in zip(["x"] + list(p), grads(y_native), grads(y_torch)):
+        if b is None or (knee == "hard" and name == "log_knee") or (not smoother and name == "z"):
+            continue
+        scale = b.abs().max().clamp_min(1e-6)
+        assert (a - b).abs().max() <= 2e-3 * scale, f"{name}: {(a - b).abs().max().item():.3e} vs scale {scale.item():.3e}"
