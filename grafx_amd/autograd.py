@@ -182,16 +182,17 @@ def one_pole_backward(u, z_alpha, y, N, g, need_u=True, need_z=True):
         a = sig.clamp(max=1 - 1e-5)
         one_m_a = 1 - a
         inf = L + 1  # longer than the signal: no truncation term
-        U = ops.onepole(u, z_alpha, inf, relu=False) / one_m_a
-        D = ops.onepole(F.pad(U, (1, 0))[:, :L], z_alpha, inf, relu=False) / one_m_a
-        dlin = -U + one_m_a * D
-        if N < L:
-            aN = torch.pow(a.double(), N).float()
-            aN1 = torch.pow(a.double(), N - 1).float()
-            Ud, Dd = F.pad(U, (N, 0))[:, :L], F.pad(D, (N, 0))[:, :L]
-            dlin = dlin + aN * Ud - one_m_a * (N * aN1 * Ud + aN * Dd)
-        da = (g * dlin).sum(-1, keepdim=True)
-        gz = (da * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
+        # with a^N = aN:  da = sum_n g[n] ( -U[n] + (aN - (1-a) N a^(N-1)) U[n-N] + (1-a) (D[n] - aN D[n-N]) ),
+        # D[n] = S[n-1], S = scan of U.  The scan kernel returns U1 = (1-a) U and S2 = (1-a)^2 S; the powers of
+        # 1/(1-a) go into the coefficients and the one-sample shift of D onto g.
+        U1 = ops.onepole(u, z_alpha, inf, relu=False)
+        S2 = ops.onepole(U1, z_alpha, inf, relu=False)
+        aN = torch.pow(a.double(), N).float()
+        aN1 = torch.pow(a.double(), N - 1).float()
+        inv, zero = 1 / one_m_a, torch.zeros_like(a)
+        da = ops.onepole_dz(g, U1, U1, torch.cat([-inv, zero, (aN - one_m_a * N * aN1) * inv, zero], 1), N)
+        da = da + ops.onepole_dz(F.pad(g, (0, 1))[:, 1:], S2, S2, torch.cat([inv, zero, -aN * inv, zero], 1), N)
+        gz = (da.reshape(R, 1) * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
     return gu, gz
 
 

@@ -532,6 +532,29 @@ __global__ __launch_bounds__(256) void dyn_gain_bwd_kernel(const float* __restri
     }
 }
 
+// da[r] = sum_n g[n] * (c0 U[n] + c1 D[n] + c2 U[n-N] + c3 D[n-N]),  U/D zero before the row start:
+// the pole gradient of the truncated one-pole smoother from its two scans (see autograd.one_pole_backward).
+__global__ __launch_bounds__(256) void onepole_dz_kernel(const float* __restrict__ g, const float* __restrict__ U,
+                                                         const float* __restrict__ D, const float* __restrict__ coef,
+                                                         float* __restrict__ da, int64_t L, int64_t N) {
+    __shared__ float part[4];
+    const int64_t r = blockIdx.x;
+    const float c0 = coef[4 * r], c1 = coef[4 * r + 1], c2 = coef[4 * r + 2], c3 = coef[4 * r + 3];
+    const float* gr = g + r * L;
+    const float* Ur = U + r * L;
+    const float* Dr = D + r * L;
+    float s = 0.0f;
+    for (int64_t n = threadIdx.x; n < L; n += 256) {
+        float v = c0 * Ur[n] + c1 * Dr[n];
+        if (n >= N) v += c2 * Ur[n - N] + c3 * Dr[n - N];
+        s = fmaf(gr[n], v, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) da[r] = part[0] + part[1] + part[2] + part[3];
+}
+
 // gx[r,c,n] = gain[r,n] * gy[r,c,n] + (2/C) * de[r,n] * x[r,c,n]   (de = dL/d energy, energy = mean_c x^2)
 __global__ void dyn_dx_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, const float* __restrict__ gy,
                               gfx_rowmap_t gmap, const float* __restrict__ gain, const float* __restrict__ de,
@@ -643,6 +666,13 @@ int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_gain_bwd_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, gy, gmap, env,
                        log_threshold, log_ratio, log_knee, R, L, (int)C, knee, gate, gain, denv, gparams);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,
+                       int64_t L, int64_t N, void* stream) {
+    if (!g || !U || !D || !coef || !da || R <= 0 || L <= 0 || N < 1 || R > 0x7fffffffLL) return GFX_EINVAL;
+    hipLaunchKernelGGL(onepole_dz_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, g, U, D, coef, da, L, N);
     return GFX_LAUNCH_OK();
 }
 

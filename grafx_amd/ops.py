@@ -209,6 +209,16 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
     return gain, denv, gp
 
 
+def onepole_dz(g, U, D, coef, N):
+    """Row sums sum_n g (c0 U[n] + c1 D[n] + c2 U[n-N] + c3 D[n-N]); coef (R,4)."""
+    _require_gpu(g, U, D, coef)
+    R, L = g.shape
+    da = torch.empty(R, dtype=torch.float32, device=g.device)
+    check(lib().gfx_onepole_dz_f32(_ptr(g.contiguous()), _ptr(U.contiguous()), _ptr(D.contiguous()),
+                                   _ptr(coef.contiguous()), _ptr(da), R, L, N, _stream()), "gfx_onepole_dz_f32")
+    return da
+
+
 def dyn_dx(x, gy, gain, de):
     _require_gpu(x, gy, gain, de)
     xmap, R, C, L = rowmap(x)

@@ -71,6 +71,27 @@ def _gather_plan(step, device):
     return plan
 
 
+def _transposed_plan(step, plan, device):
+    """The adjoint of a gather plan: for every distinct source row, the list of destination slots it fed.
+    -> (unique source rows (list), dst_idx tensor, seg_ptr tensor, contiguous?)"""
+    cache = step.__dict__.setdefault("_plans_T", {})
+    key = (device.type, device.index)
+    if key not in cache:
+        src, seg = plan[0].tolist(), plan[1].tolist()
+        by_src = {}
+        for j in range(len(seg) - 1):
+            for e in range(seg[j], seg[j + 1]):
+                by_src.setdefault(src[e], []).append(j)
+        uniq = sorted(by_src)
+        dst, ptr = [], [0]
+        for u in uniq:
+            dst.extend(by_src[u])
+            ptr.append(len(dst))
+        cache[key] = (uniq, torch.tensor(dst, dtype=torch.long, device=device),
+                      torch.tensor(ptr, dtype=torch.long, device=device), uniq == list(range(uniq[0], uniq[0] + len(uniq))))
+    return cache[key]
+
+
 def _gather(ops, buf, plan, out):
     if plan[3] is not None and ops.gather_sum_fanout(buf, plan[3][0], plan[3][1], out):
         return out
@@ -334,10 +355,14 @@ class _BufferRenderFn(torch.autograd.Function):
                 a, b = step.source_reads[0].idx
                 gbuf.narrow(1, a, b - a).add_(g_in)
             else:
-                src_idx, seg_ptr = plan[0], plan[1]
-                counts = (seg_ptr[1:] - seg_ptr[:-1])
-                dst_of_edge = torch.repeat_interleave(torch.arange(counts.numel(), device=dev), counts)
-                gbuf.index_add_(1, src_idx, g_in.index_select(1, dst_of_edge))
+                # adjoint of the gather-sum: every source row collects the gradients of the slots it fed --
+                # the same gather-sum kernel with the transposed plan
+                uniq, dst_idx, ptr, contiguous = _transposed_plan(step, plan, dev)
+                g_src = ops.gather_sum(g_in.contiguous(), dst_idx, ptr, torch.empty(B, len(uniq), C, L, device=dev))
+                if contiguous:
+                    gbuf.narrow(1, uniq[0], len(uniq)).add_(g_src)
+                else:
+                    gbuf.index_add_(1, torch.tensor(uniq, dtype=torch.long, device=dev), g_src)
         g_x = gbuf.narrow(1, 0, ctx.n_src)
         g_x = g_x[0] if squeeze else g_x
         return (None, g_x.contiguous() if ctx.needs_input_grad[1] else None, *leaf_grads)

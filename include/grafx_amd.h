@@ -161,6 +161,10 @@ int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
                          float* gain, float* denv, float* gparams, void* stream);
 int gfx_dyn_dx_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap, const float* gain,
                    const float* de, float* gx, int64_t R, int64_t C, int64_t L, void* stream);
+/* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from its two untruncated scans U (of the
+ * input) and D = dU/da:  da[r] = sum_n g[r,n] (c0 U[n] + c1 D[n] + c2 U[n-N] + c3 D[n-N]),  coef = (R, 4). */
+int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,
+                       int64_t L, int64_t N, void* stream);
 int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float* y, gfx_rowmap_t ymap,
                        int64_t R, int64_t C, int64_t L, int exp_gain, void* stream);
 int gfx_stereo_gain_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
