@@ -244,18 +244,21 @@ def truncated_one_pole(u, z_alpha, iir_len, exact=False):
 
 
 class BallisticsFn(torch.autograd.Function):
-    """Native forward (gfx_ballistics_f32); the adjoint recursion is not implemented yet."""
+    """Attack/release smoother (core/envelope.py:84-101 -> torchcomp.compressor_core, semantics as recalled):
+    native forward recursion and native adjoint recursion (run backwards in time over the saved output)."""
 
     @staticmethod
     def forward(ctx, x, z_alpha):
-        return ops.ballistics(x.contiguous(), z_alpha.contiguous())
+        x, z_alpha = x.contiguous(), z_alpha.contiguous()
+        y = ops.ballistics(x, z_alpha)
+        ctx.save_for_backward(x, z_alpha, y)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError(
-            "backward of the ballistics smoother is not implemented yet (forward-only); use the 'iir' smoother "
-            "for training, as the reference recommends for speed (dynamics.py:227)."
-        )
+        x, z_alpha, y = ctx.saved_tensors
+        gx, gz = ops.ballistics_bwd(x, y, g, z_alpha)
+        return gx, gz.reshape(z_alpha.shape)
 
 
 def log_gain(G, T, log_ratio, log_knee, knee, gate):

@@ -391,6 +391,77 @@ __global__ __launch_bounds__(64) void ballistics_kernel(const float* __restrict_
     }
 }
 
+// Adjoint of the ballistics recursion (the branch choice c[n] is piecewise constant in the inputs):
+//   lambda[n] = g[n] + (1 - c[n+1]) lambda[n+1];   gx[n] = c[n] lambda[n];
+//   d/d(at) = sum over attack steps of lambda[n] (x[n] - y[n-1]),  d/d(rt) likewise over release steps,
+// walked backwards in time with the same tiling as the forward kernel (x, y, g tiles in LDS, one lane per row).
+__global__ __launch_bounds__(64) void ballistics_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ z_alpha, float* __restrict__ gx,
+                                                            float* __restrict__ gz, int64_t R, int64_t L) {
+    __shared__ __attribute__((aligned(16))) float tx[BROWS * BPAD], ty[BROWS * BPAD], tg[BROWS * BPAD];
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * BROWS;
+    const int64_t my = r0 + lane;
+    float at = 0.0f, rt = 0.0f;
+    if (my < R) {
+        at = sigmoidf(z_alpha[2 * my]);
+        rt = sigmoidf(z_alpha[2 * my + 1]);
+    }
+    float carry = 0.0f, sa = 0.0f, sr = 0.0f;
+    const int cr = lane >> 4, cc = (lane & 15) * 4;
+    const bool vec = (L % 4 == 0) && vec_ok(x) && vec_ok(y) && vec_ok(g) && vec_ok(gx);
+    const int64_t ntiles = (L + BCOLS - 1) / BCOLS;
+    for (int64_t tile = ntiles - 1; tile >= 0; --tile) {
+        const int64_t n0 = tile * BCOLS;
+#pragma unroll 4
+        for (int pass = 0; pass < BROWS / 4; ++pass) {
+            const int row = pass * 4 + cr;
+            const int64_t rr = r0 + row;
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b[4] = {0.0f, 0.0f, 0.0f, 0.0f}, c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (rr < R) {
+                load4(x + rr * L, n0 + cc, L, vec, a);
+                load4(y + rr * L, n0 + cc, L, vec, b);
+                load4(g + rr * L, n0 + cc, L, vec, c);
+            }
+            *reinterpret_cast<float4*>(&tx[row * BPAD + cc]) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(&ty[row * BPAD + cc]) = make_float4(b[0], b[1], b[2], b[3]);
+            *reinterpret_cast<float4*>(&tg[row * BPAD + cc]) = make_float4(c[0], c[1], c[2], c[3]);
+        }
+        const float y_before = (my < R && n0 > 0) ? y[my * L + n0 - 1] : 1.0f;  // y[-1] = 1
+        __syncthreads();
+        const int last = (int)((L - n0 < BCOLS ? L - n0 : BCOLS) - 1);
+        for (int j = last; j >= 0; --j) {
+            const float xv = tx[lane * BPAD + j];
+            const float yp = j > 0 ? ty[lane * BPAD + j - 1] : y_before;
+            const bool attack = xv < yp;
+            const float c = attack ? at : rt;
+            const float lam = tg[lane * BPAD + j] + carry;
+            tg[lane * BPAD + j] = c * lam;
+            const float d = lam * (xv - yp);
+            sa += attack ? d : 0.0f;
+            sr += attack ? 0.0f : d;
+            carry = (1.0f - c) * lam;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pass = 0; pass < BROWS / 4; ++pass) {
+            const int row = pass * 4 + cr;
+            const int64_t rr = r0 + row;
+            if (rr < R) {
+                const float4 q = *reinterpret_cast<const float4*>(&tg[row * BPAD + cc]);
+                const float v[4] = {q.x, q.y, q.z, q.w};
+                store4(gx + rr * L, n0 + cc, L, vec, v);
+            }
+        }
+        __syncthreads();
+    }
+    if (my < R) {
+        gz[2 * my] = sa * at * (1.0f - at);
+        gz[2 * my + 1] = sr * rt * (1.0f - rt);
+    }
+}
+
 // env (R,L) -> gain (R,L):  g = log_gain(log(env + 1e-5));  out = exp(g) or g (log_out)
 __global__ void dyn_gain_kernel(const float* __restrict__ env, float* __restrict__ gain,
                                 const float* __restrict__ log_threshold, const float* __restrict__ log_ratio,
@@ -647,6 +718,14 @@ int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R
     if (!u || !z_alpha || !y || R <= 0 || L <= 0) return GFX_EINVAL;
     hipLaunchKernelGGL(ballistics_kernel, dim3((unsigned)((R + BROWS - 1) / BROWS)), dim3(64), 0, (hipStream_t)stream,
                        u, z_alpha, y, R, L);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_ballistics_bwd_f32(const float* x, const float* y, const float* g, const float* z_alpha, float* gx, float* gz,
+                           int64_t R, int64_t L, void* stream) {
+    if (!x || !y || !g || !z_alpha || !gx || !gz || R <= 0 || L <= 0) return GFX_EINVAL;
+    hipLaunchKernelGGL(ballistics_bwd_kernel, dim3((unsigned)((R + BROWS - 1) / BROWS)), dim3(64), 0,
+                       (hipStream_t)stream, x, y, g, z_alpha, gx, gz, R, L);
     return GFX_LAUNCH_OK();
 }
 

@@ -265,6 +265,17 @@ def ballistics(u, z_alpha):
     return y
 
 
+def ballistics_bwd(x, y, g, z_alpha):
+    """Adjoint of :func:`ballistics`: -> (dL/dx (R,L), dL/dz_alpha (R,2))."""
+    _require_gpu(x, y, g, z_alpha)
+    x, y, g, z_alpha = x.contiguous(), y.contiguous(), g.contiguous(), z_alpha.contiguous()
+    R, L = x.shape
+    gx, gz = torch.empty_like(x), torch.empty((R, 2), dtype=torch.float32, device=x.device)
+    check(lib().gfx_ballistics_bwd_f32(_ptr(x), _ptr(y), _ptr(g), _ptr(z_alpha), _ptr(gx), _ptr(gz), R, L, _stream()),
+          "gfx_ballistics_bwd_f32")
+    return gx, gz
+
+
 def dyn_gain(env, log_threshold, log_ratio, log_knee, knee, gate, log_out):
     _require_gpu(env)
     env = env.contiguous()

@@ -146,6 +146,10 @@ int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R,
                     int64_t iir_len, int relu, void* stream);
 int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_len, void* stream);
 int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R, int64_t L, void* stream);
+/* Adjoint of the recursion above given the forward input x, output y and g = dL/dy:
+ * gx = dL/dx (R, L), gz = dL/dz_alpha (R, 2).  The attack/release choice is treated as locally constant. */
+int gfx_ballistics_bwd_f32(const float* x, const float* y, const float* g, const float* z_alpha, float* gx, float* gz,
+                           int64_t R, int64_t L, void* stream);
 int gfx_dyn_gain_f32(const float* env, float* gain, const float* log_threshold, const float* log_ratio,
                      const float* log_knee, int64_t R, int64_t L, int knee, int gate, int log_out, void* stream);
 /* Backward of the gain computer, for the training path (forward: gfx_dynamics_fused_f32).

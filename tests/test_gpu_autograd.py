@@ -152,3 +152,53 @@ def test_native_dynamics_backward_matches_torch_autograd_of_the_same_formulas(ga
             continue
         scale = b.abs().max().clamp_min(1e-6)
         assert (a - b).abs().max() <= 2e-3 * scale, f"{name}: {(a - b).abs().max().item():.3e} vs scale {scale.item():.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [64, 200, 1031])
+def test_native_ballistics_backward_matches_torch_autograd_of_the_recursion(L):
+    """gfx_ballistics_bwd_f32 (adjoint recursion, backwards in time) against torch autograd of the same recursion
+    written as a Python loop in float64 on the CPU (branch choice detached, as autograd of torch.where does)."""
+    import torch
+
+    from grafx_amd.processors import Ballistics
+
+    torch.manual_seed(3)
+    R = 70  # more than one 64-row workgroup, ragged
+    x = torch.rand(R, L) * 2
+    z = torch.randn(R, 2)
+    w = torch.randn(R, L)
+    x64, z64 = x.double().requires_grad_(True), z.double().requires_grad_(True)
+    ts = torch.sigmoid(z64)
+    prev, ys = torch.ones(R, dtype=torch.float64), []
+    for n in range(L):
+        c = torch.where(x64[:, n] < prev, ts[:, 0], ts[:, 1])
+        prev = (1 - c) * prev + c * x64[:, n]
+        ys.append(prev)
+    y64 = torch.stack(ys, 1)
+    gx64, gz64 = torch.autograd.grad((y64 * w.double()).sum(), [x64, z64])
+    xg, zg = x.cuda().requires_grad_(True), z.cuda().requires_grad_(True)
+    y = Ballistics()(xg, zg)
+    gx, gz = torch.autograd.grad((y * w.cuda()).sum(), [xg, zg])
+    assert (y.detach().cpu() - y64.float()).abs().max() <= 1e-5 * y64.abs().max()
+    assert (gx.cpu() - gx64.float()).abs().max() <= 1e-4 * gx64.abs().max()
+    assert (gz.cpu() - gz64.float()).abs().max() <= 1e-3 * gz64.abs().max()
+
+
+@pytest.mark.gpu
+def test_compressor_with_ballistics_smoother_trains():
+    import torch
+
+    import grafx_amd.processors as P
+
+    torch.manual_seed(0)
+    m = P.Compressor(energy_smoother="ballistics", flashfftconv=False).cuda()
+    x = torch.randn(3, 2, 4096, device="cuda")
+    # threshold near the signal's log-energy (T = log_threshold - 6 ~ 0) so that the knee region is populated
+    p = {"log_threshold": 0.5 * torch.randn(3, 1, device="cuda") + 6, "log_ratio": torch.randn(3, 1, device="cuda"),
+         "log_knee": torch.randn(3, 1, device="cuda") + 1, "z_alpha_pre": torch.randn(3, 2, device="cuda")}
+    for v in p.values():
+        v.requires_grad_(True)
+    m(x, **p).square().mean().backward()
+    for k, v in p.items():
+        assert v.grad is not None and torch.isfinite(v.grad).all() and v.grad.abs().sum() > 0, (k, v.grad)
