@@ -25,9 +25,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         self.register_buffer("window", torch.hann_window(n_fft))
         self.register_buffer("arange", torch.arange(self.num_frames).view(1, 1, 1, -1))
         self.fixed_noise = fixed_noise
-        if not fixed_noise:
-            raise NotImplementedError("fixed_noise=False (fresh noise every forward) is not part of this release")
-        self.get_fixed_noise()
+        if fixed_noise:
+            self.get_fixed_noise()
         self.gain_envelope = gain_envelope
         self.processor_channel = processor_channel
         if processor_channel not in ("mono", "stereo", "midside", "pseudo_midside"):
@@ -43,6 +42,12 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
                           return_complex=True)
         self.register_buffer("noise_stft", spec[None].contiguous())
 
+    def sample_noise(self, num_noises, device):
+        """Fresh uniform noise per row and its STFT (reverb.py:116-128), drawn with the device generator."""
+        noise = torch.rand(num_noises * 2, self.ir_len, device=device) * 2 - 1
+        spec = torch.stft(noise, n_fft=self.n_fft, hop_length=self.hop_length, window=self.window, return_complex=True)
+        return spec.view(num_noises, 2, self.num_bins, self.num_frames)
+
     def _istft_basis(self, device):
         key = (device.type, device.index)
         if key not in self._basis:
@@ -56,7 +61,7 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
 
     def compute_ir(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
         """Un-normalised mid/side impulse responses (R,2,ir_len) (reverb.py:161-187)."""
-        if needs_grad(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
+        if not self.fixed_noise or needs_grad(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
             return self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         return self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, False)[0]
 
@@ -65,7 +70,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         logmag = init_log_magnitude[..., None] - F.softplus(delta_log_magnitude)[..., None] * self.arange
         if self.gain_envelope:
             logmag = logmag + gain_env_log_magnitude[:, :, None, :]
-        spec = self.noise_stft * torch.exp(logmag / 8)
+        noise_stft = self.noise_stft if self.fixed_noise else self.sample_noise(logmag.shape[0], logmag.device)
+        spec = noise_stft * torch.exp(logmag / 8)
         R = spec.shape[0]
         ir = torch.istft(spec.reshape(R * 2, self.num_bins, self.num_frames), n_fft=self.n_fft,
                          hop_length=self.hop_length, window=self.window, length=self.ir_len)
@@ -83,14 +89,17 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
     def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _out=None,
                 _shared_rows=None):
         pseudo = self.processor_channel == "pseudo_midside"
-        if _shared_rows is not None and needs_grad(input_signals, init_log_magnitude, delta_log_magnitude,
-                                                   gain_env_log_magnitude):
+        if _shared_rows is not None and (not self.fixed_noise or needs_grad(
+                input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)):
             reps = input_signals.shape[0]
             init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude = (
                 None if t is None else t.repeat(reps, 1, 1)
                 for t in (init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude))
             _shared_rows = None
-        if needs_grad(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
+        if not self.fixed_noise or needs_grad(input_signals, init_log_magnitude, delta_log_magnitude,
+                                              gain_env_log_magnitude):
+            # per-row noise (fixed_noise=False) and training: mask + istft as torch ops on the GPU (R x 193 x 313),
+            # the convolution below is native either way
             x = input_signals.reshape(-1, *input_signals.shape[-2:])
             ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
             if pseudo:

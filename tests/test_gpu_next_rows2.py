@@ -200,3 +200,31 @@ def test_envelope_followers(golden, det):
         assert_close(y.cpu(), g[f"envf_iir_{det}_y"], 2e-5, "IIR envelope follower")
         y = BallisticsEnvelopeFollower(detect_with=det).cuda()(x, g[f"envf_bal_{det}_z"].cuda())
         assert_close(y.cpu(), g[f"envf_bal_{det}_y"], 2e-5, "ballistics envelope follower")
+
+
+def test_stft_reverb_with_fresh_noise_per_forward():
+    """fixed_noise=False (reverb.py:116-128, 165-169): every row draws its own noise on each forward.  With the
+    drawn noise pinned, the result must equal the oracle's formula fed the same noise; unpinned, two forwards
+    differ and a seed reproduces them."""
+    import grafx_amd.processors as P
+    import oracle
+
+    torch.manual_seed(2)
+    R, L = 3, 4096
+    x = torch.randn(R, 2, L)
+    p = {"init_log_magnitude": torch.randn(R, 2, 193), "delta_log_magnitude": torch.randn(R, 2, 193)}
+    m = P.STFTMaskedNoiseReverb(ir_len=3001, fixed_noise=False, flashfftconv=False).cuda()
+    pg = cuda(p)
+    with torch.no_grad():
+        torch.manual_seed(11)
+        y1 = m(x.cuda(), **pg)
+        y2 = m(x.cuda(), **pg)
+        torch.manual_seed(11)
+        y3 = m(x.cuda(), **pg)
+    assert torch.equal(y1, y3) and not torch.allclose(y1, y2)
+    noise = m.sample_noise(R, torch.device("cuda"))
+    m.sample_noise = lambda n, device: noise
+    o = oracle.OracleSTFTMaskedNoiseReverb(ir_len=3001)
+    o.noise_stft = noise.cpu()
+    with torch.no_grad():
+        assert_close(m(x.cuda(), **pg).cpu(), o(x, **p), 2e-5, "fresh-noise reverb vs oracle with the same noise")
