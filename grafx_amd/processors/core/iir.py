@@ -42,10 +42,25 @@ class IIRFilter(nn.Module):
             self._plans[key] = ops.iir_fsm_plan(self.fsm_fir_len, device)
         return self._plans[key]
 
+    FSM_NATIVE_MAX = 4096  # the Bluestein inverse DFT runs on one 8192-point LDS tile: 2N - 1 <= 8192
+
+    def _taps(self, Bs, As):
+        """(R,Cf,K,3) coefficients -> (R*Cf, N) frequency-sampled taps (iir.py:148-150): the native response +
+        Bluestein kernel up to 4096 taps; beyond that the same formula as torch ops on the GPU (complex64 response as
+        upstream, inverse real FFT in float64 so that the library transform adds no fp32 noise of its own)."""
+        N = self.fsm_fir_len
+        if N <= self.FSM_NATIVE_MAX:
+            return ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
+        k = torch.arange(N // 2 + 1, device=Bs.device)
+        d = torch.arange(3, device=Bs.device)
+        delays = torch.exp(-1j * ((d[:, None] * k[None, :]).to(Bs.dtype) / N * 2 * torch.pi))
+        resp = ((Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)).prod(-2)
+        return torch.fft.irfft(resp.to(torch.complex128), dim=-1, n=N).float().reshape(-1, N)
+
     def fsm_fir(self, Bs, As):
         """(R,Cf,K,3) coefficients -> (R,Cf,N) FIR the FSM backend convolves with (iir.py:148-150)."""
         R, Cf = Bs.shape[0], Bs.shape[1]
-        return ops.iir_fsm_fir(Bs, As, self.fsm_fir_len, self._plan(Bs.device)).view(R, Cf, self.fsm_fir_len)
+        return self._taps(Bs, As).view(R, Cf, self.fsm_fir_len)
 
     def _process_recursive(self, input_signal, Bs, As, out=None):
         if needs_grad(input_signal, Bs, As):
@@ -78,6 +93,6 @@ class IIRFilter(nn.Module):
             return out
         R, Cf = Bs.shape[0], Bs.shape[1]
         N = self.fsm_fir_len
-        h = ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
+        h = self._taps(Bs, As)
         return convolve_taps(input_signal, ops.fir_spectrum(h), N, Cf, "causal", out=out, tee=tee, exact=self.flashfftconv,
                              h_rows=shared_rows)

@@ -84,13 +84,11 @@ def test_fsm_fir_lengths_and_limits():
     torch.manual_seed(2)
     Bs = torch.randn(2, 1, 2, 3) * 0.2 + torch.tensor([1.0, 0, 0])
     As = torch.tensor([1.0, -1.2, 0.5]).expand(2, 1, 2, 3).contiguous()
-    for N in (2, 3, 64, 1000, 4095, 4096):
+    for N in (2, 3, 64, 1000, 4095, 4096, 4097, 8192):   # the last two: beyond the native tile, torch front-end
         f = IIRFilter(flashfftconv=False, fsm_fir_len=N)
         with torch.no_grad():
             fir = f.fsm_fir(Bs.cuda(), As.cuda()).cpu()
         assert_close(fir, lti.iir_fsm_fir(Bs, As, N), 1e-5, f"fsm N={N}")
-    with pytest.raises(NotImplementedError):
-        IIRFilter(flashfftconv=False, fsm_fir_len=8192).fsm_fir(Bs.cuda(), As.cuda())
 
 
 def test_render_3d_input_and_index_reads():
@@ -117,3 +115,24 @@ def test_render_3d_input_and_index_reads():
         got, _, buf = render_grafx({"gain": StereoGain()}, x.cuda(), {"gain": {"log_gain": lg.cuda()}}, rd_gpu)
     assert got.shape == want.shape
     assert_close(got.cpu(), want, 1e-6, "3-D render")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [8192, 6001, 16384])
+def test_fsm_fir_len_beyond_the_native_tile(N):
+    """fsm_fir_len > 4096: the taps come from the torch front-end (same formula, float64 inverse FFT), the
+    convolution from the HIP kernels (single tile up to 8193 taps, partitioned beyond)."""
+    import torch
+
+    import grafx_amd.processors as P
+    import oracle
+
+    torch.manual_seed(0)
+    L = 20001 if N % 2 == 0 else 20000   # keep L + N - 1 even: the reference's own exact case
+    x = torch.randn(2, 2, L)
+    p = {k: 0.3 * torch.randn(2, 1, 4) for k in ("w0", "q_inv", "log_gain")}
+    m = P.ParametricEqualizer(num_filters=4, flashfftconv=False, fsm_fir_len=N).cuda()
+    o = oracle.OracleParametricEqualizer(num_filters=4, fsm_fir_len=N)
+    with torch.no_grad():
+        y = m(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+    assert_close(y, o(x, **p), 2e-5, f"PEQ fsm_fir_len={N}")
