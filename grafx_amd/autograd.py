@@ -31,15 +31,21 @@ def needs_grad(*tensors):
 
 
 class LinearConvFn(torch.autograd.Function):
-    """y[r,c,n] = sum_k h[r,cf,k] x[r,cx,n+off-k], n in [0,Lout); channels broadcast 1<->2."""
+    """y[r,c,n] = sum_k h[r % Rh,cf,k] x[r,cx,n+off-k], n in [0,Lout); channels broadcast 1<->2.
+
+    ``h`` may hold fewer rows than ``x`` (Rh divides R; rows are batch-major, so Rh = nodes shares one filter per
+    node across the batch): the spectra are built once per filter, and grad_h is the per-row gradient summed over
+    the batch."""
 
     @staticmethod
     def forward(ctx, x, h, Lout, off):
         x, h = x.contiguous(), h.contiguous()
-        R, Cf, N = h.shape
+        Rh, Cf, N = h.shape
+        if x.shape[0] % Rh != 0:
+            raise ValueError(f"{x.shape[0]} signal rows cannot share {Rh} filters")
         ctx.save_for_backward(x, h)
         ctx.off = off
-        return ops.fftconv(x, ops.fir_spectrum(h.reshape(R * Cf, N)), N, Cf, Lout=Lout, off=off)
+        return ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
 
     @staticmethod
     def backward(ctx, g):
@@ -47,11 +53,11 @@ class LinearConvFn(torch.autograd.Function):
         off = ctx.off
         g = g.contiguous()
         R, Cin, L = x.shape
-        _, Cf, N = h.shape
+        Rh, Cf, N = h.shape
         gx = gh = None
         if ctx.needs_input_grad[0]:
             hr = h.flip(-1).contiguous()
-            gx = ops.fftconv(g, ops.fir_spectrum(hr.reshape(R * Cf, N)), N, Cf, Lout=L, off=N - 1 - off)
+            gx = ops.fftconv(g, ops.fir_spectrum(hr.reshape(Rh * Cf, N)), N, Cf, Lout=L, off=N - 1 - off, h_rows=Rh)
             if gx.shape[1] != Cin:  # x was broadcast over the output channels
                 gx = gx.sum(1, keepdim=True)
         if ctx.needs_input_grad[1]:
@@ -59,6 +65,8 @@ class LinearConvFn(torch.autograd.Function):
             gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L)), L, Cin, Lout=N, off=L - 1 - off)
             if gh.shape[1] != Cf:  # one filter shared by both channels
                 gh = gh.sum(1, keepdim=True)
+            if Rh != R:  # one filter shared by the batch
+                gh = gh.view(R // Rh, Rh, Cf, N).sum(0)
         return gx, gh, None, None
 
 

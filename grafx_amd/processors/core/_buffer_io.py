@@ -12,3 +12,16 @@ class BufferIO:
         y = self.forward(x4.reshape(-1, *x4.shape[2:]), **params)
         out4.copy_(y.view(out4.shape))
         return out4
+
+
+def shared_reps(x, shared_rows):
+    """How many times `shared_rows` parameter rows repeat over the rows of x ((R,C,L) or a (B,n,C,L) view)."""
+    rows = x.shape[0] * x.shape[1] if x.ndim == 4 else x.shape[0]
+    if rows % shared_rows != 0:
+        raise ValueError(f"{rows} signal rows cannot share {shared_rows} parameter rows")
+    return rows // shared_rows
+
+
+def expand_shared(t, reps):
+    """(n, ...) per-node parameter -> (reps*n, ...) batch-major rows (what upstream's expand + flatten produces)."""
+    return None if t is None else t.repeat(reps, *([1] * (t.ndim - 1)))

@@ -73,9 +73,9 @@ class IIRFilter(nn.Module):
 
     def forward(self, input_signal, Bs, As, out=None, tee=None, shared_rows=None):
         """``shared_rows``: Bs/As hold that many rows, shared by the batch (signal row r uses r % shared_rows)."""
-        if shared_rows is not None and (self.backend != "fsm" or needs_grad(input_signal, Bs, As)):
-            reps = input_signal.shape[0] if input_signal.ndim == 4 else input_signal.shape[0] // shared_rows
-            Bs, As = Bs.repeat(reps, 1, 1, 1), As.repeat(reps, 1, 1, 1)  # paths without row sharing
+        if shared_rows is not None and self.backend != "fsm":
+            rows = input_signal.shape[0] * input_signal.shape[1] if input_signal.ndim == 4 else input_signal.shape[0]
+            Bs, As = Bs.repeat(rows // shared_rows, 1, 1, 1), As.repeat(rows // shared_rows, 1, 1, 1)  # no row sharing
             shared_rows = None
         if self.backend != "fsm":
             if tee is not None:

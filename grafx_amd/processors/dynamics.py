@@ -5,7 +5,7 @@ import torch.nn as nn
 from .. import autograd as diff
 from .. import ops
 from ..autograd import needs_grad
-from .core._buffer_io import BufferIO
+from .core._buffer_io import BufferIO, expand_shared, shared_reps
 from .core.convolution import reference_aliases
 from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
 
@@ -44,6 +44,15 @@ class _Dynamics(BufferIO, nn.Module):
 
     def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None,
                 _out=None, _shared_rows=None):
+        if _shared_rows is not None and (needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
+                                                    z_alpha_post) or self.gain_smoother is not None
+                                         or self.energy_smoother == "ballistics"
+                                         or (self.energy_smoother == "iir" and reference_aliases(
+                                             input_signals.shape[-1], self.iir_len, self.flashfftconv))):
+            reps = shared_reps(input_signals, _shared_rows)  # paths without row sharing: one parameter row per signal row
+            log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post = (
+                expand_shared(t, reps) for t in (log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post))
+            _shared_rows = None
         if needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
             y = self._forward_differentiable(input_signals.reshape(-1, *input_signals.shape[-2:]), log_threshold,
                                              log_ratio, log_knee, z_alpha_pre, z_alpha_post)
@@ -54,16 +63,6 @@ class _Dynamics(BufferIO, nn.Module):
         L = input_signals.shape[-1]
         if self.knee == "hard":
             log_knee = None
-        if _shared_rows is not None and (needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
-                                                    z_alpha_post) or self.gain_smoother is not None
-                                         or self.energy_smoother == "ballistics"
-                                         or (self.energy_smoother == "iir" and reference_aliases(
-                                             input_signals.shape[-1], self.iir_len, self.flashfftconv))):
-            reps = input_signals.shape[0]  # paths without row sharing: expand to one parameter row per signal row
-            log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post = (
-                None if t is None else t.repeat(reps, *([1] * (t.ndim - 1)))
-                for t in (log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post))
-            _shared_rows = None
         fusable = self.gain_smoother is None and (
             self.energy_smoother is None or (self.energy_smoother == "iir" and not reference_aliases(L, self.iir_len, self.flashfftconv))
         )

@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from .. import ops
-from .core._buffer_io import BufferIO
+from .core._buffer_io import BufferIO, expand_shared, shared_reps
 from .core.convolution import convolve
 from .core.fir import ZeroPhaseFilterBankFIR, ZeroPhaseFIR
 from .core.geq import GraphicEqualizerBiquad
@@ -31,7 +31,7 @@ class ParametricEqualizer(BufferIO, nn.Module):
         else:
             Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":
-            return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
+            return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As, shared_rows=_shared_rows))
         return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows)
 
     def render_into(self, x4, out4, tee=None, _shared_rows=None, **params):
@@ -39,7 +39,7 @@ class ParametricEqualizer(BufferIO, nn.Module):
             if tee is not None:
                 tee.copy_(x4)
             if _shared_rows is not None:
-                params = {k: v.repeat(x4.shape[0], *([1] * (v.ndim - 1))) for k, v in params.items()}
+                params = {k: expand_shared(v, shared_reps(x4, _shared_rows)) for k, v in params.items()}
             return super().render_into(x4, out4, **params)
         return self.forward(x4, _out=out4, _tee=tee, _shared_rows=_shared_rows, **params)
 

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from .. import autograd as diff
 from .. import ops
 from ..autograd import needs_grad
-from .core._buffer_io import BufferIO
+from .core._buffer_io import BufferIO, expand_shared, shared_reps
 from .core.utils import normalize_impulse
 from .core.convolution import convolve_taps
 from .core.midside import lr_to_ms, ms_to_lr
@@ -82,7 +82,7 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
     def render_into(self, x4, out4, _shared_rows=None, **params):
         if self.processor_channel == "midside":
             if _shared_rows is not None:
-                params = {k: v.repeat(x4.shape[0], *([1] * (v.ndim - 1))) for k, v in params.items()}
+                params = {k: expand_shared(v, shared_reps(x4, _shared_rows)) for k, v in params.items()}
             return super().render_into(x4, out4, **params)
         return self.forward(x4, _out=out4, _shared_rows=_shared_rows, **params)
 
@@ -91,10 +91,9 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         pseudo = self.processor_channel == "pseudo_midside"
         if _shared_rows is not None and (not self.fixed_noise or needs_grad(
                 input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)):
-            reps = input_signals.shape[0]
+            reps = shared_reps(input_signals, _shared_rows)
             init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude = (
-                None if t is None else t.repeat(reps, 1, 1)
-                for t in (init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude))
+                expand_shared(t, reps) for t in (init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude))
             _shared_rows = None
         if not self.fixed_noise or needs_grad(input_signals, init_log_magnitude, delta_log_magnitude,
                                               gain_env_log_magnitude):

@@ -333,14 +333,22 @@ class _BufferRenderFn(torch.autograd.Function):
                     local = [t.detach().requires_grad_(t.requires_grad) for t in leaves]
                     params = _unflatten_tree(p_spec, local)[node_type]
                     common = None if c_spec is None else _unflatten_tree(c_spec, local)
-                    if not squeeze:
-                        params = expand_tensor_or_tensor_dict(params, expand=B, dim=0)
-                        if common is not None:
-                            common = expand_tensor_or_tensor_dict(common, expand=B, dim=0)
-                    params = read_tensor_or_tensor_dict(params, step.parameter_read, dim=node_dim, postprocess=postprocess)
+                    extra = {}
+                    if not squeeze and common is None and getattr(processors[node_type], "accepts_shared_params", False):
+                        # per-node parameters stay un-expanded: the processor's front-end runs once per node and
+                        # its gradient is summed over the batch inside the convolution's backward
+                        params = read_tensor_or_tensor_dict(params, step.parameter_read, dim=0)
+                        extra["_shared_rows"] = d1 - d0
+                    else:
+                        if not squeeze:
+                            params = expand_tensor_or_tensor_dict(params, expand=B, dim=0)
+                            if common is not None:
+                                common = expand_tensor_or_tensor_dict(common, expand=B, dim=0)
+                        params = read_tensor_or_tensor_dict(params, step.parameter_read, dim=node_dim,
+                                                            postprocess=postprocess)
                     common_i = {} if common is None else read_tensor_or_tensor_dict(
                         common, step.dest_write, dim=node_dim, postprocess=postprocess)
-                    y = processors[node_type](x_in, **params, **common_i)
+                    y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
                     wrt = [x_in] + [local[j] for j in live]
                     grads = torch.autograd.grad(y, wrt, grad_outputs=g_out.reshape(y.shape), allow_unused=True)
