@@ -144,6 +144,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # RCCL builds its communicator (device buffers, proxy threads) lazily at the first collectives; do that now,
+        # not inside the timed region (its hipMallocs are device-synchronising: seen as 250 ms "steps" with --warmup 1)
+        warm = torch.zeros(1, device=torch.device("cuda", local))
+        dist.all_reduce(warm)
+        dist.barrier()
+        torch.cuda.synchronize()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -174,6 +180,9 @@ def main():
     # a first hipMalloc of ~30 GB on a freshly booted box can take most of a second.
     pool = [torch.empty(B, render_data.num_nodes, 2, L, device=dev) for _ in range(2)]
     del pool
+    with torch.no_grad():  # one single-graph render: loads every kernel's code object and builds the per-device tables
+        render_grafx(procs, x[:1], params, rd_dev, parameters_grad=False)
+    torch.cuda.synchronize()
     y = None
     for _ in range(args.warmup):
         y = step()
