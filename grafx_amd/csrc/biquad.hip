@@ -31,7 +31,7 @@ constexpr int BQ_T = 256;            // threads per workgroup = 4 independent wa
 constexpr int BQ_W = BQ_T / 64;      // row-channels per workgroup
 constexpr int BQ_E = 8;              // samples per lane
 constexpr int BQ_TILE = 64 * BQ_E;   // samples per wave tile
-constexpr int BQ_MAX_K = 36;
+constexpr int BQ_MAX_K = 32;  // 4 waves x K x (160 B constants + 1 KB lane powers) of LDS: 148 KB at K = 32
 
 struct M2 {  // 2x2 matrix, row-major
     float a, b, c, d;

@@ -216,7 +216,7 @@ int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, 
  * section / the state-space form on torchlpc).  K second-order sections in series per row-channel, zero initial
  * state, coefficients normalised by a0:  y = b0 w[n] + b1 w[n-1] + b2 w[n-2],  w[n] = x[n] - a1 w[n-1] - a2 w[n-2].
  * A parallel scan over time (matrix powers of the 2x2 transition matrix), no FFT.
- * Bs, As: (R, C_f, K, 3) contiguous; channels broadcast 1<->C like gfx_fftconv_f32; K <= 36.
+ * Bs, As: (R, C_f, K, 3) contiguous; channels broadcast 1<->C like gfx_fftconv_f32; K <= 32.
  * ssm_quirk != 0 reproduces upstream's "ssm" backend for K > 1, which feeds the ORIGINAL input to the
  * recursive part of every section (core/iir.py:226-246); for K == 1 both settings are the same filter. */
 int gfx_biquad_cascade_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* Bs,

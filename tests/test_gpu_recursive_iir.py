@@ -89,3 +89,43 @@ def test_recursive_backend_refuses_gradients_and_bad_orders():
         m(torch.randn(1, 1, 64, device="cuda"), Bs, torch.tensor([[[[1.0, 0.1, 0.1]]]], device="cuda"))
     with pytest.raises(NotImplementedError):
         IIRFilter(order=4, backend="ssm", flashfftconv=False)
+
+
+def test_graphic_equalizer_on_the_exact_backend_with_31_sections():
+    """The largest cascade upstream builds (third-octave GEQ, 31 bands; sr = 48 kHz keeps the 20.16 kHz band) on the
+    recursive kernel (4 waves x 31 sections of scan constants in LDS) against a float64 direct-form recursion."""
+    import grafx_amd.processors as P
+    from grafx_amd.processors.core.geq import GraphicEqualizerBiquad
+
+    torch.manual_seed(4)
+    L = 700
+    x = torch.randn(2, 2, L)
+    lg = 0.4 * torch.randn(2, 1, 31)
+    m = P.GraphicEqualizer(scale="third_octave", sr=48000, backend="lfilter", flashfftconv=False).cuda()
+    assert m.geq.num_bands == 31
+    with torch.no_grad():
+        y = m(x.cuda(), log_gains=lg.cuda()).cpu()
+    # The 20 Hz bands put poles at radius 0.9994 and angle 0.0026 rad, where a direct-form biquad is ill-conditioned
+    # in fp32: with identical (fp32-rounded, a0-normalised) coefficients a plain sequential fp32 recursion is itself
+    # ~4e-4 away from the float64 one.  The kernel must be as close to float64 as that, not closer than fp32 allows.
+    Bs, As = GraphicEqualizerBiquad(scale="third_octave", sr=48000)(lg)
+    Bn, An = Bs / As[..., :1], As / As[..., :1]
+
+    def direct_form(dtype):
+        sig = x.to(dtype)
+        for k in range(31):
+            b, a = Bn[:, 0, k].to(dtype), An[:, 0, k].to(dtype)
+            out = torch.zeros_like(sig)
+            w1 = torch.zeros(2, 2, dtype=dtype)
+            w2 = torch.zeros(2, 2, dtype=dtype)
+            for n in range(L):
+                w = sig[..., n] - a[:, 1:2] * w1 - a[:, 2:3] * w2
+                out[..., n] = b[:, 0:1] * w + b[:, 1:2] * w1 + b[:, 2:3] * w2
+                w2, w1 = w1, w
+            sig = out
+        return sig
+
+    ref64, ref32 = direct_form(torch.float64), direct_form(torch.float32)
+    fp32_noise = (ref32.double() - ref64).abs().max() / ref64.abs().max()
+    ours = (y.double() - ref64).abs().max() / ref64.abs().max()
+    assert ours <= max(2 * fp32_noise, 5e-5), f"kernel {ours:.2e} vs sequential fp32 {fp32_noise:.2e} (both against float64)"
