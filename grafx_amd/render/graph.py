@@ -134,11 +134,18 @@ def _complement(rng, n):
 
 
 def _touches_inputs(read, n_src):
-    if read.method == "slice":
-        return read.idx[0] < n_src
-    if read.method == "index":
-        return bool((read.idx < n_src).any()) if isinstance(read.idx, torch.Tensor) else any(i < n_src for i in read.idx)
-    return False
+    """Does this read access a source row?  Cached on the descriptor: an index read lives on the device, and asking
+    it costs a host sync (which would also be illegal while the render is being captured into a HIP graph)."""
+    cache = read.__dict__.setdefault("_touches", {})
+    if n_src not in cache:
+        if read.method == "slice":
+            cache[n_src] = read.idx[0] < n_src
+        elif read.method == "index":
+            idx = read.idx
+            cache[n_src] = bool((idx < n_src).any()) if isinstance(idx, torch.Tensor) else any(i < n_src for i in idx)
+        else:
+            cache[n_src] = False
+    return cache[n_src]
 
 
 def _any_requires_grad(p):
