@@ -148,13 +148,15 @@ __device__ __forceinline__ float log_gain(const Knee& q, float G) {
 }
 
 // ---- loads / stores of 4 consecutive samples with bounds -----------------------------------------
-__device__ __forceinline__ void load4(const float* __restrict__ row, int64_t n, int64_t L, bool vec, float (&v)[DE]) {
-    if (vec && n + DE <= L && n >= 0) {
+// samples [n, n+4) of a row, zero outside [lo, L)
+__device__ __forceinline__ void load4(const float* __restrict__ row, int64_t n, int64_t L, bool vec, float (&v)[DE],
+                                      int64_t lo = 0) {
+    if (vec && n + DE <= L && n >= lo) {
         const float4 q = *reinterpret_cast<const float4*>(row + n);
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
 #pragma unroll
-        for (int i = 0; i < DE; ++i) v[i] = (n + i >= 0 && n + i < L) ? row[n + i] : 0.0f;
+        for (int i = 0; i < DE; ++i) v[i] = (n + i >= lo && n + i < L) ? row[n + i] : 0.0f;
     }
 }
 __device__ __forceinline__ void store4(float* __restrict__ row, int64_t n, int64_t L, bool vec, const float (&v)[DE]) {
@@ -176,23 +178,29 @@ struct DynArgs {
     int smoother;          // 0 none, 1 truncated one-pole
     int knee, gate;
     unsigned prows;        // parameter rows: row r uses parameters r % prows
+    int nchunks;           // workgroups per row (time chunks; > 1 only with few rows, see the launcher)
+    int64_t chunk_tiles;   // tiles per chunk
 };
 
 // ---- fused compressor / gate: energy -> one-pole -> log -> knee -> exp -> multiply -----------------
+// Tiles [t_lo, t_hi) of the row are produced.  The smoother is a truncated FIR (N taps), so a chunk that does not
+// start at the row start is exact if its scans start N samples early from a zero state: tiles [t_warm, t_lo) are
+// scanned without producing output, and samples before `s0 = t_warm * DTILE` count as zero for both scans.
 template <bool TRUNC>
 __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
-                                           const float* x1, float* y0, float* y1, float* slots, int t) {
+                                           const float* x1, float* y0, float* y1, float* slots, int t,
+                                           int64_t t_warm, int64_t t_lo, int64_t t_hi) {
     const int lane = t & 63, wave = t >> 6;
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
     const float invC = 1.0f / (float)a.C;
     float carry = 0.0f, carry2 = 0.0f;
-    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    const int64_t s0 = t_warm * DTILE;
     // software prefetch: the next tile's samples are requested before the current tile is scanned, so the
     // HBM round trip overlaps the scan / log / exp work (the barrier inside scan_tile would otherwise fence it)
     float na[DE], nb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
-    load4(x0, (int64_t)DE * t, a.L, vx, na);
-    if (a.C == 2) load4(x1, (int64_t)DE * t, a.L, vx, nb);
-    for (int64_t tile = 0; tile < ntiles; ++tile) {
+    load4(x0, t_warm * DTILE + (int64_t)DE * t, a.L, vx, na);
+    if (a.C == 2) load4(x1, t_warm * DTILE + (int64_t)DE * t, a.L, vx, nb);
+    for (int64_t tile = t_warm; tile < t_hi; ++tile) {
         const int64_t n = tile * DTILE + DE * t;
         float xa[DE], xb[DE], e[DE], env[DE];
 #pragma unroll
@@ -200,7 +208,7 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
             xa[i] = na[i];
             xb[i] = nb[i];
         }
-        if (tile + 1 < ntiles) {
+        if (tile + 1 < t_hi) {
             load4(x0, n + DTILE, a.L, vx, na);
             if (a.C == 2) load4(x1, n + DTILE, a.L, vx, nb);
         }
@@ -214,8 +222,8 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
             scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
             if (TRUNC) {
                 float da[DE], db[DE], e2[DE], u2[DE];
-                load4(x0, n - a.N, a.L, false, da);
-                if (a.C == 2) load4(x1, n - a.N, a.L, false, db);
+                load4(x0, n - a.N, a.L, false, da, s0);
+                if (a.C == 2) load4(x1, n - a.N, a.L, false, db, s0);
 #pragma unroll
                 for (int i = 0; i < DE; ++i)
                     e2[i] = (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC;
@@ -223,6 +231,7 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
 #pragma unroll
                 for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
             }
+            if (tile < t_lo) continue;  // warm-up tile: only the scan state matters (uniform branch)
 #pragma unroll
             for (int i = 0; i < DE; ++i) env[i] = fmaxf(p.one_m_a * u[i], 0.0f);  // relu, envelope.py:48
         } else {
@@ -249,7 +258,8 @@ __global__ __launch_bounds__(DT) void dyn_fused_kernel(const float* __restrict__
                                                        const float* __restrict__ z_alpha, DynArgs a) {
     __shared__ float slots[16];
     const int t = threadIdx.x;
-    const int64_t r = blockIdx.x;
+    const int64_t r = blockIdx.x / a.nchunks;
+    const int chunk = (int)(blockIdx.x - r * a.nchunks);
     OnePole p;
     p.trunc = false;
     const unsigned pr = (unsigned)r % a.prows;
@@ -260,10 +270,16 @@ __global__ __launch_bounds__(DT) void dyn_fused_kernel(const float* __restrict__
     const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
     float* y0 = y + drow_off(a.ymap, r, 0);
     float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
+    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    const int64_t t_lo = chunk * a.chunk_tiles, t_hi = min(t_lo + a.chunk_tiles, ntiles);
+    if (t_lo >= t_hi) return;
+    // warm-up: N taps of history (none without a smoother), whole tiles, not before the row start
+    const int64_t warm_tiles = a.smoother == 1 ? (a.N + DTILE - 1) / DTILE : 0;
+    const int64_t t_warm = t_lo > warm_tiles ? t_lo - warm_tiles : 0;
     if (p.trunc)
-        dyn_stream<true>(a, p, q, x0, x1, y0, y1, slots, t);
+        dyn_stream<true>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi);
     else
-        dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t);
+        dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi);
 }
 
 // ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
@@ -689,8 +705,18 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = smoother; a.knee = knee; a.gate = gate;
     a.prows = (unsigned)param_rows;
-    hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, x, y, log_threshold,
-                       log_ratio, log_knee, z_alpha, a);
+    // Few rows: one workgroup per row walks the whole length serially (~2 us per tile) and the launch is bound by
+    // that latency, not by bandwidth.  Split every row into time chunks then; a chunk re-scans N samples of history
+    // (exact, the smoother is an N-tap FIR), so chunks are kept at least as long as that history.
+    const int64_t ntiles = (L + DTILE - 1) / DTILE;
+    const int64_t warm = smoother == 1 ? (iir_len + DTILE - 1) / DTILE : 0;
+    int64_t nchunks = 1;
+    while (R * nchunks < 2048 && nchunks < 16 && ntiles / (2 * nchunks) >= (warm > 4 ? warm : 4)) nchunks *= 2;
+    a.nchunks = (int)nchunks;
+    a.chunk_tiles = (ntiles + nchunks - 1) / nchunks;
+    if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
+    hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, (hipStream_t)stream, x, y,
+                       log_threshold, log_ratio, log_knee, z_alpha, a);
     return GFX_LAUNCH_OK();
 }
 

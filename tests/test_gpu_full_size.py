@@ -107,3 +107,28 @@ def test_compressor_extreme_poles_full_length():
         ref = oracle.OracleCompressor(iir_len=iir_len)(x, **p)
         ref64 = oracle.OracleCompressor(iir_len=iir_len)(x.double(), **{k: v.double() for k, v in p.items()})
         assert_parity(y, ref, ref64, 1e-5, f"compressor iir_len={iir_len}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("iir_len", [16383, 1023])
+def test_time_chunked_dynamics_equals_the_serial_scan(iir_len):
+    """With few rows gfx_dynamics_fused_f32 splits every row into time chunks that re-scan iir_len samples of
+    history; with many rows it walks each row serially.  Same rows, both ways, including a pole clamped at
+    1 - 1e-5 (a^N = 0.85: the truncation term matters) and a hard gate."""
+    import torch
+
+    from grafx_amd import ops
+
+    torch.manual_seed(9)
+    R, Lc = 4, 131072
+    x = torch.randn(R, 2, Lc, device="cuda") * torch.linspace(0.05, 1.0, Lc, device="cuda")
+    p = dict(log_threshold=torch.randn(R, 1, device="cuda") - 2, log_ratio=torch.randn(R, 1, device="cuda"),
+             log_knee=torch.randn(R, 1, device="cuda"), z_alpha=torch.tensor([[20.0], [6.0], [2.0], [-1.0]], device="cuda"))
+    for knee, gate in (("quadratic", False), ("hard", True)):
+        few = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], smoother=1,
+                                 iir_len=iir_len, knee=knee, gate=gate)
+        reps = 512  # 2048 rows: serial walk
+        many = ops.dynamics_fused(x.repeat(reps, 1, 1), *(p[k].repeat(reps, 1) for k in
+                                                           ("log_threshold", "log_ratio", "log_knee", "z_alpha")),
+                                  smoother=1, iir_len=iir_len, knee=knee, gate=gate)
+        assert (few - many[:R]).abs().max() <= 1e-5 * many[:R].abs().max(), (knee, gate)
