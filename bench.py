@@ -195,8 +195,13 @@ def main():
 
     fence()
     t0 = time.perf_counter()
+    debug = os.environ.get("GRAFX_BENCH_DEBUG")
     for _ in range(args.steps):
         y = step()
+        if debug:  # per-step wall times (adds a sync per step: diagnostics only)
+            torch.cuda.synchronize()
+            print(f"[bench] step done at +{(time.perf_counter() - t0) * 1e3:.1f} ms, reserved "
+                  f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -129,6 +129,10 @@ __device__ __forceinline__ void load_window(cx (&v)[32], const float* __restrict
 template <bool NATURAL = false>
 __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict__ row, int64_t n0, int64_t O,
                                             int64_t Lout, int t) {
+    // opaque copy of the lane index: the tee store (before the transforms) and the output store (after them) use
+    // the same 32 lane masks, and without this the compiler keeps them alive across the whole kernel (16 spilled
+    // dwords = 2.8 GB of scratch write-back per 8192-row launch) instead of recomputing 32 compares
+    asm volatile("" : "+v"(t));
     const int64_t room = Lout - (n0 - O);                      // samples from the descriptor base to the row end
     const rsrc_t r = make_rsrc(row + (n0 - O), room * 4);
     const int o32 = (int)O;

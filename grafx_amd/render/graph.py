@@ -203,13 +203,18 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
     # registers that hold it anyway) makes the copy of the rows it reads free.
     teed = _tee_range(render_data, processors, n_src, x.device)
     main = torch.cuda.current_stream(x.device)
-    side = _side_stream(x.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        for a, b in _complement(teed, n_src):
-            buf[:, a:b].copy_(x[:, a:b], non_blocking=True)
-    x.record_stream(side)
-    buf.record_stream(side)
+    rest = _complement(teed, n_src)
+    side = _side_stream(x.device) if rest else None
+    if side is not None:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for a, b in rest:
+                buf[:, a:b].copy_(x[:, a:b], non_blocking=True)
+        # No record_stream() on x / buf: the main stream joins the side stream before this function returns, so
+        # everything the caller (or the allocator, on reuse) does with them afterwards is ordered behind the copy.
+        # record_stream would instead make the caching allocator hold the 30 GB buffer back until it has *observed*
+        # the side stream's event; with the host running a few steps ahead it then cannot recycle the buffer and
+        # falls back to a fresh hipMalloc per step (seen as intermittent 150-800 ms steps).
     copied = False  # has the main stream joined the copy yet?
     out_view = None
     for i in range(1, render_data.max_order + 1):
@@ -220,7 +225,7 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         node_type = step.node_type
         src_read = step.source_reads[0]
         from_inputs = plan is None and src_read.idx[1] <= n_src  # plain slice of source rows
-        if not from_inputs and not copied and _touches_inputs(src_read, n_src):
+        if side is not None and not from_inputs and not copied and _touches_inputs(src_read, n_src):
             main.wait_stream(side)
             copied = True
         if node_type not in processors:  # in / out / mix: the (summed) input is the output
@@ -255,7 +260,7 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             a, b = teed
             extra["tee"] = buf.narrow(1, a, b - a)
         proc.render_into(x_view, out_view, **extra, **params, **common_i)
-    if not copied:
+    if side is not None and not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:
         return out_view[0], [], buf[0]
