@@ -35,8 +35,8 @@ struct WsRow {
     float pre, post, dc;
     float b, tb;                    // tanh: bias, tanh(bias)
     float kp, kn, gp, gn, ap, an, bp, bn;  // piecewise
-    float w[WS_MAX_K];              // polynomial weights (already tanh'ed)
-};
+    const float* w;                 // polynomial weights (already tanh'ed), in LDS: a run-time-indexed register
+};                                  // array would live in scratch memory
 
 template <int MODE>
 __device__ __forceinline__ float shape(float x, const WsRow& q, int K, bool use_tanh) {
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void waveshaper_kernel(const float* __restrict
                                                          const float* __restrict__ log_post,
                                                          const float* __restrict__ p0, const float* __restrict__ p1,
                                                          const float* __restrict__ dc, WsArgs a, int vec) {
+    __shared__ float sw[WS_MAX_K];
     for (int64_t r = blockIdx.y; r < a.R; r += gridDim.y) {
         WsRow q;
+        q.w = sw;
         q.pre = log_pre ? expf(log_pre[r]) : 1.0f;
         q.post = a.inverse_post ? 1.0f / q.pre : (log_post ? expf(log_post[r]) : 1.0f);
         q.b = q.tb = 0.0f;
@@ -99,7 +101,9 @@ __global__ __launch_bounds__(256) void waveshaper_kernel(const float* __restrict
             q.an = (1.0f + q.bn) / q.gn;
         }
         if (MODE == GFX_WS_POWER || MODE == GFX_WS_CHEBYSHEV) {
-            for (int k = 0; k < a.K; ++k) q.w[k] = tanhf(p0[r * a.K + k]);
+            __syncthreads();  // previous row's readers are done
+            if ((int)threadIdx.x < a.K) sw[threadIdx.x] = tanhf(p0[r * a.K + threadIdx.x]);
+            __syncthreads();
         }
         for (int c = 0; c < a.C; ++c) {
             q.dc = dc ? dc[r * a.C + c] : 0.0f;
