@@ -308,21 +308,55 @@ class _BufferRenderFn(torch.autograd.Function):
         ctx.squeeze = input_signals.ndim == 3
         ctx.n_src = input_signals.shape[0 if ctx.squeeze else 1]
         ctx.save_for_backward(buf, *leaves)
-        return buf
+        # The output rows are returned as an output of their own (a small copy) next to the full buffer: a loss that
+        # only looks at the output then sends back a small gradient instead of a zero-filled buffer-sized one.
+        d0, d1 = render_data.iter_list[render_data.max_order].dest_write.idx
+        ctx.out_rows = (d0, d1)
+        ctx.set_materialize_grads(False)
+        return buf.narrow(0 if ctx.squeeze else 1, d0, d1 - d0).clone(), buf
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gbuf):
+    def backward(ctx, g_out_rows, g_buf):
         from .. import ops
 
         processors, render_data, p_spec, c_spec = ctx.meta
         buf, *leaves = ctx.saved_tensors
         squeeze = ctx.squeeze
         if squeeze:
-            buf, gbuf = buf.unsqueeze(0), gbuf.unsqueeze(0)
-        gbuf = gbuf.clone()  # accumulated into below
+            buf = buf.unsqueeze(0)
+            g_out_rows = None if g_out_rows is None else g_out_rows.unsqueeze(0)
+            g_buf = None if g_buf is None else g_buf.unsqueeze(0)
         B, V, C, L = buf.shape
         dev = buf.device
+        # Gradient of every node's signal, accumulated while walking the schedule backwards.  Never zero-filled as a
+        # whole: `written` tracks which rows hold a value, the first contribution to a row is a copy, later ones add.
+        gbuf = torch.empty_like(buf)
+        written = [False] * V
+
+        def accumulate(a, b, g):  # rows [a, b) += g  (g: (B, b-a, C, L))
+            i = a
+            while i < b:
+                j = i
+                while j < b and written[j] == written[i]:
+                    j += 1
+                dst, src = gbuf.narrow(1, i, j - i), g.narrow(1, i - a, j - i)
+                dst.add_(src) if written[i] else dst.copy_(src)
+                written[i:j] = [True] * (j - i)
+                i = j
+
+        def settled(a, b):  # rows [a, b) as they stand; rows nothing contributed to are zero
+            for i in range(a, b):
+                if not written[i]:
+                    gbuf.narrow(1, i, 1).zero_()
+                    written[i] = True
+            return gbuf.narrow(1, a, b - a)
+
+        if g_buf is not None:
+            gbuf.copy_(g_buf)
+            written = [True] * V
+        if g_out_rows is not None:
+            accumulate(*ctx.out_rows, g_out_rows)
         node_dim = 0 if squeeze else 1
         postprocess = None if squeeze else flatten_batch_and_node
         leaf_grads = [None] * len(leaves)
@@ -331,7 +365,9 @@ class _BufferRenderFn(torch.autograd.Function):
         for i in range(render_data.max_order, 0, -1):
             step = render_data.iter_list[i]
             d0, d1 = step.dest_write.idx
-            g_out = gbuf.narrow(1, d0, d1 - d0)
+            if not any(written[d0:d1]):
+                continue  # nothing downstream depends on this stage
+            g_out = settled(d0, d1)
             plan = _gather_plan(step, dev)
             node_type = step.node_type
             if node_type in processors:
@@ -373,29 +409,29 @@ class _BufferRenderFn(torch.autograd.Function):
             # add the stage's input gradient onto the rows it read
             if plan is None:
                 a, b = step.source_reads[0].idx
-                gbuf.narrow(1, a, b - a).add_(g_in)
+                accumulate(a, b, g_in)
             else:
                 # adjoint of the gather-sum: every source row collects the gradients of the slots it fed --
                 # the same gather-sum kernel with the transposed plan
                 uniq, dst_idx, ptr, contiguous = _transposed_plan(step, plan, dev)
                 g_src = ops.gather_sum(g_in.contiguous(), dst_idx, ptr, torch.empty(B, len(uniq), C, L, device=dev))
                 if contiguous:
-                    gbuf.narrow(1, uniq[0], len(uniq)).add_(g_src)
+                    accumulate(uniq[0], uniq[0] + len(uniq), g_src)
                 else:
-                    gbuf.index_add_(1, torch.tensor(uniq, dtype=torch.long, device=dev), g_src)
-        g_x = gbuf.narrow(1, 0, ctx.n_src)
-        g_x = g_x[0] if squeeze else g_x
-        return (None, g_x.contiguous() if ctx.needs_input_grad[1] else None, *leaf_grads)
+                    for k, u in enumerate(uniq):
+                        accumulate(u, u + 1, g_src.narrow(1, k, 1))
+        g_x = None
+        if ctx.needs_input_grad[1]:
+            g_x = settled(0, ctx.n_src)
+            g_x = (g_x[0] if squeeze else g_x).contiguous()
+        return (None, g_x, *leaf_grads)
 
 
 def _render_buffer_io_with_grad(processors, input_signals, per_type_parameters, render_data, common_parameters):
     leaves = []
     p_spec = _flatten_tree(per_type_parameters, leaves)
     c_spec = None if common_parameters is None else _flatten_tree(common_parameters, leaves)
-    buf = _BufferRenderFn.apply((processors, render_data, p_spec, c_spec), input_signals, *leaves)
-    last = render_data.iter_list[render_data.max_order]
-    d0, d1 = last.dest_write.idx
-    out = buf.narrow(0 if input_signals.ndim == 3 else 1, d0, d1 - d0)
+    out, buf = _BufferRenderFn.apply((processors, render_data, p_spec, c_spec), input_signals, *leaves)
     return out, [], buf
 
 

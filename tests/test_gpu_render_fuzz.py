@@ -87,9 +87,12 @@ def test_random_graph_gradients_match_the_oracle(seed):
     def run(procs, dev):
         p = {t: {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in d.items()} for t, d in params.items()}
         xin = x.detach().clone().to(dev).requires_grad_(True)
-        y = render_grafx(procs, xin, p, rd.to(dev) if dev != "cpu" else rd, input_signal_grad=True)[0]
+        y, _, buf = render_grafx(procs, xin, p, rd.to(dev) if dev != "cpu" else rd, input_signal_grad=True)
         w = torch.linspace(0.5, 1.5, L, device=dev)
-        (y * w).square().mean().backward()
+        loss = (y * w).square().mean()
+        if seed % 2 == 1:  # the loss also looks at an intermediate node of the returned signal buffer
+            loss = loss + 0.3 * (buf[:, buf.shape[1] // 2] * w).abs().mean()
+        loss.backward()
         return xin.grad.cpu(), {(t, k): v.grad.cpu() for t, d in p.items() for k, v in d.items() if v.grad is not None}
 
     gx_ref, gp_ref = run(ref, "cpu")
