@@ -57,3 +57,21 @@ def test_processors_refuse_cpu_tensors_and_missing_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB", "/nonexistent/libgrafx_amd.so")
     with pytest.raises(ImportError, match="not built"):
         _lib.lib()
+
+
+def test_plain_c_program_links_and_runs_against_the_library(tmp_path):
+    """The boundary is a C ABI: a C translation unit must be able to include the header and link the library."""
+    import os
+    import subprocess
+
+    from grafx_amd import build
+
+    lib = build.build()
+    exe = tmp_path / "abi_smoke"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(lib)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+           "-L", libdir, "-lgrafx_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True)
+    assert "abi_smoke ok" in out.stdout
