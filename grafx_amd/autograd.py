@@ -186,22 +186,27 @@ def one_pole_backward(u, z_alpha, y, N, g, need_u=True, need_z=True):
     if need_u:
         gu = ops.onepole(g.flip(-1), z_alpha, N, relu=False).flip(-1)
     if need_z:
-        sig = torch.sigmoid(z_alpha.reshape(R, 1))
-        a = sig.clamp(max=1 - 1e-5)
-        one_m_a = 1 - a
-        inf = L + 1  # longer than the signal: no truncation term
-        # with a^N = aN:  da = sum_n g[n] ( -U[n] + (aN - (1-a) N a^(N-1)) U[n-N] + (1-a) (D[n] - aN D[n-N]) ),
-        # D[n] = S[n-1], S = scan of U.  The scan kernel returns U1 = (1-a) U and S2 = (1-a)^2 S; the powers of
-        # 1/(1-a) go into the coefficients and the one-sample shift of D onto g.
-        U1 = ops.onepole(u, z_alpha, inf, relu=False)
-        S2 = ops.onepole(U1, z_alpha, inf, relu=False)
-        aN = torch.pow(a.double(), N).float()
-        aN1 = torch.pow(a.double(), N - 1).float()
-        inv, zero = 1 / one_m_a, torch.zeros_like(a)
-        da = ops.onepole_dz(g, U1, U1, torch.cat([-inv, zero, (aN - one_m_a * N * aN1) * inv, zero], 1), N)
-        da = da + ops.onepole_dz(F.pad(g, (0, 1))[:, 1:], S2, S2, torch.cat([inv, zero, -aN * inv, zero], 1), N)
-        gz = (da.reshape(R, 1) * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
+        gz = pole_gradient(g, ops.onepole(u, z_alpha, L + 1, relu=False), z_alpha, N)
     return gu, gz
+
+
+def pole_gradient(g, U1, z_alpha, N):
+    """dL/dz_alpha of the truncated one-pole given the (relu-masked) output gradient g and U1 = (1-a) * (the
+    un-truncated scan of the input).  With a^N = aN:
+        da = sum_n g[n] ( -U[n] + (aN - (1-a) N a^(N-1)) U[n-N] + (1-a) (D[n] - aN D[n-N]) ),   D[n] = S[n-1],
+    S = scan of U.  The scan kernel returns S2 = (1-a)^2 S from U1; the powers of 1/(1-a) go into the coefficients
+    and the one-sample shift of D onto g."""
+    R, L = g.shape
+    sig = torch.sigmoid(z_alpha.reshape(R, 1))
+    a = sig.clamp(max=1 - 1e-5)
+    one_m_a = 1 - a
+    S2 = ops.onepole(U1, z_alpha, L + 1, relu=False)  # iir_len > L: no truncation term
+    aN = torch.pow(a.double(), N).float()
+    aN1 = torch.pow(a.double(), N - 1).float()
+    inv, zero = 1 / one_m_a, torch.zeros_like(a)
+    da = ops.onepole_dz(g, U1, U1, torch.cat([-inv, zero, (aN - one_m_a * N * aN1) * inv, zero], 1), N)
+    da = da + ops.onepole_dz(F.pad(g, (0, 1))[:, 1:], S2, S2, torch.cat([inv, zero, -aN * inv, zero], 1), N)
+    return (da.reshape(R, 1) * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
 
 
 class DynamicsFn(torch.autograd.Function):
@@ -227,16 +232,15 @@ class DynamicsFn(torch.autograd.Function):
         x, log_threshold, log_ratio, log_knee, z_alpha = ctx.saved_tensors
         smoother, iir_len, knee, gate = ctx.cfg
         gy = gy.contiguous()
-        e = ops.energy(x)
-        env = ops.onepole(e, z_alpha, iir_len, relu=True) if smoother else e
-        gain, denv, gp = ops.dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee if knee != "hard" else None,
-                                          knee, gate)
-        gz = None
-        if smoother:
-            de, gz = one_pole_backward(e, z_alpha, env, iir_len, denv, True, ctx.needs_input_grad[4])
+        lk = log_knee if knee != "hard" else None
+        if smoother:  # two fused passes over the rows (forward, then backward in time) + the pole-gradient reduction
+            gx, gp, denv, u1 = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate)
+            gz = pole_gradient(denv, u1, z_alpha, iir_len) if ctx.needs_input_grad[4] else None
         else:
-            de = denv
-        gx = ops.dyn_dx(x, gy, gain, de) if ctx.needs_input_grad[0] else None
+            e = ops.energy(x)
+            gain, denv, gp = ops.dyn_gain_bwd(x, gy, e, log_threshold, log_ratio, lk, knee, gate)
+            gx = ops.dyn_dx(x, gy, gain, denv) if ctx.needs_input_grad[0] else None
+            gz = None
         like = lambda t, col: None if t is None else gp[:, col].reshape(t.shape)  # noqa: E731
         return (gx, like(log_threshold, 0), like(log_ratio, 1), like(log_knee if knee != "hard" else None, 2), gz,
                 None, None, None, None)

@@ -569,6 +569,190 @@ __device__ __forceinline__ KneeGrad log_gain_grad(const Knee& q, float G) {
     return o;
 }
 
+// ---- fused backward of the compressor / gate with the one-pole energy smoother ------------------------------
+// Pass A, forward in time, one workgroup per row: recompute energy -> smoothed energy -> gain exactly as the
+// forward kernel does, and from the output gradient gy emit
+//   gain[n] = exp(g(G))                               (R, L)
+//   denv[n] = dL/d(smoothed energy), relu-masked       (R, L)
+//   u1[n]   = (1-a) * (untruncated scan of the energy) (R, L)   -- input of the pole-gradient reduction
+//   gparams[r, 0..2] = dL/d(log_threshold, log_ratio, log_knee)
+template <bool TRUNC>
+__device__ __forceinline__ void dyn_bwd_a_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
+                                                 const float* x1, const float* g0, const float* g1, float* gain,
+                                                 float* denv, float* u1, float* slots, int t, float (&acc)[3]) {
+    const int lane = t & 63, wave = t >> 6;
+    const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = (a.L % 4) == 0;
+    const float invC = 1.0f / (float)a.C;
+    float carry = 0.0f, carry2 = 0.0f;
+    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int64_t n = tile * DTILE + DE * t;
+        float xa[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, ga[DE], gb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, e[DE], u[DE];
+        load4(x0, n, a.L, vx, xa);
+        load4(g0, n, a.L, vx, ga);
+        if (a.C == 2) {
+            load4(x1, n, a.L, vx, xb);
+            load4(g1, n, a.L, vx, gb);
+        }
+#pragma unroll
+        for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
+        scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
+        float lin[DE], raw[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) raw[i] = p.one_m_a * u[i];
+        if (TRUNC) {
+            float da[DE], db[DE], e2[DE], u2[DE];
+            load4(x0, n - a.N, a.L, false, da);
+            if (a.C == 2) load4(x1, n - a.N, a.L, false, db);
+#pragma unroll
+            for (int i = 0; i < DE; ++i)
+                e2[i] = (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC;
+            scan_tile(p, e2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+        }
+        float gn[DE], dv[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            lin[i] = p.one_m_a * u[i];
+            const float env = fmaxf(lin[i], 0.0f);
+            const float G = logf(env + 1e-5f);
+            gn[i] = expf(log_gain(q, G));
+            const float dgain = a.C == 2 ? (ga[i] * xa[i] + gb[i] * xb[i]) : ga[i] * xa[i];
+            const float dg = dgain * gn[i];
+            const KneeGrad k = log_gain_grad(q, G);
+            dv[i] = lin[i] > 0.0f ? dg * k.dG / (env + 1e-5f) : 0.0f;
+            if (n + i < a.L) {
+                acc[0] += dg * k.dT;
+                acc[1] += dg * k.dlr;
+                acc[2] += dg * k.dlk;
+            }
+        }
+        store4(gain, n, a.L, vo, gn);
+        store4(denv, n, a.L, vo, dv);
+        store4(u1, n, a.L, vo, raw);
+    }
+}
+
+__global__ __launch_bounds__(DT) void dyn_bwd_a_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       gfx_rowmap_t gmap, const float* __restrict__ log_threshold,
+                                                       const float* __restrict__ log_ratio,
+                                                       const float* __restrict__ log_knee,
+                                                       const float* __restrict__ z_alpha, float* __restrict__ gain,
+                                                       float* __restrict__ denv, float* __restrict__ u1,
+                                                       float* __restrict__ gparams, DynArgs a) {
+    __shared__ float slots[16];
+    __shared__ float red[3][4];
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    OnePole p;
+    onepole_setup(p, z_alpha[r], a.N, t & 63);
+    Knee q;
+    knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, a.knee, a.gate);
+    const float* x0 = x + drow_off(a.xmap, r, 0);
+    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
+    const float* g0 = gy + drow_off(gmap, r, 0);
+    const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    if (p.trunc)
+        dyn_bwd_a_stream<true>(a, p, q, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, u1 + r * a.L, slots, t, acc);
+    else
+        dyn_bwd_a_stream<false>(a, p, q, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, u1 + r * a.L, slots, t, acc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((t & 63) == 0) red[k][t >> 6] = v;
+    }
+    __syncthreads();
+    if (t < 3) gparams[3 * r + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
+}
+
+// Pass B, backward in time: de[m] = sum_{k<N} h[k] denv[m+k] (the smoother's adjoint = the same scan on the
+// reversed sequence), then gx = gain * gy + (2/C) * de * x.  Position j of the reversed walk is sample L-1-j.
+__device__ __forceinline__ void rload4(const float* __restrict__ row, int64_t j, int64_t L, bool vec, float (&v)[DE]) {
+    // v[i] = row[L-1-(j+i)], zero outside [0, L)
+    const int64_t hi = L - 1 - j;  // sample of v[0]
+    if (vec && hi - 3 >= 0 && hi < L) {
+        const float4 q = *reinterpret_cast<const float4*>(row + hi - 3);
+        v[0] = q.w; v[1] = q.z; v[2] = q.y; v[3] = q.x;
+    } else {
+#pragma unroll
+        for (int i = 0; i < DE; ++i) v[i] = (hi - i >= 0 && hi - i < L) ? row[hi - i] : 0.0f;
+    }
+}
+__device__ __forceinline__ void rstore4(float* __restrict__ row, int64_t j, int64_t L, bool vec, const float (&v)[DE]) {
+    const int64_t hi = L - 1 - j;
+    if (vec && hi - 3 >= 0 && hi < L) {
+        *reinterpret_cast<float4*>(row + hi - 3) = make_float4(v[3], v[2], v[1], v[0]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DE; ++i)
+            if (hi - i >= 0 && hi - i < L) row[hi - i] = v[i];
+    }
+}
+
+template <bool TRUNC>
+__device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole& p, const float* x0, const float* x1,
+                                                 const float* g0, const float* g1, const float* gain,
+                                                 const float* denv, float* o0, float* o1, float* slots, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    const bool al = (a.L % 4) == 0;  // reversed float4 groups stay 16-byte aligned only then
+    const bool vx = al && vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = al;
+    const float k2 = 2.0f / (float)a.C;
+    float carry = 0.0f, carry2 = 0.0f;
+    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int64_t j = tile * DTILE + DE * t;
+        float d[DE], u[DE];
+        rload4(denv, j, a.L, vo, d);
+        scan_tile(p, d, u, carry, slots + 8 * (tile & 1), lane, wave);
+        if (TRUNC) {
+            float d2[DE], u2[DE];
+            rload4(denv, j - a.N, a.L, false, d2);
+            scan_tile(p, d2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+        }
+        float gn[DE], xa[DE], ga[DE], oa[DE];
+        rload4(gain, j, a.L, vo, gn);
+        rload4(x0, j, a.L, vx, xa);
+        rload4(g0, j, a.L, vx, ga);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) oa[i] = fmaf(gn[i], ga[i], k2 * p.one_m_a * u[i] * xa[i]);
+        rstore4(o0, j, a.L, vo, oa);
+        if (a.C == 2) {
+            float xb[DE], gb[DE], ob[DE];
+            rload4(x1, j, a.L, vx, xb);
+            rload4(g1, j, a.L, vx, gb);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) ob[i] = fmaf(gn[i], gb[i], k2 * p.one_m_a * u[i] * xb[i]);
+            rstore4(o1, j, a.L, vo, ob);
+        }
+    }
+}
+
+__global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       gfx_rowmap_t gmap, const float* __restrict__ z_alpha,
+                                                       const float* __restrict__ gain, const float* __restrict__ denv,
+                                                       float* __restrict__ gx, DynArgs a) {
+    __shared__ float slots[16];
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    OnePole p;
+    onepole_setup(p, z_alpha[r], a.N, t & 63);
+    const float* x0 = x + drow_off(a.xmap, r, 0);
+    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
+    const float* g0 = gy + drow_off(gmap, r, 0);
+    const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
+    float* o0 = gx + (r * a.C) * a.L;
+    float* o1 = gx + (r * a.C + (a.C == 2 ? 1 : 0)) * a.L;
+    if (p.trunc)
+        dyn_bwd_b_stream<true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, o0, o1, slots, t);
+    else
+        dyn_bwd_b_stream<false>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, o0, o1, slots, t);
+}
+
 // One pass over (x, gy, env): gain = exp(g(log(env + 1e-5))),  dgain = sum_c gy x,  dg = dgain * gain,
 //   denv = dg * dg/dG / (env + 1e-5),   gparams[r] += sum_n dg * (dg/dT, dg/dlog_ratio, dg/dlog_knee).
 __global__ __launch_bounds__(256) void dyn_gain_bwd_kernel(const float* __restrict__ x, gfx_rowmap_t xmap,
@@ -771,6 +955,25 @@ int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_gain_bwd_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, gy, gmap, env,
                        log_threshold, log_ratio, log_knee, R, L, (int)C, knee, gate, gain, denv, gparams);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                         const float* log_threshold, const float* log_ratio, const float* log_knee,
+                         const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                         float* gx, float* gparams, float* denv, float* u1, float* gain_ws, void* stream) {
+    if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !denv || !u1 || !gain_ws)
+        return GFX_EINVAL;
+    if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
+        return GFX_EINVAL;
+    if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0) return GFX_EINVAL;
+    DynArgs a;
+    a.xmap = xmap; a.ymap = gmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
+    a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dyn_bwd_a_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
+                       log_knee, z_alpha, gain_ws, denv, u1, gparams, a);
+    hipLaunchKernelGGL(dyn_bwd_b_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, z_alpha, gain_ws, denv, gx, a);
     return GFX_LAUNCH_OK();
 }
 
