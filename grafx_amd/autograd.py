@@ -204,8 +204,7 @@ def pole_gradient(g, U1, z_alpha, N):
     aN = torch.pow(a.double(), N).float()
     aN1 = torch.pow(a.double(), N - 1).float()
     inv, zero = 1 / one_m_a, torch.zeros_like(a)
-    da = ops.onepole_dz(g, U1, U1, torch.cat([-inv, zero, (aN - one_m_a * N * aN1) * inv, zero], 1), N)
-    da = da + ops.onepole_dz(F.pad(g, (0, 1))[:, 1:], S2, S2, torch.cat([inv, zero, -aN * inv, zero], 1), N)
+    da = ops.onepole_dz(g, U1, S2, torch.cat([-inv, inv, (aN - one_m_a * N * aN1) * inv, -aN * inv], 1), N)
     return (da.reshape(R, 1) * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
 
 

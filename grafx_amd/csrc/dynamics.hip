@@ -803,22 +803,27 @@ __global__ __launch_bounds__(256) void dyn_gain_bwd_kernel(const float* __restri
     }
 }
 
-// da[r] = sum_n g[n] * (c0 U[n] + c1 D[n] + c2 U[n-N] + c3 D[n-N]),  U/D zero before the row start:
-// the pole gradient of the truncated one-pole smoother from its two scans (see autograd.one_pole_backward).
+// da[r] = sum_n g[n] (c0 U[n] + c2 U[n-N]) + g[n+1] (c1 S[n] + c3 S[n-N]),  U/S zero before the row start, g[L] = 0:
+// the pole gradient of the truncated one-pole smoother from its two scans (see autograd.pole_gradient; the
+// one-sample shift pairs g[n+1] with S[n] = D[n+1]).
 __global__ __launch_bounds__(256) void onepole_dz_kernel(const float* __restrict__ g, const float* __restrict__ U,
-                                                         const float* __restrict__ D, const float* __restrict__ coef,
+                                                         const float* __restrict__ S, const float* __restrict__ coef,
                                                          float* __restrict__ da, int64_t L, int64_t N) {
     __shared__ float part[4];
     const int64_t r = blockIdx.x;
     const float c0 = coef[4 * r], c1 = coef[4 * r + 1], c2 = coef[4 * r + 2], c3 = coef[4 * r + 3];
     const float* gr = g + r * L;
     const float* Ur = U + r * L;
-    const float* Dr = D + r * L;
+    const float* Sr = S + r * L;
     float s = 0.0f;
     for (int64_t n = threadIdx.x; n < L; n += 256) {
-        float v = c0 * Ur[n] + c1 * Dr[n];
-        if (n >= N) v += c2 * Ur[n - N] + c3 * Dr[n - N];
-        s = fmaf(gr[n], v, s);
+        float u = c0 * Ur[n], d = c1 * Sr[n];
+        if (n >= N) {
+            u += c2 * Ur[n - N];
+            d += c3 * Sr[n - N];
+        }
+        s = fmaf(gr[n], u, s);
+        if (n + 1 < L) s = fmaf(gr[n + 1], d, s);
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;

@@ -225,7 +225,7 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
 
 
 def onepole_dz(g, U, D, coef, N):
-    """Row sums sum_n g (c0 U[n] + c1 D[n] + c2 U[n-N] + c3 D[n-N]); coef (R,4)."""
+    """Row sums sum_n g[n] (c0 U[n] + c2 U[n-N]) + g[n+1] (c1 D[n] + c3 D[n-N]); coef (R,4)."""
     _require_gpu(g, U, D, coef)
     R, L = g.shape
     da = torch.empty(R, dtype=torch.float32, device=g.device)

@@ -174,8 +174,8 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                          float* gx, float* gparams, float* denv, float* u1, float* gain_ws, void* stream);
-/* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from its two untruncated scans U (of the
- * input) and D = dU/da:  da[r] = sum_n g[r,n] (c0 U[n] + c1 D[n] + c2 U[n-N] + c3 D[n-N]),  coef = (R, 4). */
+/* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
+ * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,
                        int64_t L, int64_t N, void* stream);
 int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float* y, gfx_rowmap_t ymap,
