@@ -39,20 +39,30 @@ class LinearConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, Lout, off):
-        x, h = x.contiguous(), h.contiguous()
+        # x: (R,C,L), or a strided (B,n,C,L) view of the signal buffer, read in place through its row map; the
+        # output then comes back as (B,n,C,Lout) so that a strided 4-D gradient can be fed in without a copy
+        four = x.ndim == 4
+        if x.stride(-1) != 1 or not (four or x.is_contiguous()):
+            x = x.contiguous()
+        h = h.contiguous()
         Rh, Cf, N = h.shape
-        if x.shape[0] % Rh != 0:
-            raise ValueError(f"{x.shape[0]} signal rows cannot share {Rh} filters")
+        rows = x.shape[0] * x.shape[1] if four else x.shape[0]
+        if rows % Rh != 0:
+            raise ValueError(f"{rows} signal rows cannot share {Rh} filters")
         ctx.save_for_backward(x, h)
         ctx.off = off
-        return ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
+        y = ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
+        return y.view(x.shape[0], x.shape[1], y.shape[1], Lout) if four else y
 
     @staticmethod
     def backward(ctx, g):
         x, h = ctx.saved_tensors
         off = ctx.off
-        g = g.contiguous()
-        R, Cin, L = x.shape
+        four = x.ndim == 4
+        if g.stride(-1) != 1 or not (g.ndim == 4 or g.is_contiguous()):
+            g = g.contiguous()
+        Cin, L = x.shape[-2], x.shape[-1]
+        R = x.shape[0] * x.shape[1] if four else x.shape[0]
         Rh, Cf, N = h.shape
         gx = gh = None
         if ctx.needs_input_grad[0]:
@@ -60,6 +70,7 @@ class LinearConvFn(torch.autograd.Function):
             gx = ops.fftconv(g, ops.fir_spectrum(hr.reshape(Rh * Cf, N)), N, Cf, Lout=L, off=N - 1 - off, h_rows=Rh)
             if gx.shape[1] != Cin:  # x was broadcast over the output channels
                 gx = gx.sum(1, keepdim=True)
+            gx = gx.view(x.shape)
         if ctx.needs_input_grad[1]:
             xr = x.flip(-1).contiguous()
             gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L)), L, Cin, Lout=N, off=L - 1 - off)
@@ -219,26 +230,30 @@ class DynamicsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate):
-        x = x.contiguous()
+        four = x.ndim == 4  # a strided (B,n,C,L) view of the signal buffer is read in place
+        if x.stride(-1) != 1 or not (four or x.is_contiguous()):
+            x = x.contiguous()
         y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
                                smoother=int(smoother), iir_len=iir_len, knee=knee, gate=gate)
         ctx.save_for_backward(x, log_threshold, log_ratio, log_knee, z_alpha)
         ctx.cfg = (smoother, iir_len, knee, gate)
-        return y
+        return y.view(x.shape) if four else y
 
     @staticmethod
     def backward(ctx, gy):
         x, log_threshold, log_ratio, log_knee, z_alpha = ctx.saved_tensors
         smoother, iir_len, knee, gate = ctx.cfg
-        gy = gy.contiguous()
+        if gy.stride(-1) != 1 or not (gy.ndim == 4 or gy.is_contiguous()):
+            gy = gy.contiguous()
         lk = log_knee if knee != "hard" else None
         if smoother:  # two fused passes over the rows (forward, then backward in time) + the pole-gradient reduction
             gx, gp, denv, u1 = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate)
             gz = pole_gradient(denv, u1, z_alpha, iir_len) if ctx.needs_input_grad[4] else None
+            gx = gx.view(x.shape)
         else:
             e = ops.energy(x)
             gain, denv, gp = ops.dyn_gain_bwd(x, gy, e, log_threshold, log_ratio, lk, knee, gate)
-            gx = ops.dyn_dx(x, gy, gain, denv) if ctx.needs_input_grad[0] else None
+            gx = ops.dyn_dx(x, gy, gain, denv).view(x.shape) if ctx.needs_input_grad[0] else None
             gz = None
         like = lambda t, col: None if t is None else gp[:, col].reshape(t.shape)  # noqa: E731
         return (gx, like(log_threshold, 0), like(log_ratio, 1), like(log_knee if knee != "hard" else None, 2), gz,

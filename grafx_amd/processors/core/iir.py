@@ -85,8 +85,8 @@ class IIRFilter(nn.Module):
             tee.copy_(input_signal)
             tee = None
         if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
-            x = input_signal.reshape(-1, *input_signal.shape[-2:])
-            y = diff.convolve(x, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal", exact=self.flashfftconv)
+            # a strided (B,n,C,L) view goes through as it is (the native convolution reads it in place)
+            y = diff.convolve(input_signal, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal", exact=self.flashfftconv)
             if out is None:
                 return y
             out.copy_(y.view(out.shape))

@@ -38,6 +38,7 @@ class _Dynamics(BufferIO, nn.Module):
         self.gain_smooth_in_log = gain_smooth_in_log
 
     accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
+    accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
 
     def render_into(self, x4, out4, _shared_rows=None, **params):
         return self.forward(x4, _out=out4, _shared_rows=_shared_rows, **params)
@@ -54,8 +55,7 @@ class _Dynamics(BufferIO, nn.Module):
                 expand_shared(t, reps) for t in (log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post))
             _shared_rows = None
         if needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
-            y = self._forward_differentiable(input_signals.reshape(-1, *input_signals.shape[-2:]), log_threshold,
-                                             log_ratio, log_knee, z_alpha_pre, z_alpha_post)
+            y = self._forward_differentiable(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post)
             if _out is None:
                 return y
             _out.copy_(y.view(_out.shape))
@@ -94,6 +94,7 @@ class _Dynamics(BufferIO, nn.Module):
                 self.energy_smoother == "iir" and not reference_aliases(x.shape[-1], self.iir_len, self.flashfftconv))):
             return diff.DynamicsFn.apply(x, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                          self.energy_smoother == "iir", self.iir_len, self.knee, self._gate)
+        x = x.reshape(-1, *x.shape[-2:])
         energy = x.square().mean(-2)
         if self.energy_smoother is not None:
             energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)

@@ -24,6 +24,7 @@ class ParametricEqualizer(BufferIO, nn.Module):
 
     accepts_tee = True  # render_into(..., tee=view) also leaves a copy of the input in `view`
     accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
+    accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
 
     def forward(self, input_signals, w0, q_inv, log_gain, _out=None, _tee=None, _shared_rows=None):
         if needs_grad(input_signals, w0, q_inv, log_gain):

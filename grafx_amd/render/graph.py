@@ -377,7 +377,9 @@ class _BufferRenderFn(torch.autograd.Function):
                 else:
                     x_in = _gather(ops, buf, plan, torch.empty(B, plan[2], C, L, device=dev))
                 with torch.enable_grad():
-                    x_in = x_in.reshape(-1, C, L).detach().requires_grad_(True)
+                    if not getattr(processors[node_type], "accepts_strided_rows", False):
+                        x_in = x_in.reshape(-1, C, L)  # the (R, C, L) rows of the upstream contract (a copy)
+                    x_in = x_in.detach().requires_grad_(True)  # else: (B, n, C, L) view of the buffer, no copy
                     local = [t.detach().requires_grad_(t.requires_grad) for t in leaves]
                     params = _unflatten_tree(p_spec, local)[node_type]
                     common = None if c_spec is None else _unflatten_tree(c_spec, local)
@@ -399,8 +401,9 @@ class _BufferRenderFn(torch.autograd.Function):
                     y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
                     wrt = [x_in] + [local[j] for j in live]
-                    grads = torch.autograd.grad(y, wrt, grad_outputs=g_out.reshape(y.shape), allow_unused=True)
-                g_in = grads[0].view(B, -1, C, L)
+                    grads = torch.autograd.grad(y, wrt, grad_outputs=g_out if y.shape == g_out.shape
+                                                else g_out.reshape(y.shape), allow_unused=True)
+                g_in = grads[0].reshape(B, -1, C, L)
                 for j, g in zip(live, grads[1:]):
                     if g is not None:
                         leaf_grads[j] = g if leaf_grads[j] is None else leaf_grads[j] + g
