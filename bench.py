@@ -130,7 +130,7 @@ def main():
                          "the FlashFFTConv flavour, i.e. plain causal convolutions; not the headline configuration")
     ap.add_argument("--train", action="store_true",
                     help="also time forward+backward+gradient all-reduce (BASELINE configs[4]) at --train-batch per GPU")
-    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-batch", type=int, default=256, help="graphs per GPU in the training step (configs[4]: 256)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
