@@ -26,6 +26,23 @@ import torch.nn.functional as F
 from . import ops
 
 
+# Set by the stage-wise backward of render_grafx while it re-traces a stage only to obtain its tape: the stage's
+# output VALUES are then never read (only its gradient function runs), so autograd nodes whose output is the
+# processor's output up to linear operations may skip their forward kernels and hand back uninitialised storage.
+TAPE_ONLY = False
+
+
+class tape_only:
+    def __enter__(self):
+        global TAPE_ONLY
+        self.prev, TAPE_ONLY = TAPE_ONLY, True
+
+    def __exit__(self, *exc):
+        global TAPE_ONLY
+        TAPE_ONLY = self.prev
+        return False
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
@@ -38,7 +55,7 @@ class LinearConvFn(torch.autograd.Function):
     the batch."""
 
     @staticmethod
-    def forward(ctx, x, h, Lout, off):
+    def forward(ctx, x, h, Lout, off, final=False):
         # x: (R,C,L), or a strided (B,n,C,L) view of the signal buffer, read in place through its row map; the
         # output then comes back as (B,n,C,Lout) so that a strided 4-D gradient can be fed in without a copy
         four = x.ndim == 4
@@ -51,7 +68,10 @@ class LinearConvFn(torch.autograd.Function):
             raise ValueError(f"{rows} signal rows cannot share {Rh} filters")
         ctx.save_for_backward(x, h)
         ctx.off = off
-        y = ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
+        if final and TAPE_ONLY:  # see TAPE_ONLY: nobody will read these values
+            y = torch.empty((rows, max(x.shape[-2], Cf), Lout), dtype=torch.float32, device=x.device)
+        else:
+            y = ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
         return y.view(x.shape[0], x.shape[1], y.shape[1], Lout) if four else y
 
     @staticmethod
@@ -78,12 +98,13 @@ class LinearConvFn(torch.autograd.Function):
                 gh = gh.sum(1, keepdim=True)
             if Rh != R:  # one filter shared by the batch
                 gh = gh.view(R // Rh, Rh, Cf, N).sum(0)
-        return gx, gh, None, None
+        return gx, gh, None, None, None
 
 
-def convolve(x, h, mode="causal", exact=False):
+def convolve(x, h, mode="causal", exact=False, final=False):
     """Differentiable twin of processors.core.convolution.convolve (reference core/convolution.py:119-134),
-    including the odd-P aliasing (which is plain torch.fft and differentiates itself)."""
+    including the odd-P aliasing (which is plain torch.fft and differentiates itself).  ``final``: the result is
+    the calling processor's output up to linear operations (see TAPE_ONLY)."""
     from .processors.core.convolution import reference_aliases
 
     flat = x.ndim == 2
@@ -92,13 +113,13 @@ def convolve(x, h, mode="causal", exact=False):
     L, N = x.shape[-1], h.shape[-1]
     if not reference_aliases(L, N, exact):
         if mode == "causal":
-            y = LinearConvFn.apply(x, h, L, 0)
+            y = LinearConvFn.apply(x, h, L, 0, final)
         elif mode == "zerophase":
-            y = LinearConvFn.apply(x, h, L, N // 2)
+            y = LinearConvFn.apply(x, h, L, N // 2, final)
         else:
-            y = LinearConvFn.apply(x, h, L + N - 1, 0)
+            y = LinearConvFn.apply(x, h, L + N - 1, 0, final)
     else:
-        z = LinearConvFn.apply(x, h, L + N - 1, 0)
+        z = LinearConvFn.apply(x, h, L + N - 1, 0, final)
         y_pad = torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)  # float64 aliasing, see odd_length_alias
         if mode == "causal":
             y = y_pad[..., :L]
@@ -233,8 +254,12 @@ class DynamicsFn(torch.autograd.Function):
         four = x.ndim == 4  # a strided (B,n,C,L) view of the signal buffer is read in place
         if x.stride(-1) != 1 or not (four or x.is_contiguous()):
             x = x.contiguous()
-        y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
-                               smoother=int(smoother), iir_len=iir_len, knee=knee, gate=gate)
+        if TAPE_ONLY:  # the output of this node is the processor's output: its values are not read (see TAPE_ONLY)
+            rows = x.shape[0] * x.shape[1] if four else x.shape[0]
+            y = torch.empty((rows, x.shape[-2], x.shape[-1]), dtype=torch.float32, device=x.device)
+        else:
+            y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
+                                   smoother=int(smoother), iir_len=iir_len, knee=knee, gate=gate)
         ctx.save_for_backward(x, log_threshold, log_ratio, log_knee, z_alpha)
         ctx.cfg = (smoother, iir_len, knee, gate)
         return y.view(x.shape) if four else y

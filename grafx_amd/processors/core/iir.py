@@ -71,8 +71,9 @@ class IIRFilter(nn.Module):
         # "ssm" with K > 1: upstream drives every section's recursion with the original input (iir.py:226-246)
         return ops.biquad_cascade(input_signal, Bs, As, ssm_quirk=self.backend == "ssm", out=out)
 
-    def forward(self, input_signal, Bs, As, out=None, tee=None, shared_rows=None):
-        """``shared_rows``: Bs/As hold that many rows, shared by the batch (signal row r uses r % shared_rows)."""
+    def forward(self, input_signal, Bs, As, out=None, tee=None, shared_rows=None, final=False):
+        """``shared_rows``: Bs/As hold that many rows, shared by the batch (signal row r uses r % shared_rows).
+        ``final``: the caller returns this output as its own up to linear operations (autograd.TAPE_ONLY)."""
         if shared_rows is not None and self.backend != "fsm":
             rows = input_signal.shape[0] * input_signal.shape[1] if input_signal.ndim == 4 else input_signal.shape[0]
             Bs, As = Bs.repeat(rows // shared_rows, 1, 1, 1), As.repeat(rows // shared_rows, 1, 1, 1)  # no row sharing
@@ -86,7 +87,8 @@ class IIRFilter(nn.Module):
             tee = None
         if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
             # a strided (B,n,C,L) view goes through as it is (the native convolution reads it in place)
-            y = diff.convolve(input_signal, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal", exact=self.flashfftconv)
+            y = diff.convolve(input_signal, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal", exact=self.flashfftconv,
+                              final=final)
             if out is None:
                 return y
             out.copy_(y.view(out.shape))

@@ -32,8 +32,8 @@ class ParametricEqualizer(BufferIO, nn.Module):
         else:
             Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":
-            return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As, shared_rows=_shared_rows))
-        return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows)
+            return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As, shared_rows=_shared_rows, final=True))
+        return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows, final=True)
 
     def render_into(self, x4, out4, tee=None, _shared_rows=None, **params):
         if self.processor_channel == "midside":

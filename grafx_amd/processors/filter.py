@@ -74,7 +74,7 @@ class BiquadFilter(BufferIO, nn.Module):
     def forward(self, input_signals, Bs, A1_pre, A2_pre, A0=None, _out=None):
         A0 = A0 if self.normalized else None
         if needs_grad(input_signals, Bs, A1_pre, A2_pre, A0):
-            return self.biquad(input_signals, *diff.biquad_coefficients(Bs, A1_pre, A2_pre, A0), out=_out)
+            return self.biquad(input_signals, *diff.biquad_coefficients(Bs, A1_pre, A2_pre, A0), out=_out, final=True)
         Bs, As = ops.biquad_coeffs(Bs, A1_pre, A2_pre, A0)
         return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1), out=_out)
 

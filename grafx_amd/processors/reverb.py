@@ -102,11 +102,12 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
             x = input_signals.reshape(-1, *input_signals.shape[-2:])
             ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
             if pseudo:
-                y = diff.convolve(x, normalize_impulse(ms_to_lr(ir)), "causal", exact=self.flashfftconv)
+                y = diff.convolve(x, normalize_impulse(ms_to_lr(ir)), "causal", exact=self.flashfftconv, final=True)
             elif self.processor_channel == "midside":
-                y = ms_to_lr(diff.convolve(lr_to_ms(x), normalize_impulse(ir), "causal", exact=self.flashfftconv))
+                y = ms_to_lr(diff.convolve(lr_to_ms(x), normalize_impulse(ir), "causal", exact=self.flashfftconv,
+                                           final=True))
             else:
-                y = diff.convolve(x, normalize_impulse(ir), "causal", exact=self.flashfftconv)
+                y = diff.convolve(x, normalize_impulse(ir), "causal", exact=self.flashfftconv, final=True)
             if _out is None:
                 return y
             _out.copy_(y.view(_out.shape))

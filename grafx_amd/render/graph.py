@@ -318,6 +318,7 @@ class _BufferRenderFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out_rows, g_buf):
+        from .. import autograd as diff
         from .. import ops
 
         processors, render_data, p_spec, c_spec = ctx.meta
@@ -398,7 +399,8 @@ class _BufferRenderFn(torch.autograd.Function):
                                                             postprocess=postprocess)
                     common_i = {} if common is None else read_tensor_or_tensor_dict(
                         common, step.dest_write, dim=node_dim, postprocess=postprocess)
-                    y = processors[node_type](x_in, **extra, **params, **common_i)
+                    with diff.tape_only():  # only the stage's tape is wanted here, not its output values
+                        y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
                     wrt = [x_in] + [local[j] for j in live]
                     grads = torch.autograd.grad(y, wrt, grad_outputs=g_out if y.shape == g_out.shape
