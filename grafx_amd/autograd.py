@@ -43,6 +43,18 @@ class tape_only:
         return False
 
 
+# Gradient sink (set by the same stage-wise backward): (data_ptr of the stage's input view, destination view).  An
+# autograd node whose input IS that view writes its input gradient straight into the destination -- a slice of the
+# render's gradient buffer -- instead of a fresh tensor that would then be copied there.
+GRAD_SINK = None
+
+
+def _sink_for(x):
+    if GRAD_SINK is not None and x.data_ptr() == GRAD_SINK[0] and tuple(x.shape) == tuple(GRAD_SINK[1].shape):
+        return GRAD_SINK[1]
+    return None
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
@@ -87,10 +99,13 @@ class LinearConvFn(torch.autograd.Function):
         gx = gh = None
         if ctx.needs_input_grad[0]:
             hr = h.flip(-1).contiguous()
-            gx = ops.fftconv(g, ops.fir_spectrum(hr.reshape(Rh * Cf, N)), N, Cf, Lout=L, off=N - 1 - off, h_rows=Rh)
-            if gx.shape[1] != Cin:  # x was broadcast over the output channels
-                gx = gx.sum(1, keepdim=True)
-            gx = gx.view(x.shape)
+            sink = _sink_for(x) if max(Cin, Cf) == Cin else None
+            gx = ops.fftconv(g, ops.fir_spectrum(hr.reshape(Rh * Cf, N)), N, Cf, Lout=L, off=N - 1 - off, h_rows=Rh,
+                             out=sink)
+            if sink is None:
+                if gx.shape[1] != Cin:  # x was broadcast over the output channels
+                    gx = gx.sum(1, keepdim=True)
+                gx = gx.view(x.shape)
         if ctx.needs_input_grad[1]:
             xr = x.flip(-1).contiguous()
             gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L)), L, Cin, Lout=N, off=L - 1 - off)
@@ -272,7 +287,9 @@ class DynamicsFn(torch.autograd.Function):
             gy = gy.contiguous()
         lk = log_knee if knee != "hard" else None
         if smoother:  # two fused passes over the rows (forward, then backward in time) + the pole-gradient reduction
-            gx, gp, denv, u1 = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate)
+            sink = _sink_for(x)
+            gx, gp, denv, u1 = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate,
+                                                out=sink)
             gz = pole_gradient(denv, u1, z_alpha, iir_len) if ctx.needs_input_grad[4] else None
             gx = gx.view(x.shape)
         else:

@@ -699,6 +699,7 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
     const int lane = t & 63, wave = t >> 6;
     const bool al = (a.L % 4) == 0;  // reversed float4 groups stay 16-byte aligned only then
     const bool vx = al && vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = al;
+    const bool vgx = al && vec_ok(o0) && vec_ok(o1);
     const float k2 = 2.0f / (float)a.C;
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
@@ -720,14 +721,14 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
         rload4(g0, j, a.L, vx, ga);
 #pragma unroll
         for (int i = 0; i < DE; ++i) oa[i] = fmaf(gn[i], ga[i], k2 * p.one_m_a * u[i] * xa[i]);
-        rstore4(o0, j, a.L, vo, oa);
+        rstore4(o0, j, a.L, vgx, oa);
         if (a.C == 2) {
             float xb[DE], gb[DE], ob[DE];
             rload4(x1, j, a.L, vx, xb);
             rload4(g1, j, a.L, vx, gb);
 #pragma unroll
             for (int i = 0; i < DE; ++i) ob[i] = fmaf(gn[i], gb[i], k2 * p.one_m_a * u[i] * xb[i]);
-            rstore4(o1, j, a.L, vo, ob);
+            rstore4(o1, j, a.L, vgx, ob);
         }
     }
 }
@@ -745,8 +746,8 @@ __global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__
     const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
     const float* g0 = gy + drow_off(gmap, r, 0);
     const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
-    float* o0 = gx + (r * a.C) * a.L;
-    float* o1 = gx + (r * a.C + (a.C == 2 ? 1 : 0)) * a.L;
+    float* o0 = gx + drow_off(a.ymap, r, 0);
+    float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
     if (p.trunc)
         dyn_bwd_b_stream<true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, o0, o1, slots, t);
     else
@@ -966,14 +967,15 @@ int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
 int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
-                         float* gx, float* gparams, float* denv, float* u1, float* gain_ws, void* stream) {
+                         float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* gain_ws,
+                         void* stream) {
     if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !denv || !u1 || !gain_ws)
         return GFX_EINVAL;
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
         return GFX_EINVAL;
-    if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0) return GFX_EINVAL;
+    if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0 || gxmap.inner <= 0) return GFX_EINVAL;
     DynArgs a;
-    a.xmap = xmap; a.ymap = gmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
+    a.xmap = xmap; a.ymap = gxmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dyn_bwd_a_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,

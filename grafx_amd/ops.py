@@ -209,18 +209,19 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
     return gain, denv, gp
 
 
-def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate):
-    """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), denv (R,L), u1 (R,L))."""
-    _require_gpu(x, gy)
+def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None):
+    """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), denv (R,L), u1 (R,L)).
+    ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view)."""
+    _require_gpu(x, gy, out)
     xmap, R, C, L = rowmap(x)
     gmap = rowmap(gy)[0]
-    gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device) if out is None else out
     gp = torch.empty((R, 3), dtype=torch.float32, device=x.device)
     denv, u1, ws = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(3))
     check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(_rowvec(log_threshold, R)),
                                      _ptr(_rowvec(log_ratio, R)), _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)),
-                                     R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), _ptr(gp), _ptr(denv), _ptr(u1),
-                                     _ptr(ws), _stream()), "gfx_dynamics_bwd_f32")
+                                     R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), _ptr(denv),
+                                     _ptr(u1), _ptr(ws), _stream()), "gfx_dynamics_bwd_f32")
     return gx, gp, denv, u1
 
 

@@ -342,7 +342,12 @@ class _BufferRenderFn(torch.autograd.Function):
                 while j < b and written[j] == written[i]:
                     j += 1
                 dst, src = gbuf.narrow(1, i, j - i), g.narrow(1, i - a, j - i)
-                dst.add_(src) if written[i] else dst.copy_(src)
+                if src.data_ptr() == dst.data_ptr():
+                    pass  # the stage wrote its input gradient straight into these rows (autograd.GRAD_SINK)
+                elif written[i]:
+                    dst.add_(src)
+                else:
+                    dst.copy_(src)
                 written[i:j] = [True] * (j - i)
                 i = j
 
@@ -403,8 +408,14 @@ class _BufferRenderFn(torch.autograd.Function):
                         y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
                     wrt = [x_in] + [local[j] for j in live]
-                    grads = torch.autograd.grad(y, wrt, grad_outputs=g_out if y.shape == g_out.shape
-                                                else g_out.reshape(y.shape), allow_unused=True)
+                    if plan is None and x_in.ndim == 4 and not any(written[a:b]):
+                        # first (usually only) contribution to these rows: let the stage write it in place
+                        diff.GRAD_SINK = (x_in.data_ptr(), gbuf.narrow(1, a, b - a))
+                    try:
+                        grads = torch.autograd.grad(y, wrt, grad_outputs=g_out if y.shape == g_out.shape
+                                                    else g_out.reshape(y.shape), allow_unused=True)
+                    finally:
+                        diff.GRAD_SINK = None
                 g_in = grads[0].reshape(B, -1, C, L)
                 for j, g in zip(live, grads[1:]):
                     if g is not None:

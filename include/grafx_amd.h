@@ -168,12 +168,14 @@ int gfx_dyn_dx_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowma
 /* The whole backward of Compressor / NoiseGate with the one-pole energy smoother and no gain smoother, in two
  * passes over the row (forward in time: recompute energy -> smoother -> gain, emit gain, the relu-masked d/d(smoothed
  * energy), the un-truncated scan u1 and the per-row parameter gradients; backward in time: the smoother's adjoint scan
- * and gx = gain * gy + (2/C) * de * x).  gx (R,C,L) contiguous; gparams (R,3); denv, u1, gain_ws (R,L) each (denv and
- * u1 feed gfx_onepole_dz_f32 for the pole gradient, gain_ws is workspace). */
+ * and gx = gain * gy + (2/C) * de * x).  gx rows addressed by gxmap (e.g. a slice of the render's gradient buffer);
+ * gparams (R,3); denv, u1, gain_ws (R,L) each (denv and u1 feed gfx_onepole_dz_f32 for the pole gradient, gain_ws is
+ * workspace). */
 int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
-                         float* gx, float* gparams, float* denv, float* u1, float* gain_ws, void* stream);
+                         float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* gain_ws,
+                         void* stream);
 /* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
  * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,
