@@ -108,7 +108,9 @@ class LinearConvFn(torch.autograd.Function):
                 gx = gx.view(x.shape)
         if ctx.needs_input_grad[1]:
             xr = x.flip(-1).contiguous()
-            gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L)), L, Cin, Lout=N, off=L - 1 - off)
+            P = ops.part_len_for(L, N)  # long signal as the filter, N outputs: fewer, longer partitions
+            gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L), part_len=P), L, Cin, Lout=N, off=L - 1 - off,
+                             part_len=P)
             if gh.shape[1] != Cf:  # one filter shared by both channels
                 gh = gh.sum(1, keepdim=True)
             if Rh != R:  # one filter shared by the batch

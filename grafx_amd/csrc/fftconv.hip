@@ -22,29 +22,43 @@
 namespace gfx {
 
 struct ConvGeom {
-    int64_t nparts, part_len, O, V, ntiles;
+    int64_t nparts, part_len, O, V, ntiles, hop;
+    bool ok;
 };
 
-static inline ConvGeom conv_geom(int64_t N, int64_t Lout) {
+// part_len = 0: the default geometry (one tile-sized filter up to 8193 taps, else 8192-tap partitions with windows
+// hopping by 8192).  A longer partition (8192 < part_len <= 16384 - Lout, even) is legal when one output tile covers
+// all Lout samples: the windows of the partitions then hop by part_len while the tile keeps 16384 - part_len valid
+// samples -- fewer partitions and windows for "long filter, short output" problems (the filter gradient).
+static inline ConvGeom conv_geom(int64_t N, int64_t Lout, int64_t part_len = 0) {
     ConvGeom g;
+    g.ok = true;
     if (N <= TILE_M + 1) {
         g.nparts = 1;
         g.part_len = N;
         g.O = (N - 1 + 1) & ~int64_t(1);  // overlap >= N-1, even so tiles stay 8-byte aligned
-    } else {
+        g.ok = part_len == 0;
+    } else if (part_len == 0 || part_len == TILE_M) {
         g.part_len = TILE_M;
         g.nparts = (N + TILE_M - 1) / TILE_M;
         g.O = TILE_M;
+    } else {
+        g.ok = part_len > TILE_M && (part_len & 1) == 0 && part_len + Lout <= TILE_F;
+        g.part_len = part_len;
+        g.nparts = (N + part_len - 1) / part_len;
+        g.O = part_len;
     }
     g.V = TILE_F - g.O;
+    g.hop = g.nparts == 1 ? g.V : g.part_len;
     g.ntiles = (Lout + g.V - 1) / g.V;
+    if (g.hop != g.V && g.ntiles != 1) g.ok = false;
     return g;
 }
 
 struct ConvArgs {
     gfx_rowmap_t xmap, ymap, cmap;  // cmap: rows of the optional input copy (fftconv1 only)
     int64_t L, Lout, off;    // signal length, outputs per row, output offset into the full convolution
-    int64_t O, V;            // overlap and valid samples per tile
+    int64_t O, V, hop;       // overlap and valid samples per tile; start-to-start distance of the partition windows
     int64_t ntiles, nblocks; // tiles per row-channel, total workgroups of real work
     int nparts;
     int Cin, Cf, Cout;
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
     if (lb >= (unsigned)a.nblocks) return;
     const unsigned rcx = lb / (unsigned)nwin;
     const int64_t jj = lb - rcx * (unsigned)nwin;
-    const int64_t s = a.off - a.O + (jj - (a.nparts - 1)) * a.V;
+    const int64_t s = a.off - a.O + (jj - (a.nparts - 1)) * a.hop;
     if (!window_live(s, a.L)) return;
     const unsigned xr = rcx / (unsigned)a.Cin;
     const float* xrow = x + row_off(a.xmap, xr, (int)(rcx - xr * (unsigned)a.Cin));
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
 
     for (int p = 0; p < a.nparts; ++p) {
         const int64_t j = tile - p;
-        if (!window_live(a.off - a.O + j * a.V, a.L)) continue;
+        if (!window_live(a.off - a.O + j * a.hop, a.L)) continue;
         const cx* Zj = Z + (j + a.nparts - 1) * TILE_M;
         const f4v* Hp = H + (int64_t)p * H_TILE_F4;
         cx w[2][16];
@@ -326,24 +340,43 @@ extern "C" {
 
 int64_t gfx_fftconv_nparts(int64_t N) { return N <= 0 ? 0 : conv_geom(N, 1).nparts; }
 
-size_t gfx_fir_spectrum_bytes(int64_t RCf, int64_t N) {
+int64_t gfx_fftconv_part_len(int64_t N, int64_t Lout) {
+    if (N <= TILE_M + 1 || Lout <= 0 || Lout > TILE_M - 2) return 0;  // default geometry
+    return (TILE_F - Lout) & ~int64_t(1);
+}
+
+size_t gfx_fir_spectrum_bytes(int64_t RCf, int64_t N) { return gfx_fir_spectrum_bytes_ex(RCf, N, 0); }
+
+size_t gfx_fir_spectrum_bytes_ex(int64_t RCf, int64_t N, int64_t part_len) {
     if (RCf <= 0 || N <= 0) return 0;
-    return (size_t)RCf * conv_geom(N, 1).nparts * H_TILE_F4 * sizeof(float4);
+    const ConvGeom g = conv_geom(N, 1, part_len);
+    return g.ok ? (size_t)RCf * g.nparts * H_TILE_F4 * sizeof(float4) : 0;
 }
 
 size_t gfx_fftconv_workspace_bytes(int64_t R, int64_t C_in, int64_t L, int64_t Lout, int64_t off, int64_t N) {
+    return gfx_fftconv_workspace_bytes_ex(R, C_in, L, Lout, off, N, 0);
+}
+
+size_t gfx_fftconv_workspace_bytes_ex(int64_t R, int64_t C_in, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                                      int64_t part_len) {
     (void)L;
     (void)off;
     if (R <= 0 || N <= 0 || Lout <= 0) return 0;
-    const ConvGeom g = conv_geom(N, Lout);
-    if (g.nparts == 1) return 0;
+    const ConvGeom g = conv_geom(N, Lout, part_len);
+    if (!g.ok || g.nparts == 1) return 0;
     return (size_t)R * C_in * (g.ntiles + g.nparts - 1) * TILE_M * sizeof(float2);
 }
 
 int gfx_fir_spectrum_f32(const float* h, const float* gain, int64_t gain_div, void* Hs, int64_t RCf, int64_t N,
                          void* stream) {
+    return gfx_fir_spectrum_ex_f32(h, gain, gain_div, Hs, RCf, N, 0, stream);
+}
+
+int gfx_fir_spectrum_ex_f32(const float* h, const float* gain, int64_t gain_div, void* Hs, int64_t RCf, int64_t N,
+                            int64_t part_len, void* stream) {
     if (!h || !Hs || RCf <= 0 || N <= 0 || (gain && gain_div <= 0)) return GFX_EINVAL;
-    const ConvGeom g = conv_geom(N, 1);
+    const ConvGeom g = conv_geom(N, 1, part_len);
+    if (!g.ok) return GFX_EINVAL;
     if (RCf * g.nparts > 0x7fffffffLL) return GFX_EINVAL;
     if (allow_lds(hspec_kernel)) return GFX_ELAUNCH;
     const float2* tw = tile_twiddle_table((hipStream_t)stream);
@@ -357,26 +390,29 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
                     int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws,
                     size_t ws_bytes, void* stream) {
     const gfx_rowmap_t none = {1, 0, 0, 0};
-    return gfx_fftconv_ex_f32(x, xmap, Hs, R, y, ymap, nullptr, none, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes, stream);
+    return gfx_fftconv_ex_f32(x, xmap, Hs, R, 0, y, ymap, nullptr, none, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes,
+                              stream);
 }
 
 int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap, float* xcopy,
                         gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off,
                         int64_t N, void* ws, size_t ws_bytes, void* stream) {
     if (!xcopy) return GFX_EINVAL;
-    return gfx_fftconv_ex_f32(x, xmap, Hs, R, y, ymap, xcopy, cmap, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes, stream);
+    return gfx_fftconv_ex_f32(x, xmap, Hs, R, 0, y, ymap, xcopy, cmap, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes,
+                              stream);
 }
 
-int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, float* y, gfx_rowmap_t ymap,
-                       float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout,
-                       int64_t off, int64_t N, void* ws, size_t ws_bytes, void* stream) {
+int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len, float* y,
+                       gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
+                       int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
     if (xcopy && (off != 0 || Lout != L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
         return GFX_EINVAL;
     if (C_in < 1 || C_f < 1 || (C_in != C_f && C_in != 1 && C_f != 1)) return GFX_EINVAL;
     if (xmap.inner <= 0 || ymap.inner <= 0 || xmap.inner > 0x7fffffffLL || ymap.inner > 0x7fffffffLL) return GFX_EINVAL;
-    const ConvGeom g = conv_geom(N, Lout);
+    const ConvGeom g = conv_geom(N, Lout, part_len);
+    if (!g.ok) return GFX_EINVAL;
     ConvArgs a;
     a.xmap = xmap;
     a.ymap = ymap;
@@ -387,6 +423,7 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
     a.off = off;
     a.O = g.O;
     a.V = g.V;
+    a.hop = g.hop;
     a.ntiles = g.ntiles;
     a.nparts = (int)g.nparts;
     a.Cin = (int)C_in;

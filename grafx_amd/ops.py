@@ -69,13 +69,19 @@ def rowmap(t):
 
 
 # ----------------------------------------------------------------------------------------- FIR conv
-def fir_spectrum(h, gain=None, gain_div=1):
-    """Taps (RCf, N) -> opaque tile-spectrum buffer for :func:`fftconv`."""
+def part_len_for(N, Lout):
+    """Partition length the library prefers for an N-tap filter producing Lout samples per row (0 = default)."""
+    return lib().gfx_fftconv_part_len(N, Lout)
+
+
+def fir_spectrum(h, gain=None, gain_div=1, part_len=0):
+    """Taps (RCf, N) -> opaque tile-spectrum buffer for :func:`fftconv` (same ``part_len`` there)."""
     _require_gpu(h, gain)
     h = h.contiguous()
     RCf, N = h.shape
-    Hs = torch.empty(lib().gfx_fir_spectrum_bytes(RCf, N), dtype=torch.uint8, device=h.device)
-    check(lib().gfx_fir_spectrum_f32(_ptr(h), _ptr(gain), gain_div, _ptr(Hs), RCf, N, _stream()), "gfx_fir_spectrum_f32")
+    Hs = torch.empty(lib().gfx_fir_spectrum_bytes_ex(RCf, N, part_len), dtype=torch.uint8, device=h.device)
+    check(lib().gfx_fir_spectrum_ex_f32(_ptr(h), _ptr(gain), gain_div, _ptr(Hs), RCf, N, part_len, _stream()),
+          "gfx_fir_spectrum_ex_f32")
     return Hs
 
 
@@ -84,7 +90,7 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
-def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None):
+def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, part_len=0):
     """y[r,c,n] = sum_k h[r % h_rows,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
 
     ``x`` / ``out`` may be (R,C,L) tensors or strided (B,n,C,L) views (see :func:`rowmap`).
@@ -102,9 +108,9 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None):
     ymap, Ry, Cy, Ly = rowmap(out)
     if (Ry, Cy) != (R, Cout) or Ly < Lout:
         raise ValueError(f"output shape {tuple(out.shape)} does not match rows={R}, channels={Cout}, length>={Lout}")
-    if Hs.numel() != lib().gfx_fir_spectrum_bytes(h_rows * Cf, N):
+    if Hs.numel() != lib().gfx_fir_spectrum_bytes_ex(h_rows * Cf, N, part_len):
         raise ValueError(f"filter spectra hold {Hs.numel()} bytes, expected {h_rows} x {Cf} filters of {N} taps")
-    nbytes = lib().gfx_fftconv_workspace_bytes(R, Cin, L, Lout, off, N)
+    nbytes = lib().gfx_fftconv_workspace_bytes_ex(R, Cin, L, Lout, off, N, part_len)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     name = "fftconv1_kernel" if nbytes == 0 else "xspec+macinv_kernels"
     cmap = RowMap(1, 0, 0, 0)
@@ -114,8 +120,8 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None):
             raise ValueError(f"tee shape {tuple(tee.shape)} does not match the input {tuple(x.shape)}")
     with _timed(name, 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)):
         check(
-            lib().gfx_fftconv_ex_f32(_ptr(x), xmap, _ptr(Hs), h_rows, _ptr(out), ymap, _ptr(tee), cmap, R, Cin, Cf, L, Lout,
-                                     off, N, _ptr(ws), nbytes, _stream()),
+            lib().gfx_fftconv_ex_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R, Cin, Cf,
+                                     L, Lout, off, N, _ptr(ws), nbytes, _stream()),
             "gfx_fftconv_ex_f32",
         )
     return out

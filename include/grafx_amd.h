@@ -86,9 +86,19 @@ int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float
 /* The general form of the two above.  `h_rows` <= R: row r convolves with filter (r % h_rows) -- rows are
  * batch-major (r = b * nodes + node), so h_rows = nodes shares one filter per node across the batch, which is
  * what render_grafx's 4-D path means by un-batched parameters (render/graph.py:68-75 expands them B times;
- * here the spectra are built once per node and every batch row reads them).  xcopy may be null (no tee). */
-int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, float* y, gfx_rowmap_t ymap,
-                       float* xcopy, gfx_rowmap_t cmap,
+ * here the spectra are built once per node and every batch row reads them).  xcopy may be null (no tee).
+ * `part_len`: 0 for the default filter partitioning, or the value of gfx_fftconv_part_len(N, Lout) -- longer
+ * partitions (fewer of them, fewer signal windows) for "long filter, short output" problems such as the filter
+ * gradient of a training step (N = signal length taps, Lout = filter taps); the spectra must then come from
+ * gfx_fir_spectrum_ex_f32 with the same part_len, sizes from the *_ex queries. */
+int64_t gfx_fftconv_part_len(int64_t N, int64_t Lout);
+size_t gfx_fir_spectrum_bytes_ex(int64_t RCf, int64_t N, int64_t part_len);
+size_t gfx_fftconv_workspace_bytes_ex(int64_t R, int64_t C_in, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                                      int64_t part_len);
+int gfx_fir_spectrum_ex_f32(const float* h, const float* gain, int64_t gain_div, void* Hs,
+                            int64_t RCf, int64_t N, int64_t part_len, void* stream);
+int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
+                       float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
                        int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                        void* ws, size_t ws_bytes, void* stream);
 

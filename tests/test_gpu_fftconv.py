@@ -106,3 +106,28 @@ def test_fftconv_tee_copies_the_input_and_leaves_the_output_unchanged(L, N, Cin,
     assert torch.equal(tee.reshape(6, Cin, L), x)
     assert torch.isnan(big[:, 0]).all() and torch.isnan(big[:, 4]).all()
     assert not ops.fftconv_can_tee(Cin, Cf, L, L, 1, N) and not ops.fftconv_can_tee(1, 2, L, L, 0, N)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nf,Lout", [(131072, 4001), (40000, 513), (20001, 8000)])
+def test_long_partitions_give_the_same_convolution(Nf, Lout):
+    """"Long filter, short output" (the filter gradient of a training step): gfx_fftconv_part_len picks partitions
+    longer than 8192 taps (fewer of them, one output tile); the result must equal the default partitioning."""
+    import torch
+
+    from grafx_amd import ops
+
+    torch.manual_seed(1)
+    R, L = 3, 30000
+    x = torch.randn(R, 2, L, device="cuda")
+    h = torch.randn(R, 2, Nf, device="cuda") / Nf**0.5
+    P = ops.part_len_for(Nf, Lout)
+    assert P > 8192 and P % 2 == 0 and P + Lout <= 16384
+    off = Nf - 1 - 17
+    y0 = ops.fftconv(x, ops.fir_spectrum(h.view(-1, Nf)), Nf, 2, Lout=Lout, off=off)
+    y1 = ops.fftconv(x, ops.fir_spectrum(h.view(-1, Nf), part_len=P), Nf, 2, Lout=Lout, off=off, part_len=P)
+    assert (y0 - y1).abs().max() <= 2e-6 * y0.abs().max()
+    assert ops.part_len_for(4001, 1000) == 0 and ops.part_len_for(60001, 131072) == 0   # default geometry cases
+    if -(-Nf // P) != -(-Nf // 8192):  # different partition counts: spectra built for one geometry are refused by the other
+        with pytest.raises(Exception):
+            ops.fftconv(x, ops.fir_spectrum(h.view(-1, Nf), part_len=P), Nf, 2, Lout=Lout, off=off)
