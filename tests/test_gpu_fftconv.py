@@ -131,3 +131,36 @@ def test_long_partitions_give_the_same_convolution(Nf, Lout):
     if -(-Nf // P) != -(-Nf // 8192):  # different partition counts: spectra built for one geometry are refused by the other
         with pytest.raises(Exception):
             ops.fftconv(x, ops.fir_spectrum(h.view(-1, Nf), part_len=P), Nf, 2, Lout=Lout, off=off)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometries_match_the_oracle_convolution(seed):
+    """Random signal / filter lengths (around the 8193-tap and 16384-sample tile boundaries too), output windows,
+    channel broadcasts, shared filters and strided buffer views against the oracle's linear convolution."""
+    import random
+
+    import torch
+
+    from grafx_amd import ops
+
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    L = rng.choice([1, 2, 3, 17, 1000, 4097, 12383, 12384, 12385, 16384, 16385, 40001, 70000])
+    N = rng.choice([1, 2, 3, 64, 4001, 8191, 8192, 8193, 8194, 16383, 20000, 33000])
+    Cin, Cf = rng.choice([(1, 1), (2, 1), (1, 2), (2, 2)])
+    B, n = rng.choice([(1, 1), (2, 3), (3, 2)])
+    shared = rng.random() < 0.5
+    full = L + N - 1
+    off = rng.choice([0, N // 2, N - 1, rng.randint(0, N - 1)])
+    Lout = rng.choice([L, full - off, max(1, min(L, 777))])
+    Lout = max(1, min(Lout, full - off))
+    buf = torch.randn(B, n + 2, Cin, L, device="cuda")
+    x4 = buf.narrow(1, 1, n)                                  # strided (B, n, C, L) view
+    h = torch.randn(n if shared else B * n, Cf, N, device="cuda") / max(N, 1) ** 0.5
+    y = ops.fftconv(x4, ops.fir_spectrum(h.reshape(-1, N)), N, Cf, Lout=Lout, off=off, h_rows=h.shape[0])
+    hx = (h.repeat(B, 1, 1) if shared else h).cpu()
+    ref = lti.linear_convolve(x4.reshape(B * n, Cin, L).cpu(), hx, "full")[..., off : off + Lout]
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    scale = ref.abs().max().clamp_min(1e-6)
+    assert (y.cpu() - ref).abs().max() <= 2e-5 * scale, f"L={L} N={N} C={Cin}/{Cf} off={off} Lout={Lout} shared={shared}"
