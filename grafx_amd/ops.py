@@ -51,6 +51,12 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _expect(t, shape, what):
+    """The kernels trust their sizes: every secondary tensor's shape is checked here, before its pointer is passed."""
+    if t is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
 def rowmap(t):
     """RowMap for a (R, C, L) tensor or a (B, n, C, L) view whose last dim is contiguous.
 
@@ -205,7 +211,10 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
     """-> (gain (R,L), denv (R,L), gparams (R,3) = d/d(log_threshold, log_ratio, log_knee)); see the header."""
     _require_gpu(x, gy, env)
     xmap, R, C, L = rowmap(x)
-    gmap = rowmap(gy)[0]
+    gmap, Rg, Cg, Lg = rowmap(gy)
+    if (Rg, Cg, Lg) != (R, C, L):
+        raise ValueError(f"dyn_gain_bwd: gradient {tuple(gy.shape)} does not match the input {tuple(x.shape)}")
+    _expect(env, (R, L), "dyn_gain_bwd: env")
     env = env.contiguous()
     gain, denv = torch.empty_like(env), torch.empty_like(env)
     gp = torch.zeros((R, 3), dtype=torch.float32, device=x.device)
@@ -220,7 +229,9 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
     ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view)."""
     _require_gpu(x, gy, out)
     xmap, R, C, L = rowmap(x)
-    gmap = rowmap(gy)[0]
+    gmap, Rg, Cg, Lg = rowmap(gy)
+    if (Rg, Cg, Lg) != (R, C, L) or (out is not None and rowmap(out)[1:] != (R, C, L)):
+        raise ValueError(f"dynamics_bwd: gradient / output shapes do not match the input {tuple(x.shape)}")
     gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device) if out is None else out
     gp = torch.empty((R, 3), dtype=torch.float32, device=x.device)
     denv, u1, ws = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(3))
@@ -235,6 +246,9 @@ def onepole_dz(g, U, D, coef, N):
     """Row sums sum_n g[n] (c0 U[n] + c2 U[n-N]) + g[n+1] (c1 D[n] + c3 D[n-N]); coef (R,4)."""
     _require_gpu(g, U, D, coef)
     R, L = g.shape
+    _expect(U, (R, L), "onepole_dz: U")
+    _expect(D, (R, L), "onepole_dz: D")
+    _expect(coef, (R, 4), "onepole_dz: coef")
     da = torch.empty(R, dtype=torch.float32, device=g.device)
     check(lib().gfx_onepole_dz_f32(_ptr(g.contiguous()), _ptr(U.contiguous()), _ptr(D.contiguous()),
                                    _ptr(coef.contiguous()), _ptr(da), R, L, N, _stream()), "gfx_onepole_dz_f32")
@@ -244,6 +258,10 @@ def onepole_dz(g, U, D, coef, N):
 def dyn_dx(x, gy, gain, de):
     _require_gpu(x, gy, gain, de)
     xmap, R, C, L = rowmap(x)
+    if rowmap(gy)[1:] != (R, C, L):
+        raise ValueError(f"dyn_dx: gradient {tuple(gy.shape)} does not match the input {tuple(x.shape)}")
+    _expect(gain, (R, L), "dyn_dx: gain")
+    _expect(de, (R, L), "dyn_dx: de")
     gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     check(lib().gfx_dyn_dx_f32(_ptr(x), xmap, _ptr(gy), rowmap(gy)[0], _ptr(gain.contiguous()), _ptr(de.contiguous()),
                                _ptr(gx), R, C, L, _stream()), "gfx_dyn_dx_f32")
@@ -292,6 +310,9 @@ def ballistics_bwd(x, y, g, z_alpha):
     _require_gpu(x, y, g, z_alpha)
     x, y, g, z_alpha = x.contiguous(), y.contiguous(), g.contiguous(), z_alpha.contiguous()
     R, L = x.shape
+    _expect(y, (R, L), "ballistics_bwd: y")
+    _expect(g, (R, L), "ballistics_bwd: g")
+    _expect(z_alpha, (R, 2), "ballistics_bwd: z_alpha")
     gx, gz = torch.empty_like(x), torch.empty((R, 2), dtype=torch.float32, device=x.device)
     check(lib().gfx_ballistics_bwd_f32(_ptr(x), _ptr(y), _ptr(g), _ptr(z_alpha), _ptr(gx), _ptr(gz), R, L, _stream()),
           "gfx_ballistics_bwd_f32")
@@ -314,9 +335,12 @@ def dyn_gain(env, log_threshold, log_ratio, log_knee, knee, gate, log_out):
 def apply_gain(x, g, exp_gain=False, out=None):
     _require_gpu(x, g, out)
     xmap, R, C, L = rowmap(x)
+    _expect(g, (R, L), "apply_gain: gain")
     g = g.contiguous()
     if out is None:
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    elif rowmap(out)[1:] != (R, C, L):
+        raise ValueError(f"apply_gain: output {tuple(out.shape)} does not match input rows/channels/length {(R, C, L)}")
     check(lib().gfx_apply_gain_f32(_ptr(x), xmap, _ptr(g), _ptr(out), rowmap(out)[0], R, C, L, int(exp_gain), _stream()), "gfx_apply_gain_f32")
     return out
 
@@ -324,8 +348,11 @@ def apply_gain(x, g, exp_gain=False, out=None):
 def stereo_gain(x, log_gain, out=None):
     _require_gpu(x, log_gain, out)
     xmap, R, C, L = rowmap(x)
+    _expect(log_gain, (R, 2), "stereo_gain: log_gain")
     if out is None:
         out = torch.empty((R, 2, L), dtype=torch.float32, device=x.device)
+    elif rowmap(out)[1:] != (R, 2, L):
+        raise ValueError(f"stereo_gain: output {tuple(out.shape)} does not match {(R, 2, L)}")
     check(lib().gfx_stereo_gain_f32(_ptr(x), xmap, _ptr(log_gain.contiguous()), _ptr(out), rowmap(out)[0], R, C, L, _stream()), "gfx_stereo_gain_f32")
     return out
 
@@ -435,6 +462,9 @@ def gather_sum(buf, src_idx, seg_ptr, out):
         raise ValueError("last dimension must be contiguous")
     B, _, C, L = buf.shape
     J = out.shape[1]
+    if (out.shape[0], out.shape[2], out.shape[3]) != (B, C, L) or seg_ptr.numel() != J + 1:
+        raise ValueError(f"gather_sum: output {tuple(out.shape)} / {seg_ptr.numel() - 1} segments do not match the "
+                         f"buffer {tuple(buf.shape)}")
     with _timed("gather_sum_kernel", 4 * B * C * L * (src_idx.numel() + J)):
         check(
             lib().gfx_gather_sum_f32(_ptr(buf), buf.stride(0), buf.stride(1), buf.stride(2), _ptr(src_idx), _ptr(seg_ptr),
@@ -449,6 +479,8 @@ def gather_sum_fanout(buf, unique_src, dest_mask, out):
     _require_gpu(buf, out)
     B, _, C, L = buf.shape
     J = out.shape[1]
+    if (out.shape[0], out.shape[2], out.shape[3]) != (B, C, L) or dest_mask.numel() != unique_src.numel():
+        raise ValueError(f"gather_sum_fanout: output {tuple(out.shape)} does not match the buffer {tuple(buf.shape)}")
     with _timed("gather_sum_kernel", 4 * B * C * L * (unique_src.numel() + J)):
         code = lib().gfx_gather_sum_fanout_f32(_ptr(buf), buf.stride(0), buf.stride(1), buf.stride(2), _ptr(unique_src),
                                                _ptr(dest_mask), unique_src.numel(), _ptr(out), out.stride(0),

@@ -72,7 +72,8 @@ def assert_parity(y, ref32, ref64, tol=1e-5, what=""):
     Pass when y is within ``tol`` of the reference.  Where the reference's own fp32 result is
     farther than that from a float64 evaluation of the same formulas (its FFT/complex64 rounding
     amplified by a steep gain curve or a high-Q pole), y must instead be at least as close to
-    the float64 result as the reference is (x1.5 slack) and within 10*tol of the reference.
+    the float64 result as the reference is (x1.5 slack) and within 10*tol of the reference -- or, when the
+    reference's own noise is larger than that, within the triangle bound |y - f64| + |ref - f64|.
     """
     assert y.shape == ref32.shape, f"{what}: shape {tuple(y.shape)} vs {tuple(ref32.shape)}"
     peak, l2 = rel_err(y, ref32)
@@ -80,6 +81,6 @@ def assert_parity(y, ref32, ref64, tol=1e-5, what=""):
         return
     ours64, _ = rel_err(y, ref64)
     ref_noise, _ = rel_err(ref32, ref64)
-    ok = ref_noise > 0.5 * tol and ours64 <= 1.5 * ref_noise and peak <= 10 * tol
+    ok = ref_noise > 0.5 * tol and ours64 <= 1.5 * ref_noise and peak <= max(10 * tol, 1.05 * (ours64 + ref_noise))
     assert ok, (f"{what}: vs reference peak-rel {peak:.3e} / rel-L2 {l2:.3e} (tol {tol:g}); "
                 f"vs float64: ours {ours64:.3e}, reference itself {ref_noise:.3e}")
