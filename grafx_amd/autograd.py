@@ -107,10 +107,9 @@ class LinearConvFn(torch.autograd.Function):
                     gx = gx.sum(1, keepdim=True)
                 gx = gx.view(x.shape)
         if ctx.needs_input_grad[1]:
-            xr = x.flip(-1).contiguous()
             P = ops.part_len_for(L, N)  # long signal as the filter, N outputs: fewer, longer partitions
-            gh = ops.fftconv(g, ops.fir_spectrum(xr.reshape(R * Cin, L), part_len=P), L, Cin, Lout=N, off=L - 1 - off,
-                             part_len=P)
+            # the reversed signal is the filter of this correlation; its spectra are taken from x in place
+            gh = ops.fftconv(g, ops.fir_spectrum_reversed(x, part_len=P), L, Cin, Lout=N, off=L - 1 - off, part_len=P)
             if gh.shape[1] != Cf:  # one filter shared by both channels
                 gh = gh.sum(1, keepdim=True)
             if Rh != R:  # one filter shared by the batch
@@ -290,9 +289,12 @@ class DynamicsFn(torch.autograd.Function):
         lk = log_knee if knee != "hard" else None
         if smoother:  # two fused passes over the rows (forward, then backward in time) + the pole-gradient reduction
             sink = _sink_for(x)
-            gx, gp, denv, u1 = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate,
-                                                out=sink)
-            gz = pole_gradient(denv, u1, z_alpha, iir_len) if ctx.needs_input_grad[4] else None
+            gx, gp, da = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate,
+                                          out=sink, pole=ctx.needs_input_grad[4])
+            gz = None
+            if da is not None:  # chain rule through a = min(sigmoid(z), 1 - 1e-5)
+                sig = torch.sigmoid(z_alpha.reshape(-1))
+                gz = (da * sig * (1 - sig) * (sig < 1 - 1e-5)).reshape(z_alpha.shape)
             gx = gx.view(x.shape)
         else:
             e = ops.energy(x)

@@ -692,15 +692,22 @@ __device__ __forceinline__ void rstore4(float* __restrict__ row, int64_t j, int6
     }
 }
 
-template <bool TRUNC>
+// POLE: also accumulate the pole gradient of the truncated smoother.  With U = u1 / (1-a) (pass A's un-truncated scan),
+// g = denv and de = this pass's adjoint scan,
+//   dL/da = sum_m  -g[m] U[m] + (a^N - (1-a) N a^(N-1)) g[m] U[m-N] + de[m] U[m-1]
+// (the last term is sum_n g[n] (1-a) (D[n] - a^N D[n-N]), D = dU/da, moved onto the adjoint scan: D is a scan of U,
+// so pairing it with g equals pairing U with the backward scan of g, which is de one sample later).
+template <bool TRUNC, bool POLE>
 __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole& p, const float* x0, const float* x1,
                                                  const float* g0, const float* g1, const float* gain,
-                                                 const float* denv, float* o0, float* o1, float* slots, int t) {
+                                                 const float* denv, const float* u1, float* o0, float* o1,
+                                                 float* slots, int t, float& pole) {
     const int lane = t & 63, wave = t >> 6;
     const bool al = (a.L % 4) == 0;  // reversed float4 groups stay 16-byte aligned only then
     const bool vx = al && vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = al;
     const bool vgx = al && vec_ok(o0) && vec_ok(o1);
     const float k2 = 2.0f / (float)a.C;
+    const float pole_c2 = p.a_N - p.one_m_a * (float)a.N * (p.a_N / p.a);
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
     for (int64_t tile = 0; tile < ntiles; ++tile) {
@@ -714,6 +721,19 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
             scan_tile(p, d2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
 #pragma unroll
             for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+        }
+        if (POLE) {
+            float uu[DE], un[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+            rload4(u1, j, a.L, vo, uu);
+            const int64_t below = a.L - 1 - j - DE;  // sample under this thread's four
+            const float um = (below >= 0 && below < a.L) ? u1[below] : 0.0f;
+            if (TRUNC) rload4(u1, j + a.N, a.L, false, un);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                const float prev = i + 1 < DE ? uu[i + 1] : um;
+                pole += p.one_m_a * u[i] * prev - d[i] * uu[i];
+                if (TRUNC) pole = fmaf(pole_c2 * d[i], un[i], pole);
+            }
         }
         float gn[DE], xa[DE], ga[DE], oa[DE];
         rload4(gain, j, a.L, vo, gn);
@@ -736,8 +756,10 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
 __global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                        gfx_rowmap_t gmap, const float* __restrict__ z_alpha,
                                                        const float* __restrict__ gain, const float* __restrict__ denv,
+                                                       const float* __restrict__ u1, float* __restrict__ dalpha,
                                                        float* __restrict__ gx, DynArgs a) {
     __shared__ float slots[16];
+    __shared__ float red[4];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x;
     OnePole p;
@@ -748,10 +770,22 @@ __global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__
     const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
     float* o0 = gx + drow_off(a.ymap, r, 0);
     float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
-    if (p.trunc)
-        dyn_bwd_b_stream<true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, o0, o1, slots, t);
-    else
-        dyn_bwd_b_stream<false>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, o0, o1, slots, t);
+    float pole = 0.0f;
+    const float* ur = u1 ? u1 + r * a.L : nullptr;
+    if (u1) {
+        if (p.trunc)
+            dyn_bwd_b_stream<true, true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+        else
+            dyn_bwd_b_stream<false, true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+        for (int o = 32; o > 0; o >>= 1) pole += __shfl_down(pole, o, 64);
+        if ((t & 63) == 0) red[t >> 6] = pole;
+        __syncthreads();
+        if (t == 0) dalpha[r] = (red[0] + red[1] + red[2] + red[3]) / p.one_m_a;  // u1 = (1-a) U
+    } else if (p.trunc) {
+        dyn_bwd_b_stream<true, false>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+    } else {
+        dyn_bwd_b_stream<false, false>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+    }
 }
 
 // One pass over (x, gy, env): gain = exp(g(log(env + 1e-5))),  dgain = sum_c gy x,  dg = dgain * gain,
@@ -968,7 +1002,7 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                          float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* gain_ws,
-                         void* stream) {
+                         float* dalpha, void* stream) {
     if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !denv || !u1 || !gain_ws)
         return GFX_EINVAL;
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
@@ -980,7 +1014,8 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dyn_bwd_a_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
                        log_knee, z_alpha, gain_ws, denv, u1, gparams, a);
-    hipLaunchKernelGGL(dyn_bwd_b_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, z_alpha, gain_ws, denv, gx, a);
+    hipLaunchKernelGGL(dyn_bwd_b_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, z_alpha, gain_ws, denv,
+                       dalpha ? u1 : nullptr, dalpha, gx, a);
     return GFX_LAUNCH_OK();
 }
 

@@ -139,6 +139,25 @@ __device__ __forceinline__ void load_window(cx (&v)[32], const float* __restrict
     }
 }
 
+// Time-reversed window of a segment of `len` (<= 16384) samples: v[a] = (seg[len-1-2m], seg[len-2-2m]), m = t + 256 a,
+// zero below the segment.  Lets the filter-gradient correlation use the signal as its own "filter" without a flipped
+// copy of it.
+__device__ __forceinline__ void load_window_rev(cx (&v)[32], const float* __restrict__ seg, int64_t len, int t) {
+    const rsrc_t r = make_rsrc(seg, len * 4);
+    const int base = (int)len - 2;
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        const int e = base - 2 * (t + 256 * a);                // index of the pair's lower sample
+        v[a] = cswap(buf_load_f2(r, e < 0 ? OOB : 4u * (uint32_t)e, 0));
+    }
+    if (len & 1) {                                             // uniform: the pair (seg[-1], seg[0]) was masked as a whole
+        const float x0 = seg[0];
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            if (base - 2 * (t + 256 * a) == -1) v[a] = cx{x0, 0.0f};
+    }
+}
+
 // y[n0 + (2m - O)] for 2m >= O, n < Lout;  v[brev5(a)] = (z'[2m], z'[2m+1])  (NATURAL: v[a] instead)
 template <bool NATURAL = false>
 __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict__ row, int64_t n0, int64_t O,
@@ -173,9 +192,11 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
 #define NAT(arr, i) arr[(i) >> 4][brev((i) & 15, 4)]
 
 // ------------------------------------------------------------------------------------------------
+// REV: the taps of filter (r, c) are row (r, c) of `h` read backwards through `hmap` (tap k = h[r, c, N-1-k]).
+template <bool REV>
 __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restrict__ h, const float* __restrict__ gain,
                                                           int64_t gain_div, float4* __restrict__ Hs, int64_t N,
-                                                          int nparts, int64_t part_len,
+                                                          int nparts, int64_t part_len, gfx_rowmap_t hmap, int C,
                                                           const float2* __restrict__ twtab) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
@@ -184,11 +205,15 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
     const int p = (int)(b - rc * (unsigned)nparts);
     const int64_t start = (int64_t)p * part_len;
     const int64_t len = min(part_len, N - start);
-    const float g = gain ? gain[rc / (unsigned)gain_div] : 1.0f;
 
     TileTw tw;
     cx v[32], w[2][16];
-    load_window(v, h + (int64_t)rc * N + start, 0, len, t, g);
+    if (REV) {
+        const unsigned r = rc / (unsigned)C;
+        load_window_rev(v, h + row_off(hmap, r, (int)(rc - r * (unsigned)C)) + (N - start - len), len, t);
+    } else {
+        load_window(v, h + (int64_t)rc * N + start, 0, len, t, gain ? gain[rc / (unsigned)gain_div] : 1.0f);
+    }
     tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
 
@@ -378,11 +403,27 @@ int gfx_fir_spectrum_ex_f32(const float* h, const float* gain, int64_t gain_div,
     const ConvGeom g = conv_geom(N, 1, part_len);
     if (!g.ok) return GFX_EINVAL;
     if (RCf * g.nparts > 0x7fffffffLL) return GFX_EINVAL;
-    if (allow_lds(hspec_kernel)) return GFX_ELAUNCH;
+    if (allow_lds(hspec_kernel<false>)) return GFX_ELAUNCH;
     const float2* tw = tile_twiddle_table((hipStream_t)stream);
     if (!tw) return GFX_ELAUNCH;
-    hipLaunchKernelGGL(hspec_kernel, dim3((unsigned)(RCf * g.nparts)), dim3(TILE_T), TILE_LDS_BYTES,
-                       (hipStream_t)stream, h, gain, gain_div, (float4*)Hs, N, (int)g.nparts, g.part_len, tw);
+    const gfx_rowmap_t none = {1, 0, 0, 0};
+    hipLaunchKernelGGL(hspec_kernel<false>, dim3((unsigned)(RCf * g.nparts)), dim3(TILE_T), TILE_LDS_BYTES,
+                       (hipStream_t)stream, h, gain, gain_div, (float4*)Hs, N, (int)g.nparts, g.part_len, none, 1, tw);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_fir_spectrum_rev_f32(const float* x, gfx_rowmap_t xmap, int64_t R, int64_t C, int64_t L, int64_t part_len,
+                             void* Hs, void* stream) {
+    if (!x || !Hs || R <= 0 || C <= 0 || L <= 0 || xmap.inner <= 0 || xmap.inner > 0x7fffffffLL) return GFX_EINVAL;
+    const ConvGeom g = conv_geom(L, 1, part_len);
+    if (!g.ok) return GFX_EINVAL;
+    if (R * C * g.nparts > 0x7fffffffLL) return GFX_EINVAL;
+    if (allow_lds(hspec_kernel<true>)) return GFX_ELAUNCH;
+    const float2* tw = tile_twiddle_table((hipStream_t)stream);
+    if (!tw) return GFX_ELAUNCH;
+    hipLaunchKernelGGL(hspec_kernel<true>, dim3((unsigned)(R * C * g.nparts)), dim3(TILE_T), TILE_LDS_BYTES,
+                       (hipStream_t)stream, x, (const float*)nullptr, (int64_t)1, (float4*)Hs, L, (int)g.nparts,
+                       g.part_len, xmap, (int)C, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

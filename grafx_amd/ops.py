@@ -91,6 +91,17 @@ def fir_spectrum(h, gain=None, gain_div=1, part_len=0):
     return Hs
 
 
+def fir_spectrum_reversed(x, part_len=0):
+    """Spectra of the time-reversed rows of ``x`` ((R,C,L) or a strided (B,n,C,L) view, read in place): what
+    ``fir_spectrum(x.flip(-1).reshape(R * C, L), part_len=part_len)`` returns, without the flipped copy."""
+    _require_gpu(x)
+    xmap, R, C, L = rowmap(x)
+    Hs = torch.empty(lib().gfx_fir_spectrum_bytes_ex(R * C, L, part_len), dtype=torch.uint8, device=x.device)
+    check(lib().gfx_fir_spectrum_rev_f32(_ptr(x), xmap, R, C, L, part_len, _ptr(Hs), _stream()),
+          "gfx_fir_spectrum_rev_f32")
+    return Hs
+
+
 def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     """Whether :func:`fftconv` can also write a copy of its input (gfx_fftconv_tee_f32's conditions)."""
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
@@ -224,9 +235,10 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
     return gain, denv, gp
 
 
-def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None):
-    """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), denv (R,L), u1 (R,L)).
-    ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view)."""
+def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True):
+    """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), dalpha (R) or None).
+    ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view).  ``dalpha`` is the gradient with
+    respect to the clamped pole a = min(sigmoid(z_alpha), 1 - 1e-5); the caller applies the chain rule to z_alpha."""
     _require_gpu(x, gy, out)
     xmap, R, C, L = rowmap(x)
     gmap, Rg, Cg, Lg = rowmap(gy)
@@ -235,11 +247,12 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
     gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device) if out is None else out
     gp = torch.empty((R, 3), dtype=torch.float32, device=x.device)
     denv, u1, ws = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(3))
+    da = torch.empty(R, dtype=torch.float32, device=x.device) if pole else None
     check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(_rowvec(log_threshold, R)),
                                      _ptr(_rowvec(log_ratio, R)), _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)),
                                      R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), _ptr(denv),
-                                     _ptr(u1), _ptr(ws), _stream()), "gfx_dynamics_bwd_f32")
-    return gx, gp, denv, u1
+                                     _ptr(u1), _ptr(ws), _ptr(da), _stream()), "gfx_dynamics_bwd_f32")
+    return gx, gp, da
 
 
 def onepole_dz(g, U, D, coef, N):

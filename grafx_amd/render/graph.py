@@ -92,6 +92,14 @@ def _transposed_plan(step, plan, device):
     return cache[key]
 
 
+def _plan_max_row(step, plan):
+    """Highest buffer row a gather plan reads (cached: the plan lives on the device)."""
+    cache = step.__dict__.setdefault("_plan_max", [])
+    if not cache:
+        cache.append(int(plan[0].max()))
+    return cache[0]
+
+
 def _gather(ops, buf, plan, out):
     if plan[3] is not None and ops.gather_sum_fanout(buf, plan[3][0], plan[3][1], out):
         return out
@@ -385,7 +393,10 @@ class _BufferRenderFn(torch.autograd.Function):
                 with torch.enable_grad():
                     if not getattr(processors[node_type], "accepts_strided_rows", False):
                         x_in = x_in.reshape(-1, C, L)  # the (R, C, L) rows of the upstream contract (a copy)
-                    x_in = x_in.detach().requires_grad_(True)  # else: (B, n, C, L) view of the buffer, no copy
+                    # a stage fed by the sources alone needs no input gradient unless the caller asked for g_x
+                    want_gx = ctx.needs_input_grad[1] or (
+                        step.source_reads[0].idx[1] > ctx.n_src if plan is None else _plan_max_row(step, plan) >= ctx.n_src)
+                    x_in = x_in.detach().requires_grad_(want_gx)  # else: (B, n, C, L) view of the buffer, no copy
                     local = [t.detach().requires_grad_(t.requires_grad) for t in leaves]
                     params = _unflatten_tree(p_spec, local)[node_type]
                     common = None if c_spec is None else _unflatten_tree(c_spec, local)
@@ -407,8 +418,8 @@ class _BufferRenderFn(torch.autograd.Function):
                     with diff.tape_only():  # only the stage's tape is wanted here, not its output values
                         y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
-                    wrt = [x_in] + [local[j] for j in live]
-                    if plan is None and x_in.ndim == 4 and not any(written[a:b]):
+                    wrt = ([x_in] if want_gx else []) + [local[j] for j in live]
+                    if want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]):
                         # first (usually only) contribution to these rows: let the stage write it in place
                         diff.GRAD_SINK = (x_in.data_ptr(), gbuf.narrow(1, a, b - a))
                     try:
@@ -416,10 +427,12 @@ class _BufferRenderFn(torch.autograd.Function):
                                                     else g_out.reshape(y.shape), allow_unused=True)
                     finally:
                         diff.GRAD_SINK = None
-                g_in = grads[0].reshape(B, -1, C, L)
-                for j, g in zip(live, grads[1:]):
+                for j, g in zip(live, grads[1:] if want_gx else grads):
                     if g is not None:
                         leaf_grads[j] = g if leaf_grads[j] is None else leaf_grads[j] + g
+                if not want_gx:
+                    continue
+                g_in = grads[0].reshape(B, -1, C, L)
             else:  # in / out / mix: the (summed) input is the output
                 g_in = g_out
             # add the stage's input gradient onto the rows it read
@@ -430,7 +443,11 @@ class _BufferRenderFn(torch.autograd.Function):
                 # adjoint of the gather-sum: every source row collects the gradients of the slots it fed --
                 # the same gather-sum kernel with the transposed plan
                 uniq, dst_idx, ptr, contiguous = _transposed_plan(step, plan, dev)
-                g_src = ops.gather_sum(g_in.contiguous(), dst_idx, ptr, torch.empty(B, len(uniq), C, L, device=dev))
+                if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]):
+                    g_src = gbuf.narrow(1, uniq[0], len(uniq))  # first contribution: gather straight into the rows
+                else:
+                    g_src = torch.empty(B, len(uniq), C, L, device=dev)
+                g_src = ops.gather_sum(g_in if g_in.stride(-1) == 1 else g_in.contiguous(), dst_idx, ptr, g_src)
                 if contiguous:
                     accumulate(uniq[0], uniq[0] + len(uniq), g_src)
                 else:

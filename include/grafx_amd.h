@@ -97,6 +97,11 @@ size_t gfx_fftconv_workspace_bytes_ex(int64_t R, int64_t C_in, int64_t L, int64_
                                       int64_t part_len);
 int gfx_fir_spectrum_ex_f32(const float* h, const float* gain, int64_t gain_div, void* Hs,
                             int64_t RCf, int64_t N, int64_t part_len, void* stream);
+/* Spectra of the time-reversed signal rows: filter (r, c) has the L taps x[r, c, L-1-k], read in place through
+ * `xmap` -- the "filter" of the filter-gradient correlation (autograd of convolve(): grad_h[k] = sum_n g[n] x[n+off-k])
+ * without materialising x.flip(-1).  Buffer size: gfx_fir_spectrum_bytes_ex(R * C, L, part_len). */
+int gfx_fir_spectrum_rev_f32(const float* x, gfx_rowmap_t xmap, int64_t R, int64_t C, int64_t L, int64_t part_len,
+                             void* Hs, void* stream);
 int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
                        float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
                        int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
@@ -179,13 +184,14 @@ int gfx_dyn_dx_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowma
  * passes over the row (forward in time: recompute energy -> smoother -> gain, emit gain, the relu-masked d/d(smoothed
  * energy), the un-truncated scan u1 and the per-row parameter gradients; backward in time: the smoother's adjoint scan
  * and gx = gain * gy + (2/C) * de * x).  gx rows addressed by gxmap (e.g. a slice of the render's gradient buffer);
- * gparams (R,3); denv, u1, gain_ws (R,L) each (denv and u1 feed gfx_onepole_dz_f32 for the pole gradient, gain_ws is
- * workspace). */
+ * gparams (R,3); denv, u1, gain_ws (R,L) each (workspace).  dalpha (R), optional: dL/d(pole) of the smoother before
+ * the sigmoid/clamp chain rule, accumulated by the second pass from u1, denv and its own adjoint scan (the D = dU/da
+ * scan of core/envelope.py's truncated filter is moved onto the adjoint side, so no third scan is needed). */
 int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                          float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* gain_ws,
-                         void* stream);
+                         float* dalpha, void* stream);
 /* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
  * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,

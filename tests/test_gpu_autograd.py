@@ -127,11 +127,12 @@ def test_native_dynamics_backward_matches_torch_autograd_of_the_same_formulas(ga
     from grafx_amd import autograd as diff
 
     torch.manual_seed(7)
-    R, C, L, N = 4, 2, 3000, 257
+    R, C, L, N = 4, 2, 3000 if gate else 2999, 257   # aligned and ragged row ends
     x = (0.5 * torch.randn(R, C, L, device="cuda")).requires_grad_(True)
     p = {"log_threshold": torch.randn(R, 1, device="cuda") - 3, "log_ratio": torch.randn(R, 1, device="cuda"),
          "log_knee": torch.randn(R, 1, device="cuda"), "z": torch.randn(R, 1, device="cuda") + 2}
     p["z"][0] = 20.0  # sigmoid saturates: the clamp at 1 - 1e-5 is active, a^N is far from negligible
+    p["z"][1] = 5.0   # a = 0.9933: not clamped and a^N = 0.18, so the truncation terms carry the pole gradient
     for v in p.values():
         v.requires_grad_(True)
     w = torch.randn(R, C, L, device="cuda")

@@ -164,3 +164,23 @@ def test_random_geometries_match_the_oracle_convolution(seed):
     assert y.shape == ref.shape, (y.shape, ref.shape)
     scale = ref.abs().max().clamp_min(1e-6)
     assert (y.cpu() - ref).abs().max() <= 2e-5 * scale, f"L={L} N={N} C={Cin}/{Cf} off={off} Lout={Lout} shared={shared}"
+
+
+@pytest.mark.parametrize("L,N", [(1, 1), (2, 5), (7, 3), (4001, 33), (8193, 100), (8194, 9), (20001, 4001),
+                                 (131072, 4001), (40000, 1), (33333, 8193)])
+def test_reversed_spectra_equal_the_spectra_of_the_flipped_copy(L, N):
+    """gfx_fir_spectrum_rev_f32 (the filter-gradient correlation's "filter") reads the rows backwards in place:
+    bit-identical to flipping first, for contiguous rows and for strided (B, n, C, L) views of a buffer."""
+    from grafx_amd import ops
+
+    def same(a, b):  # (filters x partitions, 17 slots, 256 threads, 4 floats); slot 16 is written by thread 0 only
+        a, b = a.view(torch.float32).view(-1, 17, 256, 4), b.view(torch.float32).view(-1, 17, 256, 4)
+        return torch.equal(a[:, :16], b[:, :16]) and torch.equal(a[:, 16, 0], b[:, 16, 0])
+
+    torch.manual_seed(L + N)
+    P = ops.part_len_for(L, N)
+    x = torch.randn(3, 2, L, device="cuda")
+    assert same(ops.fir_spectrum_reversed(x, part_len=P), ops.fir_spectrum(x.flip(-1).reshape(6, L), part_len=P))
+    buf = torch.randn(3, 5, 2, L, device="cuda")
+    view = buf.narrow(1, 1, 2)
+    assert same(ops.fir_spectrum_reversed(view, part_len=P), ops.fir_spectrum(view.flip(-1).reshape(12, L), part_len=P))
