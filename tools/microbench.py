@@ -84,6 +84,26 @@ def main():
             print(f"reverb  R={Rr} {ms:8.3f} ms  {16 * Rr * L / 1e9 / ms * 1e3:8.1f} GB/s")
             ms = timeit(lambda: rv._ir_and_gain(p["init_log_magnitude"], p["delta_log_magnitude"], None, True), a.iters)
             print(f"  ir synthesis        {ms:8.3f} ms")
+        if a.what in ("cfg2", "configs"):   # BASELINE configs[1]: ParametricEqualizer, 1024 mono rows of 10 s
+            for N in (4001, 4000):
+                R2, L2 = 1024, 480000
+                eq = P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=N).to(dev)
+                x2 = torch.randn(R2, 1, L2, device=dev)
+                p = {k: torch.randn(R2, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
+                ms = timeit(lambda: eq(x2, **p), a.iters)
+                print(f"cfg2 PEQ fsm_fir_len={N} R={R2} L={L2}: {ms:8.3f} ms  {8 * R2 * L2 / 1e9 / ms * 1e3:8.1f} GB/s  "
+                      f"{R2 * L2 / ms * 1e3:.3e} samples/s")
+                del x2, eq
+        if a.what in ("cfg3", "configs"):   # BASELINE configs[2]: STFTMaskedNoiseReverb, 512 stereo rows of 5 s
+            for N in (60001, 60000):
+                R3, L3 = 512, 240000
+                rv = P.STFTMaskedNoiseReverb(ir_len=N, flashfftconv=False).to(dev)
+                x3 = torch.randn(R3, 2, L3, device=dev)
+                p = {k: torch.randn(R3, 2, 193, device=dev) for k in rv.parameter_size()}
+                ms = timeit(lambda: rv(x3, **p), a.iters)
+                print(f"cfg3 reverb ir_len={N} R={R3} L={L3}: {ms:8.3f} ms  {16 * R3 * L3 / 1e9 / ms * 1e3:8.1f} GB/s  "
+                      f"{R3 * L3 / ms * 1e3:.3e} samples/s")
+                del x3, rv
 
 
 if __name__ == "__main__":
