@@ -266,7 +266,8 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
         NAT(w, ia) = za;
         if (!self) NAT(w, ib) = zb;
     });
-    __syncthreads();  // every thread is done reading S2 before the inverse overwrites it
+    // no barrier here: the inverse starts by writing S2 rows j = t and 512 - t, the very rows (and the only rows)
+    // this thread read at the end of the forward transform -- nobody else touches them in between
     tile_inverse(w, v, tw, lds, t);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
 }

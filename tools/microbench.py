@@ -61,6 +61,72 @@ def main():
             print(f"  iir_fsm only        {ms:8.3f} ms")
             ms = timeit(lambda: ops.fir_spectrum(h), a.iters)
             print(f"  hspec only          {ms:8.3f} ms")
+        if a.what in ("eqbuf",):   # the first stage exactly as the console render runs it: strided views of the buffer
+            B, n, V = R // 32, 32, 111
+            eq = P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=4001).to(dev)
+            p = {k: 0.1 * torch.randn(n, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
+            Bs, As = ops.peq_coeffs(p["w0"], p["q_inv"], p["log_gain"])
+            Hs = ops.fir_spectrum(ops.iir_fsm_fir(Bs, As, 4001, eq.biquad._plan(x.device)).reshape(n, 4001))
+            x4 = x.view(B, n, 2, L)
+            buf = torch.empty(B, V, 2, L, device=dev)
+            for name, out, tee, xin in (("contiguous in/out, shared H", y.view(B, n, 2, L), None, x4),
+                                        ("buffer out", buf.narrow(1, 32, n), None, x4),
+                                        ("buffer out + tee", buf.narrow(1, 32, n), buf.narrow(1, 0, n), x4),
+                                        ("buffer in/out", buf.narrow(1, 64, n), None, buf.narrow(1, 32, n))):
+                ms = timeit(lambda: ops.fftconv(xin, Hs, 4001, 1, out=out, tee=tee, h_rows=n), a.iters)
+                print(f"  fftconv1 {name:32s} {ms:8.3f} ms  {(1.5 if tee is not None else 1.0) * gb / ms * 1e3:8.1f} GB/s")
+        if a.what in ("eqcold",):  # the tee launch back to back vs. after other traffic (as inside a render step)
+            B, n, V = R // 32, 32, 111
+            eq = P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=4001).to(dev)
+            p = {k: 0.1 * torch.randn(n, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
+            Bs, As = ops.peq_coeffs(p["w0"], p["q_inv"], p["log_gain"])
+            Hs = ops.fir_spectrum(ops.iir_fsm_fir(Bs, As, 4001, eq.biquad._plan(x.device)).reshape(n, 4001))
+            x4 = x.view(B, n, 2, L)
+            bufs = [torch.empty(B, V, 2, L, device=dev) for _ in range(2)]
+            other = torch.empty(B, 8, 2, L, device=dev)
+
+            def timed(prep, k):
+                ts = []
+                for i in range(a.iters + 1):
+                    buf = bufs[i % k]
+                    prep(buf)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.fftconv(x4, Hs, 4001, 1, out=buf.narrow(1, 32, n), tee=buf.narrow(1, 0, n), h_rows=n)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return sum(ts[1:]) / a.iters
+
+            for reps in (1, 5, 20, 60):  # sustained load: does the per-launch time creep up (clocks)?
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for i in range(reps):
+                    ops.fftconv(x4, Hs, 4001, 1, out=bufs[0].narrow(1, 32, n), tee=bufs[0].narrow(1, 0, n), h_rows=n)
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"  {reps:3d} tee launches in a row: {e0.elapsed_time(e1) / reps:8.3f} ms each")
+            cp = P.Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).to(dev)
+            pc = {k: 0.1 * torch.randn(n, 1, device=dev) for k in cp.parameter_size()}
+            ts = []
+            for i in range(8):  # interleaved with the compressor stage, as in the render
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.fftconv(x4, Hs, 4001, 1, out=bufs[0].narrow(1, 32, n), tee=bufs[0].narrow(1, 0, n), h_rows=n)
+                e1.record()
+                cp.render_into(bufs[0].narrow(1, 32, n), bufs[0].narrow(1, 64, n), _shared_rows=n, **pc)
+                cp.render_into(bufs[0].narrow(1, 32, n), bufs[0].narrow(1, 64, n), _shared_rows=n, **pc)
+                ts.append((e0, e1))
+            torch.cuda.synchronize()
+            print("  tee launch interleaved with 2 compressor stages: " + " ".join(f"{a_.elapsed_time(b_):.2f}" for a_, b_ in ts))
+            print(f"  tee launch, back to back, one buffer      {timed(lambda b: None, 1):8.3f} ms")
+            print(f"  tee launch, alternating two buffers       {timed(lambda b: None, 2):8.3f} ms")
+            print(f"  tee launch after rewriting the other 30 GB buffer {timed(lambda b: bufs[1].fill_(1.0), 1):8.3f} ms")
+            print(f"  tee launch after rewriting its own 30 GB buffer   {timed(lambda b: b.fill_(1.0), 1):8.3f} ms")
+            print(f"  tee launch after reading x and the buffer (sum)   {timed(lambda b: (b.sum(), x4.sum()), 1):8.3f} ms")
+            print(f"  tee launch after a 2 GB copy              {timed(lambda b: other.copy_(b.narrow(1, 100, 8)), 1):8.3f} ms")
+            print(f"  tee launch after writing the buffer tail  {timed(lambda b: b.narrow(1, 64, 47).fill_(1.0), 2):8.3f} ms")
         if a.what in ("eqx", "all"):
             eqx = P.ParametricEqualizer(num_filters=6, backend="lfilter", flashfftconv=False).to(dev)
             p = {k: 0.1 * torch.randn(R, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
