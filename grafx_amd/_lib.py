@@ -45,7 +45,7 @@ SIGNATURES = {
                                             ctypes.c_int, f32p, f32p, f32p, vp]),
     "gfx_dyn_dx_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, i64, i64, i64, vp]),
     "gfx_dynamics_bwd_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
-                                            ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, f32p, f32p, vp]),
+                                            ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, f32p, vp]),
     "gfx_onepole_dz_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, i64, vp]),
     "gfx_energy_f32": (ctypes.c_int, [f32p, RowMap, f32p, i64, i64, i64, vp]),
     "gfx_onepole_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, i64, i64, ctypes.c_int, vp]),

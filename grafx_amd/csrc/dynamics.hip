@@ -572,13 +572,12 @@ __device__ __forceinline__ KneeGrad log_gain_grad(const Knee& q, float G) {
 // ---- fused backward of the compressor / gate with the one-pole energy smoother ------------------------------
 // Pass A, forward in time, one workgroup per row: recompute energy -> smoothed energy -> gain exactly as the
 // forward kernel does, and from the output gradient gy emit
-//   gain[n] = exp(g(G))                               (R, L)
 //   denv[n] = dL/d(smoothed energy), relu-masked       (R, L)
 //   u1[n]   = (1-a) * (untruncated scan of the energy) (R, L)   -- input of the pole-gradient reduction
 //   gparams[r, 0..2] = dL/d(log_threshold, log_ratio, log_knee)
 template <bool TRUNC>
 __device__ __forceinline__ void dyn_bwd_a_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
-                                                 const float* x1, const float* g0, const float* g1, float* gain,
+                                                 const float* x1, const float* g0, const float* g1,
                                                  float* denv, float* u1, float* slots, int t, float (&acc)[3]) {
     const int lane = t & 63, wave = t >> 6;
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = (a.L % 4) == 0;
@@ -611,15 +610,15 @@ __device__ __forceinline__ void dyn_bwd_a_stream(const DynArgs& a, const OnePole
 #pragma unroll
             for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
         }
-        float gn[DE], dv[DE];
+        float dv[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
             lin[i] = p.one_m_a * u[i];
             const float env = fmaxf(lin[i], 0.0f);
             const float G = logf(env + 1e-5f);
-            gn[i] = expf(log_gain(q, G));
+            const float gn = expf(log_gain(q, G));
             const float dgain = a.C == 2 ? (ga[i] * xa[i] + gb[i] * xb[i]) : ga[i] * xa[i];
-            const float dg = dgain * gn[i];
+            const float dg = dgain * gn;
             const KneeGrad k = log_gain_grad(q, G);
             dv[i] = lin[i] > 0.0f ? dg * k.dG / (env + 1e-5f) : 0.0f;
             if (n + i < a.L) {
@@ -628,7 +627,6 @@ __device__ __forceinline__ void dyn_bwd_a_stream(const DynArgs& a, const OnePole
                 acc[2] += dg * k.dlk;
             }
         }
-        store4(gain, n, a.L, vo, gn);
         store4(denv, n, a.L, vo, dv);
         store4(u1, n, a.L, vo, raw);
     }
@@ -638,7 +636,7 @@ __global__ __launch_bounds__(DT) void dyn_bwd_a_kernel(const float* __restrict__
                                                        gfx_rowmap_t gmap, const float* __restrict__ log_threshold,
                                                        const float* __restrict__ log_ratio,
                                                        const float* __restrict__ log_knee,
-                                                       const float* __restrict__ z_alpha, float* __restrict__ gain,
+                                                       const float* __restrict__ z_alpha,
                                                        float* __restrict__ denv, float* __restrict__ u1,
                                                        float* __restrict__ gparams, DynArgs a) {
     __shared__ float slots[16];
@@ -655,9 +653,9 @@ __global__ __launch_bounds__(DT) void dyn_bwd_a_kernel(const float* __restrict__
     const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
     float acc[3] = {0.0f, 0.0f, 0.0f};
     if (p.trunc)
-        dyn_bwd_a_stream<true>(a, p, q, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, u1 + r * a.L, slots, t, acc);
+        dyn_bwd_a_stream<true>(a, p, q, x0, x1, g0, g1, denv + r * a.L, u1 + r * a.L, slots, t, acc);
     else
-        dyn_bwd_a_stream<false>(a, p, q, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, u1 + r * a.L, slots, t, acc);
+        dyn_bwd_a_stream<false>(a, p, q, x0, x1, g0, g1, denv + r * a.L, u1 + r * a.L, slots, t, acc);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float v = acc[k];
@@ -669,7 +667,9 @@ __global__ __launch_bounds__(DT) void dyn_bwd_a_kernel(const float* __restrict__
 }
 
 // Pass B, backward in time: de[m] = sum_{k<N} h[k] denv[m+k] (the smoother's adjoint = the same scan on the
-// reversed sequence), then gx = gain * gy + (2/C) * de * x.  Position j of the reversed walk is sample L-1-j.
+// reversed sequence), then gx = gain * gy + (2/C) * de * x with the gain recomputed from pass A's scan
+// (env = relu(u1[m] - a^N u1[m-N])): cheaper than a (R, L) gain array written by A and read back here.
+// Position j of the reversed walk is sample L-1-j.
 __device__ __forceinline__ void rload4(const float* __restrict__ row, int64_t j, int64_t L, bool vec, float (&v)[DE]) {
     // v[i] = row[L-1-(j+i)], zero outside [0, L)
     const int64_t hi = L - 1 - j;  // sample of v[0]
@@ -698,8 +698,8 @@ __device__ __forceinline__ void rstore4(float* __restrict__ row, int64_t j, int6
 // (the last term is sum_n g[n] (1-a) (D[n] - a^N D[n-N]), D = dU/da, moved onto the adjoint scan: D is a scan of U,
 // so pairing it with g equals pairing U with the backward scan of g, which is de one sample later).
 template <bool TRUNC, bool POLE>
-__device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole& p, const float* x0, const float* x1,
-                                                 const float* g0, const float* g1, const float* gain,
+__device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
+                                                 const float* x1, const float* g0, const float* g1,
                                                  const float* denv, const float* u1, float* o0, float* o1,
                                                  float* slots, int t, float& pole) {
     const int lane = t & 63, wave = t >> 6;
@@ -722,12 +722,12 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
 #pragma unroll
             for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
         }
+        float uu[DE], un[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        rload4(u1, j, a.L, vo, uu);
+        if (TRUNC) rload4(u1, j + a.N, a.L, false, un);
         if (POLE) {
-            float uu[DE], un[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
-            rload4(u1, j, a.L, vo, uu);
             const int64_t below = a.L - 1 - j - DE;  // sample under this thread's four
             const float um = (below >= 0 && below < a.L) ? u1[below] : 0.0f;
-            if (TRUNC) rload4(u1, j + a.N, a.L, false, un);
 #pragma unroll
             for (int i = 0; i < DE; ++i) {
                 const float prev = i + 1 < DE ? uu[i + 1] : um;
@@ -736,7 +736,11 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
             }
         }
         float gn[DE], xa[DE], ga[DE], oa[DE];
-        rload4(gain, j, a.L, vo, gn);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            const float lin = TRUNC ? fmaf(-p.a_N, un[i], uu[i]) : uu[i];
+            gn[i] = expf(log_gain(q, logf(fmaxf(lin, 0.0f) + 1e-5f)));
+        }
         rload4(x0, j, a.L, vx, xa);
         rload4(g0, j, a.L, vx, ga);
 #pragma unroll
@@ -754,8 +758,10 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
 }
 
 __global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                       gfx_rowmap_t gmap, const float* __restrict__ z_alpha,
-                                                       const float* __restrict__ gain, const float* __restrict__ denv,
+                                                       gfx_rowmap_t gmap, const float* __restrict__ log_threshold,
+                                                       const float* __restrict__ log_ratio,
+                                                       const float* __restrict__ log_knee,
+                                                       const float* __restrict__ z_alpha, const float* __restrict__ denv,
                                                        const float* __restrict__ u1, float* __restrict__ dalpha,
                                                        float* __restrict__ gx, DynArgs a) {
     __shared__ float slots[16];
@@ -770,21 +776,23 @@ __global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__
     const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
     float* o0 = gx + drow_off(a.ymap, r, 0);
     float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
+    Knee q;
+    knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, a.knee, a.gate);
     float pole = 0.0f;
-    const float* ur = u1 ? u1 + r * a.L : nullptr;
-    if (u1) {
+    const float* ur = u1 + r * a.L;
+    if (dalpha) {
         if (p.trunc)
-            dyn_bwd_b_stream<true, true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+            dyn_bwd_b_stream<true, true>(a, p, q, x0, x1, g0, g1, denv + r * a.L, ur, o0, o1, slots, t, pole);
         else
-            dyn_bwd_b_stream<false, true>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+            dyn_bwd_b_stream<false, true>(a, p, q, x0, x1, g0, g1, denv + r * a.L, ur, o0, o1, slots, t, pole);
         for (int o = 32; o > 0; o >>= 1) pole += __shfl_down(pole, o, 64);
         if ((t & 63) == 0) red[t >> 6] = pole;
         __syncthreads();
         if (t == 0) dalpha[r] = (red[0] + red[1] + red[2] + red[3]) / p.one_m_a;  // u1 = (1-a) U
     } else if (p.trunc) {
-        dyn_bwd_b_stream<true, false>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+        dyn_bwd_b_stream<true, false>(a, p, q, x0, x1, g0, g1, denv + r * a.L, ur, o0, o1, slots, t, pole);
     } else {
-        dyn_bwd_b_stream<false, false>(a, p, x0, x1, g0, g1, gain + r * a.L, denv + r * a.L, ur, o0, o1, slots, t, pole);
+        dyn_bwd_b_stream<false, false>(a, p, q, x0, x1, g0, g1, denv + r * a.L, ur, o0, o1, slots, t, pole);
     }
 }
 
@@ -1001,10 +1009,9 @@ int gfx_dyn_gain_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
 int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
-                         float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* gain_ws,
-                         float* dalpha, void* stream) {
-    if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !denv || !u1 || !gain_ws)
-        return GFX_EINVAL;
+                         float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* dalpha,
+                         void* stream) {
+    if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !denv || !u1) return GFX_EINVAL;
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
         return GFX_EINVAL;
     if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0 || gxmap.inner <= 0) return GFX_EINVAL;
@@ -1013,9 +1020,9 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
     a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dyn_bwd_a_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
-                       log_knee, z_alpha, gain_ws, denv, u1, gparams, a);
-    hipLaunchKernelGGL(dyn_bwd_b_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, z_alpha, gain_ws, denv,
-                       dalpha ? u1 : nullptr, dalpha, gx, a);
+                       log_knee, z_alpha, denv, u1, gparams, a);
+    hipLaunchKernelGGL(dyn_bwd_b_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
+                       log_knee, z_alpha, denv, u1, dalpha, gx, a);
     return GFX_LAUNCH_OK();
 }
 

@@ -348,6 +348,52 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
 }
 
+// One output tile per row (ntiles == 1, the filter-gradient shape: a long "filter", few outputs): every signal window
+// meets exactly one filter partition, so its spectrum is used once -- transform it here instead of writing it to
+// a workspace (xspec_kernel) and reading it back (macinv_kernel).
+__global__ __launch_bounds__(TILE_T, 2) void winmac_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
+                                                           float* __restrict__ y, ConvArgs a,
+                                                           const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
+    const int t = threadIdx.x;
+    const unsigned rco = xcd_logical_block();
+    if (rco >= (unsigned)a.nblocks) return;
+    const unsigned r = rco / (unsigned)a.Cout;
+    const int c = (int)(rco - r * (unsigned)a.Cout);
+    const float* xrow = x + row_off(a.xmap, r, a.Cin == 1 ? 0 : c);
+    float* yrow = y + row_off(a.ymap, r, c);
+    const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
+
+    cx ye[H_SLOTS], yo[H_SLOTS];
+#pragma unroll
+    for (int s = 0; s < H_SLOTS; ++s) ye[s] = yo[s] = cx{0.0f, 0.0f};
+    TileTw tw;
+    tile_twiddles(tw, twtab, t);
+    for (int p = 0; p < a.nparts; ++p) {
+        const int64_t s = a.off - a.O - (int64_t)p * a.hop;  // window of partition p for output tile 0
+        if (!window_live(s, a.L)) continue;
+        const f4v* Hp = H + (int64_t)p * H_TILE_F4;
+        cx v[32], w[2][16];
+        load_window(v, xrow, s, a.L, t, 1.0f);
+        tile_forward(v, w, tw, lds, t);
+        for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool) {
+            cx xe, xo;
+            pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
+            pair_product_acc(xe, xo, Hp[slot * TILE_T + t], wk, ye[slot], yo[slot]);
+        });
+        __syncthreads();  // S2 reads of this window are done before the next window's S1 writes
+    }
+    cx pz[2][16], v[32];
+    for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx, bool self) {
+        cx za, zb;
+        pair_merge(ye[slot], yo[slot], za, zb);
+        NAT(pz, ia) = za;
+        if (!self) NAT(pz, ib) = zb;
+    });
+    tile_inverse(pz, v, tw, lds, t);
+    store_valid(v, yrow, 0, a.O, a.Lout, t);
+}
+
 static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
 
 template <typename K>
@@ -389,7 +435,7 @@ size_t gfx_fftconv_workspace_bytes_ex(int64_t R, int64_t C_in, int64_t L, int64_
     (void)off;
     if (R <= 0 || N <= 0 || Lout <= 0) return 0;
     const ConvGeom g = conv_geom(N, Lout, part_len);
-    if (!g.ok || g.nparts == 1) return 0;
+    if (!g.ok || g.nparts == 1 || g.ntiles == 1) return 0;  // one output tile: windows are transformed in place
     return (size_t)R * C_in * (g.ntiles + g.nparts - 1) * TILE_M * sizeof(float2);
 }
 
@@ -485,6 +531,12 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
         else
             hipLaunchKernelGGL(fftconv1_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
                                (const float4*)Hs, y, xcopy, a, tw);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    }
+    if (g.ntiles == 1) {
+        if (allow_lds(winmac_kernel)) return GFX_ELAUNCH;
+        hipLaunchKernelGGL(winmac_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, (const float4*)Hs, y,
+                           a, tw);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     const int64_t nwin = g.ntiles + g.nparts - 1;

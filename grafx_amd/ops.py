@@ -129,7 +129,7 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
         raise ValueError(f"filter spectra hold {Hs.numel()} bytes, expected {h_rows} x {Cf} filters of {N} taps")
     nbytes = lib().gfx_fftconv_workspace_bytes_ex(R, Cin, L, Lout, off, N, part_len)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    name = "fftconv1_kernel" if nbytes == 0 else "xspec+macinv_kernels"
+    name = "xspec+macinv_kernels" if nbytes else ("fftconv1_kernel" if lib().gfx_fftconv_nparts(N) == 1 else "winmac_kernel")
     cmap = RowMap(1, 0, 0, 0)
     if tee is not None:
         cmap, Rc, Cc, Lc = rowmap(tee)
@@ -246,12 +246,12 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
         raise ValueError(f"dynamics_bwd: gradient / output shapes do not match the input {tuple(x.shape)}")
     gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device) if out is None else out
     gp = torch.empty((R, 3), dtype=torch.float32, device=x.device)
-    denv, u1, ws = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(3))
+    denv, u1 = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(2))
     da = torch.empty(R, dtype=torch.float32, device=x.device) if pole else None
     check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(_rowvec(log_threshold, R)),
                                      _ptr(_rowvec(log_ratio, R)), _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)),
                                      R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), _ptr(denv),
-                                     _ptr(u1), _ptr(ws), _ptr(da), _stream()), "gfx_dynamics_bwd_f32")
+                                     _ptr(u1), _ptr(da), _stream()), "gfx_dynamics_bwd_f32")
     return gx, gp, da
 
 

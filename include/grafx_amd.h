@@ -184,14 +184,15 @@ int gfx_dyn_dx_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowma
  * passes over the row (forward in time: recompute energy -> smoother -> gain, emit gain, the relu-masked d/d(smoothed
  * energy), the un-truncated scan u1 and the per-row parameter gradients; backward in time: the smoother's adjoint scan
  * and gx = gain * gy + (2/C) * de * x).  gx rows addressed by gxmap (e.g. a slice of the render's gradient buffer);
- * gparams (R,3); denv, u1, gain_ws (R,L) each (workspace).  dalpha (R), optional: dL/d(pole) of the smoother before
+ * gparams (R,3); denv, u1 (R,L) each (workspace; the second pass recomputes the gain from u1 instead of reading a
+ * stored copy).  dalpha (R), optional: dL/d(pole) of the smoother before
  * the sigmoid/clamp chain rule, accumulated by the second pass from u1, denv and its own adjoint scan (the D = dU/da
  * scan of core/envelope.py's truncated filter is moved onto the adjoint side, so no third scan is needed). */
 int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
                          const float* log_threshold, const float* log_ratio, const float* log_knee,
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
-                         float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* gain_ws,
-                         float* dalpha, void* stream);
+                         float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* dalpha,
+                         void* stream);
 /* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
  * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,
