@@ -173,6 +173,20 @@ class ApproxNoiseGate(nn.Module):
         return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}
 
 
+class FactorizedCompressor(nn.Module):
+    """Reference dynamics.py:724-739: a constructor only upstream (no ``forward``, no ``parameter_size``) -- kept so
+    that code importing the name keeps working; calling it fails with nn.Module's NotImplementedError, as upstream."""
+
+    def __init__(self, gain_smooth_in_log=False, with_knee=True, frame_len=1024):
+        super().__init__()
+        self.energy_smoother_module = Ballistics()
+        self.gain_smooth_in_log = gain_smooth_in_log
+        self.with_knee = with_knee
+        self.frame_len = frame_len
+        self.stride = frame_len // 2
+        self.register_buffer("window", torch.hann_window(frame_len))
+
+
 # ---- envelope followers (reference dynamics.py:1053-1117) ----------------------------------------------
 class BaseEnvelopeFollower(nn.Module):
     """log(smoother(loudness) + 1e-5) with loudness = channel-mean energy or amplitude; the smoother is one of
