@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--reference-default-args", action="store_true",
                     help="build the processors with upstream's constructor defaults (flashfftconv=True, 4000/16384/60000 taps): "
                          "the FlashFFTConv flavour, i.e. plain causal convolutions; not the headline configuration")
+    ap.add_argument("--capture", action="store_true",
+                    help="replay the render as one captured HIP graph (grafx_amd.render.CapturedRender): the serving "
+                         "path for small batches, where the eager loop is host-bound")
     ap.add_argument("--train", action="store_true",
                     help="also time forward+backward+gradient all-reduce (BASELINE configs[4]) at --train-batch per GPU")
     ap.add_argument("--train-batch", type=int, default=256, help="graphs per GPU in the training step (configs[4]: 256)")
@@ -171,7 +174,11 @@ def main():
     x = torch.randn(B, 32, 2, L, device=dev)
     rd_dev = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
 
+    captured = []
+
     def step():
+        if captured:
+            return captured[0]()[0]
         with torch.no_grad():
             return render_grafx(procs, x, params, rd_dev, parameters_grad=False)[0]
 
@@ -183,6 +190,10 @@ def main():
     with torch.no_grad():  # one single-graph render: loads every kernel's code object and builds the per-device tables
         render_grafx(procs, x[:1], params, rd_dev, parameters_grad=False)
     torch.cuda.synchronize()
+    if args.capture:
+        from grafx_amd.render import CapturedRender
+
+        captured.append(CapturedRender(procs, x, params, rd_dev))
     y = None
     for _ in range(args.warmup):
         y = step()
@@ -301,7 +312,8 @@ def main():
                        "mode": ("forward render, reference-default even lengths (odd L+N-1: aliasing compatibility path)"
                                 if args.reference_default_lengths else
                                 "forward render, upstream default constructor arguments (flashfftconv=True: plain causal convolutions)"
-                                if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"), "parallelism": f"batch-shard x{world}"},
+                                if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"), "parallelism": f"batch-shard x{world}",
+                       "launch": "one captured HIP graph per step" if args.capture else "eager render loop"},
             "per_gpu_value": B * L * args.steps / elapsed,
             "roofline": roof,
         }

@@ -4,7 +4,19 @@
 signal buffer (input slice, destination slice) and per-row parameters flattened batch-major
 (B*n, ...), exactly the rows ``forward`` would get.  Processors whose kernels address rows
 through a gfx_rowmap_t read and write the buffer directly; the default falls back to
-``forward`` on a flattened copy."""
+``forward`` on a flattened copy.
+
+``prepare(**params[, _shared_rows]) -> Prepared | None`` (optional): the parameter-only part of ``render_into``
+(filter design, impulse-response synthesis, spectra).  The render loop runs it ahead of time on a side stream,
+under the signal kernels of the earlier stages, and hands the result back as ``render_into(..., _prepared=...)``."""
+
+
+class Prepared:
+    """What ``prepare`` returns: device tensors (so the render can order their lifetime across streams) + scalars."""
+
+    def __init__(self, *tensors, **scalars):
+        self.tensors = tensors
+        self.__dict__.update(scalars)
 
 
 class BufferIO:

@@ -2,8 +2,8 @@
 import torch.nn as nn
 
 from .. import ops
-from .core._buffer_io import BufferIO, expand_shared, shared_reps
-from .core.convolution import convolve
+from .core._buffer_io import BufferIO, Prepared, expand_shared, shared_reps
+from .core.convolution import convolve, convolve_taps
 from .core.fir import ZeroPhaseFilterBankFIR, ZeroPhaseFIR
 from .core.geq import GraphicEqualizerBiquad
 from .. import autograd as diff
@@ -35,7 +35,18 @@ class ParametricEqualizer(BufferIO, nn.Module):
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As, shared_rows=_shared_rows, final=True))
         return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows, final=True)
 
-    def render_into(self, x4, out4, tee=None, _shared_rows=None, **params):
+    def prepare(self, w0, q_inv, log_gain, _shared_rows=None):
+        """The parameter-only part of render_into (coefficients -> sampled response -> taps -> tile spectra), so that
+        the render can run it ahead of time on a side stream; None when this configuration has no such split."""
+        if self.processor_channel == "midside" or self.biquad.backend != "fsm" or needs_grad(w0, q_inv, log_gain):
+            return None
+        Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
+        return Prepared(ops.fir_spectrum(self.biquad._taps(Bs, As)), Cf=Bs.shape[1])
+
+    def render_into(self, x4, out4, tee=None, _shared_rows=None, _prepared=None, **params):
+        if _prepared is not None:
+            return convolve_taps(x4, _prepared.tensors[0], self.biquad.fsm_fir_len, _prepared.Cf, "causal", out=out4,
+                                 tee=tee, exact=self.biquad.flashfftconv, h_rows=_shared_rows)
         if self.processor_channel == "midside":
             if tee is not None:
                 tee.copy_(x4)

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from .. import autograd as diff
 from .. import ops
 from ..autograd import needs_grad
-from .core._buffer_io import BufferIO, expand_shared, shared_reps
+from .core._buffer_io import BufferIO, Prepared, expand_shared, shared_reps
 from .core.utils import normalize_impulse
 from .core.convolution import convolve_taps
 from .core.midside import lr_to_ms, ms_to_lr
@@ -86,8 +86,20 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
             return super().render_into(x4, out4, **params)
         return self.forward(x4, _out=out4, _shared_rows=_shared_rows, **params)
 
+    def prepare(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _shared_rows=None):
+        """Impulse-response synthesis + tile spectra (everything before the convolution), for the render's side stream."""
+        if (not self.fixed_noise or self.processor_channel == "midside"
+                or needs_grad(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)):
+            return None
+        ir, gain = self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude,
+                                     self.processor_channel == "pseudo_midside")
+        return Prepared(ops.fir_spectrum(ir.view(ir.shape[0] * 2, self.ir_len), gain=gain, gain_div=2))
+
     def forward(self, input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None, _out=None,
-                _shared_rows=None):
+                _shared_rows=None, _prepared=None):
+        if _prepared is not None:
+            return convolve_taps(input_signals, _prepared.tensors[0], self.ir_len, 2, "causal", out=_out,
+                                 exact=self.flashfftconv, h_rows=_shared_rows)
         pseudo = self.processor_channel == "pseudo_midside"
         if _shared_rows is not None and (not self.fixed_noise or needs_grad(
                 input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)):

@@ -116,6 +116,16 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+_PREPARE_STREAMS = {}
+
+
+def _prepare_stream(device):
+    key = (device.type, device.index)
+    if key not in _PREPARE_STREAMS:
+        _PREPARE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _PREPARE_STREAMS[key]
+
+
 def _first_order(render_data):
     return 1
 
@@ -225,6 +235,54 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         # falls back to a fresh hipMalloc per step (seen as intermittent 150-800 ms steps).
     copied = False  # has the main stream joined the copy yet?
     out_view = None
+
+    def stage_parameters(step, proc):
+        nonlocal expanded_tree
+        extra = {}
+        if squeeze:
+            params = read_tensor_or_tensor_dict(per_type_parameters[step.node_type], step.parameter_read, dim=0)
+        elif shared_tree is not None and getattr(proc, "accepts_shared_params", False):
+            params = read_tensor_or_tensor_dict(shared_tree[step.node_type], step.parameter_read, dim=0)
+            extra["_shared_rows"] = step.dest_write.idx[1] - step.dest_write.idx[0]
+        else:
+            if expanded_tree is None:
+                expanded_tree = expand_tensor_or_tensor_dict(per_type_parameters, expand=B, dim=0)
+            params = read_tensor_or_tensor_dict(expanded_tree[step.node_type], step.parameter_read, dim=1,
+                                                postprocess=flatten_batch_and_node)
+        common_i = {}
+        if common_parameters is not None:
+            common_i = read_tensor_or_tensor_dict(common_parameters, step.dest_write, dim=node_dim,
+                                                  postprocess=postprocess)
+        return extra, params, common_i
+
+    def prepare_later_stages(after):
+        """Parameter-only work of the stages after `after` (filter design, impulse responses, spectra) on a side
+        stream, under the signal kernels of the earlier stages; -> {order: (Prepared, event)}."""
+        todo = [j for j in range(after + 1, render_data.max_order + 1)
+                if hasattr(processors[render_data.iter_list[j].node_type] if render_data.iter_list[j].node_type in processors
+                           else None, "prepare")]
+        if not todo:
+            return {}
+        # parameter views (and, where a processor needs them, the batch-expanded copies) are made on the main stream
+        args = {j: stage_parameters(render_data.iter_list[j], processors[render_data.iter_list[j].node_type]) for j in todo}
+        prep = _prepare_stream(x.device)
+        prep.wait_stream(main)  # the parameters may have been produced on the caller's stream
+        ready = {}
+        with torch.cuda.stream(prep):
+            for j in todo:
+                proc_j = processors[render_data.iter_list[j].node_type]
+                extra_j, params_j, common_j = args[j]
+                state = proc_j.prepare(**extra_j, **params_j, **common_j)
+                if state is None:
+                    continue
+                for tns in state.tensors:  # allocated on the side stream, read on the main one
+                    tns.record_stream(main)
+                event = torch.cuda.Event()
+                event.record(prep)
+                ready[j] = (state, event)
+        return ready
+
+    prepared = None
     for i in range(1, render_data.max_order + 1):
         step = render_data.iter_list[i]
         d0, d1 = step.dest_write.idx
@@ -249,25 +307,17 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         else:
             x_view = _gather(ops, buf, plan, torch.empty(B, plan[2], C, L, device=x.device))
         proc = processors[node_type]
-        extra = {}
-        if squeeze:
-            params = read_tensor_or_tensor_dict(per_type_parameters[node_type], step.parameter_read, dim=0)
-        elif shared_tree is not None and getattr(proc, "accepts_shared_params", False):
-            params = read_tensor_or_tensor_dict(shared_tree[node_type], step.parameter_read, dim=0)
-            extra["_shared_rows"] = d1 - d0
-        else:
-            if expanded_tree is None:
-                expanded_tree = expand_tensor_or_tensor_dict(per_type_parameters, expand=B, dim=0)
-            params = read_tensor_or_tensor_dict(expanded_tree[node_type], step.parameter_read, dim=1,
-                                                postprocess=flatten_batch_and_node)
-        common_i = {}
-        if common_parameters is not None:
-            common_i = read_tensor_or_tensor_dict(common_parameters, step.dest_write, dim=node_dim,
-                                                  postprocess=postprocess)
+        extra, params, common_i = stage_parameters(step, proc)
         if teed is not None and i == _first_order(render_data):
             a, b = teed
             extra["tee"] = buf.narrow(1, a, b - a)
+        if prepared is not None and i in prepared:
+            state, event = prepared[i]
+            main.wait_event(event)
+            extra["_prepared"] = state
         proc.render_into(x_view, out_view, **extra, **params, **common_i)
+        if prepared is None:  # the first processor stage is on its way: now design the later ones underneath it
+            prepared = prepare_later_stages(i)
     if side is not None and not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:
