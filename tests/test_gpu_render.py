@@ -80,3 +80,38 @@ def test_batch_shared_parameters_equal_expanded_parameters():
             assert (a - b).abs().max() <= 2e-6 * b.abs().max(), type(m).__name__
         else:
             assert torch.equal(a, b), type(m).__name__
+
+
+@pytest.mark.gpu
+def test_prepared_stage_state_gives_the_same_output_as_the_inline_design():
+    """prepare() + render_into(_prepared=...) (what the render's side stream does) vs. render_into alone."""
+    import torch
+
+    import grafx_amd.processors as P
+
+    torch.manual_seed(9)
+    B, n, L = 2, 3, 30000
+    x4 = torch.randn(B, n, 2, L, device="cuda")
+    cases = [
+        (P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=2049),
+         {k: 0.3 * torch.randn(n, 1, 6, device="cuda") for k in ("w0", "q_inv", "log_gain")}),
+        (P.ParametricEqualizer(num_filters=4, processor_channel="stereo"),   # upstream default lengths / flashfftconv
+         {k: 0.3 * torch.randn(n, 2, 4, device="cuda") for k in ("w0", "q_inv", "log_gain")}),
+        (P.STFTMaskedNoiseReverb(ir_len=9001, flashfftconv=False),
+         {"init_log_magnitude": torch.randn(n, 2, 193, device="cuda"), "delta_log_magnitude": torch.randn(n, 2, 193, device="cuda")}),
+    ]
+    for m, p in cases:
+        m = m.cuda()
+        a, b = torch.empty_like(x4), torch.empty_like(x4)
+        with torch.no_grad():
+            state = m.prepare(_shared_rows=n, **p)
+            assert state is not None
+            m.render_into(x4, a, _shared_rows=n, _prepared=state, **p)
+            m.render_into(x4, b, _shared_rows=n, **p)
+        if isinstance(m, P.STFTMaskedNoiseReverb):  # its energy normalisation accumulates with atomics
+            assert (a - b).abs().max() <= 2e-6 * b.abs().max()
+        else:
+            assert torch.equal(a, b), type(m).__name__
+    # configurations without a parameter-only split say so
+    assert P.ParametricEqualizer(num_filters=3, processor_channel="midside", flashfftconv=False, fsm_fir_len=257).cuda().prepare(
+        **{k: torch.zeros(n, 2, 3, device="cuda") for k in ("w0", "q_inv", "log_gain")}) is None
