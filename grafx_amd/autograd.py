@@ -147,14 +147,115 @@ def convolve(x, h, mode="causal", exact=False, final=False):
 
 
 # ----------------------------------------------------------------------------------------- front-ends
+_CHIRPS = {}
+
+
+def _irfft_odd(resp, N):
+    """irfft(resp, n=N) for odd N as a chirp-z transform on power-of-two FFTs (differentiable torch ops).
+
+    The FFT library runs odd lengths through its own Bluestein plans, which cannot be recorded into a HIP graph;
+    spelled out here, the training step stays capturable.  With w_j = exp(i pi j^2 / N) (angles reduced in integer
+    arithmetic, evaluated in float64):  x[n] = (2/N) Re( w_n * sum_k (b_k X[k] w_k) conj(w_{n-k}) ),  b_0 = 1/2."""
+    M = N // 2
+    P2 = 1 << (N + M - 1).bit_length()
+    key = (N, resp.device.type, resp.device.index)
+    if key not in _CHIRPS:
+        j = torch.arange(-M, N, dtype=torch.int64)
+        w = torch.polar(torch.ones(j.numel(), dtype=torch.float64), math.pi * ((j * j) % (2 * N)).double() / N)
+        v = torch.zeros(P2, dtype=torch.complex128)
+        v[:N] = w[M:].conj()
+        v[P2 - M:] = w[:M].conj()
+        scale = torch.full((M + 1,), 1.0, dtype=torch.float64)
+        scale[0] = 0.5
+        _CHIRPS[key] = ((w[M : 2 * M + 1] * scale).to(torch.complex64).to(resp.device),       # b_k w_k
+                        torch.fft.fft(v).to(torch.complex64).to(resp.device),                  # FFT of conj(w_{j})
+                        (w[M:] * (2.0 / N)).to(torch.complex64).to(resp.device))               # (2/N) w_n
+    wk, V, wn = _CHIRPS[key]
+    S = torch.fft.ifft(torch.fft.fft(resp * wk, n=P2, dim=-1) * V, dim=-1)[..., :N]
+    return (S * wn).real
+
+
 def fsm_fir(Bs, As, fir_len):
     """core/iir.py:147-150, 263-276: sampled cascade response -> irfft(n=N)."""
     d = torch.arange(Bs.shape[-1], device=Bs.device)
     k = torch.arange(fir_len // 2 + 1, device=Bs.device)
     phase = (d[:, None] * k[None, :]).to(Bs.dtype) / fir_len * 2 * math.pi
     delays = torch.exp(-1j * phase)
-    resp = ((Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)).prod(-2)
+    sections = (Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)
+    resp = sections[..., 0, :]
+    for i in range(1, sections.shape[-2]):  # not .prod(): its backward asks the host whether any factor is zero
+        resp = resp * sections[..., i, :]
+    if fir_len % 2 == 1 and resp.is_cuda:
+        return _irfft_odd(resp, fir_len)
     return torch.fft.irfft(resp, dim=-1, n=fir_len)
+
+
+class PeqCoeffsFn(torch.autograd.Function):
+    """eq.py:291-314 + filter.py:593-754 as one native kernel each way (gfx_peq_coeffs_f32 / _bwd_f32) instead of the
+    ~40 + ~120 elementwise kernels torch autograd makes of :func:`peq_coefficients`."""
+
+    @staticmethod
+    def forward(ctx, w0, q_inv, log_gain, use_shelving_filters):
+        ctx.save_for_backward(w0, q_inv, log_gain)
+        ctx.shelving = use_shelving_filters
+        return ops.peq_coeffs(w0, q_inv, log_gain, use_shelving_filters)
+
+    @staticmethod
+    def backward(ctx, gBs, gAs):
+        w0, q_inv, log_gain = ctx.saved_tensors
+        gBs = torch.zeros_like(w0).unsqueeze(-1).expand(*w0.shape, 3) if gBs is None else gBs
+        gAs = torch.zeros_like(w0).unsqueeze(-1).expand(*w0.shape, 3) if gAs is None else gAs
+        return (*ops.peq_coeffs_bwd(w0, q_inv, log_gain, gBs, gAs, ctx.shelving), None)
+
+
+_DELAYS = {}
+
+
+def _fsm_delays(N, device):
+    """exp(-j 2 pi d k / N), d = 0..2, k = 0..N//2 with the float32 phase upstream uses (core/iir.py:263-276)."""
+    key = (N, device.type, device.index)
+    if key not in _DELAYS:
+        d = torch.arange(3, device=device)
+        k = torch.arange(N // 2 + 1, device=device)
+        _DELAYS[key] = torch.exp(-1j * ((d[:, None] * k[None, :]).to(torch.float32) / N * 2 * math.pi))
+    return _DELAYS[key]
+
+
+class FsmFirFn(torch.autograd.Function):
+    """(R,Cf,K,3) biquad coefficients -> (R,Cf,N) frequency-sampled taps (core/iir.py:147-150): forward is the native
+    response + Bluestein kernel; backward is written out (a dozen batched complex ops instead of autograd's ~80):
+
+        h = irfft(resp),  resp = prod_i num_i / den_i,  num_i = sum_d B[i,d] D_d
+        dL/dB[i,d] =  Re sum_k conj(G_k) resp_k D_d[k] / num_i[k],   G = (c_k / N) rfft(dL/dh),  c = (1, 2, 2, ...)
+        dL/dA[i,d] = -Re sum_k conj(G_k) resp_k D_d[k] / den_i[k]
+    """
+
+    @staticmethod
+    def forward(ctx, Bs, As, N, plan):
+        ctx.save_for_backward(Bs, As)
+        ctx.N = N
+        R, Cf = Bs.shape[0], Bs.shape[1]
+        return ops.iir_fsm_fir(Bs, As, N, plan).view(R, Cf, N)
+
+    @staticmethod
+    def backward(ctx, gh):
+        Bs, As = ctx.saved_tensors
+        N = ctx.N
+        D = _fsm_delays(N, Bs.device)                      # (3, F)
+        num, den = Bs.to(torch.complex64) @ D, As.to(torch.complex64) @ D   # (R,Cf,K,F)
+        sections = num / den
+        resp = sections[..., 0, :]
+        for i in range(1, sections.shape[-2]):
+            resp = resp * sections[..., i, :]
+        G = torch.fft.rfft(gh, n=N, dim=-1) * (2.0 / N)
+        G[..., 0] = G[..., 0] * 0.5
+        if N % 2 == 0:
+            G[..., -1] = G[..., -1] * 0.5
+        T = (G.conj() * resp).unsqueeze(-2)                # (R,Cf,1,F)
+        Dt = D.transpose(0, 1).contiguous()                # (F, 3)
+        gB = ((T / num) @ Dt).real if ctx.needs_input_grad[0] else None
+        gA = -((T / den) @ Dt).real if ctx.needs_input_grad[1] else None
+        return gB, gA, None, None
 
 
 def peq_coefficients(w0, q_inv, log_gain, use_shelving_filters=True):

@@ -177,6 +177,49 @@ __global__ void peq_coeffs_kernel(const float* __restrict__ w0, const float* __r
     As[3 * i + 2] = a2;
 }
 
+// Backward of peq_coeffs_kernel: (gBs, gAs) -> (g w0, g q_inv, g log_gain), one thread per (row-channel, band).
+// Partials with respect to the intermediates (A, cos w, alpha, s = 2 sqrt(A) alpha), then the activations' chain rule:
+//   A = exp(log_gain), alpha = sin(w) exp(q_inv) / 2, w = pi sigmoid(w0).
+__global__ void peq_coeffs_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ q_inv,
+                                      const float* __restrict__ log_gain, const float* __restrict__ gBs,
+                                      const float* __restrict__ gAs, float* __restrict__ gw0, float* __restrict__ gq,
+                                      float* __restrict__ glg, int64_t n, int K, int shelving) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int band = (int)(i % K);
+    const float pi32 = 3.14159274101257324219f;
+    const float sig = 1.0f / (1.0f + expf(-w0[i]));
+    const float w = pi32 * sig;
+    const float qi = expf(q_inv[i]);
+    const float A = expf(log_gain[i]);
+    float sw, cw;
+    sincosf(w, &sw, &cw);
+    const float alpha = sw * qi * 0.5f;
+    const float gb0 = gBs[3 * i], gb1 = gBs[3 * i + 1], gb2 = gBs[3 * i + 2];
+    const float ga0 = gAs[3 * i], ga1 = gAs[3 * i + 1], ga2 = gAs[3 * i + 2];
+    float dA, dcw, dal;  // dL/dA, dL/dcos(w), dL/dalpha
+    const bool low = shelving && band == 0, high = shelving && band == K - 1;
+    if (low || high) {
+        const float sg = low ? 1.0f : -1.0f;
+        const float ap1 = A + 1.0f, am1 = A - 1.0f, rA = sqrtf(A);
+        const float s = 2.0f * rA * alpha;
+        const float e = ap1 - sg * am1 * cw;   // shared term of b0, b2
+        const float ds = A * (gb0 - gb2) + (ga0 - ga2);                    // dL/ds
+        dA = gb0 * ((e + s) + A * (1.0f - sg * cw)) + gb1 * sg * 2.0f * ((am1 - sg * ap1 * cw) + A * (1.0f - sg * cw)) +
+             gb2 * ((e - s) + A * (1.0f - sg * cw)) + (ga0 + ga2) * (1.0f + sg * cw) - ga1 * sg * 2.0f * (1.0f + sg * cw) +
+             ds * alpha / rA;
+        dcw = -(gb0 + gb2) * A * sg * am1 - gb1 * 2.0f * A * ap1 + (ga0 + ga2) * sg * am1 - ga1 * 2.0f * ap1;
+        dal = ds * 2.0f * rA;
+    } else {
+        dA = alpha * (gb0 - gb2) - alpha / (A * A) * (ga0 - ga2);
+        dcw = -2.0f * (gb1 + ga1);
+        dal = A * (gb0 - gb2) + (ga0 - ga2) / A;
+    }
+    glg[i] = dA * A;
+    gq[i] = dal * alpha;
+    gw0[i] = (-dcw * sw + dal * cw * qi * 0.5f) * pi32 * sig * (1.0f - sig);
+}
+
 // BiquadFilter: filter.py:144-153.
 __global__ void biquad_coeffs_kernel(const float* __restrict__ Bin, const float* __restrict__ A1_pre,
                                      const float* __restrict__ A2_pre, const float* __restrict__ A0,
@@ -239,6 +282,16 @@ int gfx_peq_coeffs_f32(const float* w0, const float* q_inv, const float* log_gai
     const int64_t total = n * K;
     hipLaunchKernelGGL(peq_coeffs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w0,
                        q_inv, log_gain, Bs, As, n, (int)K, use_shelving);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_peq_coeffs_bwd_f32(const float* w0, const float* q_inv, const float* log_gain, const float* gBs, const float* gAs,
+                           float* gw0, float* gq_inv, float* glog_gain, int64_t n, int64_t K, int use_shelving,
+                           void* stream) {
+    if (!w0 || !q_inv || !log_gain || !gBs || !gAs || !gw0 || !gq_inv || !glog_gain || n <= 0 || K <= 0) return GFX_EINVAL;
+    const int64_t total = n * K;
+    hipLaunchKernelGGL(peq_coeffs_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w0,
+                       q_inv, log_gain, gBs, gAs, gw0, gq_inv, glog_gain, n, (int)K, use_shelving);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

@@ -177,6 +177,20 @@ def peq_coeffs(w0, q_inv, log_gain, use_shelving=True):
     return Bs, As
 
 
+def peq_coeffs_bwd(w0, q_inv, log_gain, gBs, gAs, use_shelving=True):
+    """Gradient of :func:`peq_coeffs` -> (g_w0, g_q_inv, g_log_gain), each shaped like w0."""
+    _require_gpu(w0, q_inv, log_gain, gBs, gAs)
+    w0, q_inv, log_gain = w0.contiguous(), q_inv.contiguous(), log_gain.contiguous()
+    _expect(gBs, (*w0.shape, 3), "peq_coeffs_bwd: gBs")
+    _expect(gAs, (*w0.shape, 3), "peq_coeffs_bwd: gAs")
+    K = w0.shape[-1]
+    out = [torch.empty_like(w0) for _ in range(3)]
+    check(lib().gfx_peq_coeffs_bwd_f32(_ptr(w0), _ptr(q_inv), _ptr(log_gain), _ptr(gBs.contiguous()), _ptr(gAs.contiguous()),
+                                       *(_ptr(o) for o in out), w0.numel() // K, K, int(use_shelving), _stream()),
+          "gfx_peq_coeffs_bwd_f32")
+    return tuple(out)
+
+
 def biquad_coeffs(Bs_in, A1_pre, A2_pre, A0=None):
     _require_gpu(Bs_in, A1_pre, A2_pre, A0)
     Bs_in, A1_pre, A2_pre = Bs_in.contiguous(), A1_pre.contiguous(), A2_pre.contiguous()

@@ -87,8 +87,11 @@ class IIRFilter(nn.Module):
             tee = None
         if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
             # a strided (B,n,C,L) view goes through as it is (the native convolution reads it in place)
-            y = diff.convolve(input_signal, diff.fsm_fir(Bs, As, self.fsm_fir_len), "causal", exact=self.flashfftconv,
-                              final=final)
+            if self.fsm_fir_len <= self.FSM_NATIVE_MAX:  # native taps, written-out backward
+                h = diff.FsmFirFn.apply(Bs, As, self.fsm_fir_len, self._plan(Bs.device))
+            else:
+                h = diff.fsm_fir(Bs, As, self.fsm_fir_len)
+            y = diff.convolve(input_signal, h, "causal", exact=self.flashfftconv, final=final)
             if out is None:
                 return y
             out.copy_(y.view(out.shape))

@@ -27,8 +27,12 @@ class ParametricEqualizer(BufferIO, nn.Module):
     accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
 
     def forward(self, input_signals, w0, q_inv, log_gain, _out=None, _tee=None, _shared_rows=None):
+        if self.use_shelving_filters and self.num_filters < 2:
+            # upstream splits the bands [1, K-2, 1] (eq.py:254, 300-302): torch.split rejects the negative size
+            raise RuntimeError(f"split expects non-negative sizes, got [1, {self.num_filters - 2}, 1]: "
+                               "shelving filters need num_filters >= 2")
         if needs_grad(input_signals, w0, q_inv, log_gain):
-            Bs, As = diff.peq_coefficients(w0, q_inv, log_gain, self.use_shelving_filters)
+            Bs, As = diff.PeqCoeffsFn.apply(w0, q_inv, log_gain, self.use_shelving_filters)
         else:
             Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)
         if self.processor_channel == "midside":

@@ -32,6 +32,7 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         if processor_channel not in ("mono", "stereo", "midside", "pseudo_midside"):
             raise ValueError(f"Invalid processor_channel: {processor_channel}")
         self._basis = {}
+        self._envelope = {}  # overlap-added squared window per (device, frames), for _istft
 
     def get_fixed_noise(self):
         """One-time constant, built exactly like upstream (reverb.py:101-114): RandomState(0) uniform
@@ -73,11 +74,37 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         noise_stft = self.noise_stft if self.fixed_noise else self.sample_noise(logmag.shape[0], logmag.device)
         spec = noise_stft * torch.exp(logmag / 8)
         R = spec.shape[0]
-        ir = torch.istft(spec.reshape(R * 2, self.num_bins, self.num_frames), n_fft=self.n_fft,
-                         hop_length=self.hop_length, window=self.window, length=self.ir_len)
-        return ir.view(R, 2, self.ir_len)
+        return self._istft(spec.reshape(R * 2, self.num_bins, self.num_frames)).view(R, 2, self.ir_len)
+
+    def _istft(self, spec):
+        """torch.istft(center=True, length=ir_len) spelled out (windowed inverse frames, overlap-add, division by the
+        overlap-added squared window, trim): same arithmetic, but without istft's host-side envelope check, so that a
+        training step can be captured into a HIP graph."""
+        n_fft, hop, T = self.n_fft, self.hop_length, spec.shape[-1]
+        total = n_fft + hop * (T - 1)
+        frames = torch.fft.irfft(spec, n=n_fft, dim=-2) * self.window[:, None]
+        y = self._overlap_add(frames.transpose(-1, -2))
+        key = (spec.device.type, spec.device.index, T)
+        if key not in self._envelope:
+            self._envelope[key] = self._overlap_add((self.window * self.window).expand(1, T, n_fft))[0]
+        a = n_fft // 2
+        return y[:, a : a + self.ir_len] / self._envelope[key][a : a + self.ir_len]
+
+    def _overlap_add(self, frames):
+        """(R, T, n_fft) frames -> (R, n_fft + hop (T - 1)) with n_fft a multiple of hop: the q-th hop-sized piece of
+        frame m lands in output block m + q, i.e. n_fft / hop shifted slice additions over the whole batch (F.fold
+        would do the same, but its backward runs one im2col kernel per row)."""
+        R, T, n_fft = frames.shape
+        hop = self.hop_length
+        pieces = n_fft // hop
+        assert pieces * hop == n_fft
+        out = frames.new_zeros(R, T + pieces - 1, hop)
+        for q in range(pieces):
+            out[:, q : q + T] = out[:, q : q + T] + frames[:, :, q * hop : (q + 1) * hop]
+        return out.reshape(R, (T + pieces - 1) * hop)
 
     accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
+    accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
 
     def render_into(self, x4, out4, _shared_rows=None, **params):
         if self.processor_channel == "midside":
@@ -101,8 +128,7 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
             return convolve_taps(input_signals, _prepared.tensors[0], self.ir_len, 2, "causal", out=_out,
                                  exact=self.flashfftconv, h_rows=_shared_rows)
         pseudo = self.processor_channel == "pseudo_midside"
-        if _shared_rows is not None and (not self.fixed_noise or needs_grad(
-                input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)):
+        if _shared_rows is not None and not self.fixed_noise:  # a noise per row: one parameter row per signal row
             reps = shared_reps(input_signals, _shared_rows)
             init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude = (
                 expand_shared(t, reps) for t in (init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude))
@@ -111,15 +137,20 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
                                               gain_env_log_magnitude):
             # per-row noise (fixed_noise=False) and training: mask + istft as torch ops on the GPU (R x 193 x 313),
             # the convolution below is native either way
-            x = input_signals.reshape(-1, *input_signals.shape[-2:])
+            # the impulse responses are synthesised once per parameter row (per node when the batch shares them) and
+            # the native convolution lets every batch row read them; a strided (B, n, C, L) view is read in place
             ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
             if pseudo:
-                y = diff.convolve(x, normalize_impulse(ms_to_lr(ir)), "causal", exact=self.flashfftconv, final=True)
+                y = diff.convolve(input_signals, normalize_impulse(ms_to_lr(ir)), "causal", exact=self.flashfftconv,
+                                  final=True)
             elif self.processor_channel == "midside":
-                y = ms_to_lr(diff.convolve(lr_to_ms(x), normalize_impulse(ir), "causal", exact=self.flashfftconv,
-                                           final=True))
+                x = input_signals.reshape(-1, *input_signals.shape[-2:])
+                h = normalize_impulse(ir)
+                if h.shape[0] != x.shape[0]:
+                    h = expand_shared(h, x.shape[0] // h.shape[0])
+                y = ms_to_lr(diff.convolve(lr_to_ms(x), h, "causal", exact=self.flashfftconv, final=True))
             else:
-                y = diff.convolve(x, normalize_impulse(ir), "causal", exact=self.flashfftconv, final=True)
+                y = diff.convolve(input_signals, normalize_impulse(ir), "causal", exact=self.flashfftconv, final=True)
             if _out is None:
                 return y
             _out.copy_(y.view(_out.shape))

@@ -128,6 +128,11 @@ int gfx_peq_coeffs_f32(const float* w0, const float* q_inv, const float* log_gai
                        int64_t n, int64_t K, int use_shelving, void* stream);
 int gfx_biquad_coeffs_f32(const float* Bin, const float* A1_pre, const float* A2_pre, const float* A0,
                           float* Bs, float* As, int64_t n, void* stream);
+/* autograd of gfx_peq_coeffs_f32: (dL/dBs, dL/dAs) (n, K, 3) -> dL/d(w0, q_inv, log_gain) (n, K), the chain rule
+ * through the RBJ formulas and the activations in one elementwise pass (what torch autograd does with ~120 kernels). */
+int gfx_peq_coeffs_bwd_f32(const float* w0, const float* q_inv, const float* log_gain, const float* gBs,
+                           const float* gAs, float* gw0, float* gq_inv, float* glog_gain,
+                           int64_t n, int64_t K, int use_shelving, void* stream);
 
 /* ---- dynamics ---------------------------------------------------------------------------
  * gfx_dynamics_fused_f32 replaces Compressor.forward / NoiseGate.forward (dynamics.py:361-409,

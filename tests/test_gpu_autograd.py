@@ -203,3 +203,52 @@ def test_compressor_with_ballistics_smoother_trains():
     m(x, **p).square().mean().backward()
     for k, v in p.items():
         assert v.grad is not None and torch.isfinite(v.grad).all() and v.grad.abs().sum() > 0, (k, v.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shelving", [True, False])
+@pytest.mark.parametrize("K", [1, 2, 6])
+def test_native_peq_coefficient_backward_matches_torch_autograd(shelving, K):
+    """gfx_peq_coeffs_bwd_f32 against torch autograd of the same formulas (eq.py:291-314, filter.py:593-754)."""
+    import torch
+
+    from grafx_amd import autograd as diff
+
+    if shelving and K < 2:
+        pytest.skip("upstream splits the bands [1, K-2, 1]: fewer than two bands cannot have shelving filters")
+    torch.manual_seed(K)
+    p = [torch.randn(5, 2, K, device="cuda", requires_grad=True) for _ in range(3)]
+    wB, wA = torch.randn(5, 2, K, 3, device="cuda"), torch.randn(5, 2, K, 3, device="cuda")
+    Bs, As = diff.PeqCoeffsFn.apply(*p, shelving)
+    Bt, At = diff.peq_coefficients(*p, shelving)
+    assert (Bs - Bt).abs().max() <= 1e-5 * Bt.abs().max() and (As - At).abs().max() <= 1e-5 * At.abs().max()
+    got = torch.autograd.grad((Bs * wB).sum() + (As * wA).sum(), p)
+    want = torch.autograd.grad((Bt * wB).sum() + (At * wA).sum(), p)
+    for g, w, name in zip(got, want, ("w0", "q_inv", "log_gain")):
+        assert (g - w).abs().max() <= 2e-5 * w.abs().max(), f"{name}: {(g - w).abs().max().item():.3e} / {w.abs().max().item():.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [64, 513, 4000, 4001])
+def test_fsm_taps_backward_matches_torch_autograd(N):
+    """FsmFirFn (native taps, written-out adjoint) against torch autograd of core/iir.py:147-150 in float64."""
+    import torch
+
+    from grafx_amd import autograd as diff
+    from grafx_amd.processors import IIRFilter
+
+    torch.manual_seed(N)
+    R, Cf, K = 3, 2, 4
+    Bs = (torch.randn(R, Cf, K, 3, device="cuda") * 0.2 + torch.tensor([1.0, 0, 0], device="cuda")).requires_grad_(True)
+    As = (torch.tensor([1.0, -1.2, 0.5], device="cuda").expand(R, Cf, K, 3) + 0.05 * torch.randn(R, Cf, K, 3, device="cuda"))
+    As = As.detach().requires_grad_(True)
+    w = torch.randn(R, Cf, N, device="cuda")
+    f = IIRFilter(flashfftconv=False, fsm_fir_len=N).cuda()
+    h = diff.FsmFirFn.apply(Bs, As, N, f._plan(Bs.device))
+    B64, A64 = Bs.detach().double().requires_grad_(True), As.detach().double().requires_grad_(True)
+    h64 = diff.fsm_fir(B64, A64, N)
+    assert (h - h64.float()).abs().max() <= 1e-5 * h64.abs().max()
+    got = torch.autograd.grad((h * w).sum(), (Bs, As))
+    want = torch.autograd.grad((h64 * w.double()).sum(), (B64, A64))
+    for g, wv, name in zip(got, want, ("Bs", "As")):
+        assert (g - wv.float()).abs().max() <= 2e-4 * wv.abs().max(), f"{name}: {(g - wv.float()).abs().max().item():.3e}"
