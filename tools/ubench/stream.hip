@@ -1,5 +1,5 @@
 // Streaming-copy variants on gfx950: what bandwidth can a read+write kernel reach on this box?
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench/stream.hip -o /tmp/stream && /tmp/stream
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/stream.hip -o tools/ubench/bin/stream && tools/ubench/bin/stream
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
