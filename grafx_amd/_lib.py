@@ -29,6 +29,7 @@ SIGNATURES = {
     "gfx_fir_spectrum_bytes_ex": (sz, [i64, i64, i64]),
     "gfx_fftconv_workspace_bytes_ex": (sz, [i64, i64, i64, i64, i64, i64, i64]),
     "gfx_fir_spectrum_ex_f32": (ctypes.c_int, [f32p, f32p, i64, vp, i64, i64, i64, vp]),
+    "gfx_fir_grad_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, i64, i64, i64, i64, i64, i64, i64, vp]),
     "gfx_fir_spectrum_rev_f32": (ctypes.c_int, [f32p, RowMap, i64, i64, i64, i64, vp, vp]),
     "gfx_fftconv_tee_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_iir_fsm_plan_bytes": (sz, [i64]),

@@ -107,9 +107,13 @@ class LinearConvFn(torch.autograd.Function):
                     gx = gx.sum(1, keepdim=True)
                 gx = gx.view(x.shape)
         if ctx.needs_input_grad[1]:
-            P = ops.part_len_for(L, N)  # long signal as the filter, N outputs: fewer, longer partitions
-            # the reversed signal is the filter of this correlation; its spectra are taken from x in place
-            gh = ops.fftconv(g, ops.fir_spectrum_reversed(x, part_len=P), L, Cin, Lout=N, off=L - 1 - off, part_len=P)
+            if N <= 8193 and abs(off) <= 8192:  # short filter: tile-wise correlation, x and g read once
+                gh = ops.fir_grad(x, g, N, off)
+            else:
+                P = ops.part_len_for(L, N)  # long signal as the filter, N outputs: fewer, longer partitions
+                # the reversed signal is the filter of this correlation; its spectra are taken from x in place
+                gh = ops.fftconv(g, ops.fir_spectrum_reversed(x, part_len=P), L, Cin, Lout=N, off=L - 1 - off,
+                                 part_len=P)
             if gh.shape[1] != Cf:  # one filter shared by both channels
                 gh = gh.sum(1, keepdim=True)
             if Rh != R:  # one filter shared by the batch

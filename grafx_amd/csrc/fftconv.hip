@@ -394,6 +394,75 @@ __global__ __launch_bounds__(TILE_T, 2) void winmac_kernel(const float* __restri
     store_valid(v, yrow, 0, a.O, a.Lout, t);
 }
 
+// Filter gradient of the short-filter convolution, gh[r,c,k] = sum_n g[r,cg,n] x[r,cx,n+off-k], k < N <= 8193, as a
+// tile-wise circular correlation: per tile i the V-sample slice x[iV, iV+V) (zero-padded to the tile) is correlated with
+// the window g[iV-off, iV-off+16384) -- C = conj(X) G, written with the same polyphase product as the convolution
+// (he = conj(Xe), ho = conj(Xo) conj(W^k)) -- and the first N lags of the inverse transform are accumulated in
+// registers over the tiles of the row.  Three transforms per tile, but x and g are read exactly once and nothing
+// else touches memory (the partitioned form writes and re-reads 12.5 GB of spectra at the console sizes).
+struct CorrArgs {
+    gfx_rowmap_t xmap, gmap;
+    int64_t L, Lg, off, N, V, ntiles, nblocks;
+    int Cx, Cg, Cout;
+};
+
+__global__ __launch_bounds__(TILE_T, 2) void corr1_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          float* __restrict__ gh, CorrArgs a,
+                                                          const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
+    const int t = threadIdx.x;
+    const unsigned rco = xcd_logical_block();
+    if (rco >= (unsigned)a.nblocks) return;
+    const unsigned r = rco / (unsigned)a.Cout;
+    const int c = (int)(rco - r * (unsigned)a.Cout);
+    const float* xrow = x + row_off(a.xmap, r, a.Cx == 1 ? 0 : c);
+    const float* grow = g + row_off(a.gmap, r, a.Cg == 1 ? 0 : c);
+    TileTw tw;
+    tile_twiddles(tw, twtab, t);
+    constexpr int NA = 17;  // lags 2(t + 256 a), a < 17, cover N <= 8193
+    // the running sum lives in the output row itself (16 KB, L2-resident, owned by this workgroup): no registers
+    const rsrc_t acc = make_rsrc(gh + ((int64_t)r * a.Cout + c) * a.N, a.N * 4);
+    const float sc = 1.0f / (4.0f * TILE_M);
+    for (int64_t i = 0; i < a.ntiles; ++i) {
+        const int64_t s = i * a.V;
+        cx v[32], w[2][16];
+        f4v hreg[H_SLOTS];
+        const int64_t xend = s + a.V < a.L ? s + a.V : a.L;
+        load_window(v, xrow, s, xend, t, 1.0f);            // x[s, s+V), zero beyond: the range check does the masking
+        tile_forward(v, w, tw, lds, t);
+        for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool) {
+            cx xe, xo;
+            pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
+            hreg[slot] = __builtin_shufflevector(cconj(xe) * sc, cmulc(cconj(xo), wk) * sc, 0, 1, 2, 3);
+        });
+        __syncthreads();  // S2 reads of the x transform are done before the g transform's S1 writes
+        load_window(v, grow, s - a.off, a.Lg, t, 1.0f);
+        tile_forward(v, w, tw, lds, t);
+        for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool self) {
+            cx ge, go, ye, yo, za, zb;
+            pair_split(NAT(w, ia), NAT(w, ib), ge, go);
+            pair_product(ge, go, hreg[slot], wk, ye, yo);
+            pair_merge(ye, yo, za, zb);
+            NAT(w, ia) = za;
+            if (!self) NAT(w, ib) = zb;
+        });
+        tile_inverse(w, v, tw, lds, t);   // own S2 rows first; ends on S1 column t = what the next forward writes first
+        // (the range check is per dword: a pair straddling the row end loads a zero and drops the store of its half)
+        if (i != 0) {
+            cx prev[NA];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) prev[q] = buf_load_f2(acc, 8u * (uint32_t)t, 2048u * q);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) v[brev(q, 5)] += prev[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[brev(q, 5)]), acc, 8u * (uint32_t)t, 2048u * q, 0);
+        }
+    }
+}
+
 static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
 
 template <typename K>
@@ -471,6 +540,34 @@ int gfx_fir_spectrum_rev_f32(const float* x, gfx_rowmap_t xmap, int64_t R, int64
     hipLaunchKernelGGL(hspec_kernel<true>, dim3((unsigned)(R * C * g.nparts)), dim3(TILE_T), TILE_LDS_BYTES,
                        (hipStream_t)stream, x, (const float*)nullptr, (int64_t)1, (float4*)Hs, L, (int)g.nparts,
                        g.part_len, xmap, (int)C, tw);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_fir_grad_f32(const float* x, gfx_rowmap_t xmap, const float* g, gfx_rowmap_t gmap, float* gh, int64_t R,
+                     int64_t C_x, int64_t C_g, int64_t L, int64_t Lg, int64_t N, int64_t off, void* stream) {
+    if (!x || !g || !gh || R <= 0 || L <= 0 || Lg <= 0 || N <= 0 || N > TILE_M + 1) return GFX_EINVAL;
+    if (C_x < 1 || C_g < 1 || (C_x != C_g && C_x != 1 && C_g != 1)) return GFX_EINVAL;
+    if (xmap.inner <= 0 || gmap.inner <= 0 || xmap.inner > 0x7fffffffLL || gmap.inner > 0x7fffffffLL) return GFX_EINVAL;
+    if (off < -TILE_M || off > TILE_M) return GFX_EINVAL;  // |window start - tile start| stays within the 32-bit clip math
+    CorrArgs a;
+    a.xmap = xmap;
+    a.gmap = gmap;
+    a.L = L;
+    a.Lg = Lg;
+    a.off = off;
+    a.N = N;
+    a.V = TILE_F - (N & ~int64_t(1));  // tile slice: V + N - 1 <= 16384, V even
+    a.ntiles = (L + a.V - 1) / a.V;
+    a.Cx = (int)C_x;
+    a.Cg = (int)C_g;
+    a.Cout = (int)(C_x > C_g ? C_x : C_g);
+    a.nblocks = R * a.Cout;
+    if (a.nblocks > 0x7ffffff0LL) return GFX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const float2* tw = tile_twiddle_table(st);
+    if (!tw) return GFX_ELAUNCH;
+    if (allow_lds(corr1_kernel)) return GFX_ELAUNCH;
+    hipLaunchKernelGGL(corr1_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, g, gh, a, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

@@ -102,6 +102,21 @@ def fir_spectrum_reversed(x, part_len=0):
     return Hs
 
 
+def fir_grad(x, g, N, off):
+    """gh[r,c,k] = sum_n g[r,cg,n] x[r,cx,n+off-k], k < N <= 8193: the filter gradient of a short-filter convolution
+    in one pass over x and g ((R,C,L) tensors or strided (B,n,C,L) views) -> (R, max(Cx,Cg), N)."""
+    _require_gpu(x, g)
+    xmap, R, Cx, L = rowmap(x)
+    gmap, Rg, Cg, Lg = rowmap(g)
+    if Rg != R:
+        raise ValueError(f"fir_grad: {Rg} gradient rows for {R} signal rows")
+    gh = torch.empty((R, max(Cx, Cg), N), dtype=torch.float32, device=x.device)
+    with _timed("corr1_kernel", 4 * R * (Cx * L + Cg * Lg)):
+        check(lib().gfx_fir_grad_f32(_ptr(x), xmap, _ptr(g), gmap, _ptr(gh), R, Cx, Cg, L, Lg, N, off, _stream()),
+              "gfx_fir_grad_f32")
+    return gh
+
+
 def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     """Whether :func:`fftconv` can also write a copy of its input (gfx_fftconv_tee_f32's conditions)."""
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1

@@ -102,6 +102,11 @@ int gfx_fir_spectrum_ex_f32(const float* h, const float* gain, int64_t gain_div,
  * without materialising x.flip(-1).  Buffer size: gfx_fir_spectrum_bytes_ex(R * C, L, part_len). */
 int gfx_fir_spectrum_rev_f32(const float* x, gfx_rowmap_t xmap, int64_t R, int64_t C, int64_t L, int64_t part_len,
                              void* Hs, void* stream);
+/* Filter gradient of a short-filter convolve() (autograd of core/convolution.py:119-134), N <= 8193 taps:
+ *   gh[r, c, k] = sum_n g[r, c_g, n] x[r, c_x, n + off - k],  k in [0, N),  x zero outside [0, L), g outside [0, Lg)
+ * (channels broadcast 1 <-> 2; gh is (R, max(C_x, C_g), N) contiguous).  One pass over x and g, no workspace. */
+int gfx_fir_grad_f32(const float* x, gfx_rowmap_t xmap, const float* g, gfx_rowmap_t gmap, float* gh,
+                     int64_t R, int64_t C_x, int64_t C_g, int64_t L, int64_t Lg, int64_t N, int64_t off, void* stream);
 int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
                        float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
                        int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,

@@ -184,3 +184,37 @@ def test_reversed_spectra_equal_the_spectra_of_the_flipped_copy(L, N):
     buf = torch.randn(3, 5, 2, L, device="cuda")
     view = buf.narrow(1, 1, 2)
     assert same(ops.fir_spectrum_reversed(view, part_len=P), ops.fir_spectrum(view.flip(-1).reshape(12, L), part_len=P))
+
+
+@pytest.mark.parametrize("L,Lg,N,off,Cx,Cg", [(1, 1, 1, 0, 1, 1), (5, 5, 3, 0, 2, 2), (100, 100, 8, 4, 1, 2), (40000, 40000, 4001, 0, 2, 2),
+                                               (40001, 40001, 4000, 2000, 2, 1), (12384, 12384, 4001, 0, 1, 1),
+                                               (12385, 12385, 4001, 0, 2, 2), (30000, 38192, 8193, 0, 2, 2),
+                                               (131072, 131072, 4001, 0, 2, 2), (9000, 9000, 2, 1, 2, 2)])
+def test_filter_gradient_correlation_matches_float64(L, Lg, N, off, Cx, Cg):
+    """gfx_fir_grad_f32: gh[k] = sum_n g[n] x[n + off - k] against a float64 FFT correlation (ragged tiles, odd
+    lengths, channel broadcast, a 'full' gradient longer than the signal), contiguous rows and buffer views."""
+    from grafx_amd import ops
+
+    torch.manual_seed(L + N)
+    R = 3
+    x = torch.randn(R, Cx, L, device="cuda")
+    g = torch.randn(R, Cg, Lg, device="cuda")
+
+    def reference(x, g):
+        P = L + Lg + N
+        X = torch.fft.rfft(x.double(), n=P)
+        G = torch.fft.rfft(g.double(), n=P)
+        c = torch.fft.irfft(G * X.conj(), n=P)       # c[j] = sum_n g[n + j] x[n]  (circular, P long enough)
+        k = torch.arange(N, device=x.device)
+        return c[..., (k - off) % P]                 # gh[k] = sum_m x[m] g[m - off + k]
+
+    want = reference(x, g).float()
+    got = ops.fir_grad(x, g, N, off)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+    buf = torch.randn(R, 4, Cx, L, device="cuda")
+    view = buf.narrow(1, 1, 2)
+    g4 = torch.randn(R, 2, Cg, Lg, device="cuda")
+    want4 = reference(view.reshape(-1, Cx, L), g4.reshape(-1, Cg, Lg)).float()
+    got4 = ops.fir_grad(view, g4, N, off)
+    assert (got4 - want4).abs().max() <= 2e-5 * want4.abs().max()
