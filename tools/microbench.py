@@ -127,6 +127,13 @@ def main():
             print(f"  tee launch after reading x and the buffer (sum)   {timed(lambda b: (b.sum(), x4.sum()), 1):8.3f} ms")
             print(f"  tee launch after a 2 GB copy              {timed(lambda b: other.copy_(b.narrow(1, 100, 8)), 1):8.3f} ms")
             print(f"  tee launch after writing the buffer tail  {timed(lambda b: b.narrow(1, 64, 47).fill_(1.0), 2):8.3f} ms")
+        if a.what in ("grad",):  # the equaliser's filter gradient: one-pass correlation vs partitioned form
+            g = torch.randn_like(x)
+            ms = timeit(lambda: ops.fir_grad(x, g, 4001, 0), a.iters)
+            print(f"fir_grad (corr1)            R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            Pl = ops.part_len_for(L, 4001)
+            ms = timeit(lambda: ops.fftconv(g, ops.fir_spectrum_reversed(x, part_len=Pl), L, 2, Lout=4001, off=L - 1, part_len=Pl), a.iters)
+            print(f"hspec<rev> + winmac         R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
         if a.what in ("eqx", "all"):
             eqx = P.ParametricEqualizer(num_filters=6, backend="lfilter", flashfftconv=False).to(dev)
             p = {k: 0.1 * torch.randn(R, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
