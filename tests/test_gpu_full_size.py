@@ -132,3 +132,35 @@ def test_time_chunked_dynamics_equals_the_serial_scan(iir_len):
                                                            ("log_threshold", "log_ratio", "log_knee", "z_alpha")),
                                   smoother=1, iir_len=iir_len, knee=knee, gate=gate)
         assert (few - many[:R]).abs().max() <= 1e-5 * many[:R].abs().max(), (knee, gate)
+
+
+def test_headline_batch_256_repeats_the_checked_batch_of_2():
+    """BASELINE configs[3] at its full size (256 graphs, a 30 GB signal buffer: row offsets beyond 2^32 bytes, 180 k
+    workgroups per launch).  Graphs of a batch never interact, so a batch that repeats two graphs 128 times must
+    reproduce -- in every one of its 256 slots, for every node -- what the two graphs give on their own (the batch-2
+    render is the one compared with the oracle sample by sample above)."""
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+
+    G = build_console(32, 4)
+    hip = {"eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=4001).cuda(),
+           "compressor": Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).cuda(),
+           "reverb": STFTMaskedNoiseReverb(ir_len=60001, flashfftconv=False).cuda()}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    params = {t: {k: v.cuda() for k, v in d.items()} for t, d in _params(hip, G, 0.1, 7).items()}
+    torch.manual_seed(8)
+    x2 = torch.randn(2, 32, 2, L, device="cuda")
+    with torch.no_grad():
+        y2, _, buf2 = render_grafx(hip, x2, params, rd)
+        x = x2.repeat(128, 1, 1, 1)
+        y, _, buf = render_grafx(hip, x, params, rd)
+    del x
+    assert y.shape == (256, 1, 2, L) and buf.shape == (256, 111, 2, L)
+    peak = buf2.abs().amax(dim=(0, 2, 3))                      # per node
+    for b in range(0, 256, 2):
+        pair = buf[b : b + 2]
+        assert torch.equal(pair[:, :109], buf2[:, :109]), f"graphs {b}, {b + 1}: a node before the reverb differs"
+        # the reverb's energy normalisation accumulates with float atomics: last-bit differences behind it
+        assert ((pair[:, 109:] - buf2[:, 109:]).abs().amax(dim=(0, 2, 3)) <= 2e-6 * peak[109:]).all(), f"graphs {b}, {b + 1}"
+    assert (y - y2.repeat(128, 1, 1, 1)).abs().max() <= 2e-6 * y2.abs().max()
