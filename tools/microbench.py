@@ -120,6 +120,23 @@ def main():
                 ts.append((e0, e1))
             torch.cuda.synchronize()
             print("  tee launch interleaved with 2 compressor stages: " + " ".join(f"{a_.elapsed_time(b_):.2f}" for a_, b_ in ts))
+            def design():
+                b_, a_ = ops.peq_coeffs(p["w0"], p["q_inv"], p["log_gain"])
+                return ops.fir_spectrum(ops.iir_fsm_fir(b_, a_, 4001, eq.biquad._plan(x.device)).reshape(n, 4001))
+
+            for label, pre in (("2 compressor stages, then the 3 design kernels", True), ("2 compressor stages only", False)):
+                ts = []
+                for i in range(8):
+                    cp.render_into(bufs[0].narrow(1, 32, n), bufs[0].narrow(1, 64, n), _shared_rows=n, **pc)
+                    cp.render_into(bufs[0].narrow(1, 32, n), bufs[0].narrow(1, 64, n), _shared_rows=n, **pc)
+                    H2 = design() if pre else Hs
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.fftconv(x4, H2, 4001, 1, out=bufs[0].narrow(1, 32, n), tee=bufs[0].narrow(1, 0, n), h_rows=n)
+                    e1.record()
+                    ts.append((e0, e1))
+                torch.cuda.synchronize()
+                print(f"  tee launch after {label}: " + " ".join(f"{a_.elapsed_time(b_):.2f}" for a_, b_ in ts))
             print(f"  tee launch, back to back, one buffer      {timed(lambda b: None, 1):8.3f} ms")
             print(f"  tee launch, alternating two buffers       {timed(lambda b: None, 2):8.3f} ms")
             print(f"  tee launch after rewriting the other 30 GB buffer {timed(lambda b: bufs[1].fill_(1.0), 1):8.3f} ms")
