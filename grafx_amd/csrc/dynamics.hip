@@ -219,18 +219,17 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
         }
         if (a.smoother == 1) {
             float u[DE];
-            scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
             if (TRUNC) {
-                float da[DE], db[DE], e2[DE], u2[DE];
+                // ONE scan of e[n] - a^N e[n-N]: the scan is linear, and subtracting before accumulating keeps the
+                // truncation exact where U[n] - a^N U[n-N] would cancel (short filters, poles near one)
+                float da[DE], db[DE];
                 load4(x0, n - a.N, a.L, false, da, s0);
                 if (a.C == 2) load4(x1, n - a.N, a.L, false, db, s0);
 #pragma unroll
                 for (int i = 0; i < DE; ++i)
-                    e2[i] = (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC;
-                scan_tile(p, e2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
-#pragma unroll
-                for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+                    e[i] = fmaf(-p.a_N, (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC, e[i]);
             }
+            scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
             if (tile < t_lo) continue;  // warm-up tile: only the scan state matters (uniform branch)
 #pragma unroll
             for (int i = 0; i < DE; ++i) env[i] = fmaxf(p.one_m_a * u[i], 0.0f);  // relu, envelope.py:48
@@ -308,14 +307,13 @@ __device__ __forceinline__ void onepole_stream(const OnePole& p, const float* u_
         const int64_t n = tile * DTILE + DE * t;
         float e[DE], u[DE];
         load4(u_in, n, L, vi, e);
-        scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
-        if (TRUNC) {
-            float e2[DE], u2[DE];
+        if (TRUNC) {  // one scan of e[n] - a^N e[n-N] (see dyn_stream)
+            float e2[DE];
             load4(u_in, n - N, L, false, e2);
-            scan_tile(p, e2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
 #pragma unroll
-            for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+            for (int i = 0; i < DE; ++i) e[i] = fmaf(-p.a_N, e2[i], e[i]);
         }
+        scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
             u[i] = p.one_m_a * u[i];

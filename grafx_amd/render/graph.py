@@ -503,6 +503,27 @@ class _BufferRenderFn(torch.autograd.Function):
                 else:
                     for k, u in enumerate(uniq):
                         accumulate(u, u + 1, g_src.narrow(1, k, 1))
+        # parameters of stages nothing downstream depends on: upstream's taped loop hands back zeros for them (their
+        # rows are part of the returned buffer), not None -- optimisers treat the two differently
+        # (parameters of a type that has no node in the graph never entered upstream's tape: those stay None)
+        def leaf_indices(spec, acc):
+            if isinstance(spec, int):
+                acc.add(spec)
+            elif hasattr(spec, "items"):
+                for v in spec.values():
+                    leaf_indices(v, acc)
+            return acc
+
+        scheduled = {render_data.iter_list[i].node_type for i in range(1, render_data.max_order + 1)} & set(processors)
+        taped = set()
+        for node_type in scheduled:
+            if hasattr(p_spec, "items") and node_type in p_spec:
+                leaf_indices(p_spec[node_type], taped)
+        if scheduled and c_spec is not None:
+            leaf_indices(c_spec, taped)
+        for j in live:
+            if leaf_grads[j] is None and j in taped:
+                leaf_grads[j] = torch.zeros_like(leaves[j])
         g_x = None
         if ctx.needs_input_grad[1]:
             g_x = settled(0, ctx.n_src)

@@ -139,7 +139,7 @@ def test_fsm_fir_len_beyond_the_native_tile(N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GRAFX_FUZZ_DYN_SEEDS", 64))))
 def test_random_dynamics_configurations_match_the_oracle(seed):
     """Compressor / NoiseGate over random knees, smoothers, lengths (ragged, shorter and longer than the smoother,
     both parities), channel counts and row counts (time-chunked and serial scans) against the CPU oracle."""
