@@ -134,7 +134,7 @@ def test_long_partitions_give_the_same_convolution(Nf, Lout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GRAFX_FUZZ_CONV_SEEDS", 48))))
 def test_random_geometries_match_the_oracle_convolution(seed):
     """Random signal / filter lengths (around the 8193-tap and 16384-sample tile boundaries too), output windows,
     channel broadcasts, shared filters and strided buffer views against the oracle's linear convolution."""

@@ -1,0 +1,101 @@
+"""Randomised processor configurations against the CPU oracle (seed counts: GRAFX_FUZZ_PROC_SEEDS)."""
+import os
+import random
+
+import pytest
+import torch
+
+import oracle
+from conftest import assert_close, assert_parity
+
+pytestmark = pytest.mark.gpu
+SEEDS = int(os.environ.get("GRAFX_FUZZ_PROC_SEEDS", 32))
+
+
+def _run(hip, ref, x, p, what):
+    """Forward through the HIP module and the oracle (fp32 and fp64); where the oracle fails on the shape (the
+    reference's degenerate odd-length cases), the HIP module has to fail as well."""
+    with torch.no_grad():
+        try:
+            ref32 = ref(x, **p)
+        except RuntimeError:
+            with pytest.raises((RuntimeError, ValueError)):
+                hip(x.cuda(), **{k: v.cuda() for k, v in p.items()})
+            return
+        y = hip(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+        ref64 = ref.double()(x.double(), **{k: v.double() for k, v in p.items()}).float()
+    assert_parity(y, ref32, ref64, 2e-5, what)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_parametric_equalizers(seed):
+    import grafx_amd.processors as P
+
+    rng = random.Random(1000 + seed)
+    torch.manual_seed(seed)
+    K = rng.choice([2, 3, 6, 10])
+    ch = rng.choice(["mono", "stereo", "midside"])
+    shelving = rng.random() < 0.7
+    N = rng.choice([64, 257, 1000, 1001, 4000, 4001, 4096])
+    L = rng.choice([5, 1000, 4097, 20000, 20001])
+    R = rng.choice([1, 3, 5])
+    C = 2 if ch != "mono" else rng.choice([1, 2])
+    std = rng.choice([0.1, 0.5, 1.0])
+    hip = P.ParametricEqualizer(num_filters=K, processor_channel=ch, use_shelving_filters=shelving, flashfftconv=False,
+                                fsm_fir_len=N).cuda()
+    ref = oracle.OracleParametricEqualizer(num_filters=K, processor_channel=ch, use_shelving_filters=shelving, fsm_fir_len=N)
+    x = torch.randn(R, C, L)
+    p = {k: std * torch.randn(R, 1 if ch == "mono" else 2, K) for k in ("w0", "q_inv", "log_gain")}
+    _run(hip, ref, x, p, f"PEQ K={K} {ch} shelving={shelving} N={N} L={L} R={R} C={C} std={std}")
+
+
+@pytest.mark.parametrize("seed", range(max(SEEDS // 2, 1)))
+def test_random_stft_reverbs(seed):
+    import grafx_amd.processors as P
+
+    rng = random.Random(2000 + seed)
+    torch.manual_seed(seed)
+    ir_len = rng.choice([200, 385, 3000, 3001, 9000, 20001])
+    ch = rng.choice(["pseudo_midside", "midside", "stereo"])
+    env = rng.random() < 0.3
+    L = rng.choice([1000, 4097, 20000, 20001])
+    R = rng.choice([1, 2, 4])
+    hip = P.STFTMaskedNoiseReverb(ir_len=ir_len, processor_channel=ch, gain_envelope=env, flashfftconv=False).cuda()
+    ref = oracle.OracleSTFTMaskedNoiseReverb(ir_len=ir_len, processor_channel=ch, gain_envelope=env)
+    x = torch.randn(R, 2, L)
+    p = {"init_log_magnitude": torch.randn(R, 2, 193), "delta_log_magnitude": torch.randn(R, 2, 193)}
+    if env:
+        p["gain_env_log_magnitude"] = 0.5 * torch.randn(R, 2, 1 + ir_len // 192)
+    _run(hip, ref, x, p, f"reverb ir_len={ir_len} {ch} env={env} L={L} R={R}")
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_convolution_gradients(seed):
+    """LinearConvFn forward / grad_x / grad_h (short-filter correlation kernel and the partitioned form) against a
+    float64 FFT convolution, over random lengths, offsets, channel broadcasts and shared filters."""
+    from grafx_amd.autograd import LinearConvFn
+
+    rng = random.Random(3000 + seed)
+    torch.manual_seed(seed)
+    L = rng.choice([1, 7, 1000, 4097, 12385, 20000, 33001])
+    N = rng.choice([1, 2, 33, 4000, 4001, 8193, 8194, 12001])
+    C, Cf = rng.choice([(1, 1), (2, 1), (1, 2), (2, 2)])
+    B, n = rng.choice([(1, 1), (2, 2), (3, 1)])
+    shared = rng.random() < 0.5
+    off = rng.choice([0, N // 2, N - 1])
+    Lout = rng.choice([L, L + N - 1 - off])
+    x = torch.randn(B * n, C, L, device="cuda", requires_grad=True)
+    h = (torch.randn(n if shared else B * n, Cf, N, device="cuda") / N**0.5).requires_grad_()
+    w = torch.randn(B * n, max(C, Cf), Lout, device="cuda")
+    y = LinearConvFn.apply(x, h, Lout, off)
+    gx, gh = torch.autograd.grad((y * w).sum(), [x, h])
+    x2, h2 = x.detach().double().requires_grad_(), h.detach().double().requires_grad_()
+    P2 = L + N
+    hx = h2.repeat(B, 1, 1) if shared else h2
+    full = torch.fft.irfft(torch.fft.rfft(x2, n=P2) * torch.fft.rfft(hx, n=P2), n=P2)
+    y2 = full[..., off : off + Lout]
+    gx2, gh2 = torch.autograd.grad((y2 * w.double()).sum(), [x2, h2])
+    what = f"L={L} N={N} C={C} Cf={Cf} B={B} n={n} shared={shared} off={off} Lout={Lout}"
+    assert_close(y.detach().cpu(), y2.detach().float().cpu(), 1e-5, "y " + what)
+    assert_close(gx.cpu(), gx2.float().cpu(), 2e-5, "grad_x " + what)
+    assert_close(gh.cpu(), gh2.float().cpu(), 2e-5, "grad_h " + what)
