@@ -201,3 +201,46 @@ def test_random_recursive_cascades(seed):
     # long cascades of high-Q sections amplify fp32 rounding in ANY evaluation order: the float64 tie-breaker applies
     assert_parity(y, torch.from_numpy(want[np.float32]), torch.from_numpy(want[np.float64]).float(), 2e-5,
                   f"cascade K={K} L={L} R={R} C={C} Cf={Cf}")
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_dynamics_gradients(seed):
+    """Compressor / NoiseGate gradients (native two-pass backward, torch front-ends for the other smoothers) against
+    torch autograd of the float64 oracle."""
+    import grafx_amd.processors as P
+
+    rng = random.Random(7000 + seed)
+    torch.manual_seed(seed)
+    gate = rng.random() < 0.5
+    knee = rng.choice(["hard", "quadratic", "exponential"])
+    es = rng.choice(["iir", "iir", None])   # (the oracle's ballistics is a numpy loop without autograd: tested on its own)
+    iir_len = rng.choice([15, 63, 255, 1023, 4095])
+    L = rng.choice([1024, 1026, 4098, 20000])
+    R, C = rng.choice([(1, 2), (3, 1), (6, 2)])
+    cls, ocls = (P.NoiseGate, oracle.OracleNoiseGate) if gate else (P.Compressor, oracle.OracleCompressor)
+    kw = dict(energy_smoother=es, knee=knee, iir_len=iir_len)
+    hip, ref = cls(flashfftconv=False, **kw).cuda(), ocls(**kw).double()
+    x = torch.randn(R, C, L) * (0.2 + torch.rand(R, 1, 1))
+    p = {"log_threshold": torch.randn(R, 1) - 2, "log_ratio": torch.randn(R, 1)}
+    if knee != "hard":
+        p["log_knee"] = torch.randn(R, 1)
+    if es == "iir":
+        p["z_alpha_pre"] = torch.randn(R, 1) * 2
+    w = torch.randn(R, C, L)
+
+    def grads(mod, dev, dt):
+        xs = x.to(dev, dt).requires_grad_(True)
+        ps = {k: v.to(dev, dt).requires_grad_(True) for k, v in p.items()}
+        y = mod(xs, **ps)
+        leaves = [xs] + list(ps.values())
+        gs = torch.autograd.grad((y * w.to(dev, dt)).sum(), leaves, allow_unused=True)
+        return [torch.zeros_like(v).cpu().double() if g is None else g.detach().cpu().double() for g, v in zip(gs, leaves)]
+
+    got, want = grads(hip, "cuda", torch.float32), grads(ref, "cpu", torch.float64)
+    what = f"gate={gate} knee={knee} energy={es} N={iir_len} L={L} R={R} C={C}"
+    # parameter gradients are sums over 1e3-1e5 samples of terms that partly cancel (the knee width most of all):
+    # measure them against the largest parameter gradient of the draw, not against themselves
+    pscale = max(wv.abs().max().item() for wv in want[1:])
+    for name, g, wv in zip(["x"] + list(p), got, want):
+        scale = max(wv.abs().max().item(), 1e-9) if name == "x" else max(wv.abs().max().item(), 0.05 * pscale, 1e-9)
+        assert (g - wv).abs().max().item() <= 3e-3 * scale, f"{what}: d/d{name} off by {(g - wv).abs().max().item() / scale:.2e}"
