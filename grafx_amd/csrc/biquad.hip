@@ -11,15 +11,10 @@
 // per workgroup, no barriers in the time loop.  The recursion is the linear system s[n] = M s[n-1] + (x[n], 0),
 // M = [[-a1, -a2], [1, 0]], s = (w[n], w[n-1]):
 //   1. each lane runs its 8 samples from a zero state                 -> end state e_t
-//   2. Hillis-Steele scan over the 64 lanes with M^(8*2^d), lane 0 seeded with M^8 * (state entering the tile)
-//                                                                      -> state at the end of every chunk
-//   3. every lane reruns its 8 samples from the true state and applies the numerator; lane 63's end state is the
-//      state entering the next tile.
-// The scan (matrix powers, chunk end states, the carried state) runs in DOUBLE: sections with poles at radius
-// 0.999 have powers and states three orders of magnitude above the signal, and an fp32 scan of them is noisier
-// than it has to be.  (Running the sections in direct form I instead -- the recursion on y, as torchaudio does -- was
-// tried as well and is not better: 31 third-octave sections with poles next to z = 1 then fail.)
-// The per-lane 8-sample recursions -- all of the arithmetic that scales with the signal -- stay fp32.
+//   2. Hillis-Steele scan over the 64 lanes with M^(8*2^d)            -> state at the end of every chunk
+//   3. every lane adds M^(8*lane) * (carry entering the tile), reruns its 8 samples from the true state and
+//      applies the numerator; the tile's end state (lane 63, plus M^512 * carry) is the next carry.
+// Matrix powers are formed in double per (row-channel, section) when the wave starts and live in LDS.
 //
 // ssm_quirk: upstream's "ssm" backend drives the recursive part of every section with the ORIGINAL input
 // instead of the previous section's output (core/iir.py:226-246 index `input_signal`, not `x`); for K = 1
@@ -36,7 +31,7 @@ constexpr int BQ_T = 256;            // threads per workgroup = 4 independent wa
 constexpr int BQ_W = BQ_T / 64;      // row-channels per workgroup
 constexpr int BQ_E = 8;              // samples per lane
 constexpr int BQ_TILE = 64 * BQ_E;   // samples per wave tile
-constexpr int BQ_MAX_K = 32;  // 4 waves x K x 240 B of constants in LDS
+constexpr int BQ_MAX_K = 32;  // 4 waves x K x (160 B constants + 1 KB lane powers) of LDS: 148 KB at K = 32
 
 struct M2 {  // 2x2 matrix, row-major
     float a, b, c, d;
@@ -53,11 +48,13 @@ __device__ __forceinline__ float2 apply(const M2& m, float2 s) {
 }
 
 struct SecConst {       // per (wave, section), in LDS
-    M2d step[6];        // M^(E * 2^d)
+    M2 step[6];         // M^(E * 2^d)
+    M2 wave;            // M^(E * 64)
     float b0, b1, b2, a1, a2, pad0, pad1, pad2;
-    double cx, cy;      // state entering the current tile
+    float2 carry;       // state entering the current tile
+    float2 pad3;
 };
-// LDS: SecConst sec[4][K]
+// LDS: SecConst sec[4][K]; M2 lanepow[4][K][64]
 
 __device__ __forceinline__ int64_t brow_off(const gfx_rowmap_t& m, int64_t r, int c) {
     const unsigned inner = (unsigned)m.inner, rr = (unsigned)r;
@@ -77,6 +74,7 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     SecConst* sec = reinterpret_cast<SecConst*>(smem) + wave * a.K;
+    M2* lanepow = reinterpret_cast<M2*>(reinterpret_cast<SecConst*>(smem) + BQ_W * a.K) + (size_t)wave * a.K * 64;
 
     const int64_t rc = (int64_t)blockIdx.x * BQ_W + wave;
     const bool live = rc < a.total;
@@ -94,18 +92,22 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
         m = mul(m, m);
         m = mul(m, m);
         M2d s = mul(m, m);  // M^8
-        if (lane == 0) {
+        M2d p = {1.0, 0.0, 0.0, 1.0};
 #pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                sec[k].step[d] = s;
-                s = mul(s, s);
-            }
+        for (int d = 0; d < 6; ++d) {
+            if (lane == 0) sec[k].step[d] = narrow(s);
+            if ((lane >> d) & 1) p = mul(p, s);
+            s = mul(s, s);
+        }
+        lanepow[k * 64 + lane] = narrow(p);  // M^(8*lane)
+        if (lane == 0) {
+            sec[k].wave = narrow(s);  // M^512
             sec[k].b0 = B[3 * k] / a0;
             sec[k].b1 = B[3 * k + 1] / a0;
             sec[k].b2 = B[3 * k + 2] / a0;
             sec[k].a1 = a1;
             sec[k].a2 = a2;
-            sec[k].cx = sec[k].cy = 0.0;
+            sec[k].carry = make_float2(0.0f, 0.0f);
         }
     }
     __syncthreads();  // the only barrier: tables written, every wave now works alone
@@ -142,36 +144,28 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
                 s2 = s1;
                 s1 = w;
             }
-            // 2. inclusive scan (double) of the chunk end states across the wave; lane 0 carries the tile's entry state
-            const double cx = q.cx, cy = q.cy;
-            double ix = s1, iy = s2;
-            if (lane == 0) {
-                ix += q.step[0].a * cx + q.step[0].b * cy;
-                iy += q.step[0].c * cx + q.step[0].d * cy;
-            }
+            // 2. inclusive scan of the chunk end states across the wave
+            float2 inc = make_float2(s1, s2);
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
-                const double ux = __shfl_up(ix, 1 << d, 64), uy = __shfl_up(iy, 1 << d, 64);
+                const float ux = __shfl_up(inc.x, 1 << d, 64), uy = __shfl_up(inc.y, 1 << d, 64);
                 if (lane >= (1 << d)) {
-                    const M2d& m = q.step[d];
-                    ix += m.a * ux + m.b * uy;
-                    iy += m.c * ux + m.d * uy;
+                    const float2 m = apply(q.step[d], make_float2(ux, uy));
+                    inc.x += m.x;
+                    inc.y += m.y;
                 }
             }
-            double ex = __shfl_up(ix, 1, 64), ey = __shfl_up(iy, 1, 64);
-            if (lane == 0) {
-                ex = cx;
-                ey = cy;
-            }
-            // 3. lane 63's end state enters the next tile
-            const double nx = __shfl(ix, 63, 64), ny = __shfl(iy, 63, 64);
-            if (lane == 0) {  // same-wave LDS accesses are ordered: read above, write here
-                q.cx = nx;
-                q.cy = ny;
-            }
+            float2 excl = make_float2(__shfl_up(inc.x, 1, 64), __shfl_up(inc.y, 1, 64));
+            if (lane == 0) excl = make_float2(0.0f, 0.0f);
+            // 3. carry: state entering the tile; its successor is lane 63's total plus M^512 * carry
+            const float2 carry = q.carry;
+            const float2 h = apply(lanepow[k * 64 + lane], carry);
+            const float2 adv = apply(q.wave, carry);
+            const float2 next = make_float2(__shfl(inc.x, 63, 64) + adv.x, __shfl(inc.y, 63, 64) + adv.y);
+            if (lane == 0) q.carry = next;  // same-wave LDS accesses are ordered: read above, write here
             // 4. true state before this lane's first sample, rerun, numerator
-            s1 = (float)ex;
-            s2 = (float)ey;
+            s1 = h.x + excl.x;
+            s2 = h.y + excl.y;
             if (!a.quirk) {
 #pragma unroll
                 for (int i = 0; i < BQ_E; ++i) {
@@ -205,7 +199,7 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
 }
 
 static inline size_t bq_lds_bytes(int64_t K) {
-    return (size_t)BQ_W * K * sizeof(SecConst);
+    return (size_t)BQ_W * K * sizeof(SecConst) + (size_t)BQ_W * K * 64 * sizeof(M2);
 }
 static inline bool bq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool bq_map_vec(const gfx_rowmap_t& m) {

@@ -179,7 +179,7 @@ def test_random_recursive_cascades(seed):
     C, Cf = rng.choice([(1, 1), (2, 1), (1, 2), (2, 2)])
     # radius 0.999 only for short cascades: 12-32 random sections that sharp leave the parallel scan (8-sample
     # direct-form-II chunks re-started from a rounded state) 2-5x noisier than the sequential fp32 recursion
-    # (6.6e-5 vs 3.8e-5 at K = 12, 8.7e-4 vs 1.7e-4 at K = 32, both relative to a float64 evaluation)
+    # (8.4e-5 vs 3.8e-5 at K = 12, 1.1e-3 vs 1.7e-4 at K = 32, both relative to a float64 evaluation)
     radius = torch.rand(R, Cf, K) * rng.choice([0.9, 0.99, 0.999] if K <= 6 else [0.9, 0.97])
     theta = torch.rand(R, Cf, K) * 3.0 + 0.05
     As = torch.stack([torch.ones_like(radius), -2 * radius * torch.cos(theta), radius.square()], -1)
