@@ -38,6 +38,10 @@ class Golden:
     def keys(self):
         return self._z.files
 
+    def text(self, k):
+        """A string entry (e.g. the JSON specs of a randomised fixture)."""
+        return str(self._z[k])
+
 
 @pytest.fixture(scope="session")
 def golden():

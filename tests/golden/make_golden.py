@@ -512,6 +512,89 @@ def g12():
     save("g12_recursive_iir", **out)
 
 
+def g13(n_draws=48):
+    """Randomised sweep over the "next" rows: class, constructor options, row count, length and parameter scale drawn at
+    random; inputs, parameters, the reference's fp32 output and its float64 output (stored rounded) per draw.  The spec
+    of every draw (class name + kwargs) travels as JSON so that the GPU test can rebuild the module."""
+    import random
+
+    import grafx.processors as P
+
+    rng = random.Random(13)
+    torch.manual_seed(13)
+    out, specs = {}, []
+    iir = dict(flashfftconv=False)
+    menu = [
+        ("LowPassFilter", lambda: dict(fsm_fir_len=rng.choice([64, 255, 256, 513]), **iir)),
+        ("HighPassFilter", lambda: dict(fsm_fir_len=rng.choice([64, 255, 256, 513]), **iir)),
+        ("BandPassFilter", lambda: dict(fsm_fir_len=rng.choice([64, 255, 256, 513]), **iir)),
+        ("BandRejectFilter", lambda: dict(fsm_fir_len=rng.choice([64, 255, 256, 513]), **iir)),
+        ("AllPassFilter", lambda: dict(fsm_fir_len=rng.choice([64, 255, 256, 513]), **iir)),
+        ("PeakingFilter", lambda: dict(num_filters=rng.choice([1, 3]), fsm_fir_len=rng.choice([255, 513]), **iir)),
+        ("LowShelf", lambda: dict(num_filters=rng.choice([1, 2]), fsm_fir_len=rng.choice([255, 513]), **iir)),
+        ("HighShelf", lambda: dict(num_filters=rng.choice([1, 2]), fsm_fir_len=rng.choice([255, 513]), **iir)),
+        ("StateVariableFilter", lambda: dict(num_filters=rng.choice([1, 2, 4]), fsm_fir_len=rng.choice([255, 513]), **iir)),
+        ("BiquadFilter", lambda: dict(num_filters=rng.choice([1, 3]), normalized=rng.random() < 0.5,
+                                      fsm_fir_len=rng.choice([255, 256, 513]), **iir)),
+        ("ParametricEqualizer", lambda: dict(num_filters=rng.choice([2, 5]), processor_channel=rng.choice(["mono", "stereo", "midside"]),
+                                             use_shelving_filters=rng.random() < 0.5, fsm_fir_len=rng.choice([255, 256, 513]), **iir)),
+        ("GraphicEqualizer", lambda: dict(processor_channel=rng.choice(["mono", "stereo"]), scale=rng.choice(["bark", "third_octave"]),
+                                          fsm_fir_len=1025, **iir)),
+        ("ZeroPhaseFIREqualizer", lambda: dict(num_magnitude_bins=rng.choice([64, 257]))),
+        ("NewZeroPhaseFIREqualizer", lambda: dict(num_frequency_bins=rng.choice([64, 256]),
+                                                  processor_channel=rng.choice(["mono", "stereo", "midside"]))),
+        ("TanhDistortion", lambda: dict(pre_post_gain=rng.random() < 0.5, inverse_post_gain=rng.random() < 0.5,
+                                        remove_dc=rng.random() < 0.5, use_bias=rng.random() < 0.5)),
+        ("PowerDistortion", lambda: dict(max_order=rng.choice([3, 8]), pre_gain=rng.random() < 0.5,
+                                         remove_dc=rng.random() < 0.5, use_tanh=rng.random() < 0.5)),
+        ("ChebyshevDistortion", lambda: dict(max_order=rng.choice([3, 8]), pre_gain=rng.random() < 0.5,
+                                             remove_dc=rng.random() < 0.5, use_tanh=rng.random() < 0.5)),
+        ("SideGainImager", lambda: dict()),
+        ("Compressor", lambda: dict(energy_smoother=rng.choice(["iir", None]), knee=rng.choice(["hard", "quadratic", "exponential"]),
+                                    iir_len=rng.choice([63, 255]), flashfftconv=False)),
+        ("NoiseGate", lambda: dict(energy_smoother=rng.choice(["iir", None]), knee=rng.choice(["hard", "quadratic", "exponential"]),
+                                   iir_len=rng.choice([63, 255]), flashfftconv=False)),
+    ]
+    i = 0
+    while i < n_draws:
+        name, make_kwargs = menu[i % len(menu)] if i < len(menu) else rng.choice(menu)
+        kwargs = make_kwargs()
+        try:
+            m = getattr(P, name)(**kwargs)
+        except TypeError:
+            # constructor option not offered by this class upstream: draw again without it
+            kwargs = {k: v for k, v in kwargs.items() if k in ("flashfftconv", "fsm_fir_len", "num_filters")}
+            m = getattr(P, name)(**kwargs)
+        R, L = rng.choice([1, 2, 3]), rng.choice([500, 1023, 1024, 1025])
+        std = rng.choice([0.1, 0.5, 1.0])
+        x = torch.randn(R, 2, L)
+        sizes = m.parameter_size()
+        p = {k: std * torch.randn(R, *((shp,) if isinstance(shp, int) else tuple(shp))) for k, shp in sizes.items()}
+        if "log_threshold" in p:
+            p["log_threshold"] = p["log_threshold"] - 2
+        try:
+            y = m(x, **p)
+            y64 = m.double()(x.double(), **{k: v.double() for k, v in p.items()})
+        except Exception as e:  # a combination the reference itself rejects: record nothing, draw again
+            print(f"  skipped {name} {kwargs}: {type(e).__name__}")
+            menu = [(n, f) for n, f in menu if n != name] if i < len(menu) else menu
+            i += 1 if i < len(menu) else 0
+            continue
+        y = y[0] if isinstance(y, tuple) else y
+        y64 = y64[0] if isinstance(y64, tuple) else y64
+        tag = f"c{len(specs):02d}"
+        out[f"{tag}_x"], out[f"{tag}_y"], out[f"{tag}_y64"] = x, y, y64.float()
+        for k, v in p.items():
+            out[f"{tag}_p_{k}"] = v
+        specs.append({"tag": tag, "cls": name, "kwargs": kwargs, "params": list(p)})
+        i += 1
+    out["specs"] = np.array(json.dumps(specs))
+    save("g13_random_next_rows", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    g1(); g2(); g3(); g4(); g5(); g6(); g7_g9(); g8(); g10(); g11(); g12()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13):
+        if not only or fn.__name__ in only:
+            fn()
