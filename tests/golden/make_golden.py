@@ -592,9 +592,59 @@ def g13(n_draws=48):
     save("g13_random_next_rows", **out)
 
 
+def g14(n_graphs=24):
+    """Random DAGs through the reference's graph API -> tensors -> the three schedulers -> RenderData, plus the
+    reference's render of each (beam schedule, StereoGain / BiquadFilter nodes, batch 2, 256 samples).  The build
+    recipe of every graph (add / connect calls in order) travels with the expected data."""
+    import random
+
+    rng = random.Random(14)
+    torch.manual_seed(14)
+    meta, arrays = [], {}
+    procs = {"gain": StereoGain(), "biquad": BiquadFilter(num_filters=2, flashfftconv=False, fsm_fir_len=65)}
+    for gi in range(n_graphs):
+        G = GRAFX(config=NodeConfigs(["gain", "biquad"]))
+        recipe, nodes = [], []
+        n_src = rng.randint(1, 4)
+        for _ in range(n_src):
+            nodes.append(G.add("in"))
+            recipe.append(["add", "in"])
+        for _ in range(rng.randint(2, 9)):
+            kind = rng.choice(["gain", "biquad", "gain", "biquad", "mix"])
+            v = G.add(kind)
+            recipe.append(["add", kind])
+            for s in rng.sample(nodes, 1 if kind != "mix" else min(len(nodes), rng.randint(2, 4))):
+                G.connect(s, v)
+                recipe.append(["connect", int(s), int(v)])
+            nodes.append(v)
+        out = G.add("out")
+        recipe.append(["add", "out"])
+        for s in rng.sample(nodes[n_src:], min(rng.randint(1, 3), len(nodes) - n_src)):
+            G.connect(s, out)
+            recipe.append(["connect", int(s), int(out)])
+        entry = {"recipe": recipe, "n_src": n_src, "schedules": {}}
+        for method in ("beam", "greedy", "one-by-one"):
+            G_t = reorder_for_fast_render(convert_to_tensor(G), method=method)
+            entry["schedules"][method] = {"tensor": tensor_json(G_t), "render": render_data_json(prepare_render(G_t))}
+        rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+        params = create_empty_parameters(procs, G, std=0.3)
+        x = torch.randn(2, n_src, 2, 256)
+        y, _, buf = render_grafx(procs, x, params, rd)
+        arrays[f"g{gi:02d}_x"], arrays[f"g{gi:02d}_y"], arrays[f"g{gi:02d}_buf"] = x, y, buf
+        for t, d in params.items():
+            for k, v in d.items():
+                arrays[f"g{gi:02d}_p_{t}_{k}"] = v
+        entry["params"] = {t: list(d) for t, d in params.items()}
+        meta.append(entry)
+    with open(os.path.join(HERE, "g14_random_graphs.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    print("g14_random_graphs.json", os.path.getsize(os.path.join(HERE, "g14_random_graphs.json")) // 1024, "KiB")
+    save("g14_random_graphs", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()

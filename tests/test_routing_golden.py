@@ -174,3 +174,48 @@ def test_mimo_config_indexing():
     assert not cfg.siso_only and cfg.max_num_outlets == 2
     assert cfg.outlet_to_index["xover"] == {"low": 0, "high": 1}
     assert "xover" in str(cfg)
+
+
+# ---- g14: random DAGs built through the reference's graph API (tests/golden/make_golden.py g14) --------------------
+with open(os.path.join(GOLDEN, "g14_random_graphs.json")) as f:
+    RANDOM_GRAPHS = json.load(f)
+
+
+def _rebuild(recipe):
+    G = GRAFX(config=NodeConfigs(["gain", "biquad"]))
+    for op in recipe:
+        if op[0] == "add":
+            G.add(op[1])
+        else:
+            G.connect(op[1], op[2])
+    return G
+
+
+@pytest.mark.parametrize("gi", range(len(RANDOM_GRAPHS)))
+def test_random_graphs_schedule_and_route_bit_exactly(gi):
+    """The same add / connect calls as the reference made, then all three schedulers: tensors, type sequence and every
+    read / aggregate / write descriptor of the RenderData must be identical."""
+    entry = RANDOM_GRAPHS[gi]
+    G = _rebuild(entry["recipe"])
+    for method, want in entry["schedules"].items():
+        G_t = reorder_for_fast_render(convert_to_tensor(G), method=method)
+        assert G_t.node_types.tolist() == want["tensor"]["node_types"], method
+        assert G_t.edge_indices.tolist() == want["tensor"]["edge_indices"], method
+        assert G_t.rendering_orders.tolist() == want["tensor"]["rendering_orders"], method
+        assert list(G_t.type_sequence) == want["tensor"]["type_sequence"], method
+        assert render_json(prepare_render(G_t)) == want["render"], method
+
+
+@pytest.mark.parametrize("gi", range(len(RANDOM_GRAPHS)))
+def test_random_graphs_render_like_the_reference(golden, gi):
+    """Our render loop (with the oracle's StereoGain / BiquadFilter) on the reference's inputs and parameters: the
+    output and every node's signal in the buffer."""
+    g = golden("g14_random_graphs")
+    entry = RANDOM_GRAPHS[gi]
+    G = _rebuild(entry["recipe"])
+    procs = {"gain": oracle.OracleStereoGain(), "biquad": oracle.OracleBiquadFilter(num_filters=2, fsm_fir_len=65)}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    params = {t: {k: g[f"g{gi:02d}_p_{t}_{k}"] for k in ks} for t, ks in entry["params"].items()}
+    y, _, buf = render_grafx(procs, g[f"g{gi:02d}_x"], params, rd)
+    assert_close(y, g[f"g{gi:02d}_y"], 5e-6, "output")
+    assert_close(buf, g[f"g{gi:02d}_buf"], 5e-6, "signal buffer")
