@@ -642,9 +642,66 @@ def g14(n_graphs=24):
     save("g14_random_graphs", **arrays)
 
 
+class TrimmedGain(torch.nn.Module):
+    """A user-defined processor with a per-type parameter and a *common* parameter (render_grafx's
+    common_parameters: one row per node of the graph, whatever its type): y = x * exp(log_gain) * trim."""
+
+    def forward(self, input_signals, log_gain, trim):
+        return input_signals * torch.exp(log_gain)[..., None] * trim[..., None]
+
+    def parameter_size(self):
+        return {"log_gain": 2}
+
+
+def g15(n_graphs=8):
+    """render_grafx with common_parameters (reference render/graph.py:72-75, 132-141), 3-D and 4-D inputs."""
+    import random
+
+    rng = random.Random(15)
+    torch.manual_seed(15)
+    meta, arrays = [], {}
+    procs = {"gain": TrimmedGain(), "trim": TrimmedGain()}
+    for gi in range(n_graphs):
+        G = GRAFX(config=NodeConfigs(["gain", "trim"]))
+        recipe, nodes = [], []
+        n_src = rng.randint(1, 3)
+        for _ in range(n_src):
+            nodes.append(G.add("in"))
+            recipe.append(["add", "in"])
+        for _ in range(rng.randint(2, 7)):
+            kind = rng.choice(["gain", "trim", "mix"])
+            v = G.add(kind)
+            recipe.append(["add", kind])
+            for s in rng.sample(nodes, 1 if kind != "mix" else min(len(nodes), rng.randint(2, 3))):
+                G.connect(s, v)
+                recipe.append(["connect", int(s), int(v)])
+            nodes.append(v)
+        out = G.add("out")
+        recipe.append(["add", "out"])
+        for s in rng.sample(nodes[n_src:], min(2, len(nodes) - n_src)):
+            G.connect(s, out)
+            recipe.append(["connect", int(s), int(out)])
+        G_t = reorder_for_fast_render(convert_to_tensor(G), method="beam")
+        rd = prepare_render(G_t)
+        params = create_empty_parameters(procs, G, std=0.3)
+        common = {"trim": 1.0 + 0.2 * torch.randn(int(rd.num_nodes), 1)}
+        batched = gi % 2 == 0
+        x = torch.randn(2, n_src, 2, 128) if batched else torch.randn(n_src, 2, 128)
+        y, _, buf = render_grafx(procs, x, params, rd, common_parameters=common)
+        tag = f"g{gi:02d}"
+        arrays[f"{tag}_x"], arrays[f"{tag}_y"], arrays[f"{tag}_buf"], arrays[f"{tag}_trim"] = x, y, buf, common["trim"]
+        for t, d in params.items():
+            for k, v in d.items():
+                arrays[f"{tag}_p_{t}_{k}"] = v
+        meta.append({"recipe": recipe, "params": {t: list(d) for t, d in params.items()}})
+    with open(os.path.join(HERE, "g15_common_parameters.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    save("g15_common_parameters", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14):
+    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()

@@ -219,3 +219,36 @@ def test_random_graphs_render_like_the_reference(golden, gi):
     y, _, buf = render_grafx(procs, g[f"g{gi:02d}_x"], params, rd)
     assert_close(y, g[f"g{gi:02d}_y"], 5e-6, "output")
     assert_close(buf, g[f"g{gi:02d}_buf"], 5e-6, "signal buffer")
+
+
+# ---- g15: common_parameters (one row per graph node, handed to every processor) ----------------------------------
+class TrimmedGain(torch.nn.Module):
+    """The user-defined processor the fixture was rendered with: y = x * exp(log_gain) * trim (trim is the common one)."""
+
+    def forward(self, input_signals, log_gain, trim):
+        return input_signals * torch.exp(log_gain)[..., None] * trim[..., None]
+
+    def parameter_size(self):
+        return {"log_gain": 2}
+
+
+with open(os.path.join(GOLDEN, "g15_common_parameters.json")) as f:
+    COMMON_GRAPHS = json.load(f)
+
+
+@pytest.mark.parametrize("gi", range(len(COMMON_GRAPHS)))
+def test_common_parameters_render_like_the_reference(golden, gi):
+    """render/graph.py:72-75, 132-141: common parameters are expanded over the batch and read by destination index;
+    batched (4-D) and unbatched (3-D) inputs alternate in the fixture."""
+    g = golden("g15_common_parameters")
+    entry = COMMON_GRAPHS[gi]
+    G = GRAFX(config=NodeConfigs(["gain", "trim"]))
+    for op in entry["recipe"]:
+        G.add(op[1]) if op[0] == "add" else G.connect(op[1], op[2])
+    procs = {"gain": TrimmedGain(), "trim": TrimmedGain()}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    tag = f"g{gi:02d}"
+    params = {t: {k: g[f"{tag}_p_{t}_{k}"] for k in ks} for t, ks in entry["params"].items()}
+    y, _, buf = render_grafx(procs, g[f"{tag}_x"], params, rd, common_parameters={"trim": g[f"{tag}_trim"]})
+    assert_close(y, g[f"{tag}_y"], 1e-6, "output")
+    assert_close(buf, g[f"{tag}_buf"], 1e-6, "signal buffer")
