@@ -115,3 +115,44 @@ def test_prepared_stage_state_gives_the_same_output_as_the_inline_design():
     # configurations without a parameter-only split say so
     assert P.ParametricEqualizer(num_filters=3, processor_channel="midside", flashfftconv=False, fsm_fir_len=257).cuda().prepare(
         **{k: torch.zeros(n, 2, 3, device="cuda") for k in ("w0", "q_inv", "log_gain")}) is None
+
+
+@pytest.mark.gpu
+def test_hip_processors_next_to_a_user_defined_torch_processor():
+    """A graph that mixes HIP processors with a plain torch module (no render_into): the render takes the generic,
+    upstream-shaped loop and the HIP processors are called through their ordinary forward()."""
+    import torch
+
+    import grafx_amd.processors as P
+    import oracle
+    from grafx_amd.data import GRAFX, NodeConfigs, convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    class Tilt(torch.nn.Module):  # a user's own processor, torch ops only
+        def forward(self, input_signals, slope):
+            ramp = torch.linspace(-1, 1, input_signals.shape[-1], device=input_signals.device)
+            return input_signals * (1 + 0.1 * torch.tanh(slope)[..., None] * ramp)
+
+        def parameter_size(self):
+            return {"slope": 1}
+
+    G = GRAFX(config=NodeConfigs(["eq", "tilt", "compressor"]))
+    a, b = G.add("in"), G.add("in")
+    e1, e2, t1, c1, m, out = G.add("eq"), G.add("eq"), G.add("tilt"), G.add("compressor"), G.add("mix"), G.add("out")
+    for s, d in ((a, e1), (b, e2), (e1, t1), (e2, c1), (t1, m), (c1, m), (m, out), (t1, out)):
+        G.connect(s, d)
+    hip = {"eq": P.ParametricEqualizer(num_filters=4, flashfftconv=False, fsm_fir_len=257).cuda(), "tilt": Tilt(),
+           "compressor": P.Compressor(energy_smoother="iir", iir_len=255, flashfftconv=False).cuda()}
+    ref = {"eq": oracle.OracleParametricEqualizer(num_filters=4, fsm_fir_len=257), "tilt": Tilt(),
+           "compressor": oracle.OracleCompressor(energy_smoother="iir", iir_len=255)}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    torch.manual_seed(4)
+    params = {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(hip, G, std=0.3).items()}
+    x = torch.randn(3, 2, 2, 3000)
+    with torch.no_grad():
+        want, _, wbuf = render_grafx(ref, x, params, rd)
+        got, _, gbuf = render_grafx(hip, x.cuda(), {t: {k: v.cuda() for k, v in d.items()} for t, d in params.items()},
+                                    rd.to("cuda"))
+    assert_close(got.cpu(), want, 2e-5, "output")
+    assert_close(gbuf.cpu(), wbuf, 2e-5, "signal buffer")
