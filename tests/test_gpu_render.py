@@ -156,3 +156,16 @@ def test_hip_processors_next_to_a_user_defined_torch_processor():
                                     rd.to("cuda"))
     assert_close(got.cpu(), want, 2e-5, "output")
     assert_close(gbuf.cpu(), wbuf, 2e-5, "signal buffer")
+
+    # and a training step through the same mixed graph (the taped generic loop around the HIP autograd functions)
+    def grads(procs, dev):
+        p = {t: {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in d.items()} for t, d in params.items()}
+        rd_ = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)  # .to() moves in place
+        y, _, _ = render_grafx(procs, x.to(dev), p, rd_)
+        y.square().mean().backward()
+        return {(t, k): v.grad.cpu() for t, d in p.items() for k, v in d.items()}
+
+    g_ref, g_hip = grads(ref, "cpu"), grads(hip, "cuda")
+    assert set(g_ref) == set(g_hip)
+    for key, wv in g_ref.items():
+        assert (g_hip[key] - wv).abs().max() <= 5e-3 * wv.abs().max().clamp_min(1e-8), key
