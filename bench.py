@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 5.2-5.5 TB/s is what a streaming copy reaches (tools/ubench/stream.hip)
 
 
 def console_graph(n_ch=32, n_bus=4):
@@ -216,8 +216,9 @@ def main():
             torch.cuda.synchronize()
             print(f"[bench] step done at +{(time.perf_counter() - t0) * 1e3:.1f} ms, reserved "
                   f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", file=sys.stderr)
-    fence()
+    torch.cuda.synchronize()          # this rank's K steps are done: stop its clock ...
     elapsed = time.perf_counter() - t0
+    fence()                           # ... then the closing barrier; the job's time is the MAX over ranks (below)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,8 +278,9 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             train_step()
-        fence()
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        fence()
         if dist is not None:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
