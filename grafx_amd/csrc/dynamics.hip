@@ -582,14 +582,31 @@ __device__ __forceinline__ void dyn_bwd_a_stream(const DynArgs& a, const OnePole
     const float invC = 1.0f / (float)a.C;
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    // software prefetch, as in dyn_stream: the next tile's samples are requested before this tile is scanned
+    float nxa[DE], nxb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, nga[DE], ngb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+    load4(x0, (int64_t)DE * t, a.L, vx, nxa);
+    load4(g0, (int64_t)DE * t, a.L, vx, nga);
+    if (a.C == 2) {
+        load4(x1, (int64_t)DE * t, a.L, vx, nxb);
+        load4(g1, (int64_t)DE * t, a.L, vx, ngb);
+    }
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         const int64_t n = tile * DTILE + DE * t;
-        float xa[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, ga[DE], gb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, e[DE], u[DE];
-        load4(x0, n, a.L, vx, xa);
-        load4(g0, n, a.L, vx, ga);
-        if (a.C == 2) {
-            load4(x1, n, a.L, vx, xb);
-            load4(g1, n, a.L, vx, gb);
+        float xa[DE], xb[DE], ga[DE], gb[DE], e[DE], u[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            xa[i] = nxa[i];
+            xb[i] = nxb[i];
+            ga[i] = nga[i];
+            gb[i] = ngb[i];
+        }
+        if (tile + 1 < ntiles) {
+            load4(x0, n + DTILE, a.L, vx, nxa);
+            load4(g0, n + DTILE, a.L, vx, nga);
+            if (a.C == 2) {
+                load4(x1, n + DTILE, a.L, vx, nxb);
+                load4(g1, n + DTILE, a.L, vx, ngb);
+            }
         }
 #pragma unroll
         for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
@@ -708,10 +725,24 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
     const float pole_c2 = p.a_N - p.one_m_a * (float)a.N * (p.a_N / p.a);
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    // software prefetch: this tile's other operands and the next tile's denv are requested before the scan (whose
+    // barrier would otherwise fence them), so their HBM round trips overlap the scan and the gain arithmetic
+    float nd[DE];
+    rload4(denv, (int64_t)DE * t, a.L, vo, nd);
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         const int64_t j = tile * DTILE + DE * t;
         float d[DE], u[DE];
-        rload4(denv, j, a.L, vo, d);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) d[i] = nd[i];
+        if (tile + 1 < ntiles) rload4(denv, j + DTILE, a.L, vo, nd);
+        float uu[DE], xa[DE], ga[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, gb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        rload4(u1, j, a.L, vo, uu);
+        rload4(x0, j, a.L, vx, xa);
+        rload4(g0, j, a.L, vx, ga);
+        if (a.C == 2) {
+            rload4(x1, j, a.L, vx, xb);
+            rload4(g1, j, a.L, vx, gb);
+        }
         scan_tile(p, d, u, carry, slots + 8 * (tile & 1), lane, wave);
         if (TRUNC) {
             float d2[DE], u2[DE];
@@ -720,8 +751,7 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
 #pragma unroll
             for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
         }
-        float uu[DE], un[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
-        rload4(u1, j, a.L, vo, uu);
+        float un[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (TRUNC) rload4(u1, j + a.N, a.L, false, un);
         if (POLE) {
             const int64_t below = a.L - 1 - j - DE;  // sample under this thread's four
@@ -733,21 +763,17 @@ __device__ __forceinline__ void dyn_bwd_b_stream(const DynArgs& a, const OnePole
                 if (TRUNC) pole = fmaf(pole_c2 * d[i], un[i], pole);
             }
         }
-        float gn[DE], xa[DE], ga[DE], oa[DE];
+        float gn[DE], oa[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
             const float lin = TRUNC ? fmaf(-p.a_N, un[i], uu[i]) : uu[i];
             gn[i] = expf(log_gain(q, logf(fmaxf(lin, 0.0f) + 1e-5f)));
         }
-        rload4(x0, j, a.L, vx, xa);
-        rload4(g0, j, a.L, vx, ga);
 #pragma unroll
         for (int i = 0; i < DE; ++i) oa[i] = fmaf(gn[i], ga[i], k2 * p.one_m_a * u[i] * xa[i]);
         rstore4(o0, j, a.L, vgx, oa);
         if (a.C == 2) {
-            float xb[DE], gb[DE], ob[DE];
-            rload4(x1, j, a.L, vx, xb);
-            rload4(g1, j, a.L, vx, gb);
+            float ob[DE];
 #pragma unroll
             for (int i = 0; i < DE; ++i) ob[i] = fmaf(gn[i], gb[i], k2 * p.one_m_a * u[i] * xb[i]);
             rstore4(o1, j, a.L, vgx, ob);
