@@ -246,7 +246,9 @@ class FsmFirFn(torch.autograd.Function):
         Bs, As = ctx.saved_tensors
         N = ctx.N
         D = _fsm_delays(N, Bs.device)                      # (3, F)
-        num, den = Bs.to(torch.complex64) @ D, As.to(torch.complex64) @ D   # (R,Cf,K,F)
+        # three-term sums written out: the library's complex GEMM takes 0.16 ms for these 3-wide contractions
+        num = Bs[..., 0:1] * D[0] + Bs[..., 1:2] * D[1] + Bs[..., 2:3] * D[2]   # (R,Cf,K,F)
+        den = As[..., 0:1] * D[0] + As[..., 1:2] * D[1] + As[..., 2:3] * D[2]
         sections = num / den
         resp = sections[..., 0, :]
         for i in range(1, sections.shape[-2]):
@@ -256,9 +258,12 @@ class FsmFirFn(torch.autograd.Function):
         if N % 2 == 0:
             G[..., -1] = G[..., -1] * 0.5
         T = (G.conj() * resp).unsqueeze(-2)                # (R,Cf,1,F)
-        Dt = D.transpose(0, 1).contiguous()                # (F, 3)
-        gB = ((T / num) @ Dt).real if ctx.needs_input_grad[0] else None
-        gA = -((T / den) @ Dt).real if ctx.needs_input_grad[1] else None
+
+        def contract(Q):  # Re sum_k Q[..., k] D_d[k], d = 0..2  ->  (..., 3)
+            return torch.stack([(Q * D[d]).real.sum(-1) for d in range(3)], -1)
+
+        gB = contract(T / num) if ctx.needs_input_grad[0] else None
+        gA = -contract(T / den) if ctx.needs_input_grad[1] else None
         return gB, gA, None, None
 
 
