@@ -303,10 +303,14 @@ __device__ __forceinline__ void onepole_stream(const OnePole& p, const float* u_
     const bool vi = vec_ok(u_in), vo = vec_ok(out);
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t ntiles = (Lout + DTILE - 1) / DTILE;
+    float ne[DE];  // software prefetch of the next tile (see dyn_stream)
+    load4(u_in, (int64_t)DE * t, L, vi, ne);
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         const int64_t n = tile * DTILE + DE * t;
         float e[DE], u[DE];
-        load4(u_in, n, L, vi, e);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) e[i] = ne[i];
+        if (tile + 1 < ntiles) load4(u_in, n + DTILE, L, vi, ne);
         if (TRUNC) {  // one scan of e[n] - a^N e[n-N] (see dyn_stream)
             float e2[DE];
             load4(u_in, n - N, L, false, e2);
