@@ -195,6 +195,12 @@ def main():
 
         captured.append(CapturedRender(procs, x, params, rd_dev))
     y = None
+    if dist is not None:
+        # line the ranks up BEFORE the warm-up: their start-up skew (seconds) then is not spent idling at the barrier
+        # that opens the timed region, right in front of the first timed step (a GPU that has idled for milliseconds
+        # runs its next large launches 20-30 % slow)
+        torch.cuda.synchronize()
+        dist.barrier()
     for _ in range(args.warmup):
         y = step()
 
