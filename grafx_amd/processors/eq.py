@@ -27,10 +27,7 @@ class ParametricEqualizer(BufferIO, nn.Module):
     accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
 
     def forward(self, input_signals, w0, q_inv, log_gain, _out=None, _tee=None, _shared_rows=None):
-        if self.use_shelving_filters and self.num_filters < 2:
-            # upstream splits the bands [1, K-2, 1] (eq.py:254, 300-302): torch.split rejects the negative size
-            raise RuntimeError(f"split expects non-negative sizes, got [1, {self.num_filters - 2}, 1]: "
-                               "shelving filters need num_filters >= 2")
+        self._check_bands()
         if needs_grad(input_signals, w0, q_inv, log_gain):
             Bs, As = diff.PeqCoeffsFn.apply(w0, q_inv, log_gain, self.use_shelving_filters)
         else:
@@ -39,9 +36,16 @@ class ParametricEqualizer(BufferIO, nn.Module):
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As, shared_rows=_shared_rows, final=True))
         return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows, final=True)
 
+    def _check_bands(self):
+        if self.use_shelving_filters and self.num_filters < 2:
+            # upstream splits the bands [1, K-2, 1] (eq.py:254, 300-302): torch.split rejects the negative size
+            raise RuntimeError(f"split expects non-negative sizes, got [1, {self.num_filters - 2}, 1]: "
+                               "shelving filters need num_filters >= 2")
+
     def prepare(self, w0, q_inv, log_gain, _shared_rows=None):
         """The parameter-only part of render_into (coefficients -> sampled response -> taps -> tile spectra), so that
         the render can run it ahead of time on a side stream; None when this configuration has no such split."""
+        self._check_bands()
         if self.processor_channel == "midside" or self.biquad.backend != "fsm" or needs_grad(w0, q_inv, log_gain):
             return None
         Bs, As = ops.peq_coeffs(w0, q_inv, log_gain, self.use_shelving_filters)

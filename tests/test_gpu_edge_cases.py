@@ -182,3 +182,19 @@ def test_random_dynamics_configurations_match_the_oracle(seed):
         y = m(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
         ref64 = o(x.double(), **{k: v.double() for k, v in p.items()}).float()
     assert_parity(y, ref32, ref64, 2e-5, what)
+
+
+@pytest.mark.gpu
+def test_single_band_equalizer_with_shelving_fails_like_upstream():
+    """use_shelving_filters splits the bands [1, K-2, 1] upstream (eq.py:254, 300-302): K = 1 cannot be split and
+    torch.split raises; so do we, from forward() and from the render's ahead-of-time prepare()."""
+    import grafx_amd.processors as P
+
+    m = P.ParametricEqualizer(num_filters=1, flashfftconv=False, fsm_fir_len=257).cuda()
+    p = {k: torch.zeros(2, 1, 1, device="cuda") for k in ("w0", "q_inv", "log_gain")}
+    with pytest.raises(RuntimeError):
+        m(torch.randn(2, 2, 1000, device="cuda"), **p)
+    with pytest.raises(RuntimeError):
+        m.prepare(**p)
+    ok = P.ParametricEqualizer(num_filters=1, use_shelving_filters=False, flashfftconv=False, fsm_fir_len=257).cuda()
+    assert ok(torch.randn(2, 2, 1000, device="cuda"), **p).shape == (2, 2, 1000)
