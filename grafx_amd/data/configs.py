@@ -40,6 +40,19 @@ class NodeConfigs:
             self.inlet_to_index = {t: {n: i for i, n in enumerate(c["inlets"])} for t, c in table.items()}
             self.outlet_to_index = {t: {n: i for i, n in enumerate(c["outlets"])} for t, c in table.items()}
 
+    # public helpers of the reference class (configs.py:71-120), for code that re-registers types on an instance
+    def get_default_config(self, node_type):
+        """Port layout a bare type name stands for: sources have no inlet, sinks no outlet, everything else is SISO."""
+        return UTILITY_DICT.get(node_type, _SISO) if node_type in ("in", "out") else _SISO
+
+    def unpack_list(self, node_type_list):
+        """(Re)build the registry from type names alone (every type gets its default port layout)."""
+        self._index({name: self.get_default_config(name) for name in node_type_list})
+
+    def unpack_dict(self, node_type_dict):
+        """(Re)build the registry from ``{type: {"inlets": [...], "outlets": [...]}}``."""
+        self._index(dict(node_type_dict))
+
     def __getitem__(self, node_type):
         return self.node_type_dict[node_type]
 

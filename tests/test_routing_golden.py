@@ -252,3 +252,15 @@ def test_common_parameters_render_like_the_reference(golden, gi):
     y, _, buf = render_grafx(procs, g[f"{tag}_x"], params, rd, common_parameters={"trim": g[f"{tag}_trim"]})
     assert_close(y, g[f"{tag}_y"], 1e-6, "output")
     assert_close(buf, g[f"{tag}_buf"], 1e-6, "signal buffer")
+
+
+def test_node_configs_public_helpers():
+    """get_default_config / unpack_list / unpack_dict (reference data/configs.py:71-120)."""
+    cfg = NodeConfigs(["eq"])
+    assert cfg.get_default_config("in") == {"inlets": [], "outlets": ["main"]}
+    assert cfg.get_default_config("out") == {"inlets": ["main"], "outlets": []}
+    assert cfg.get_default_config("mix") == cfg.get_default_config("anything") == {"inlets": ["main"], "outlets": ["main"]}
+    cfg.unpack_list(["in", "x", "out"])
+    assert cfg.node_types == ["in", "x", "out"] and cfg.siso_only and cfg.num_inlets == {"in": 0, "x": 1, "out": 1}
+    cfg.unpack_dict({"split": {"inlets": ["main"], "outlets": ["low", "high"]}})
+    assert not cfg.siso_only and cfg.max_num_outlets == 2 and cfg.outlet_to_index["split"] == {"low": 0, "high": 1}
