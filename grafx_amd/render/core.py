@@ -47,6 +47,12 @@ def read_tensor_or_tensor_dict(x, access, dim=0, return_copy=False, postprocess=
     return None
 
 
+def read_tensor_dict(x, access, dim=0, return_copy=False):
+    """Flat dict of tensors -> the same read applied to every value (reference render/core.py:73-77, which calls a
+    ``read_tensor`` that does not exist there; the single-tensor read is what it means)."""
+    return {k: read_single_tensor(v, access, dim=dim, return_copy=return_copy) for k, v in x.items()}
+
+
 def inplace_write_tensor(method, x, y, access, dim=0):
     if method == "one-by-one":
         x[access.idx[0]] = y
