@@ -62,6 +62,19 @@ class IIRFilter(nn.Module):
         R, Cf = Bs.shape[0], Bs.shape[1]
         return self._taps(Bs, As).view(R, Cf, self.fsm_fir_len)
 
+    # the two static helpers of the reference class (core/iir.py:263-276), for code that builds responses by hand
+    @staticmethod
+    def delay(delay_length, fir_length):
+        """exp(-j 2 pi d k / N) for every delay d in ``delay_length`` and k = 0..N//2 (a trailing frequency axis)."""
+        k = torch.arange(fir_length // 2 + 1, device=delay_length.device)
+        k = k.reshape((1,) * delay_length.ndim + (-1,))
+        return torch.exp(-1j * (delay_length.unsqueeze(-1) * k / fir_length * 2 * torch.pi))
+
+    @staticmethod
+    def iir_fsm(Bs, As, delays, eps=1e-10):
+        """Sampled response of every section: sum_d B_d D_d / sum_d A_d D_d (``eps`` is accepted and unused upstream)."""
+        return (Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)
+
     def _process_recursive(self, input_signal, Bs, As, out=None):
         if needs_grad(input_signal, Bs, As):
             raise NotImplementedError(f"backend={self.backend!r}: the exact recursive kernel is forward-only; "

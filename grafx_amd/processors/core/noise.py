@@ -33,3 +33,20 @@ def get_filtered_noise(fir_len, num_channels=1, num_bands=12, f_min=31.5, f_max=
     bands = apply_linkwitz_riley(noise, num_bands=num_bands, f_min=f_min, f_max=f_max, scale=scale, sr=sr,
                                  zerophase=zerophase, order=order)
     return torch.from_numpy(bands).float()
+
+
+OCTAVE_CENTRES = (31.5, 63, 125, 250, 500, 1000, 2000, 4000, 8000, 16000)
+
+
+def octave_band_filterbank(num_taps, sample_rate):
+    """(12, 1, num_taps) time-reversed windowed-sinc FIRs: a 12 Hz low-pass, ten octave band-passes centred on
+    31.5 Hz ... 16 kHz (edges a half octave either side, clipped just below Nyquist) and an 18 kHz high-pass
+    (reference core/noise.py:76-125; unused by the processors there, kept for users of the helper)."""
+    from scipy.signal import firwin
+
+    nyq = 0.999 * sample_rate / 2
+    designs = [firwin(num_taps, 12, fs=sample_rate)]
+    designs += [firwin(num_taps, [fc / 2**0.5, min(fc * 2**0.5, nyq)], fs=sample_rate, pass_zero=False) for fc in OCTAVE_CENTRES]
+    designs.append(firwin(num_taps, 18000, fs=sample_rate, pass_zero=False))
+    taps = torch.from_numpy(np.stack(designs).astype("float32"))
+    return taps.flip(-1).unsqueeze(1)

@@ -107,6 +107,28 @@ class _Dynamics(BufferIO, nn.Module):
             gain = self.gain_smoother_module(torch.exp(g), z_alpha=z_alpha_post)
         return gain[:, None, :] * x
 
+    # ---- the reference classes' helper methods (dynamics.py:411-489, 643-721), as torch ops -------------------
+    @classmethod
+    def gain_hard_knee(cls, log_energy, log_threshold, log_ratio, _=None):
+        """Log-gain of the hard knee for a log-energy envelope (threshold already shifted by the caller)."""
+        return diff.log_gain(log_energy, log_threshold, log_ratio, None, "hard", cls._gate)
+
+    @classmethod
+    def gain_quad_knee(cls, log_energy, log_threshold, log_ratio, log_knee):
+        return diff.log_gain(log_energy, log_threshold, log_ratio, log_knee, "quadratic", cls._gate)
+
+    @classmethod
+    def gain_exp_knee(cls, log_energy, log_threshold, log_ratio, log_knee):
+        return diff.log_gain(log_energy, log_threshold, log_ratio, log_knee, "exponential", cls._gate)
+
+    def smooth_in_log(self, gain, **gain_smooth_params):
+        """Smooth the log-gain, then exponentiate (gain_smooth_in_log=True)."""
+        return torch.exp(self.gain_smoother_module(gain, **gain_smooth_params))
+
+    def smooth_in_linear(self, gain, **gain_smooth_params):
+        """Exponentiate the log-gain, then smooth it."""
+        return self.gain_smoother_module(torch.exp(gain), **gain_smooth_params)
+
     def parameter_size(self):
         size = {"log_threshold": 1, "log_ratio": 1}
         if self.knee != "hard":
@@ -162,12 +184,16 @@ class ApproxNoiseGate(nn.Module):
         else:
             energy = ops.energy(input_signals)
         G = torch.log(self.smoother(energy, z_alpha) + 1e-5)
-        T = log_threshold - 6
+        return self.compute_gain(G, log_threshold - 6, log_ratio, log_knee) * input_signals
+
+    def compute_gain(self, log_energy, log_threshold, log_ratio, log_knee):
+        """(R, 1, L) linear gain of this gate's own knee (dynamics.py:185-203)."""
+        G, T = log_energy, log_threshold
         ratio, W = torch.exp(log_ratio), torch.exp(log_knee)
         below, above = G < (T - W / 2), G > (T + W / 2)
         middle = (~below) * (~above)
         out = (ratio * (G - T) + T) * below + G * above + (G + (1 - ratio) * (G - T - W / 2) ** 2 / 2 / (W + 1e-3)) * middle
-        return torch.exp(out - G)[:, None, :] * input_signals
+        return torch.exp(out - G)[:, None, :]
 
     def parameter_size(self):
         return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}

@@ -1,4 +1,5 @@
 """Equalizers (mirrors grafx.processors.eq — reference eq.py:217-336 for ParametricEqualizer)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -35,6 +36,18 @@ class ParametricEqualizer(BufferIO, nn.Module):
         if self.processor_channel == "midside":
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As, shared_rows=_shared_rows, final=True))
         return self.biquad(input_signals, Bs, As, out=_out, tee=_tee, shared_rows=_shared_rows, final=True)
+
+    def get_biquad_coefficients_with_shelving_filters(self, cos_w0, alpha, A):
+        """Band 0 a low shelf, band K-1 a high shelf, peaking filters in between (eq.py:300-314), from the common
+        parameters of filter.BaseParametricEqualizerFilter's helpers; (..., K, 3) numerators and denominators."""
+        from .filter import HighShelf, LowShelf, PeakingFilter
+
+        self._check_bands()
+        K = self.num_filters
+        parts = [LowShelf.get_biquad_coefficients(cos_w0[..., :1], alpha[..., :1], A[..., :1]),
+                 PeakingFilter.get_biquad_coefficients(cos_w0[..., 1 : K - 1], alpha[..., 1 : K - 1], A[..., 1 : K - 1]),
+                 HighShelf.get_biquad_coefficients(cos_w0[..., K - 1 :], alpha[..., K - 1 :], A[..., K - 1 :])]
+        return torch.cat([b for b, _ in parts], -2), torch.cat([a for _, a in parts], -2)
 
     def _check_bands(self):
         if self.use_shelving_filters and self.num_filters < 2:

@@ -159,44 +159,61 @@ class AllPassFilter(BaseParametricFilter):
 class BaseParametricEqualizerFilter(nn.Module):
     """Stack of `num_filters` equaliser sections of one kind (filter.py:563-617)."""
 
-    _kind = None
-
     def __init__(self, num_filters=1, **backend_kwargs):
         super().__init__()
         self.num_filters = num_filters
         self.biquad = IIRFilter(order=2, **backend_kwargs)
 
     def forward(self, input_signals, w0, q_inv, log_gain):
-        Bs, As = self._coefficients(w0, q_inv, log_gain)
+        w, qi, A = self.filter_parameter_activations(w0, q_inv, log_gain)
+        cw, alpha = self.compute_common_filter_parameters(w, qi)
+        Bs, As = self.get_biquad_coefficients(cw, alpha, A)
         return self.biquad(input_signals, Bs.unsqueeze(1), As.unsqueeze(1))
 
-    def _coefficients(self, w0, q_inv, log_gain):
-        w = math.pi * torch.sigmoid(w0)
-        A = torch.exp(log_gain)
-        cw, alpha = torch.cos(w), torch.sin(w) * torch.exp(q_inv) * 0.5
-        if self._kind == "peak":  # filter.py:645-656
-            return (torch.stack([1 + alpha * A, -2 * cw, 1 - alpha * A], -1),
-                    torch.stack([1 + alpha / A, -2 * cw, 1 - alpha / A], -1))
-        sg = 1.0 if self._kind == "low" else -1.0  # filter.py:687-705 / 736-754
-        ap1, am1, s = A + 1, A - 1, 2 * A.sqrt() * alpha
-        Bs = torch.stack([A * (ap1 - sg * am1 * cw + s), sg * 2 * A * (am1 - sg * ap1 * cw), A * (ap1 - sg * am1 * cw - s)], -1)
-        As = torch.stack([ap1 + sg * am1 * cw + s, -sg * 2 * (am1 + sg * ap1 * cw), ap1 + sg * am1 * cw - s], -1)
-        return Bs, As
+    # the reference's static helpers (filter.py:593-604 and the per-kind coefficient maps), usable on their own
+    @staticmethod
+    def filter_parameter_activations(w0, q_inv, log_gain):
+        """Raw parameters -> (angular frequency in (0, pi), 1/Q > 0, linear gain A > 0)."""
+        return math.pi * torch.sigmoid(w0), torch.exp(q_inv), torch.exp(log_gain)
+
+    @staticmethod
+    def compute_common_filter_parameters(w0, q_inv):
+        """(cos w0, alpha = sin w0 / (2 Q)) of the RBJ cookbook."""
+        return torch.cos(w0), torch.sin(w0) * q_inv * 0.5
+
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha, A):
+        raise NotImplementedError
 
     def parameter_size(self):
         return {"w0": self.num_filters, "q_inv": self.num_filters, "log_gain": self.num_filters}
 
 
+def _shelf_coefficients(cw, alpha, A, sg):
+    """RBJ shelving sections, un-normalised a0 (filter.py:687-705 low shelf, sg = +1; 736-754 high shelf, sg = -1)."""
+    ap1, am1, s = A + 1, A - 1, 2 * A.sqrt() * alpha
+    Bs = torch.stack([A * (ap1 - sg * am1 * cw + s), sg * 2 * A * (am1 - sg * ap1 * cw), A * (ap1 - sg * am1 * cw - s)], -1)
+    As = torch.stack([ap1 + sg * am1 * cw + s, -sg * 2 * (am1 + sg * ap1 * cw), ap1 + sg * am1 * cw - s], -1)
+    return Bs, As
+
+
 class PeakingFilter(BaseParametricEqualizerFilter):
-    _kind = "peak"
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha, A):  # filter.py:645-656
+        return (torch.stack([1 + alpha * A, -2 * cos_w0, 1 - alpha * A], -1),
+                torch.stack([1 + alpha / A, -2 * cos_w0, 1 - alpha / A], -1))
 
 
 class LowShelf(BaseParametricEqualizerFilter):
-    _kind = "low"
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha, A):
+        return _shelf_coefficients(cos_w0, alpha, A, 1.0)
 
 
 class HighShelf(BaseParametricEqualizerFilter):
-    _kind = "high"
+    @staticmethod
+    def get_biquad_coefficients(cos_w0, alpha, A):
+        return _shelf_coefficients(cos_w0, alpha, A, -1.0)
 
 
 class StateVariableFilter(nn.Module):

@@ -143,6 +143,18 @@ class PowerDistortion(_PolynomialDistortion):
 class ChebyshevDistortion(_PolynomialDistortion):
     mode = ops.WS_CHEBYSHEV
 
+    @staticmethod
+    def apply_distortion(input_signals, basis_weights, use_tanh=False):
+        """sum_k basis_weights[:, k] * T_k(x) (optionally tanh(T_k)) on (R, C, L) signals, weights (R, K) taken as
+        they are (reference nonlinear.py:385-403), as torch ops."""
+        K = basis_weights.shape[-1]
+        terms = [torch.ones_like(input_signals), input_signals]
+        for _ in range(2, K):
+            terms.append(2 * input_signals * terms[-1] - terms[-2])
+        terms = torch.stack(terms[:K], 0)
+        terms = torch.tanh(terms) if use_tanh else terms
+        return (terms * basis_weights.T[:, :, None, None]).sum(0)
+
     def basis(self, u):
         terms = [torch.ones_like(u), u]
         for _ in range(2, self.max_order):

@@ -66,6 +66,13 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
             return self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         return self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, False)[0]
 
+    def compute_stft_mask(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
+        """(R, 2, bins, frames) magnitude mask exp((H0 - softplus(Hd) m [+ G_m]) / 8) (reverb.py:189-200), torch ops."""
+        logmag = init_log_magnitude[..., None] - F.softplus(delta_log_magnitude)[..., None] * self.arange
+        if self.gain_envelope:
+            logmag = logmag + gain_env_log_magnitude[:, :, None, :]
+        return torch.exp(logmag / 8)
+
     def _compute_ir_differentiable(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
         """reverb.py:161-200 with torch ops (mask, istft) for the training path."""
         logmag = init_log_magnitude[..., None] - F.softplus(delta_log_magnitude)[..., None] * self.arange
