@@ -699,9 +699,69 @@ def g15(n_graphs=8):
     save("g15_common_parameters", **arrays)
 
 
+def g16(n_graphs=10):
+    """Training through render_grafx: random DAGs of the headline processor types, a loss on the output (and, for odd
+    draws, on an intermediate node of the returned buffer), the reference's autograd gradients of every parameter and
+    of the input.  Parameters that receive no gradient upstream are recorded as such (key list "nograd")."""
+    import random
+
+    rng = random.Random(16)
+    torch.manual_seed(16)
+    meta, arrays = [], {}
+    for gi in range(n_graphs):
+        L = rng.choice([1024, 2047])
+        procs = {"eq": ParametricEqualizer(num_filters=4, flashfftconv=False, fsm_fir_len=257),
+                 "compressor": Compressor(energy_smoother="iir", iir_len=255, flashfftconv=False),
+                 "reverb": STFTMaskedNoiseReverb(ir_len=1501, flashfftconv=False)}
+        G = GRAFX(config=NodeConfigs(["eq", "compressor", "reverb"]))
+        recipe, nodes = [], []
+        n_src = 2
+        for _ in range(n_src):
+            nodes.append(G.add("in"))
+            recipe.append(["add", "in"])
+        for _ in range(rng.randint(3, 5)):
+            kind = rng.choice(["eq", "compressor", "eq", "compressor", "reverb", "mix"])
+            v = G.add(kind)
+            recipe.append(["add", kind])
+            for s in rng.sample(nodes, 1 if kind != "mix" else min(len(nodes), rng.randint(2, 4))):
+                G.connect(s, v)
+                recipe.append(["connect", int(s), int(v)])
+            nodes.append(v)
+        out = G.add("out")
+        recipe.append(["add", "out"])
+        for s in rng.sample(nodes[n_src:], min(3, len(nodes) - n_src)):
+            G.connect(s, out)
+            recipe.append(["connect", int(s), int(out)])
+        G_t = reorder_for_fast_render(convert_to_tensor(G), method="beam")
+        rd = prepare_render(G_t)
+        params = create_empty_parameters(procs, G, std=0.3)
+        x = torch.randn(2, n_src, 2, L, requires_grad=True)
+        y, _, buf = render_grafx(procs, x, params, rd, input_signal_grad=True)
+        w = torch.linspace(0.5, 1.5, L)
+        loss = (y * w).square().mean()
+        if gi % 2 == 1:
+            loss = loss + 0.3 * (buf[:, buf.shape[1] // 2] * w).abs().mean()
+        loss.backward()
+        tag = f"g{gi:02d}"
+        arrays[f"{tag}_x"], arrays[f"{tag}_gx"], arrays[f"{tag}_y"] = x.detach(), x.grad, y.detach()
+        nograd, plist = [], {}
+        for t, d in params.items():
+            plist[t] = list(d)
+            for k, v in d.items():
+                arrays[f"{tag}_p_{t}_{k}"] = v.detach()
+                if v.grad is None:
+                    nograd.append([t, k])
+                else:
+                    arrays[f"{tag}_g_{t}_{k}"] = v.grad
+        meta.append({"recipe": recipe, "L": L, "params": plist, "nograd": nograd, "buffer_loss": gi % 2 == 1})
+    with open(os.path.join(HERE, "g16_render_gradients.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    save("g16_render_gradients", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()

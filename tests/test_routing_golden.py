@@ -264,3 +264,40 @@ def test_node_configs_public_helpers():
     assert cfg.node_types == ["in", "x", "out"] and cfg.siso_only and cfg.num_inlets == {"in": 0, "x": 1, "out": 1}
     cfg.unpack_dict({"split": {"inlets": ["main"], "outlets": ["low", "high"]}})
     assert not cfg.siso_only and cfg.max_num_outlets == 2 and cfg.outlet_to_index["split"] == {"low": 0, "high": 1}
+
+
+# ---- g16: the reference's autograd gradients through render_grafx on random graphs -------------------------------
+with open(os.path.join(GOLDEN, "g16_render_gradients.json")) as f:
+    GRADIENT_GRAPHS = json.load(f)
+
+
+@pytest.mark.parametrize("gi", range(len(GRADIENT_GRAPHS)))
+def test_render_gradients_with_oracle_processors_match_the_reference(golden, gi):
+    """Our (generic, taped) render loop with the oracle processors against the reference's own gradients: every
+    parameter, the input, and which parameters receive no gradient at all."""
+    g = golden("g16_render_gradients")
+    entry = GRADIENT_GRAPHS[gi]
+    G = GRAFX(config=NodeConfigs(["eq", "compressor", "reverb"]))
+    for op in entry["recipe"]:
+        G.add(op[1]) if op[0] == "add" else G.connect(op[1], op[2])
+    procs = {"eq": oracle.OracleParametricEqualizer(num_filters=4, fsm_fir_len=257),
+             "compressor": oracle.OracleCompressor(energy_smoother="iir", iir_len=255),
+             "reverb": oracle.OracleSTFTMaskedNoiseReverb(ir_len=1501)}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    tag, L = f"g{gi:02d}", entry["L"]
+    params = {t: {k: g[f"{tag}_p_{t}_{k}"].clone().requires_grad_(True) for k in ks} for t, ks in entry["params"].items()}
+    x = g[f"{tag}_x"].clone().requires_grad_(True)
+    y, _, buf = render_grafx(procs, x, params, rd, input_signal_grad=True)
+    w = torch.linspace(0.5, 1.5, L)
+    loss = (y * w).square().mean()
+    if entry["buffer_loss"]:
+        loss = loss + 0.3 * (buf[:, buf.shape[1] // 2] * w).abs().mean()
+    loss.backward()
+    assert_close(x.grad, g[f"{tag}_gx"], 1e-4, "input gradient")
+    nograd = {tuple(k) for k in entry["nograd"]}
+    for t, d in params.items():
+        for k, v in d.items():
+            assert (v.grad is None) == ((t, k) in nograd), (t, k)
+            if v.grad is not None:
+                want = g[f"{tag}_g_{t}_{k}"]
+                assert (v.grad - want).abs().max() <= 1e-3 * want.abs().max().clamp_min(1e-8), (t, k)
