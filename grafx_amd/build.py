@@ -17,8 +17,11 @@ LIB = os.path.join(LIBDIR, "libgrafx_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -pragma-unroll-threshold: the FFT tile passes are `#pragma unroll` loop nests around inline packed-FP32
 # instructions; the default size cap stops unrolling them (and then every twiddle index is a run-time value).
+# -amdgpu-schedule-relaxed-occupancy: the FFT-tile kernels sit at two waves per SIMD by design (LDS), so the scheduler
+# may spend registers on latency instead of defending an occupancy it cannot reach (A/B on MI355X: 1-2 % on fftconv1).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
-         "-mllvm", "-pragma-unroll-threshold=1048576"] + os.environ.get("GRAFX_HIPCC_FLAGS", "").split()
+         "-mllvm", "-pragma-unroll-threshold=1048576", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true",
+         ] + os.environ.get("GRAFX_HIPCC_FLAGS", "").split()
 
 
 def sources():
