@@ -51,6 +51,47 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+class _Pin:
+    """Pointer factory for ONE launch: ``pin(t)`` returns the device address of a contiguous version of ``t`` and
+    keeps that (possibly temporary) tensor referenced until the wrapper returns, i.e. until the launch is enqueued.
+    Taking ``data_ptr()`` of an unnamed ``.contiguous()`` result frees the temporary before the launch; the next
+    same-size temporary then reuses the block and two arguments silently alias (round-1 advisor finding)."""
+
+    def __init__(self):
+        self.keep = []
+
+    def __call__(self, t):
+        if t is None:
+            return 0
+        t = t.contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+
+def _on_device(fn):
+    """Run a wrapper with the tensors' device current: the stream handed to the library (``_stream()``) and the
+    library's per-device tables (``hipGetDevice`` in csrc/common.hip) both follow the *current* device, so tensors on
+    cuda:1 under a current device cuda:0 would be launched on the wrong device.  All tensor arguments must share
+    one device."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(*args, **kwargs):
+        dev = None
+        for a in (*args, *kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise ValueError(f"{fn.__name__}: tensors on different devices ({dev} and {a.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+
+    return run
+
+
 def _expect(t, shape, what):
     """The kernels trust their sizes: every secondary tensor's shape is checked here, before its pointer is passed."""
     if t is not None and tuple(t.shape) != tuple(shape):
@@ -80,6 +121,7 @@ def part_len_for(N, Lout):
     return lib().gfx_fftconv_part_len(N, Lout)
 
 
+@_on_device
 def fir_spectrum(h, gain=None, gain_div=1, part_len=0):
     """Taps (RCf, N) -> opaque tile-spectrum buffer for :func:`fftconv` (same ``part_len`` there)."""
     _require_gpu(h, gain)
@@ -91,6 +133,7 @@ def fir_spectrum(h, gain=None, gain_div=1, part_len=0):
     return Hs
 
 
+@_on_device
 def fir_spectrum_reversed(x, part_len=0):
     """Spectra of the time-reversed rows of ``x`` ((R,C,L) or a strided (B,n,C,L) view, read in place): what
     ``fir_spectrum(x.flip(-1).reshape(R * C, L), part_len=part_len)`` returns, without the flipped copy."""
@@ -102,6 +145,7 @@ def fir_spectrum_reversed(x, part_len=0):
     return Hs
 
 
+@_on_device
 def fir_grad(x, g, N, off):
     """gh[r,c,k] = sum_n g[r,cg,n] x[r,cx,n+off-k], k < N <= 8193: the filter gradient of a short-filter convolution
     in one pass over x and g ((R,C,L) tensors or strided (B,n,C,L) views) -> (R, max(Cx,Cg), N)."""
@@ -122,6 +166,7 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
+@_on_device
 def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, part_len=0):
     """y[r,c,n] = sum_k h[r % h_rows,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
 
@@ -160,6 +205,7 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
 
 
 # ----------------------------------------------------------------------------------------- IIR (FSM)
+@_on_device
 def iir_fsm_plan(N, device):
     nbytes = lib().gfx_iir_fsm_plan_bytes(N)
     if nbytes == 0:
@@ -169,6 +215,7 @@ def iir_fsm_plan(N, device):
     return plan
 
 
+@_on_device
 def iir_fsm_fir(Bs, As, N, plan):
     """(R, Cf, K, 3) biquad coefficients -> (R*Cf, N) frequency-sampled FIR taps."""
     _require_gpu(Bs, As)
@@ -180,6 +227,7 @@ def iir_fsm_fir(Bs, As, N, plan):
     return h
 
 
+@_on_device
 def peq_coeffs(w0, q_inv, log_gain, use_shelving=True):
     _require_gpu(w0, q_inv, log_gain)
     w0, q_inv, log_gain = w0.contiguous(), q_inv.contiguous(), log_gain.contiguous()
@@ -192,6 +240,7 @@ def peq_coeffs(w0, q_inv, log_gain, use_shelving=True):
     return Bs, As
 
 
+@_on_device
 def peq_coeffs_bwd(w0, q_inv, log_gain, gBs, gAs, use_shelving=True):
     """Gradient of :func:`peq_coeffs` -> (g_w0, g_q_inv, g_log_gain), each shaped like w0."""
     _require_gpu(w0, q_inv, log_gain, gBs, gAs)
@@ -200,12 +249,14 @@ def peq_coeffs_bwd(w0, q_inv, log_gain, gBs, gAs, use_shelving=True):
     _expect(gAs, (*w0.shape, 3), "peq_coeffs_bwd: gAs")
     K = w0.shape[-1]
     out = [torch.empty_like(w0) for _ in range(3)]
-    check(lib().gfx_peq_coeffs_bwd_f32(_ptr(w0), _ptr(q_inv), _ptr(log_gain), _ptr(gBs.contiguous()), _ptr(gAs.contiguous()),
+    pin = _Pin()
+    check(lib().gfx_peq_coeffs_bwd_f32(_ptr(w0), _ptr(q_inv), _ptr(log_gain), pin(gBs), pin(gAs),
                                        *(_ptr(o) for o in out), w0.numel() // K, K, int(use_shelving), _stream()),
           "gfx_peq_coeffs_bwd_f32")
     return tuple(out)
 
 
+@_on_device
 def biquad_coeffs(Bs_in, A1_pre, A2_pre, A0=None):
     _require_gpu(Bs_in, A1_pre, A2_pre, A0)
     Bs_in, A1_pre, A2_pre = Bs_in.contiguous(), A1_pre.contiguous(), A2_pre.contiguous()
@@ -231,6 +282,7 @@ def _rowvec(p, R):
     return p
 
 
+@_on_device
 def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None,
                    param_rows=None):
     """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows)."""
@@ -240,13 +292,15 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
     if out is None:
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     ymap = rowmap(out)[0]
-    args = (_ptr(x), xmap, _ptr(out), ymap, _ptr(_rowvec(log_threshold, P)), _ptr(_rowvec(log_ratio, P)),
-            _ptr(_rowvec(log_knee, P)), _ptr(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
+    pin = _Pin()
+    args = (_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)), pin(_rowvec(log_ratio, P)),
+            pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
     with _timed("dyn_fused_kernel", 8 * R * C * L):
         check(lib().gfx_dynamics_fused_ex_f32(*args), "gfx_dynamics_fused_ex_f32")
     return out
 
 
+@_on_device
 def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
     """-> (gain (R,L), denv (R,L), gparams (R,3) = d/d(log_threshold, log_ratio, log_knee)); see the header."""
     _require_gpu(x, gy, env)
@@ -258,12 +312,14 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
     env = env.contiguous()
     gain, denv = torch.empty_like(env), torch.empty_like(env)
     gp = torch.zeros((R, 3), dtype=torch.float32, device=x.device)
-    check(lib().gfx_dyn_gain_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(env), _ptr(_rowvec(log_threshold, R)),
-                                     _ptr(_rowvec(log_ratio, R)), _ptr(_rowvec(log_knee, R)), R, C, L, KNEES[knee],
+    pin = _Pin()
+    check(lib().gfx_dyn_gain_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(env), pin(_rowvec(log_threshold, R)),
+                                     pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)), R, C, L, KNEES[knee],
                                      int(gate), _ptr(gain), _ptr(denv), _ptr(gp), _stream()), "gfx_dyn_gain_bwd_f32")
     return gain, denv, gp
 
 
+@_on_device
 def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True):
     """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), dalpha (R) or None).
     ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view).  ``dalpha`` is the gradient with
@@ -277,13 +333,15 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
     gp = torch.empty((R, 3), dtype=torch.float32, device=x.device)
     denv, u1 = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(2))
     da = torch.empty(R, dtype=torch.float32, device=x.device) if pole else None
-    check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, _ptr(_rowvec(log_threshold, R)),
-                                     _ptr(_rowvec(log_ratio, R)), _ptr(_rowvec(log_knee, R)), _ptr(_rowvec(z_alpha, R)),
+    pin = _Pin()
+    check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
+                                     pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)), pin(_rowvec(z_alpha, R)),
                                      R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), _ptr(denv),
                                      _ptr(u1), _ptr(da), _stream()), "gfx_dynamics_bwd_f32")
     return gx, gp, da
 
 
+@_on_device
 def onepole_dz(g, U, D, coef, N):
     """Row sums sum_n g[n] (c0 U[n] + c2 U[n-N]) + g[n+1] (c1 D[n] + c3 D[n-N]); coef (R,4)."""
     _require_gpu(g, U, D, coef)
@@ -292,11 +350,12 @@ def onepole_dz(g, U, D, coef, N):
     _expect(D, (R, L), "onepole_dz: D")
     _expect(coef, (R, 4), "onepole_dz: coef")
     da = torch.empty(R, dtype=torch.float32, device=g.device)
-    check(lib().gfx_onepole_dz_f32(_ptr(g.contiguous()), _ptr(U.contiguous()), _ptr(D.contiguous()),
-                                   _ptr(coef.contiguous()), _ptr(da), R, L, N, _stream()), "gfx_onepole_dz_f32")
+    pin = _Pin()
+    check(lib().gfx_onepole_dz_f32(pin(g), pin(U), pin(D), pin(coef), _ptr(da), R, L, N, _stream()), "gfx_onepole_dz_f32")
     return da
 
 
+@_on_device
 def dyn_dx(x, gy, gain, de):
     _require_gpu(x, gy, gain, de)
     xmap, R, C, L = rowmap(x)
@@ -305,11 +364,13 @@ def dyn_dx(x, gy, gain, de):
     _expect(gain, (R, L), "dyn_dx: gain")
     _expect(de, (R, L), "dyn_dx: de")
     gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
-    check(lib().gfx_dyn_dx_f32(_ptr(x), xmap, _ptr(gy), rowmap(gy)[0], _ptr(gain.contiguous()), _ptr(de.contiguous()),
+    pin = _Pin()
+    check(lib().gfx_dyn_dx_f32(_ptr(x), xmap, _ptr(gy), rowmap(gy)[0], pin(gain), pin(de),
                                _ptr(gx), R, C, L, _stream()), "gfx_dyn_dx_f32")
     return gx
 
 
+@_on_device
 def energy(x):
     _require_gpu(x)
     xmap, R, C, L = rowmap(x)
@@ -318,24 +379,29 @@ def energy(x):
     return e
 
 
+@_on_device
 def onepole(u, z_alpha, iir_len, Lout=None, relu=True):
     _require_gpu(u, z_alpha)
     u = u.contiguous()
     R, L = u.shape
     Lout = L if Lout is None else Lout
     out = torch.empty((R, Lout), dtype=torch.float32, device=u.device)
-    check(lib().gfx_onepole_f32(_ptr(u), _ptr(_rowvec(z_alpha, R)), _ptr(out), R, L, Lout, iir_len, int(relu), _stream()), "gfx_onepole_f32")
+    pin = _Pin()
+    check(lib().gfx_onepole_f32(_ptr(u), pin(_rowvec(z_alpha, R)), _ptr(out), R, L, Lout, iir_len, int(relu), _stream()), "gfx_onepole_f32")
     return out
 
 
+@_on_device
 def onepole_fir(z_alpha, iir_len):
     _require_gpu(z_alpha)
     R = z_alpha.numel()
     h = torch.empty((R, iir_len), dtype=torch.float32, device=z_alpha.device)
-    check(lib().gfx_onepole_fir_f32(_ptr(z_alpha.contiguous()), _ptr(h), R, iir_len, _stream()), "gfx_onepole_fir_f32")
+    pin = _Pin()
+    check(lib().gfx_onepole_fir_f32(pin(z_alpha), _ptr(h), R, iir_len, _stream()), "gfx_onepole_fir_f32")
     return h
 
 
+@_on_device
 def ballistics(u, z_alpha):
     _require_gpu(u, z_alpha)
     u, z_alpha = u.contiguous(), z_alpha.contiguous()
@@ -347,6 +413,7 @@ def ballistics(u, z_alpha):
     return y
 
 
+@_on_device
 def ballistics_bwd(x, y, g, z_alpha):
     """Adjoint of :func:`ballistics`: -> (dL/dx (R,L), dL/dz_alpha (R,2))."""
     _require_gpu(x, y, g, z_alpha)
@@ -361,19 +428,22 @@ def ballistics_bwd(x, y, g, z_alpha):
     return gx, gz
 
 
+@_on_device
 def dyn_gain(env, log_threshold, log_ratio, log_knee, knee, gate, log_out):
     _require_gpu(env)
     env = env.contiguous()
     R, L = env.shape
     g = torch.empty_like(env)
+    pin = _Pin()
     check(
-        lib().gfx_dyn_gain_f32(_ptr(env), _ptr(g), _ptr(_rowvec(log_threshold, R)), _ptr(_rowvec(log_ratio, R)),
-                               _ptr(_rowvec(log_knee, R)), R, L, KNEES[knee], int(gate), int(log_out), _stream()),
+        lib().gfx_dyn_gain_f32(_ptr(env), _ptr(g), pin(_rowvec(log_threshold, R)), pin(_rowvec(log_ratio, R)),
+                               pin(_rowvec(log_knee, R)), R, L, KNEES[knee], int(gate), int(log_out), _stream()),
         "gfx_dyn_gain_f32",
     )
     return g
 
 
+@_on_device
 def apply_gain(x, g, exp_gain=False, out=None):
     _require_gpu(x, g, out)
     xmap, R, C, L = rowmap(x)
@@ -387,6 +457,7 @@ def apply_gain(x, g, exp_gain=False, out=None):
     return out
 
 
+@_on_device
 def stereo_gain(x, log_gain, out=None):
     _require_gpu(x, log_gain, out)
     xmap, R, C, L = rowmap(x)
@@ -395,10 +466,12 @@ def stereo_gain(x, log_gain, out=None):
         out = torch.empty((R, 2, L), dtype=torch.float32, device=x.device)
     elif rowmap(out)[1:] != (R, 2, L):
         raise ValueError(f"stereo_gain: output {tuple(out.shape)} does not match {(R, 2, L)}")
-    check(lib().gfx_stereo_gain_f32(_ptr(x), xmap, _ptr(log_gain.contiguous()), _ptr(out), rowmap(out)[0], R, C, L, _stream()), "gfx_stereo_gain_f32")
+    pin = _Pin()
+    check(lib().gfx_stereo_gain_f32(_ptr(x), xmap, pin(log_gain), _ptr(out), rowmap(out)[0], R, C, L, _stream()), "gfx_stereo_gain_f32")
     return out
 
 
+@_on_device
 def biquad_cascade(x, Bs, As, ssm_quirk=False, out=None):
     """Exact time-domain cascade of the K biquads in Bs/As (R,Cf,K,3) over x (R,C,L) or a (B,n,C,L) view."""
     _require_gpu(x, Bs, As, out)
@@ -417,17 +490,18 @@ def biquad_cascade(x, Bs, As, ssm_quirk=False, out=None):
     return out
 
 
+@_on_device
 def noise_shaping_ir(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain, ir_len, min_decay, max_decay):
     """noise (C,K,>=ir_len) view with unit last stride; parameters (R,C,K) -> ir (R,C,ir_len), un-normalised."""
     _require_gpu(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain)
     R, C, K = log_decay.shape
     if noise.shape[:2] != (C, K) or noise.stride(-1) != 1 or noise.stride(1) != noise.stride(0) // K:
         raise ValueError("noise must be a (C, K, T) view of a contiguous band-split noise buffer")
-    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    pin = _Pin()
     ir = torch.empty((R, C, ir_len), dtype=torch.float32, device=log_decay.device)
     check(
-        lib().gfx_noise_shaping_ir_f32(_ptr(noise), noise.stride(1), _ptr(c(log_decay)), _ptr(c(log_gain)), _ptr(c(log_fade_in)),
-                                       _ptr(c(z_fade_in_gain)), _ptr(ir), R, C, K, ir_len, float(min_decay), float(max_decay), _stream()),
+        lib().gfx_noise_shaping_ir_f32(_ptr(noise), noise.stride(1), pin(log_decay), pin(log_gain), pin(log_fade_in),
+                                       pin(z_fade_in_gain), _ptr(ir), R, C, K, ir_len, float(min_decay), float(max_decay), _stream()),
         "gfx_noise_shaping_ir_f32",
     )
     return ir
@@ -437,6 +511,7 @@ def noise_shaping_ir(noise, log_decay, log_gain, log_fade_in, z_fade_in_gain, ir
 WS_TANH, WS_PIECEWISE, WS_POWER, WS_CHEBYSHEV = 0, 1, 2, 3
 
 
+@_on_device
 def row_mean(x):
     """Mean over time of every row-channel: (R,C,L) or (B,n,C,L) view -> (R*C,)."""
     _require_gpu(x)
@@ -446,6 +521,7 @@ def row_mean(x):
     return mean
 
 
+@_on_device
 def waveshaper(x, mode, log_pre_gain=None, log_post_gain=None, p0=None, p1=None, use_tanh=False,
                inverse_post_gain=False, remove_dc=False, out=None):
     """Memoryless distortion of every row (see gfx_waveshaper_f32 in the header for the modes)."""
@@ -468,14 +544,17 @@ def waveshaper(x, mode, log_pre_gain=None, log_post_gain=None, p0=None, p1=None,
 
 
 # ----------------------------------------------------------------------------------------- reverb IR
+@_on_device
 def istft_basis(window):
     _require_gpu(window)
     n_fft = window.numel()
     basis = torch.empty(lib().gfx_istft_basis_bytes(n_fft) // 4, dtype=torch.float32, device=window.device)
-    check(lib().gfx_istft_basis_f32(_ptr(window.contiguous()), _ptr(basis), n_fft, _stream()), "gfx_istft_basis_f32")
+    pin = _Pin()
+    check(lib().gfx_istft_basis_f32(pin(window), _ptr(basis), n_fft, _stream()), "gfx_istft_basis_f32")
     return basis
 
 
+@_on_device
 def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_len, hop, ms_to_lr):
     """-> (ir (R,2,ir_len) un-normalised, row_gain (R) = 1/sqrt(mean_c sum_t ir^2 + 1e-12))."""
     _require_gpu(init_lm, delta_lm, gain_env, window, basis)
@@ -487,9 +566,9 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
     row_gain = torch.empty((R,), dtype=torch.float32, device=init_lm.device)
     nbytes = lib().gfx_stft_reverb_workspace_bytes(R, n_fft, T)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=init_lm.device)
+    pin = _Pin()
     check(
-        lib().gfx_stft_reverb_ir_f32(_ptr(nz), _ptr(init_lm.contiguous()), _ptr(delta_lm.contiguous()),
-                                     _ptr(None if gain_env is None else gain_env.contiguous()), _ptr(window), _ptr(basis),
+        lib().gfx_stft_reverb_ir_f32(_ptr(nz), pin(init_lm), pin(delta_lm), pin(gain_env), pin(window), pin(basis),
                                      _ptr(ir), _ptr(row_gain), R, ir_len, n_fft, hop, T, int(ms_to_lr), _ptr(ws), nbytes, _stream()),
         "gfx_stft_reverb_ir_f32",
     )
@@ -497,6 +576,7 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
 
 
 # ----------------------------------------------------------------------------------------- routing
+@_on_device
 def gather_sum(buf, src_idx, seg_ptr, out):
     """out[b,j] = sum of buf[b, src_idx[e]] over e in [seg_ptr[j], seg_ptr[j+1]); buf/out are (B,V,C,L) views."""
     _require_gpu(buf, out)
@@ -516,6 +596,7 @@ def gather_sum(buf, src_idx, seg_ptr, out):
     return out
 
 
+@_on_device
 def gather_sum_fanout(buf, unique_src, dest_mask, out):
     """Fan-out form of :func:`gather_sum`: source rows read once, up to 8 destinations (bit mask per source)."""
     _require_gpu(buf, out)

@@ -37,9 +37,23 @@ def all_reduce_gradients(parameters, average=True):
 
 
 def gather_outputs(y, dst=0):
-    """Concatenate per-rank output shards on ``dst`` (None elsewhere)."""
+    """Concatenate per-rank output shards on ``dst`` (None elsewhere).
+
+    ``shard_batch`` uses a ceil split, so shards can be uneven (10 graphs over 4 ranks: 3/3/3/1) or empty; the
+    shard sizes are exchanged first and every rank sends a buffer padded to the largest shard, because
+    ``dist.gather`` needs equal shapes on every rank."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return y
-    bucket = [torch.empty_like(y) for _ in range(dist.get_world_size())] if dist.get_rank() == dst else None
-    dist.gather(y, bucket, dst=dst)
-    return torch.cat(bucket) if bucket is not None else None
+    world = dist.get_world_size()
+    n = torch.tensor([y.shape[0]], dtype=torch.int64, device=y.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    per = max(sizes)
+    send = y.contiguous()
+    if send.shape[0] != per:
+        pad = torch.zeros((per - send.shape[0], *send.shape[1:]), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad])
+    bucket = [torch.empty_like(send) for _ in range(world)] if dist.get_rank() == dst else None
+    dist.gather(send, bucket, dst=dst)
+    return torch.cat([b[:k] for b, k in zip(bucket, sizes)]) if bucket is not None else None

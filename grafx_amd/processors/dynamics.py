@@ -161,8 +161,9 @@ class ApproxCompressor(Compressor):
         super().__init__(energy_smoother="iir", gain_smoother=None, knee="quadratic", iir_len=iir_len,
                          flashfftconv=flashfftconv, max_input_len=max_input_len)
 
-    def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None):
-        return super().forward(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre=z_alpha, _out=_out)
+    def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None, _shared_rows=None):
+        return super().forward(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre=z_alpha, _out=_out,
+                               _shared_rows=_shared_rows)
 
     def parameter_size(self):
         return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}

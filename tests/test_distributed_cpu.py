@@ -73,3 +73,29 @@ def test_shard_batch_covers_everything():
     x = torch.arange(10)[:, None]
     parts = [shard_batch(x, r, 4) for r in range(4)]
     assert torch.equal(torch.cat(parts), x)
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grafx_amd.parallel import gather_outputs, shard_batch
+
+    x = torch.arange(5 * 3, dtype=torch.float32).view(5, 3)  # 5 graphs over 3 ranks: 2 / 2 / 1
+    full = gather_outputs(shard_batch(x, rank, world) * 2.0, dst=0)
+    y = torch.arange(2 * 3, dtype=torch.float32).view(2, 3)  # 2 graphs over 3 ranks: 1 / 1 / 0 (an empty shard)
+    full2 = gather_outputs(shard_batch(y, rank, world) + 1.0, dst=0)
+    if rank == 0:
+        torch.save({"full": full, "full2": full2}, os.path.join(out_dir, "gather.pt"))
+    else:
+        assert full is None and full2 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_outputs_uneven_and_empty_shards(tmp_path):
+    port = 29850 + os.getpid() % 100
+    mp.start_processes(_gather_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True, start_method="spawn")
+    got = torch.load(os.path.join(tmp_path, "gather.pt"))
+    assert torch.equal(got["full"], torch.arange(15, dtype=torch.float32).view(5, 3) * 2.0)
+    assert torch.equal(got["full2"], torch.arange(6, dtype=torch.float32).view(2, 3) + 1.0)
