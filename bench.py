@@ -3,27 +3,110 @@
 (111 nodes: 36 EQ, 36 compressor, 1 reverb, 5 mix, 32 in, 1 out — BASELINE.json configs[3])
 at batch 256 per GPU, L = 131072 samples, stereo, fp32.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]                      # N > 1: starts N ranks itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one render_grafx pass over one resident batch.  The batch axis shards over GPUs
 (weak scaling: 256 graphs per GPU, no data-path collective for the forward render).
 Prints ONE JSON line on rank 0.
+
+`--gpus N` without a launcher (no RANK in the environment) makes this process a pure launcher: it starts
+N children — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1 — BEFORE
+anything here touches the GPU, relays rank 0's JSON line and exits non-zero if any rank failed.
+
+Other workloads (`--config`): cfg2 = BASELINE configs[1] (ParametricEqualizer, 1024 x 1 x 480000),
+cfg3 = configs[2] (STFTMaskedNoiseReverb, 512 x 2 x 240000); each prints the same kind of line with its own
+roofline.  `--dry --backend gloo` is the CPU plumbing check of the multi-rank path (pass-through processors,
+no audio arithmetic; used by tests/test_bench_launch.py) — its numbers mean nothing and the line says so.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); a one-float4-per-thread nt copy reaches 6.6 TB/s on this
+                       # pool (profiles/r2/stream2_copy_ceiling.txt), the guide measured 6.29 TB/s
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 5.2-5.5 TB/s is what a streaming copy reaches (tools/ubench/stream.hip)
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="graphs (cfg4) or rows (cfg2/cfg3) per GPU")
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--config", choices=["cfg4", "cfg2", "cfg3"], default="cfg4",
+                    help="cfg4: the headline console graph (default); cfg2 / cfg3: BASELINE configs[1] / configs[2]")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only with --dry)")
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU plumbing check: pass-through processors on CPU tensors (launch, sharding, barriers, JSON)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--reference-default-lengths", action="store_true",
+                    help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
+                         "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
+    ap.add_argument("--reference-default-args", action="store_true",
+                    help="build the processors with upstream's constructor defaults (flashfftconv=True, 4000/16384/60000 taps): "
+                         "the FlashFFTConv flavour, i.e. plain causal convolutions; not the headline configuration")
+    ap.add_argument("--capture", action="store_true",
+                    help="replay the render as one captured HIP graph (grafx_amd.render.CapturedRender): the serving "
+                         "path for small batches, where the eager loop is host-bound")
+    ap.add_argument("--train", action="store_true", help="(kept for compatibility: the training step is timed by default)")
+    ap.add_argument("--train-batch", type=int, default=256, help="graphs per GPU in the training step (configs[4]: 256)")
+    ap.add_argument("--train-steps", type=int, default=3)
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher: one child per GPU.  Nothing in this process has touched the GPU
+    (torch is not even imported yet), so this is a plain fork+exec of fresh interpreters, never a re-exec of a process
+    that holds the device."""
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRAFX_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        pending = dict(enumerate(children))
+        while pending:
+            for rank, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[rank]
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[bench] rank {rank} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending.values():  # exactly the PIDs started above
+                        q.terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for p in children:
+            p.terminate()
+        rc = 130
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ workloads
 def console_graph(n_ch=32, n_bus=4):
     from grafx_amd.data import GRAFX, NodeConfigs
 
@@ -64,6 +147,20 @@ def hip_processors(default_args=False):
     }
 
 
+def dry_processors():
+    """Pass-through stand-ins with the processors' interface, for the CPU plumbing check only."""
+    import torch.nn as nn
+
+    class Pass(nn.Module):
+        def forward(self, input_signals, **params):
+            return input_signals
+
+        def parameter_size(self):
+            return {"p": 1}
+
+    return {"eq": Pass(), "compressor": Pass(), "reverb": Pass()}
+
+
 def oracle_processors():
     import oracle
 
@@ -74,99 +171,200 @@ def oracle_processors():
     }
 
 
-def cpu_baseline(G, render_data, params_cpu, L, budget_s=25.0):
-    """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample.
+def _timed_cpu(fn, budget_s, warm=2, reps=5):
+    """median of `reps` after `warm` warm-ups, cut short when the budget runs out"""
+    t_all = time.perf_counter()
+    times = []
+    for i in range(warm + reps):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        if i >= warm:
+            times.append(dt)
+        if time.perf_counter() - t_all > budget_s and i >= warm:
+            break
+    return times
 
-    torch's CPU FFT does not scale to every core of a large host (oversubscription makes it slower),
-    so a few thread counts are tried and the best one is reported with the count actually used."""
+
+def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=20.0):
+    """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample."""
+    import torch
+
     from grafx_amd.render import render_grafx
 
     procs = oracle_processors()
-    B = 8
+    B = 4
     x = torch.randn(B, 32, 2, L)
     ncpu = os.cpu_count() or 1
-    best, best_threads, runs = None, None, 0
-    t_all = time.perf_counter()
+    threads = min(ncpu, 32)  # torch's CPU FFT gets slower when a large host is oversubscribed
+    torch.set_num_threads(threads)
     with torch.no_grad():
-        for threads in sorted({min(ncpu, t) for t in (16, 32, 64)}):
-            torch.set_num_threads(threads)
-            for i in range(3):
-                t0 = time.perf_counter()
-                render_grafx(procs, x, params_cpu, render_data, parameters_grad=False)
-                dt = time.perf_counter() - t0
-                runs += 1
-                if i > 0 and (best is None or dt < best):
-                    best, best_threads = dt, threads
-                if time.perf_counter() - t_all > budget_s:
-                    break
-            if time.perf_counter() - t_all > budget_s:
+        times = _timed_cpu(lambda: render_grafx(procs, x, params_cpu, render_data, parameters_grad=False), budget_s)
+    med = statistics.median(times)
+    return {"value": B * L / med, "unit": "audio samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
+            "seconds": [round(t, 3) for t in times],
+            "sample": f"same 111-node console graph and filter lengths, batch {B} (of 256), L={L}; median of "
+                      f"{len(times)} renders after 2 warm-ups, {threads} torch threads (torch CPU oracle, fp32)"}
+
+
+def cpu_baseline_proc(kind, L, budget_s=15.0):
+    import torch
+
+    import oracle
+
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    if kind == "cfg2":
+        R = 8
+        proc = oracle.OracleParametricEqualizer(num_filters=6, processor_channel="mono", fsm_fir_len=LENS["fsm_fir_len"])
+        x = torch.randn(R, 1, L)
+        p = {k: torch.randn(R, 1, 6) for k in ("w0", "q_inv", "log_gain")}
+        C = 1
+    else:
+        R = 8
+        proc = oracle.OracleSTFTMaskedNoiseReverb(ir_len=LENS["ir_len"])
+        x = torch.randn(R, 2, L)
+        p = {k: torch.randn(R, 2, 193) for k in ("init_log_magnitude", "delta_log_magnitude")}
+        C = 2
+    with torch.no_grad():
+        times = _timed_cpu(lambda: proc(x, **p), budget_s)
+    med = statistics.median(times)
+    return {"value": R * C * L / med, "unit": "channel-samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
+            "seconds": [round(t, 3) for t in times],
+            "sample": f"{R} rows (of the full batch) x {C} x {L}, same processor and filter length; median of {len(times)} "
+                      f"calls after 2 warm-ups, {threads} torch threads (torch CPU oracle, fp32)"}
+
+
+def roofline_from_profile(prof, steps, elapsed, B, L):
+    """Dominant kernel (largest summed launch time inside the timed region, HIP events on its stream)."""
+    stats = {}
+    for name, recs in prof.items():
+        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        stats[name] = (sum(ms), sum(ms) / len(ms), sum(r[2] for r in recs) / len(recs), len(ms))
+    name = max(stats, key=lambda k: stats[k][0])
+    total_ms, avg_ms, avg_bytes, n = stats[name]
+    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    for rnd in ("r2", "r1"):
+        pmc = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
+        if not os.path.exists(pmc):  # PMC bytes come from a separate rocprofv3 --pmc pass of this same command
+            continue
+        with open(pmc) as f:
+            rec = json.load(f)
+        cfg = rec.get("config", {})
+        if cfg.get("batch") == B and cfg.get("audio_len") == L and all(cfg.get(k) == v for k, v in LENS.items()):
+            k = rec["kernels"].get("gfx::" + name) or rec["kernels"].get(name)
+            if k:
+                traffic, traffic_src = k["hbm_bytes_per_launch"], f"profiles/{rnd}/pmc_hbm_traffic.json"
                 break
-    if best is None:
-        best, best_threads = dt, threads
-    return {
-        "value": B * L / best,
-        "unit": "audio samples/s",
-        "cores": best_threads,
-        "host_cpus": ncpu,
-        "kind": "port",
-        "sample": f"same 111-node console graph and filter lengths, batch {B} (of 256), L={L}; best of {runs} timed "
-                  f"renders over thread counts 16/32/64 (torch CPU oracle, fp32)",
-    }
+    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": avg_bytes, "launches_per_step": n // steps,
+            "share_of_step": total_ms / steps / (elapsed / steps * 1e3),
+            "per_kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(stats.items())}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
-    ap.add_argument("--length", type=int, default=131072)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reference-default-lengths", action="store_true",
-                    help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
-                         "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
-    ap.add_argument("--reference-default-args", action="store_true",
-                    help="build the processors with upstream's constructor defaults (flashfftconv=True, 4000/16384/60000 taps): "
-                         "the FlashFFTConv flavour, i.e. plain causal convolutions; not the headline configuration")
-    ap.add_argument("--capture", action="store_true",
-                    help="replay the render as one captured HIP graph (grafx_amd.render.CapturedRender): the serving "
-                         "path for small batches, where the eager loop is host-bound")
-    ap.add_argument("--train", action="store_true",
-                    help="also time forward+backward+gradient all-reduce (BASELINE configs[4]) at --train-batch per GPU")
-    ap.add_argument("--train-batch", type=int, default=256, help="graphs per GPU in the training step (configs[4]: 256)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and "RANK" in os.environ:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    if args.dry:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, min(4, (os.cpu_count() or 1) // max(world, 1))))
+    else:
+        if args.backend != "nccl":
+            raise SystemExit("--backend gloo is the CPU plumbing mode: combine it with --dry")
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
     dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one process per GPU
+    if world > 1 or "RANK" in os.environ:  # one process per GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        # RCCL builds its communicator (device buffers, proxy threads) lazily at the first collectives; do that now,
-        # not inside the timed region (its hipMallocs are device-synchronising: seen as 250 ms "steps" with --warmup 1)
-        warm = torch.zeros(1, device=torch.device("cuda", local))
-        dist.all_reduce(warm)
-        dist.barrier()
-        torch.cuda.synchronize()
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if args.dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL builds its communicator (device buffers, proxy threads) lazily at the first collectives; do that now,
+            # not inside the timed region (its hipMallocs are device-synchronising: seen as 250 ms "steps" with --warmup 1)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def sync():
+        if not args.dry:
+            torch.cuda.synchronize()
+
+    def fence():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
 
     if args.reference_default_lengths or args.reference_default_args:
         LENS.update(fsm_fir_len=4000, iir_len=16384, ir_len=60000)
+    if args.config == "cfg4":
+        out = bench_console(args, torch, dist, dev, world, rank, sync, fence)
+    else:
+        out = bench_processor(args, torch, dist, dev, world, rank, sync, fence)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _timed_region(args, torch, dist, dev, step, sync, fence, profile):
+    """W warm-up steps, then exactly K steps between barrier + synchronize fences; MAX over ranks."""
     from grafx_amd import ops
+
+    y = None
+    if dist is not None:
+        # line the ranks up BEFORE the warm-up: their start-up skew (seconds) then is not spent idling at the barrier
+        # that opens the timed region (a GPU that has idled for milliseconds runs its next large launches 20-30 % slow)
+        sync()
+        dist.barrier()
+    for _ in range(args.warmup):
+        y = step()
+    fence()
+    # the dominant kernel is timed live, inside the timed region, with a pair of stream events around every launch
+    # (recorded on the stream the kernel runs on; no synchronisation, ~120 event records per step)
+    ops.PROFILE = {} if profile else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    sync()                            # this rank's K steps are done: stop its clock ...
+    elapsed = time.perf_counter() - t0
+    fence()                           # ... then the closing barrier; the job's time is the MAX over ranks (below)
+    prof, ops.PROFILE = ops.PROFILE, None
+    per_rank = [elapsed]
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        elapsed = max(per_rank)
+    return y, elapsed, per_rank, prof
+
+
+def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     from grafx_amd.data import convert_to_tensor
     from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
     from grafx_amd.utils import create_empty_parameters
 
-    B, L = args.batch, args.length
+    B = args.batch or 256
+    L = args.length or 131072
     G = console_graph()
     render_data = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
-    procs = {k: v.to(dev) for k, v in hip_processors(args.reference_default_args).items()}
+    procs = dry_processors() if args.dry else {k: v.to(dev) for k, v in hip_processors(args.reference_default_args).items()}
     torch.manual_seed(1234)  # identical parameters on every rank (a shared mixing console)
     params_cpu = {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
     params = {t: {k: v.to(dev) for k, v in d.items()} for t, d in params_cpu.items()}
@@ -182,159 +380,182 @@ def main():
         with torch.no_grad():
             return render_grafx(procs, x, params, rd_dev, parameters_grad=False)[0]
 
-    # prime the caching allocator with the two signal buffers the loop ping-pongs between (the render
-    # returns views of its (B, 111, 2, L) buffer, so one stays alive while the next step allocates):
-    # a first hipMalloc of ~30 GB on a freshly booted box can take most of a second.
-    pool = [torch.empty(B, render_data.num_nodes, 2, L, device=dev) for _ in range(2)]
-    del pool
-    with torch.no_grad():  # one single-graph render: loads every kernel's code object and builds the per-device tables
-        render_grafx(procs, x[:1], params, rd_dev, parameters_grad=False)
-    torch.cuda.synchronize()
-    if args.capture:
-        from grafx_amd.render import CapturedRender
+    if not args.dry:
+        # prime the caching allocator with the two signal buffers the loop ping-pongs between (the render
+        # returns views of its (B, 111, 2, L) buffer, so one stays alive while the next step allocates):
+        # a first hipMalloc of ~30 GB on a freshly booted box can take most of a second.
+        pool = [torch.empty(B, render_data.num_nodes, 2, L, device=dev) for _ in range(2)]
+        del pool
+        with torch.no_grad():  # one single-graph render: loads every kernel's code object, builds the per-device tables
+            render_grafx(procs, x[:1], params, rd_dev, parameters_grad=False)
+        sync()
+        if args.capture:
+            from grafx_amd.render import CapturedRender
 
-        captured.append(CapturedRender(procs, x, params, rd_dev))
-    y = None
-    if dist is not None:
-        # line the ranks up BEFORE the warm-up: their start-up skew (seconds) then is not spent idling at the barrier
-        # that opens the timed region, right in front of the first timed step (a GPU that has idled for milliseconds
-        # runs its next large launches 20-30 % slow)
-        torch.cuda.synchronize()
-        dist.barrier()
-    for _ in range(args.warmup):
-        y = step()
+            captured.append(CapturedRender(procs, x, params, rd_dev))
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    # the dominant kernel is timed live, inside the timed region, with a pair of stream events around every launch
-    # (recorded on the stream the kernel runs on; no synchronisation, ~120 event records per 13 ms step)
-    ops.PROFILE = None if args.capture else {}
-    t0 = time.perf_counter()
-    debug = os.environ.get("GRAFX_BENCH_DEBUG")
-    for _ in range(args.steps):
-        y = step()
-        if debug:  # per-step wall times (adds a sync per step: diagnostics only)
-            torch.cuda.synchronize()
-            print(f"[bench] step done at +{(time.perf_counter() - t0) * 1e3:.1f} ms, reserved "
-                  f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", file=sys.stderr)
-    torch.cuda.synchronize()          # this rank's K steps are done: stop its clock ...
-    elapsed = time.perf_counter() - t0
-    fence()                           # ... then the closing barrier; the job's time is the MAX over ranks (below)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    y, elapsed, per_rank, prof = _timed_region(args, torch, dist, dev, step, sync, fence,
+                                               profile=not (args.capture or args.dry))
     assert torch.isfinite(y).all(), "render produced non-finite samples"
-
-    roof = None
-    prof, ops.PROFILE = ops.PROFILE, None
-    if prof:
-        stats = {}
-        for name, recs in prof.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            stats[name] = (sum(ms), sum(ms) / len(ms), sum(r[2] for r in recs) / len(recs), len(ms))
-        name = max(stats, key=lambda k: stats[k][0])
-        total_ms, avg_ms, avg_bytes, n = stats[name]
-        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic.json")
-        if os.path.exists(pmc):  # PMC bytes come from a separate rocprofv3 --pmc pass of this same command
-            with open(pmc) as f:
-                rec = json.load(f)
-            cfg = rec.get("config", {})
-            if cfg.get("batch") == B and cfg.get("audio_len") == L and all(cfg.get(k) == v for k, v in LENS.items()):
-                k = rec["kernels"].get("gfx::" + name)
-                if k:
-                    traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r1/pmc_hbm_traffic.json"
-        roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": avg_ms,
-                "algorithmic_bytes_per_launch": avg_bytes, "launches_per_step": n // args.steps,
-                "share_of_step": total_ms / args.steps / (elapsed / args.steps * 1e3)}
+    roof = roofline_from_profile(prof, args.steps, elapsed, B, L) if prof else None
 
     train = None
-    if args.train:
-        # BASELINE configs[4]: shared parameters, batch sharded over the GPUs, one flat gradient all-reduce
-        import torch.nn as nn
-
-        from grafx_amd.parallel import all_reduce_gradients
-
+    if not (args.no_train or args.dry or args.capture):
         del y
-        torch.cuda.empty_cache()
-        Bt = args.train_batch
-        tparams = nn.ParameterDict({t: nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in d.items()})
-                                    for t, d in params.items()})
-        plist = list(tparams.parameters())
-        xt = x[:Bt]
+        try:
+            train = train_leg(args, torch, dist, dev, world, procs, params, x, rd_dev, L, sync, fence)
+        except Exception as e:  # the headline line must survive a failure of the secondary measurement
+            train = {"error": f"{type(e).__name__}: {e}"}
 
-        def train_step():
-            for p in plist:
-                p.grad = None
-            out = render_grafx(procs, xt, tparams, rd_dev)[0]
-            out.square().mean().backward()
-            all_reduce_gradients(plist)
+    if rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": "audio samples/sec (rendered output frames of the 32-channel console graph, all GPUs)",
+        "value": world * B * L * args.steps / elapsed,
+        "unit": "audio samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (randn signals, randn*0.1 parameters, random-phase noise IRs)",
+        "config": {"workload": "BASELINE configs[3]: 32-channel mixing console, 111 nodes / 142 edges, "
+                               "ParametricEqualizer(6) + Compressor(iir) + STFTMaskedNoiseReverb + bus sums",
+                   "batch_per_gpu": B, "global_batch": B * world, "audio_len": L, "channels": 2,
+                   "fsm_fir_len": LENS["fsm_fir_len"], "iir_len": LENS["iir_len"], "ir_len": LENS["ir_len"],
+                   "mode": ("forward render, reference-default even lengths (odd L+N-1: aliasing compatibility path)"
+                            if args.reference_default_lengths else
+                            "forward render, upstream default constructor arguments (flashfftconv=True: plain causal convolutions)"
+                            if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"),
+                   "parallelism": f"batch-shard x{world}",
+                   "launch": "one captured HIP graph per step" if args.capture else "eager render loop"},
+        "per_gpu_value": B * L * args.steps / elapsed,
+        "world_size": world if dist is None else dist.get_world_size(),
+        "backend": None if dist is None else dist.get_backend(),
+        "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+        "roofline": roof,
+    }
+    if args.dry:
+        out["dry"] = "CPU plumbing check with pass-through processors: launch/sharding/JSON only, the numbers mean nothing"
+    # whole-graph view of the same roofline: 285 row transfers per graph
+    graph_bytes = 285 * B * 2 * L * 4
+    out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
+                             "achieved_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": graph_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if train is not None:
+        out["training"] = train
+    if world == 1 and not args.no_cpu_baseline and not args.dry:
+        out["cpu_baseline"] = cpu_baseline_console(G, render_data, params_cpu, L)
+    return out
 
+
+def train_leg(args, torch, dist, dev, world, procs, params, x, rd_dev, L, sync, fence):
+    """BASELINE configs[4]: shared parameters, batch sharded over the GPUs, forward + backward + one flat gradient
+    all-reduce, at --train-batch graphs per GPU.  Secondary measurement; `value` of the line stays the forward render."""
+    import torch.nn as nn
+
+    from grafx_amd.parallel import all_reduce_gradients
+    from grafx_amd.render import render_grafx
+
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    Bt = min(args.train_batch, x.shape[0])
+    tparams = nn.ParameterDict({t: nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in d.items()})
+                                for t, d in params.items()})
+    plist = list(tparams.parameters())
+    xt = x[:Bt]
+
+    def train_step():
+        for p in plist:
+            p.grad = None
+        out = render_grafx(procs, xt, tparams, rd_dev)[0]
+        out.square().mean().backward()
+        all_reduce_gradients(plist)
+
+    train_step()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.train_steps):
         train_step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            train_step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        fence()
-        if dist is not None:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        train = {"what": "forward + backward + flat all-reduce of shared-parameter gradients", "batch_per_gpu": Bt,
-                 "ms_per_step": dt / args.steps * 1e3, "value": world * Bt * L * args.steps / dt,
-                 "unit": "audio samples/s", "grad_floats": sum(p.numel() for p in plist),
-                 "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        out = {
-            "metric": "audio samples/sec (rendered output frames of the 32-channel console graph, all GPUs)",
-            "value": world * B * L * args.steps / elapsed,
-            "unit": "audio samples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic (randn signals, randn*0.1 parameters, random-phase noise IRs)",
-            "config": {"workload": "BASELINE configs[3]: 32-channel mixing console, 111 nodes / 142 edges, "
-                                   "ParametricEqualizer(6) + Compressor(iir) + STFTMaskedNoiseReverb + bus sums",
-                       "batch_per_gpu": B, "global_batch": B * world, "audio_len": L, "channels": 2,
-                       "fsm_fir_len": LENS["fsm_fir_len"], "iir_len": LENS["iir_len"], "ir_len": LENS["ir_len"],
-                       "mode": ("forward render, reference-default even lengths (odd L+N-1: aliasing compatibility path)"
-                                if args.reference_default_lengths else
-                                "forward render, upstream default constructor arguments (flashfftconv=True: plain causal convolutions)"
-                                if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"), "parallelism": f"batch-shard x{world}",
-                       "launch": "one captured HIP graph per step" if args.capture else "eager render loop"},
-            "per_gpu_value": B * L * args.steps / elapsed,
-            "roofline": roof,
-        }
-        # whole-graph view of the same roofline: 285 row transfers per graph
-        graph_bytes = 285 * B * 2 * L * 4
-        out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
-                                 "achieved_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9,
-                                 "frac_of_hbm_peak": graph_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if train is not None:
-            out["training"] = train
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(G, render_data, params_cpu, L)
-        print(json.dumps(out))
+    sync()
+    dt = time.perf_counter() - t1
+    fence()
     if dist is not None:
-        dist.destroy_process_group()
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return {"what": "forward + backward + flat all-reduce of shared-parameter gradients", "batch_per_gpu": Bt,
+            "steps": args.train_steps, "ms_per_step": dt / args.train_steps * 1e3,
+            "value": world * Bt * L * args.train_steps / dt, "unit": "audio samples/s",
+            "grad_floats": sum(p.numel() for p in plist), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}
+
+
+def bench_processor(args, torch, dist, dev, world, rank, sync, fence):
+    """BASELINE configs[1] / configs[2]: one processor call over a resident batch of rows."""
+    if args.dry:
+        raise SystemExit("--dry only applies to the console graph")
+    from grafx_amd.processors import ParametricEqualizer, STFTMaskedNoiseReverb
+
+    torch.manual_seed(1000 + rank)
+    if args.config == "cfg2":
+        R, C, L = args.batch or 1024, 1, args.length or 480000
+        proc = ParametricEqualizer(num_filters=6, processor_channel="mono", flashfftconv=False,
+                                   fsm_fir_len=LENS["fsm_fir_len"]).to(dev)
+        p = {k: torch.randn(R, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
+        what = (f"BASELINE configs[1]: ParametricEqualizer(num_filters=6, mono, fsm_fir_len={LENS['fsm_fir_len']}) on "
+                f"{R} x {C} x {L}, parameters randn (std 1)")
+    else:
+        R, C, L = args.batch or 512, 2, args.length or 240000
+        proc = STFTMaskedNoiseReverb(ir_len=LENS["ir_len"], flashfftconv=False).to(dev)
+        p = {k: torch.randn(R, 2, 193, device=dev) for k in ("init_log_magnitude", "delta_log_magnitude")}
+        what = (f"BASELINE configs[2]: STFTMaskedNoiseReverb(ir_len={LENS['ir_len']}, pseudo_midside) on {R} x {C} x {L}, "
+                f"parameters randn (std 1)")
+    x = torch.randn(R, C, L, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return proc(x, **p)
+
+    step()
+    sync()
+    y, elapsed, per_rank, prof = _timed_region(args, torch, dist, dev, step, sync, fence, profile=True)
+    assert torch.isfinite(y).all(), "processor produced non-finite samples"
+    roof = roofline_from_profile(prof, args.steps, elapsed, R, L) if prof else None
+    if rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    call_bytes = 8 * R * C * L  # read x once, write y once
+    out = {
+        "metric": "channel-samples/sec through one processor call (all GPUs)",
+        "value": world * R * C * L * args.steps / elapsed, "unit": "channel-samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (randn signals and parameters)",
+        "config": {"workload": what, "rows_per_gpu": R, "channels": C, "audio_len": L,
+                   "parallelism": f"row-shard x{world}"},
+        "world_size": world if dist is None else dist.get_world_size(),
+        "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+        "roofline": roof,
+        "call_roofline": {"algorithmic_bytes_per_call": call_bytes,
+                          "achieved_GBps": call_bytes / (ms_per_step * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_proc(args.config, L)
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@ from .processors import (  # noqa: F401
     OracleSTFTMaskedNoiseReverb,
     OracleStereoGain,
     ballistics,
+    ballistics_docstring_reading,
     lr_to_ms,
     ms_to_lr,
     normalize_impulse,

@@ -37,14 +37,34 @@ def normalize_impulse(ir, eps=1e-12):
 def ballistics(x, z_alpha):
     """core/envelope.py:84-101 -> torchcomp.compressor_core (third-party, absent).
 
-    PARITY UNPINNED: recursion recalled from the public torchcomp algorithm:
-    y[-1] = 1; c = at if x[n] < y[n-1] else rt; y[n] = (1-c) y[n-1] + c x[n],
-    at, rt = sigmoid(z)[..., 0], sigmoid(z)[..., 1].
+    PARITY UNPINNED.  Reading "T" (implemented here and by gfx_ballistics_f32): the recursion of torchcomp's
+    ``compressor_core(x, zi, at, rt)`` as recalled from the public algorithm (Yu et al. 2024), which is what the
+    reference's *code* calls with ``at, rt = sigmoid(z)[..., 0], sigmoid(z)[..., 1]`` and ``zi = 1``:
+        y[-1] = 1;  c = at if x[n] < y[n-1] else rt;  y[n] = (1 - c) y[n-1] + c x[n].
+    The reference's *docstring* (core/envelope.py:68-73) describes the smoother the other way round -- reading "D",
+    :func:`ballistics_docstring_reading` -- coefficient on y[n-1], and the *release* coefficient when u[n] < y[n-1].
+    The two are different functions of z_alpha; "T" is implemented because the code path, not the prose, is what a
+    user's parameters go through.  Nothing external checks the recalled recursion; tests that depend on it carry
+    the ``provisional`` marker and are reported separately.
     """
     ts = torch.sigmoid(z_alpha)
     at, rt = ts[..., 0], ts[..., 1]
+    return _attack_release(x, at, rt, on_input=True)
+
+
+def ballistics_docstring_reading(x, z_alpha):
+    """Reading "D" of core/envelope.py:68-73, NOT what the kernel implements (see :func:`ballistics`):
+    alpha_A, alpha_R = sigmoid(z)[..., 0], sigmoid(z)[..., 1];  y[-1] = 1;
+    y[n] = alpha_R y[n-1] + (1 - alpha_R) u[n] if u[n] < y[n-1] else alpha_A y[n-1] + (1 - alpha_A) u[n]."""
+    ts = torch.sigmoid(z_alpha)
+    alpha_a, alpha_r = ts[..., 0], ts[..., 1]
+    return _attack_release(x, 1 - alpha_r, 1 - alpha_a, on_input=True)
+
+
+def _attack_release(x, c_below, c_above, on_input=True):
+    """y[n] = (1 - c) y[n-1] + c x[n], c = c_below if x[n] < y[n-1] else c_above, y[-1] = 1 (numpy loop, x's dtype)."""
     xs = x.detach().cpu().double().numpy()
-    a, r = at.detach().cpu().double().numpy(), rt.detach().cpu().double().numpy()
+    a, r = c_below.detach().cpu().double().numpy(), c_above.detach().cpu().double().numpy()
     if x.dtype == torch.float32:
         xs, a, r = xs.astype(np.float32), a.astype(np.float32), r.astype(np.float32)
     y = np.empty_like(xs)

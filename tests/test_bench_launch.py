@@ -1,0 +1,64 @@
+"""`python bench.py --gpus N` must start N ranks by itself (the driver runs exactly that command shape).
+
+CPU plumbing check: `--dry --backend gloo` swaps the HIP processors for pass-through modules on CPU tensors, so the
+launcher, the rendezvous on 127.0.0.1, the batch sharding, the barrier + max-over-ranks timing and the JSON line are
+exercised without a GPU.  (The numbers of a dry line mean nothing, and the line says so.)"""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(*flags, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, cwd=ROOT,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    res = _run("--gpus", "2", "--dry", "--backend", "gloo", "--batch", "2", "--length", "4096", "--steps", "2",
+               "--warmup", "1")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["backend"] == "gloo"
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in out["per_rank_ms_per_step"])
+    assert out["config"]["global_batch"] == 4 and out["config"]["batch_per_gpu"] == 2
+    assert out["scaling"] == "weak" and out["steps"] == 2 and out["warmup"] == 1
+    assert abs(out["ms_per_step"] - max(out["per_rank_ms_per_step"])) < 1e-9  # the job's time is the MAX over ranks
+    assert "dry" in out
+
+
+def test_bench_single_rank_dry():
+    res = _run("--dry", "--backend", "gloo", "--batch", "1", "--length", "2048", "--steps", "1", "--warmup", "0")
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["world_size"] == 1
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    # rank 1 of 2 cannot join (nccl without --dry on a box with no GPU / a bad flag combination): non-zero exit, no JSON
+    res = _run("--gpus", "2", "--backend", "gloo", "--batch", "1", "--length", "2048", "--steps", "1", "--warmup", "0")
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 command: `python -m torch.distributed.run ... bench.py --gpus N` (ranks come from the env)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--dry", "--backend", "gloo", "--batch", "1", "--length", "2048", "--steps", "1",
+                          "--warmup", "0"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2

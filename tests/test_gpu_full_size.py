@@ -164,3 +164,45 @@ def test_headline_batch_256_repeats_the_checked_batch_of_2():
         # the reverb's energy normalisation accumulates with float atomics: last-bit differences behind it
         assert ((pair[:, 109:] - buf2[:, 109:]).abs().amax(dim=(0, 2, 3)) <= 2e-6 * peak[109:]).all(), f"graphs {b}, {b + 1}"
     assert (y - y2.repeat(128, 1, 1, 1)).abs().max() <= 2e-6 * y2.abs().max()
+
+
+def test_cfg2_full_batch_1024_rows_repeat_the_checked_rows():
+    """BASELINE configs[1] at its full size: ParametricEqualizer(6, mono), 1024 x 1 x 480000, N = 4001 (30 tiles per
+    row, 30720 workgroups, 1024 distinct filters).  Rows never interact, so a batch that repeats the four rows checked
+    against the oracle above (same seed) 256 times must reproduce them bit for bit in every slot."""
+    from grafx_amd.processors import ParametricEqualizer
+
+    torch.manual_seed(2)
+    Lc = 480000
+    x4 = torch.randn(4, 1, Lc)
+    p4 = {k: torch.randn(4, 1, 6) for k in ("w0", "q_inv", "log_gain")}
+    m = ParametricEqualizer(num_filters=6, processor_channel="mono", flashfftconv=False, fsm_fir_len=4001).cuda()
+    with torch.no_grad():
+        y4 = m(x4.cuda(), **{k: v.cuda() for k, v in p4.items()})
+        ref = oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=4001)(x4, **p4)
+        ref64 = oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=4001)(x4.double(), **{k: v.double() for k, v in p4.items()})
+        assert_parity(y4.cpu(), ref, ref64, 1e-5, "cfg2 rows")
+        x = x4.cuda().repeat(256, 1, 1)
+        y = m(x, **{k: v.cuda().repeat(256, 1, 1) for k, v in p4.items()})
+    assert y.shape == (1024, 1, Lc)
+    assert torch.equal(y.view(256, 4, 1, Lc), y4.expand(256, 4, 1, Lc)), "a row of the full batch differs from its checked twin"
+
+
+def test_cfg3_full_batch_512_rows_repeat_the_checked_rows():
+    """BASELINE configs[2] at its full size: STFTMaskedNoiseReverb(ir_len=60001), 512 x 2 x 240000: 8 partitions, 37
+    windows per row-channel, a 1.2 GB spectrum workspace.  Same repeat-the-checked-rows property (the energy
+    normalisation of the impulse response accumulates with float atomics: last-bit differences allowed)."""
+    from grafx_amd.processors import STFTMaskedNoiseReverb
+
+    torch.manual_seed(3)
+    Lc = 240000
+    x2 = torch.randn(2, 2, Lc)
+    p2 = {k: torch.randn(2, 2, 193) for k in ("init_log_magnitude", "delta_log_magnitude")}
+    m = STFTMaskedNoiseReverb(ir_len=60001, flashfftconv=False).cuda()
+    with torch.no_grad():
+        y2 = m(x2.cuda(), **{k: v.cuda() for k, v in p2.items()})
+        assert_close(y2.cpu(), oracle.OracleSTFTMaskedNoiseReverb(ir_len=60001)(x2, **p2), 1e-5, "cfg3 rows")
+        y = m(x2.cuda().repeat(256, 1, 1), **{k: v.cuda().repeat(256, 1, 1) for k, v in p2.items()})
+    assert y.shape == (512, 2, Lc)
+    d = (y.view(256, 2, 2, Lc) - y2).abs().amax(dim=(0, 2, 3))
+    assert (d <= 2e-6 * y2.abs().amax(dim=(1, 2))).all(), d

@@ -70,7 +70,11 @@ def test_biquad(golden, K, N, normalized):
     tag = f"K{K}_N{N}_norm{int(normalized)}"
     m = BiquadFilter(num_filters=K, normalized=normalized, flashfftconv=False, fsm_fir_len=N)
     p = {k: g[f"{k}_{tag}"] for k in m.parameter_size()}
-    assert_close(run(m, g[f"x_{tag}"], p), g[f"y_{tag}"], 3e-5, "biquad")
+    # 1e-5 against the reference's own output; where the reference's complex64 response is itself farther than that
+    # from a float64 evaluation of the same formulas (poles near the unit circle), the float64 tie-breaker decides
+    y64 = oracle.OracleBiquadFilter(num_filters=K, normalized=normalized, fsm_fir_len=N)(
+        g[f"x_{tag}"].double(), **{k: v.double() for k, v in p.items()})
+    assert_parity(run(m, g[f"x_{tag}"], p), g[f"y_{tag}"], y64.float(), TOL, "biquad")
 
 
 def test_stereo_gain(golden):
