@@ -166,14 +166,19 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
+SCHEDULES = {"auto": 0, "tile": 1, "pingpong": 2}   # GFX_SCHED_* of include/grafx_amd.h
+
+
 @_on_device
-def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, part_len=0):
+def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, part_len=0, schedule="auto"):
     """y[r,c,n] = sum_k h[r % h_rows,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
 
     ``x`` / ``out`` may be (R,C,L) tensors or strided (B,n,C,L) views (see :func:`rowmap`).
     ``tee``: optional tensor shaped like ``x`` that receives a copy of ``x`` from the same kernel.
     ``h_rows``: number of filters in ``Hs`` when fewer than the signal rows (rows are batch-major, so
     ``h_rows = nodes`` shares one filter per node across the batch); default: one filter per row.
+    ``schedule``: "auto" (the library picks), "tile" (one tile per workgroup) or "pingpong" (persistent ping-pong
+    workgroups, for N <= 8193 and rows % h_rows == 0); see gfx_fftconv_sched_f32.
     """
     _require_gpu(x, out, tee)
     xmap, R, Cin, L = rowmap(x)
@@ -197,9 +202,9 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
             raise ValueError(f"tee shape {tuple(tee.shape)} does not match the input {tuple(x.shape)}")
     with _timed(name, 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)):
         check(
-            lib().gfx_fftconv_ex_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R, Cin, Cf,
-                                     L, Lout, off, N, _ptr(ws), nbytes, _stream()),
-            "gfx_fftconv_ex_f32",
+            lib().gfx_fftconv_sched_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R, Cin,
+                                        Cf, L, Lout, off, N, _ptr(ws), nbytes, SCHEDULES[schedule], _stream()),
+            "gfx_fftconv_sched_f32",
         )
     return out
 

@@ -112,6 +112,26 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
                        int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* gfx_fftconv_ex_f32 with an explicit kernel schedule for filters of N <= 8193 taps (same results to rounding, the
+ * tile boundaries differ):
+ *   GFX_SCHED_TILE      one 16384-sample tile per 256-thread workgroup (fftconv1_kernel): spreads small problems
+ *                       over the whole chip.
+ *   GFX_SCHED_PINGPONG  one persistent 512-thread workgroup per CU; its two halves run half a tile apart so the LDS
+ *                       exchanges of one hide under the arithmetic of the other; input windows arrive by LDS-DMA
+ *                       through a ring that keeps the overlap between consecutive windows (every sample is read from
+ *                       HBM once), filter spectrum and twiddles stay in registers (fftconv1pp_kernel).  Needs
+ *                       R % h_rows == 0 and part_len == 0; GFX_EINVAL otherwise.
+ *   GFX_SCHED_AUTO      what gfx_fftconv_f32 / _tee_f32 / _ex_f32 use: currently always one tile per workgroup, which
+ *                       measures faster than the ping-pong schedule at every size on MI355X
+ *                       (profiles/r2/pingpong_ablation.md). */
+#define GFX_SCHED_AUTO 0
+#define GFX_SCHED_TILE 1
+#define GFX_SCHED_PINGPONG 2
+int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
+                          float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
+                          int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                          void* ws, size_t ws_bytes, int schedule, void* stream);
+
 /* ---- frequency-sampled IIR -------------------------------------------------------------
  * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276
  * (complex64 response of the biquad cascade on the N-point grid, then torch.fft.irfft(n=N)).

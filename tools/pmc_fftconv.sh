@@ -1,11 +1,24 @@
-# SQ counters of the fftconv1 tile kernel on the isolated launch (tools/microbench.py eq): bash tools/pmc_fftconv.sh
+# SQ counters of the fftconv kernels on the isolated launches of tools/microbench.py eq: bash tools/pmc_fftconv.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_sq
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/microbench.py eq --rows 8192 --iters 2 > $OUT/p$i.log 2>&1
 done
-ls $OUT
+python3 - <<PY
+import csv, glob, collections, re
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"\(.*$", "", re.sub(r"^void\s+", "", r["Kernel_Name"]))
+        if "fftconv1" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(agg):
+    print("==", k)
+    for c in sorted(agg[k]):
+        v = agg[k][c]
+        print(f"  {c:28s} n={len(v):2d} mean={sum(v)/len(v):.4g}")
+PY
