@@ -23,6 +23,10 @@ template <typename T> __device__ __forceinline__ void gfx_plain_store(T v, T* p)
 #define GFX_NT_STORE(...) __builtin_nontemporal_store(__VA_ARGS__)
 #endif
 
+#ifndef GFX_DYN_PF
+#define GFX_DYN_PF 1               // tiles requested ahead of the one being scanned (dyn_fused)
+#endif
+
 namespace gfx {
 
 constexpr int DT = 256;            // threads per workgroup
@@ -197,20 +201,35 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
     const int64_t s0 = t_warm * DTILE;
     // software prefetch: the next tile's samples are requested before the current tile is scanned, so the
     // HBM round trip overlaps the scan / log / exp work (the barrier inside scan_tile would otherwise fence it)
-    float na[DE], nb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
-    load4(x0, t_warm * DTILE + (int64_t)DE * t, a.L, vx, na);
-    if (a.C == 2) load4(x1, t_warm * DTILE + (int64_t)DE * t, a.L, vx, nb);
+    // (GFX_DYN_PF tiles ahead: one workgroup streams one row, so its memory parallelism is what it keeps in flight itself)
+    float na[GFX_DYN_PF][DE], nb[GFX_DYN_PF][DE];
+#pragma unroll
+    for (int k = 0; k < GFX_DYN_PF; ++k) {
+#pragma unroll
+        for (int i = 0; i < DE; ++i) na[k][i] = nb[k][i] = 0.0f;
+        if (t_warm + k < t_hi) {
+            load4(x0, (t_warm + k) * DTILE + (int64_t)DE * t, a.L, vx, na[k]);
+            if (a.C == 2) load4(x1, (t_warm + k) * DTILE + (int64_t)DE * t, a.L, vx, nb[k]);
+        }
+    }
     for (int64_t tile = t_warm; tile < t_hi; ++tile) {
         const int64_t n = tile * DTILE + DE * t;
         float xa[DE], xb[DE], e[DE], env[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
-            xa[i] = na[i];
-            xb[i] = nb[i];
+            xa[i] = na[0][i];
+            xb[i] = nb[0][i];
         }
-        if (tile + 1 < t_hi) {
-            load4(x0, n + DTILE, a.L, vx, na);
-            if (a.C == 2) load4(x1, n + DTILE, a.L, vx, nb);
+#pragma unroll
+        for (int k = 0; k + 1 < GFX_DYN_PF; ++k)
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                na[k][i] = na[k + 1][i];
+                nb[k][i] = nb[k + 1][i];
+            }
+        if (tile + GFX_DYN_PF < t_hi) {
+            load4(x0, n + (int64_t)GFX_DYN_PF * DTILE, a.L, vx, na[GFX_DYN_PF - 1]);
+            if (a.C == 2) load4(x1, n + (int64_t)GFX_DYN_PF * DTILE, a.L, vx, nb[GFX_DYN_PF - 1]);
         }
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
@@ -250,7 +269,10 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
     }
 }
 
-__global__ __launch_bounds__(DT) void dyn_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+#ifndef GFX_DYN_WAVES
+#define GFX_DYN_WAVES 1
+#endif
+__global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ log_threshold,
                                                        const float* __restrict__ log_ratio,
                                                        const float* __restrict__ log_knee,
