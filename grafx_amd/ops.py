@@ -209,6 +209,30 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
     return out
 
 
+@_on_device
+def fir_direct(x, h, Lout=None, off=0, out=None, h_rows=None):
+    """Short FIR (N <= 512 taps) on the fp32 matrix cores, taps given directly: same result as
+    ``fftconv(x, fir_spectrum(h.reshape(-1, N)), N, Cf, Lout, off)``.  ``h``: (h_rows, Cf, N)."""
+    _require_gpu(x, h, out)
+    xmap, R, Cin, L = rowmap(x)
+    h = h.contiguous()
+    hr, Cf, N = h.shape
+    h_rows = hr if h_rows is None else h_rows
+    if hr != h_rows:
+        raise ValueError(f"fir_direct: {hr} filter rows given, h_rows={h_rows}")
+    Lout = L if Lout is None else Lout
+    Cout = max(Cin, Cf)
+    if out is None:
+        out = torch.empty((R, Cout, Lout), dtype=torch.float32, device=x.device)
+    ymap, Ry, Cy, Ly = rowmap(out)
+    if (Ry, Cy) != (R, Cout) or Ly < Lout:
+        raise ValueError(f"output shape {tuple(out.shape)} does not match rows={R}, channels={Cout}, length>={Lout}")
+    with _timed("fir_mfma_kernel", 4 * R * (Cin * L + Cout * Lout)):
+        check(lib().gfx_fir_direct_f32(_ptr(x), xmap, _ptr(h), h_rows, _ptr(out), ymap, R, Cin, Cf, L, Lout, off, N, _stream()),
+              "gfx_fir_direct_f32")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- IIR (FSM)
 @_on_device
 def iir_fsm_plan(N, device):

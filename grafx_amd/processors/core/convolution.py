@@ -25,6 +25,9 @@ from ... import ops
 from ...autograd import needs_grad
 
 _EXACT = False
+# Filters up to this many taps run as Toeplitz GEMMs on the fp32 matrix cores (gfx_fir_direct_f32) instead of the FFT tile
+# kernel: the crossover measured on MI355X (profiles/r2/fir_mfma_crossover.txt).
+SHORT_FIR_TAPS = 40
 
 
 def set_exact_convolution(flag=True):
@@ -108,6 +111,11 @@ def convolve(x, h, mode="zerophase", pad_mode="min", exact=False):
     if flat:
         x, h = x.unsqueeze(1), h.unsqueeze(1)
     R, Cf, N = h.shape
+    L = x.shape[-1]
+    if N <= SHORT_FIR_TAPS and not reference_aliases(L, N, exact):
+        off, Lout = {"causal": (0, L), "zerophase": (N // 2, L)}.get(mode, (0, L + N - 1))
+        y = ops.fir_direct(x, h, Lout=Lout, off=off)
+        return y.squeeze(1) if flat else y
     Hs = ops.fir_spectrum(h.reshape(R * Cf, N))
     y = convolve_taps(x, Hs, N, Cf, mode, exact=exact)
     return y.squeeze(1) if flat else y

@@ -132,6 +132,16 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                           void* ws, size_t ws_bytes, int schedule, void* stream);
 
+/* Short filters (N <= gfx_fir_direct_max_taps() = 512) as batched Toeplitz GEMMs on the fp32 matrix cores, taps given
+ * directly (no spectra): the direct-form counterpart of gfx_fftconv_ex_f32 with the same meaning of every argument
+ *   y[r, c, n] = sum_k h[r % h_rows, c_f, k] x[r, c_x, n + off - k],  n in [0, Lout),  x zero outside [0, L)
+ * h is (h_rows * C_f, N) contiguous.  Replaces convolve() / FIRConvolution for short FIRs (core/convolution.py:85-134,
+ * filter.py:34-39); exact fp32 (v_mfma_f32_16x16x4_f32).  MFMA-bound above ~64 taps, HBM-bound below. */
+int64_t gfx_fir_direct_max_taps(void);
+int gfx_fir_direct_f32(const float* x, gfx_rowmap_t xmap, const float* h, int64_t h_rows, float* y, gfx_rowmap_t ymap,
+                       int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                       void* stream);
+
 /* ---- frequency-sampled IIR -------------------------------------------------------------
  * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276
  * (complex64 response of the biquad cascade on the N-point grid, then torch.fft.irfft(n=N)).
