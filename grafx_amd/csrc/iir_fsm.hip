@@ -17,9 +17,12 @@
 #include "../../include/grafx_amd.h"
 #include "fft_tile.hpp"
 
+#define NAT(arr, i) arr[(i) >> 4][brev((i) & 15, 4)]
+
 namespace gfx {
 
 constexpr int FSM_MAX_N = 4096;  // 2N-1 <= 8192
+static inline bool fsm_pow2(int64_t N) { return N == 8192 || N == 16384; }
 
 // exp(+i*pi*k^2/N) (sign = +1) or exp(-i*pi*k^2/N) (sign = -1); k^2 reduced mod 2N in integers
 __device__ __forceinline__ float2 chirp(int k, int N, float sign) {
@@ -128,6 +131,55 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
             const cx e = v[brev(a, 5)];
             out[n] = (e.x * c.x - e.y * c.y) * sc;
         }
+    }
+}
+
+// Power-of-two lengths above the Bluestein limit (N = 8192, 16384: the reference's own test parametrisation,
+// tests/processors/test_filter.py:27): the length-N inverse real DFT IS the tile's inverse transform.  The sampled
+// response Y[k] (k = 0..N/2) is placed on every (16384 / N)-th bin of a 16384-point Hermitian spectrum -- a spectrum
+// that lives only on those bins belongs to a signal of period N, whose first N samples are h scaled by N / 16384 -- and
+// folded into the packed form the tile inverts:  Ye[k] = (Y[k] + conj(Y[M-k])) / 2,  Yo[k] = e^{i pi k / M} (Y[k] -
+// conj(Y[M-k])) / 2,  Z'[k] = Ye + i Yo,  Z'[M-k] = conj(Ye - i Yo)  (M = 8192; fft_tile.hpp, pair_merge).
+__global__ __launch_bounds__(TILE_T, 2) void iir_fsm_pow2_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
+                                                                 float* __restrict__ h, int K, int N,
+                                                                 const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
+    const int t = threadIdx.x;
+    const int64_t rc = blockIdx.x;
+    const float* B = Bs + rc * K * 3;
+    const float* A = As + rc * K * 3;
+    const int stride = TILE_F / N;
+    TileTw tw;
+    tile_twiddles(tw, twtab, t);
+    cx v[32], w[2][16];
+    auto Y = [&](int bin) -> cx {   // tile bin 0..M of the 16384-point spectrum
+        if (bin % stride) return cx{0.0f, 0.0f};
+        const int k = bin / stride;
+        cx r = to_cx(cascade_response(B, A, K, k, N));
+        if (k == 0 || k == N / 2) r.y = 0.0f;   // a c2r transform ignores the imaginary parts of DC and Nyquist
+        return r;
+    };
+    for_each_pair(t, tw.base(), [&](int, int ia, int ib, cx, bool self) {
+        const int j = (ia >> 4) ? bf_b(t) : bf_a(t);
+        const int k = j + 512 * (ia & 15);
+        const cx ya = Y(k), yb = (self && k != 0) ? ya : Y(TILE_M - k);
+        float sn, cs;
+        sincospif((float)k / (float)TILE_M, &sn, &cs);
+        const cx ye = (ya + cconj(yb)) * 0.5f;
+        const cx yo = cmul((ya - cconj(yb)) * 0.5f, cx{cs, sn});
+        cx za, zb;
+        pair_merge(ye, yo, za, zb);
+        NAT(w, ia) = za;
+        if (!self) NAT(w, ib) = zb;
+    });
+    tile_inverse(w, v, tw, lds, t);
+    const float sc = (float)stride / (float)TILE_M;
+    float* out = h + rc * N;
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        const int n = 2 * (t + 256 * a);
+        const cx e = v[brev(a, 5)] * sc;
+        if (n + 1 < N) *reinterpret_cast<float2*>(out + n) = make_float2(e.x, e.y);
     }
 }
 
@@ -252,6 +304,7 @@ using namespace gfx;
 
 extern "C" {
 
+int gfx_iir_fsm_native(int64_t N) { return (N >= 1 && N <= FSM_MAX_N) || fsm_pow2(N); }
 size_t gfx_iir_fsm_plan_bytes(int64_t N) { return (N < 1 || N > FSM_MAX_N) ? 0 : (size_t)TILE_M * sizeof(float2); }
 
 int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream) {
@@ -266,8 +319,16 @@ int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream) {
 
 int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h, int64_t RC, int64_t K,
                         int64_t N, void* stream) {
-    if (!Bs || !As || !plan || !h || RC <= 0 || K <= 0 || N < 1 || N > FSM_MAX_N || RC > 0x7fffffffLL)
-        return GFX_EINVAL;
+    if (!Bs || !As || !h || RC <= 0 || K <= 0 || N < 1 || RC > 0x7fffffffLL) return GFX_EINVAL;
+    if (fsm_pow2(N)) {  // no plan needed
+        if (allow_lds(iir_fsm_pow2_kernel)) return GFX_ELAUNCH;
+        const float2* tw2 = tile_twiddle_table((hipStream_t)stream);
+        if (!tw2) return GFX_ELAUNCH;
+        hipLaunchKernelGGL(iir_fsm_pow2_kernel, dim3((unsigned)RC), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream, Bs,
+                           As, h, (int)K, (int)N, tw2);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    }
+    if (!plan || N > FSM_MAX_N) return GFX_EINVAL;
     if (allow_lds(iir_fsm_kernel)) return GFX_ELAUNCH;
     const float2* tw = tile_twiddle_table((hipStream_t)stream);
     if (!tw) return GFX_ELAUNCH;

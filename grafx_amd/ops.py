@@ -235,10 +235,17 @@ def fir_direct(x, h, Lout=None, off=0, out=None, h_rows=None):
 
 # ----------------------------------------------------------------------------------------- IIR (FSM)
 @_on_device
+def iir_fsm_native(N):
+    """Whether the library has a native tap kernel for fsm_fir_len = N (1..4096, 8192, 16384)."""
+    return bool(lib().gfx_iir_fsm_native(N))
+
+
 def iir_fsm_plan(N, device):
     nbytes = lib().gfx_iir_fsm_plan_bytes(N)
     if nbytes == 0:
-        raise NotImplementedError(f"fsm_fir_len={N}: the HIP FSM kernel supports 1 <= fsm_fir_len <= 4096")
+        if iir_fsm_native(N):
+            return None  # power-of-two lengths above the Bluestein limit need no plan
+        raise NotImplementedError(f"fsm_fir_len={N}: the HIP FSM kernels support 1 <= fsm_fir_len <= 4096, 8192 and 16384")
     plan = torch.empty(nbytes, dtype=torch.uint8, device=device)
     check(lib().gfx_iir_fsm_plan_f32(_ptr(plan), N, _stream()), "gfx_iir_fsm_plan_f32")
     return plan

@@ -49,7 +49,7 @@ class IIRFilter(nn.Module):
         Bluestein kernel up to 4096 taps; beyond that the same formula as torch ops on the GPU (complex64 response as
         upstream, inverse real FFT in float64 so that the library transform adds no fp32 noise of its own)."""
         N = self.fsm_fir_len
-        if N <= self.FSM_NATIVE_MAX:
+        if ops.iir_fsm_native(N):  # 1..4096 (Bluestein on the LDS tile), 8192 and 16384 (the tile's own inverse transform)
             return ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
         k = torch.arange(N // 2 + 1, device=Bs.device)
         d = torch.arange(3, device=Bs.device)

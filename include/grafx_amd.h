@@ -148,6 +148,9 @@ int gfx_fir_direct_f32(const float* x, gfx_rowmap_t xmap, const float* h, int64_
  * Bs, As: (RC, K, 3) contiguous; h: (RC, N) taps out.  N <= 4096 (Bluestein on the LDS tile).
  * `plan` is a per-N constant (gfx_iir_fsm_plan_bytes bytes) filled once by gfx_iir_fsm_plan_f32.
  */
+/* 1 when gfx_iir_fsm_fir_f32 has a native kernel for fsm_fir_len = N: 1 <= N <= 4096 (Bluestein on one LDS tile; needs the
+ * plan of gfx_iir_fsm_plan_f32) and N = 8192, 16384 (the tile's own inverse real transform; `plan` may be NULL). */
+int gfx_iir_fsm_native(int64_t N);
 size_t gfx_iir_fsm_plan_bytes(int64_t N);
 int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream);
 int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h,

@@ -195,3 +195,26 @@ def test_loud_failures():
         P.IIRFilter(backend="nope", flashfftconv=False)
     with pytest.raises(ValueError):
         P.Compressor(knee="soft")
+
+
+@pytest.mark.parametrize("N", [8192, 16384])
+@pytest.mark.parametrize("K", [1, 6])
+def test_iir_fsm_native_taps_for_power_of_two_lengths_above_4096(N, K):
+    """fsm_fir_len = 8192 / 16384 (upstream tests/processors/test_filter.py:27): the tile's own inverse real transform
+    (gfx_iir_fsm_fir_f32 without a plan) against the oracle's complex64 response + irfft, float64 tie-breaker."""
+    from grafx_amd import ops
+    from grafx_amd.processors import IIRFilter
+    from oracle import lti
+
+    assert ops.iir_fsm_native(N) and not ops.iir_fsm_native(N - 2) and not ops.iir_fsm_native(5000)
+    torch.manual_seed(N + K)
+    R, Cf = 3, 2
+    w0, q, g = (0.6 * torch.randn(R, Cf, K) for _ in range(3))
+    Bs, As = oracle.peq_biquad_coefficients(w0, q, g)
+    flt = IIRFilter(order=2, backend="fsm", flashfftconv=False, fsm_fir_len=N)
+    with torch.no_grad():
+        fir = flt.fsm_fir(Bs.cuda(), As.cuda()).cpu()
+    ref = lti.iir_fsm_fir(Bs, As, N)
+    ref64 = lti.iir_fsm_fir(Bs.double(), As.double(), N)
+    assert fir.shape == ref.shape == (R, Cf, N)
+    assert_parity(fir, ref, ref64.float(), TOL, f"fsm taps N={N} K={K}")
