@@ -467,3 +467,58 @@ def log_gain(G, T, log_ratio, log_knee, knee, gate):
         return out - G
     k = torch.exp(log_knee)
     return -torch.exp(log_ratio) * F.softplus(k * (T - G)) / k
+
+
+# ------------------------------------------------------------------ exact recursive biquad cascade (lfilter / ssm backends)
+class BiquadCascadeFn(torch.autograd.Function):
+    """y = H_K ... H_1 x with H_i = B_i(z) / A_i(z), the exact recursion of gfx_biquad_cascade_f32 (reference
+    core/iir.py:154-183: one torchaudio.lfilter call per section, differentiable upstream).
+
+    Backward, per section from the last to the first (g_K = dL/dy, u_0 = x, u_i = H_i u_{i-1} saved by the forward):
+        v_i     = (1 / A_i)^T g_i                    the all-pole part run backwards in time (same native kernel on the
+                                                     time-reversed gradient)
+        dB_i[d] =  sum_n v_i[n] u_{i-1}[n - d]       d = 0, 1, 2
+        dA_i[d] = -sum_n v_i[n] u_i[n - d]           d = 0, 1, 2   (dy/da_d = -(z^-d / A) y)
+        g_{i-1} = B_i^T v_i                          g_{i-1}[n] = sum_d b_d v_i[n + d]
+    and dL/dx = g_0.  Channel broadcasts (1 <-> C) reduce the corresponding gradient over the channel axis."""
+
+    @staticmethod
+    def forward(ctx, x, Bs, As):
+        K = Bs.shape[2]
+        us = [x.contiguous()]
+        for i in range(K):
+            us.append(ops.biquad_cascade(us[-1], Bs[:, :, i : i + 1].contiguous(), As[:, :, i : i + 1].contiguous()))
+        ctx.save_for_backward(Bs, As, *us)
+        return us[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        Bs, As, *us = ctx.saved_tensors
+        R, Cf, K, _ = Bs.shape
+        L = gy.shape[-1]
+        g = gy.contiguous()
+        Cout = g.shape[1]
+        gB, gA = torch.zeros_like(Bs), torch.zeros_like(As)
+        unit = torch.zeros((R, Cf, 1, 3), dtype=Bs.dtype, device=Bs.device)
+        unit[..., 0] = 1.0
+
+        def to_filter_channels(t):     # (R, Cout) -> (R, Cf)
+            return t.sum(1, keepdim=True) if (Cf == 1 and Cout > 1) else t
+
+        for i in reversed(range(K)):
+            Ai = As[:, :, i : i + 1].contiguous()
+            v = ops.biquad_cascade(g.flip(-1).contiguous(), unit, Ai).flip(-1)   # (R, Cout, L)
+            u_in, u_out = us[i], us[i + 1]
+            for d in range(3):
+                vd = v[..., d:]
+                gB[:, :, i, d] = to_filter_channels((vd * u_in[..., : L - d]).sum(-1).expand(R, Cout))
+                gA[:, :, i, d] = -to_filter_channels((vd * u_out[..., : L - d]).sum(-1))
+            b = Bs[:, :, i]                                                        # (R, Cf, 3), broadcasts over channels
+            gp = b[..., 0:1] * v
+            gp[..., :-1] += b[..., 1:2] * v[..., 1:]
+            gp[..., :-2] += b[..., 2:3] * v[..., 2:]
+            g = gp
+        x = us[0]
+        gx = g.sum(1, keepdim=True) if x.shape[1] == 1 and Cout > 1 else g
+        return (gx if ctx.needs_input_grad[0] else None, gB if ctx.needs_input_grad[1] else None,
+                gA if ctx.needs_input_grad[2] else None)

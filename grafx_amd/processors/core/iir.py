@@ -77,8 +77,18 @@ class IIRFilter(nn.Module):
 
     def _process_recursive(self, input_signal, Bs, As, out=None):
         if needs_grad(input_signal, Bs, As):
-            raise NotImplementedError(f"backend={self.backend!r}: the exact recursive kernel is forward-only; "
-                                      "train with backend='fsm' (the reference default)")
+            if self.backend == "ssm" and Bs.shape[2] > 1:
+                raise NotImplementedError("backend='ssm' with more than one section reproduces an upstream quirk (every "
+                                          "section's recursion is driven by the original input, core/iir.py:226-246) in "
+                                          "the forward pass only; train with backend='lfilter' or 'fsm'")
+            x3 = input_signal.reshape(-1, *input_signal.shape[-2:]) if input_signal.ndim == 4 else input_signal
+            y = diff.BiquadCascadeFn.apply(x3, Bs, As)   # native recursion both ways (autograd.BiquadCascadeFn)
+            if input_signal.ndim == 4:
+                y = y.view(*input_signal.shape[:2], *y.shape[1:])
+            if out is None:
+                return y
+            out.copy_(y.view(out.shape))
+            return out
         if self.backend == "ssm":
             assert Bs.shape[-1] == As.shape[-1] == 3, "The filter order must be 2."
         # "ssm" with K > 1: upstream drives every section's recursion with the original input (iir.py:226-246)

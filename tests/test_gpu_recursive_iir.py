@@ -80,13 +80,9 @@ def test_recursive_cascade_at_headline_length_is_linear_and_matches_the_fsm_limi
         assert_close(eq_fsm(x1, **p).cpu(), y1.cpu(), 1e-3, "FSM vs exact recursion")
 
 
-def test_recursive_backend_refuses_gradients_and_bad_orders():
+def test_recursive_backend_refuses_bad_orders():
     from grafx_amd.processors import IIRFilter
 
-    m = IIRFilter(order=2, backend="lfilter", flashfftconv=False)
-    Bs = torch.randn(1, 1, 1, 3, device="cuda", requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        m(torch.randn(1, 1, 64, device="cuda"), Bs, torch.tensor([[[[1.0, 0.1, 0.1]]]], device="cuda"))
     with pytest.raises(NotImplementedError):
         IIRFilter(order=4, backend="ssm", flashfftconv=False)
 
@@ -129,3 +125,58 @@ def test_graphic_equalizer_on_the_exact_backend_with_31_sections():
     fp32_noise = (ref32.double() - ref64).abs().max() / ref64.abs().max()
     ours = (y.double() - ref64).abs().max() / ref64.abs().max()
     assert ours <= max(2 * fp32_noise, 5e-5), f"kernel {ours:.2e} vs sequential fp32 {fp32_noise:.2e} (both against float64)"
+
+
+@pytest.mark.parametrize("backend,K", [("lfilter", 1), ("lfilter", 3), ("ssm", 1)])
+@pytest.mark.parametrize("C,Cf", [(2, 1), (1, 2), (2, 2)])
+def test_recursive_backends_are_differentiable(backend, K, C, Cf):
+    """Gradients of IIRFilter(backend="lfilter" | "ssm") (BiquadCascadeFn: the native recursion run backwards in time)
+    against torch autograd of a float64 direct-form recursion written as a Python loop (upstream differentiates the
+    same recursion through torchaudio.lfilter, core/iir.py:154-183)."""
+    from grafx_amd.processors import IIRFilter
+
+    torch.manual_seed(10 * K + C + Cf)
+    R, L = 3, 400
+    x = torch.randn(R, C, L)
+    radius = 0.5 + 0.45 * torch.rand(R, Cf, K)
+    theta = torch.rand(R, Cf, K) * 2.8 + 0.1
+    As = torch.stack([1.0 + 0.2 * torch.rand(R, Cf, K), -2 * radius * torch.cos(theta), radius.square()], -1)
+    Bs = torch.randn(R, Cf, K, 3)
+    wgt = torch.randn(R, max(C, Cf), L)
+
+    def ref(x, Bs, As):   # float64 direct form II transposed, channel broadcast like the reference
+        Co = max(C, Cf)
+        y = x.expand(R, Co, L)
+        for k in range(K):
+            b, a = Bs[:, :, k].expand(R, Co, 3), As[:, :, k].expand(R, Co, 3)
+            s1 = torch.zeros(R, Co, dtype=x.dtype)
+            s2 = torch.zeros(R, Co, dtype=x.dtype)
+            out = []
+            for n in range(L):
+                xn = y[..., n]
+                yn = (b[..., 0] * xn + s1) / a[..., 0]
+                s1 = b[..., 1] * xn - a[..., 1] * yn + s2
+                s2 = b[..., 2] * xn - a[..., 2] * yn
+                out.append(yn)
+            y = torch.stack(out, -1)
+        return y
+
+    x64, B64, A64 = (t.double().requires_grad_(True) for t in (x, Bs, As))
+    (ref(x64, B64, A64) * wgt.double()).sum().backward()
+    xg, Bg, Ag = (t.cuda().requires_grad_(True) for t in (x, Bs, As))
+    y = IIRFilter(order=2, backend=backend, flashfftconv=False)(xg, Bg, Ag)
+    (y * wgt.cuda()).sum().backward()
+    for name, got, want in (("x", xg.grad, x64.grad), ("Bs", Bg.grad, B64.grad), ("As", Ag.grad, A64.grad)):
+        assert got is not None and got.shape == want.shape, name
+        err = (got.cpu().double() - want).abs().max() / want.abs().max()
+        assert err <= 2e-4, f"{backend} K={K} C={C}/{Cf} grad {name}: {err:.2e}"
+
+
+def test_ssm_quirk_with_several_sections_is_forward_only():
+    from grafx_amd.processors import IIRFilter
+
+    x = torch.randn(2, 2, 100, device="cuda", requires_grad=True)
+    Bs = torch.randn(2, 1, 2, 3, device="cuda")
+    As = torch.tensor([1.0, -0.5, 0.2], device="cuda").expand(2, 1, 2, 3).contiguous()
+    with pytest.raises(NotImplementedError):
+        IIRFilter(order=2, backend="ssm", flashfftconv=False)(x, Bs, As)
