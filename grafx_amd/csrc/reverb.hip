@@ -50,6 +50,7 @@ struct IstftArgs {
     int64_t R;
     int n_fft, hop, T, K, kpad;   // K = n_fft/2+1 bins, T frames
     int64_t ir_len;
+    int64_t nstride;              // floats between the noise spectra of consecutive rows (0: one spectrum shared by all)
 };
 
 // grid: (column chunks of 128, frame tiles of 64, R*2); 4 waves, each 16 frames x 128 columns.
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
             float lm = __fadd_rn(H0[k], __fmul_rn(slope, mf));
             if (gain_env) lm = __fadd_rn(lm, genv);
             const float mask = expf(lm / 8.0f);
-            av = noise_stft[(((int64_t)c * a.K + k) * a.T + m) * 2 + (kk & 1)] * mask;
+            av = noise_stft[(rc >> 1) * a.nstride + (((int64_t)c * a.K + k) * a.T + m) * 2 + (kk & 1)] * mask;
         }
         const float* brow = basis + (int64_t)kk * a.n_fft + col0 + (lane & 15);
 #pragma unroll
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void istft_frames_tiled_kernel(const float* __
                 float lm = __fadd_rn(H0[k], __fmul_rn(slope, mf));
                 if (gain_env) lm = __fadd_rn(lm, genv);
                 const float mask = expf(lm / 8.0f);
-                const float2 nz = *reinterpret_cast<const float2*>(noise_stft + (((int64_t)c * a.K + k) * a.T + m) * 2);
+                const float2 nz = *reinterpret_cast<const float2*>(noise_stft + (rc >> 1) * a.nstride + (((int64_t)c * a.K + k) * a.T + m) * 2);
                 re = nz.x * mask;
                 im = nz.y * mask;
             }
@@ -335,6 +336,15 @@ int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnit
                            const float* gain_env_log_magnitude, const float* window, const float* basis, float* ir,
                            float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
                            int ms_to_lr, void* ws, size_t ws_bytes, void* stream) {
+    return gfx_stft_reverb_ir_ex_f32(noise_stft, 1, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, window,
+                                     basis, ir, row_gain, R, ir_len, n_fft, hop, num_frames, ms_to_lr, ws, ws_bytes, stream);
+}
+
+int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const float* init_log_magnitude,
+                              const float* delta_log_magnitude, const float* gain_env_log_magnitude, const float* window,
+                              const float* basis, float* ir, float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft,
+                              int64_t hop, int64_t num_frames, int ms_to_lr, void* ws, size_t ws_bytes, void* stream) {
+    if (noise_rows != 1 && noise_rows != R) return GFX_EINVAL;
     if (!noise_stft || !init_log_magnitude || !delta_log_magnitude || !window || !basis || !ir || !row_gain)
         return GFX_EINVAL;
     if (R <= 0 || ir_len <= 0 || n_fft < 2 || (n_fft & 1) || hop < 1 || hop > n_fft || num_frames < 1) return GFX_EINVAL;
@@ -349,6 +359,7 @@ int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnit
     a.K = (int)(n_fft / 2 + 1);
     a.kpad = (int)kpad_of(n_fft);
     a.ir_len = ir_len;
+    a.nstride = noise_rows == 1 ? 0 : 2 * (n_fft / 2 + 1) * num_frames * 2;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(row_gain, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
     if (n_fft <= 384) {

@@ -597,6 +597,9 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
     R = init_lm.shape[0]
     n_fft = window.numel()
     T = noise_stft.shape[-1]
+    noise_rows = noise_stft.shape[0] if noise_stft.ndim == 4 else 1   # (R,2,K,T): fresh noise per row; else shared
+    if noise_rows not in (1, R):
+        raise ValueError(f"stft_reverb_ir: {noise_rows} noise spectra for {R} rows")
     nz = torch.view_as_real(noise_stft.contiguous())  # (…,2,K,T,2) float32 view of the complex64 buffer
     ir = torch.empty((R, 2, ir_len), dtype=torch.float32, device=init_lm.device)
     row_gain = torch.empty((R,), dtype=torch.float32, device=init_lm.device)
@@ -604,9 +607,9 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
     ws = torch.empty(nbytes, dtype=torch.uint8, device=init_lm.device)
     pin = _Pin()
     check(
-        lib().gfx_stft_reverb_ir_f32(_ptr(nz), pin(init_lm), pin(delta_lm), pin(gain_env), pin(window), pin(basis),
+        lib().gfx_stft_reverb_ir_ex_f32(_ptr(nz), noise_rows, pin(init_lm), pin(delta_lm), pin(gain_env), pin(window), pin(basis),
                                      _ptr(ir), _ptr(row_gain), R, ir_len, n_fft, hop, T, int(ms_to_lr), _ptr(ws), nbytes, _stream()),
-        "gfx_stft_reverb_ir_f32",
+        "gfx_stft_reverb_ir_ex_f32",
     )
     return ir, row_gain
 

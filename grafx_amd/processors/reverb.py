@@ -57,12 +57,16 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
 
     def _ir_and_gain(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, ms_lr):
         genv = gain_env_log_magnitude if self.gain_envelope else None
-        return ops.stft_reverb_ir(self.noise_stft, init_log_magnitude, delta_log_magnitude, genv, self.window,
+        # fixed_noise=False (reverb.py:63, 80-82, 165): fresh noise for every row, its STFT from the device FFT library
+        # (torch.stft), mask + inverse STFT + overlap-add + normalisation on the same native kernels as the fixed noise
+        noise = self.noise_stft if self.fixed_noise else self.sample_noise(init_log_magnitude.shape[0],
+                                                                          init_log_magnitude.device)
+        return ops.stft_reverb_ir(noise, init_log_magnitude, delta_log_magnitude, genv, self.window,
                                   self._istft_basis(init_log_magnitude.device), self.ir_len, self.hop_length, ms_lr)
 
     def compute_ir(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude=None):
         """Un-normalised mid/side impulse responses (R,2,ir_len) (reverb.py:161-187)."""
-        if not self.fixed_noise or needs_grad(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
+        if needs_grad(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
             return self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)
         return self._ir_and_gain(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, False)[0]
 
@@ -140,10 +144,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
             init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude = (
                 expand_shared(t, reps) for t in (init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude))
             _shared_rows = None
-        if not self.fixed_noise or needs_grad(input_signals, init_log_magnitude, delta_log_magnitude,
-                                              gain_env_log_magnitude):
-            # per-row noise (fixed_noise=False) and training: mask + istft as torch ops on the GPU (R x 193 x 313),
-            # the convolution below is native either way
+        if needs_grad(input_signals, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude):
+            # training: mask + istft as torch ops on the GPU (R x 193 x 313), the convolution below is native either way
             # the impulse responses are synthesised once per parameter row (per node when the batch shares them) and
             # the native convolution lets every batch row read them; a strided (B, n, C, L) view is read in place
             ir = self._compute_ir_differentiable(init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude)

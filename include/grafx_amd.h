@@ -262,6 +262,13 @@ int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnit
                            const float* window, const float* basis, float* ir, float* row_gain,
                            int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
                            int ms_to_lr, void* ws, size_t ws_bytes, void* stream);
+/* The same with one noise spectrum per row (`noise_rows` = R, noise_stft (R, 2, n_fft/2+1, num_frames) complex64) or one
+ * shared by all rows (`noise_rows` = 1): STFTMaskedNoiseReverb(fixed_noise=False) draws fresh noise for every row
+ * (reverb.py:63, 80-82, 165). */
+int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const float* init_log_magnitude,
+                              const float* delta_log_magnitude, const float* gain_env_log_magnitude, const float* window,
+                              const float* basis, float* ir, float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft,
+                              int64_t hop, int64_t num_frames, int ms_to_lr, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- routing ----------------------------------------------------------------------------
  * replaces read_single_tensor("index") + aggregate_tensor("sum"/"scatter") + inplace_write_tensor
