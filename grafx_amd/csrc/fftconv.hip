@@ -36,7 +36,9 @@ static inline ConvGeom conv_geom(int64_t N, int64_t Lout, int64_t part_len = 0) 
     if (N <= TILE_M + 1) {
         g.nparts = 1;
         g.part_len = N;
-        g.O = (N - 1 + 1) & ~int64_t(1);  // overlap >= N-1, even so tiles stay 8-byte aligned
+        // overlap >= N-1, rounded up to whole 512-sample register rows: loads and stores of a tile then need no per-lane
+        // masks (load_window / store_valid), ~15 % fewer vector-ALU instructions per tile for <1 % more tiles
+        g.O = (N - 1 + 511) & ~int64_t(511);
         g.ok = part_len == 0;
     } else if (part_len == 0 || part_len == TILE_M) {
         g.part_len = TILE_M;
@@ -115,10 +117,28 @@ constexpr uint32_t OOB = 0xffffffffu;  // lane offset that the range check alway
 // v[a] = (x[s + 2m], x[s + 2m + 1]), m = t + 256 a; x is zero outside [0, L).  `row` = start of the signal row.
 // Straight-line in the common case: the two special cases (a window starting before the row, a pair straddling
 // sample 0) sit behind one wave-uniform branch after all 32 loads have been issued.
+template <bool FAST = true>
 __device__ __forceinline__ void load_window(cx (&v)[32], const float* __restrict__ row, int64_t s, int64_t L,
                                             int t, float gain) {
     // descriptor starts at the window (possibly before the row for the first tile: those lanes are masked)
     const rsrc_t r = make_rsrc(row + s, (L - s) * 4);
+    if (FAST && (s >= 0 || (s & 511) == 0)) {
+        // No per-lane clipping (uniform test): the window starts inside the row, or a whole number of 512-sample register
+        // rows before it (tile geometry with O a multiple of 512) -- every load is "lane offset 8 t" or skipped as a
+        // row, and the range check supplies the zeros past the row end.  Saves ~100 compare / select instructions
+        // per window on the vector ALU, which is what bounds these kernels.
+        const int a_lo = s < 0 ? (int)((-s) >> 9) : 0;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+            if (a < a_lo) v[a] = cx{0.0f, 0.0f};
+            else v[a] = buf_load_f2(r, 8u * (uint32_t)t, 2048u * a);
+        }
+        if (gain != 1.0f) {
+#pragma unroll
+            for (int a = 0; a < 32; ++a) v[a] *= gain;
+        }
+        return;
+    }
     const bool clip = s < 0;                                   // uniform; only a first tile can start before the row
     const int s32 = clip ? (int)s : 0;                         // |s| <= 16384 there
 #pragma unroll
@@ -168,6 +188,16 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
     asm volatile("" : "+v"(t));
     const int64_t room = Lout - (n0 - O);                      // samples from the descriptor base to the row end
     const rsrc_t r = make_rsrc(row + (n0 - O), room * 4);
+    if ((O & 511) == 0 && !((room & 1) && room < TILE_F)) {
+        // Row-uniform form (uniform test): the overlap is a whole number of 512-sample register rows and no sample pair
+        // straddles the row end, so a row is either skipped or stored with "lane offset 8 t" (pairs past the row end
+        // are dropped by the range check): no per-lane masks.
+        const int a_lo = (int)(O >> 9);
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            if (a >= a_lo) buf_store_f2(r, 8u * (uint32_t)t, 2048u * a, v[NATURAL ? a : brev(a, 5)]);
+        return;
+    }
     const int o32 = (int)O;
     const int tail = (room & 1) && room < TILE_F ? (int)room - 1 : -1;  // a pair straddling the row end starts here
 #pragma unroll
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(TILE_T, 2) void corr1_kernel(const float* __restric
             cx v[32], w[2][16];
             TileTw tw;
             const int64_t xend = s + a.V < a.L ? s + a.V : a.L;
-            load_window(v, xrow, s, xend, t, 1.0f);
+            load_window<false>(v, xrow, s, xend, t, 1.0f);   // (the two-form loader costs this kernel 500 B of scratch)
             fresh_twiddles(tw);
             tile_forward(v, w, tw, lds, t);
             for_each_pair(t, wj, [&](int slot, int ia, int ib, cx wk, bool) {
@@ -452,7 +482,7 @@ __global__ __launch_bounds__(TILE_T, 2) void corr1_kernel(const float* __restric
         {
             cx v[32], w[2][16];
             TileTw tw;
-            load_window(v, grow, s - a.off, a.Lg, t, 1.0f);
+            load_window<false>(v, grow, s - a.off, a.Lg, t, 1.0f);
             fresh_twiddles(tw);
             tile_forward(v, w, tw, lds, t);
             for_each_pair(t, wj, [&](int slot, int ia, int ib, cx wk, bool) {
