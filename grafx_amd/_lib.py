@@ -35,6 +35,10 @@ SIGNATURES = {
     "gfx_fir_grad_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, i64, i64, i64, i64, i64, i64, i64, vp]),
     "gfx_fir_spectrum_rev_f32": (ctypes.c_int, [f32p, RowMap, i64, i64, i64, i64, vp, vp]),
     "gfx_fftconv_tee_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
+    "gfx_odd_alias_plan_bytes": (sz, [i64]),
+    "gfx_odd_alias_workspace_bytes": (sz, [i64, i64]),
+    "gfx_odd_alias_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),
+    "gfx_odd_alias_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_iir_fsm_native": (ctypes.c_int, [i64]),
     "gfx_iir_fsm_plan_bytes": (sz, [i64]),
     "gfx_iir_fsm_plan_f32": (ctypes.c_int, [vp, i64, vp]),

@@ -233,6 +233,43 @@ def fir_direct(x, h, Lout=None, off=0, out=None, h_rows=None):
     return out
 
 
+# ----------------------------------------------------------------------------------------- odd-length aliasing
+_ALIAS_PLANS = {}
+
+
+def odd_alias_supported(P):
+    """Whether gfx_odd_alias_f32 handles a linear convolution of odd length P (3 <= P <= 174,763)."""
+    return lib().gfx_odd_alias_plan_bytes(P) > 0
+
+
+@_on_device
+def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
+    """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
+    full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (2 MB of
+    workspace per row at P ~ 135 k)."""
+    _require_gpu(z)
+    P = z.shape[-1]
+    Q = P - 1
+    length = Q - lo if length is None else length
+    key = (P, z.device.type, z.device.index)
+    plan = _ALIAS_PLANS.get(key)
+    if plan is None:
+        plan = torch.empty(lib().gfx_odd_alias_plan_bytes(P), dtype=torch.uint8, device=z.device)
+        w1 = torch.empty(lib().gfx_odd_alias_workspace_bytes(1, P), dtype=torch.uint8, device=z.device)
+        check(lib().gfx_odd_alias_plan_f32(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), "gfx_odd_alias_plan_f32")
+        _ALIAS_PLANS[key] = plan
+    flat = z.reshape(-1, P).contiguous()
+    rows = flat.shape[0]
+    out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
+    chunk = min(rows, rows_per_chunk)
+    ws = torch.empty(lib().gfx_odd_alias_workspace_bytes(chunk, P), dtype=torch.uint8, device=z.device)
+    for i in range(0, rows, chunk):
+        n = min(chunk, rows - i)
+        check(lib().gfx_odd_alias_f32(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan),
+                                      _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_f32")
+    return out.view(*z.shape[:-1], length)
+
+
 # ----------------------------------------------------------------------------------------- IIR (FSM)
 @_on_device
 def iir_fsm_native(N):

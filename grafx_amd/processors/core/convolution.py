@@ -50,19 +50,27 @@ def reference_aliases(lx, lh, exact=False):
     return (lx + lh - 1) % 2 == 1 and not (_EXACT or exact)
 
 
-def odd_length_alias(z, rows_per_chunk=2048):
-    """irfft_{P-1}(rfft_P(z)) for a full linear convolution z of odd length P (convolution.py:123-126).
+def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
+    """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for a full linear convolution z of odd length P
+    (convolution.py:123-126): two chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, fp32, no FFT library).
 
-    Evaluated in float64 (in row chunks, to bound memory): the device FFT library's fp32 transforms of these
-    awkward lengths are noisier than the reference's CPU FFT, and downstream gain curves amplify that; in
-    double the aliasing step adds nothing to the fp32 error of the HIP stages around it."""
+    Three cases still go through the device FFT library in float64: gradients (autograd of the aliasing step),
+    P > 174,763 (a 2^18-point transform no longer covers 1.5 P; e.g. 10 s of audio) and ``precise=True`` -- the
+    energy-envelope smoother of the dynamics processors, whose output feeds log() and a gain curve: there the fp32
+    chirp-z noise (~1e-6 of the peak, about twice what the reference's own mixed-radix fp32 FFT leaves) is amplified
+    on quiet passages beyond the parity bound (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths)."""
+    Q = z.shape[-1] - 1
+    length = Q - lo if length is None else length
+    if not precise and not (torch.is_grad_enabled() and z.requires_grad) and ops.odd_alias_supported(z.shape[-1]):
+        return ops.odd_alias(z, lo, length)
     if torch.is_grad_enabled() and z.requires_grad:
-        return torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)
+        return torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)[..., lo : lo + length]
     flat = z.reshape(-1, z.shape[-1])
-    out = torch.empty((flat.shape[0], 2 * (z.shape[-1] // 2)), dtype=z.dtype, device=z.device)
+    out = torch.empty((flat.shape[0], length), dtype=z.dtype, device=z.device)
     for i in range(0, flat.shape[0], rows_per_chunk):
-        out[i : i + rows_per_chunk] = torch.fft.irfft(torch.fft.rfft(flat[i : i + rows_per_chunk].double())).to(z.dtype)
-    return out.view(*z.shape[:-1], out.shape[-1])
+        out[i : i + rows_per_chunk] = torch.fft.irfft(torch.fft.rfft(flat[i : i + rows_per_chunk].double())).to(z.dtype)[
+            :, lo : lo + length]
+    return out.view(*z.shape[:-1], length)
 
 
 def compute_pad_len(x, y, pad_mode="min"):
@@ -89,13 +97,8 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False, h_rows=No
         if mode == "zerophase":
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2, out=out, h_rows=h_rows)
         return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, out=out, h_rows=h_rows)
-    y_pad = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows))
-    if mode == "causal":
-        y = y_pad[..., :L]
-    elif mode == "zerophase":
-        y = y_pad[..., N // 2 : N // 2 + L]
-    else:
-        y = y_pad
+    lo, length = {"causal": (0, L), "zerophase": (N // 2, L)}.get(mode, (0, L + N - 2))
+    y = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows), lo, length)
     if out is None:
         return y.contiguous()
     out.copy_(y.reshape(out.shape))

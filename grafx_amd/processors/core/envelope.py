@@ -27,7 +27,7 @@ class TruncatedOnePoleIIRFilter(nn.Module):
         if not reference_aliases(L, self.iir_len, self.flashfftconv):
             return ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L, relu=True)
         full = ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L + self.iir_len - 1, relu=False)
-        return torch.relu(odd_length_alias(full)[..., :L]).contiguous()
+        return torch.relu(odd_length_alias(full, 0, L, precise=True)).contiguous()
 
     def compute_impulse(self, z_alpha):
         if needs_grad(z_alpha):
