@@ -337,14 +337,15 @@ def _timed_region(args, torch, dist, dev, step, sync, fence, profile):
     fence()
     # the dominant kernel is timed live, inside the timed region, with a pair of stream events around every launch
     # (recorded on the stream the kernel runs on; no synchronisation, ~120 event records per step)
-    ops.PROFILE = {} if profile else None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = step()
-    sync()                            # this rank's K steps are done: stop its clock ...
-    elapsed = time.perf_counter() - t0
+    import contextlib
+
+    with (ops.profiling() if profile else contextlib.nullcontext()) as prof:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = step()
+        sync()                        # this rank's K steps are done: stop its clock ...
+        elapsed = time.perf_counter() - t0
     fence()                           # ... then the closing barrier; the job's time is the MAX over ranks (below)
-    prof, ops.PROFILE = ops.PROFILE, None
     per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

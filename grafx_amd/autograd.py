@@ -20,6 +20,8 @@ The formulas mirror the reference (file:line cited per function, relative to
 """
 import math
 
+import threading
+
 import torch
 import torch.nn.functional as F
 
@@ -29,29 +31,63 @@ from . import ops
 # Set by the stage-wise backward of render_grafx while it re-traces a stage only to obtain its tape: the stage's
 # output VALUES are then never read (only its gradient function runs), so autograd nodes whose output is the
 # processor's output up to linear operations may skip their forward kernels and hand back uninitialised storage.
-TAPE_ONLY = False
+# Thread-local (the re-trace runs in the thread that opened the scope), and opt-in per processor TYPE: the render only
+# opens the scope for the exact classes of TAPE_SAFE_TYPES -- a user subclass that post-processes super().forward()
+# non-linearly must get real values.
+_STATE = threading.local()
+
+
+def tape_only_active():
+    return getattr(_STATE, "tape_only", False)
 
 
 class tape_only:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
     def __enter__(self):
-        global TAPE_ONLY
-        self.prev, TAPE_ONLY = TAPE_ONLY, True
+        self.prev = tape_only_active()
+        _STATE.tape_only = self.prev or self.enabled
 
     def __exit__(self, *exc):
-        global TAPE_ONLY
-        TAPE_ONLY = self.prev
+        _STATE.tape_only = self.prev
         return False
 
 
-# Gradient sink (set by the same stage-wise backward): (data_ptr of the stage's input view, destination view).  An
+# Gradient sinks (registered by the same stage-wise backward): data_ptr of a stage's input view -> destination view.  An
 # autograd node whose input IS that view writes its input gradient straight into the destination -- a slice of the
-# render's gradient buffer -- instead of a fresh tensor that would then be copied there.
-GRAD_SINK = None
+# render's gradient buffer -- instead of a fresh tensor that would then be copied there.  Keyed by address under a lock,
+# so two renders running their backward passes on different threads (different buffers) cannot see each other's sinks;
+# every sink counts how often it was written, and the render checks that it was written exactly once.
+_SINKS = {}
+_SINKS_LOCK = threading.Lock()
+
+
+class grad_sink:
+    def __init__(self, x, dest):
+        self.key, self.entry = x.data_ptr(), [dest, 0]
+
+    def __enter__(self):
+        with _SINKS_LOCK:
+            _SINKS[self.key] = self.entry
+        return self
+
+    def __exit__(self, *exc):
+        with _SINKS_LOCK:
+            _SINKS.pop(self.key, None)
+        return False
+
+    @property
+    def writes(self):
+        return self.entry[1]
 
 
 def _sink_for(x):
-    if GRAD_SINK is not None and x.data_ptr() == GRAD_SINK[0] and tuple(x.shape) == tuple(GRAD_SINK[1].shape):
-        return GRAD_SINK[1]
+    with _SINKS_LOCK:
+        e = _SINKS.get(x.data_ptr())
+        if e is not None and tuple(x.shape) == tuple(e[0].shape):
+            e[1] += 1
+            return e[0]
     return None
 
 
@@ -80,7 +116,7 @@ class LinearConvFn(torch.autograd.Function):
             raise ValueError(f"{rows} signal rows cannot share {Rh} filters")
         ctx.save_for_backward(x, h)
         ctx.off = off
-        if final and TAPE_ONLY:  # see TAPE_ONLY: nobody will read these values
+        if final and tape_only_active():  # see tape_only: nobody will read these values
             y = torch.empty((rows, max(x.shape[-2], Cf), Lout), dtype=torch.float32, device=x.device)
         else:
             y = ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
@@ -124,7 +160,7 @@ class LinearConvFn(torch.autograd.Function):
 def convolve(x, h, mode="causal", exact=False, final=False):
     """Differentiable twin of processors.core.convolution.convolve (reference core/convolution.py:119-134),
     including the odd-P aliasing (which is plain torch.fft and differentiates itself).  ``final``: the result is
-    the calling processor's output up to linear operations (see TAPE_ONLY)."""
+    the calling processor's output up to linear operations (see tape_only)."""
     from .processors.core.convolution import reference_aliases
 
     flat = x.ndim == 2
@@ -380,7 +416,7 @@ class DynamicsFn(torch.autograd.Function):
         four = x.ndim == 4  # a strided (B,n,C,L) view of the signal buffer is read in place
         if x.stride(-1) != 1 or not (four or x.is_contiguous()):
             x = x.contiguous()
-        if TAPE_ONLY:  # the output of this node is the processor's output: its values are not read (see TAPE_ONLY)
+        if tape_only_active():  # the output of this node is the processor's output: its values are not read (see tape_only)
             rows = x.shape[0] * x.shape[1] if four else x.shape[0]
             y = torch.empty((rows, x.shape[-2], x.shape[-1]), dtype=torch.float32, device=x.device)
         else:

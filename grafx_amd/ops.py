@@ -5,13 +5,28 @@ stream to libgrafx_amd.so and return torch tensors.  torch is only the memory
 and stream plumbing; all arithmetic happens in the HIP kernels.  CPU tensors are
 rejected: there is no fallback path.
 """
+import contextvars
+
 import torch
 
 from ._lib import RowMap, check, lib
 
 
-# bench.py sets PROFILE = {} to collect (start_event, end_event, algorithmic_bytes) per kernel launch
-PROFILE = None
+# Per-launch timing hook: `with ops.profiling() as prof:` collects (start_event, end_event, algorithmic_bytes) per kernel
+# launch issued from the current context (bench.py's live roofline measurement).  A ContextVar, not a module global:
+# another thread rendering at the same time neither pays for the events nor pollutes the record.
+_PROFILE = contextvars.ContextVar("grafx_amd_profile", default=None)
+
+
+class profiling:
+    def __enter__(self):
+        self.record = {}
+        self.token = _PROFILE.set(self.record)
+        return self.record
+
+    def __exit__(self, *exc):
+        _PROFILE.reset(self.token)
+        return False
 
 
 class _timed:
@@ -19,15 +34,16 @@ class _timed:
         self.name, self.nbytes = name, nbytes
 
     def __enter__(self):
-        if PROFILE is not None:
+        self.rec = _PROFILE.get()
+        if self.rec is not None:
             self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.a.record()
         return self
 
     def __exit__(self, *exc):
-        if PROFILE is not None:
+        if self.rec is not None:
             self.b.record()
-            PROFILE.setdefault(self.name, []).append((self.a, self.b, self.nbytes))
+            self.rec.setdefault(self.name, []).append((self.a, self.b, self.nbytes))
 
 
 def _require_gpu(*tensors):

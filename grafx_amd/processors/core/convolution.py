@@ -15,6 +15,7 @@ for odd P it inverts a P-point spectrum on a (P-1)-point grid
 ``set_exact_convolution(True)`` opts out of the quirk (true linear convolution
 for every length; deviates from the reference when P is odd).
 """
+import contextvars
 import warnings
 
 import torch
@@ -24,20 +25,20 @@ from ... import autograd as diff
 from ... import ops
 from ...autograd import needs_grad
 
-_EXACT = False
+_EXACT = contextvars.ContextVar("grafx_amd_exact_convolution", default=False)   # context-local, see set_exact_convolution
 # Filters up to this many taps run as Toeplitz GEMMs on the fp32 matrix cores (gfx_fir_direct_f32) instead of the FFT tile
 # kernel: the crossover measured on MI355X (profiles/r2/fir_mfma_crossover.txt).
 SHORT_FIR_TAPS = 40
 
 
 def set_exact_convolution(flag=True):
-    """Force true linear convolution even where the reference aliases (odd Lx+Lh-1)."""
-    global _EXACT
-    _EXACT = bool(flag)
+    """Force true linear convolution even where the reference aliases (odd Lx+Lh-1).  The setting is a ContextVar: it
+    holds for the calling thread / async task (and contexts copied from it), not for unrelated threads."""
+    _EXACT.set(bool(flag))
 
 
 def exact_convolution():
-    return _EXACT
+    return _EXACT.get()
 
 
 def reference_aliases(lx, lh, exact=False):
@@ -47,7 +48,7 @@ def reference_aliases(lx, lh, exact=False):
     ``flashfftconv`` constructor flag here, because that is what the flag selects upstream — FlashFFTConv computes
     the plain causal convolution (convolution.py:85-106), only the native torch.fft path has the odd-length
     aliasing (convolution.py:119-134)."""
-    return (lx + lh - 1) % 2 == 1 and not (_EXACT or exact)
+    return (lx + lh - 1) % 2 == 1 and not (_EXACT.get() or exact)
 
 
 def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):

@@ -326,6 +326,13 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
 
 
 # ---- training: the same in-place forward, with a stage-wise backward ------------------------------------
+def _tape_safe_types():
+    """Exact processor classes whose output is linear in their one native autograd node (see the stage-wise backward)."""
+    from .. import processors as P
+
+    return (P.ParametricEqualizer, P.Compressor, P.NoiseGate, P.STFTMaskedNoiseReverb, P.BiquadFilter)
+
+
 def _flatten_tree(tree, leaves):
     """Nested dict of tensors -> spec with leaf indices (tensors appended to `leaves`)."""
     if isinstance(tree, torch.Tensor):
@@ -465,18 +472,25 @@ class _BufferRenderFn(torch.autograd.Function):
                                                             postprocess=postprocess)
                     common_i = {} if common is None else read_tensor_or_tensor_dict(
                         common, step.dest_write, dim=node_dim, postprocess=postprocess)
-                    with diff.tape_only():  # only the stage's tape is wanted here, not its output values
+                    # Both shortcuts below assume that the processor's output is a LINEAR function of the one native
+                    # autograd node that consumes the stage's input view: true for the library's own classes, not for
+                    # a user subclass that post-processes super().forward(); so they are enabled for the exact types
+                    # only (type(), not isinstance()).
+                    trusted = type(processors[node_type]) in _tape_safe_types()
+                    with diff.tape_only(trusted):  # only the stage's tape is wanted here, not its output values
                         y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
                     wrt = ([x_in] if want_gx else []) + [local[j] for j in live]
-                    if want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]):
+                    grad_out = g_out if y.shape == g_out.shape else g_out.reshape(y.shape)
+                    if trusted and want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]):
                         # first (usually only) contribution to these rows: let the stage write it in place
-                        diff.GRAD_SINK = (x_in.data_ptr(), gbuf.narrow(1, a, b - a))
-                    try:
-                        grads = torch.autograd.grad(y, wrt, grad_outputs=g_out if y.shape == g_out.shape
-                                                    else g_out.reshape(y.shape), allow_unused=True)
-                    finally:
-                        diff.GRAD_SINK = None
+                        with diff.grad_sink(x_in, gbuf.narrow(1, a, b - a)) as sink:
+                            grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
+                        if sink.writes > 1:
+                            raise RuntimeError(f"{type(processors[node_type]).__name__}: {sink.writes} autograd nodes wrote "
+                                               "the stage's input gradient in place (expected one)")
+                    else:
+                        grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
                 for j, g in zip(live, grads[1:] if want_gx else grads):
                     if g is not None:
                         leaf_grads[j] = g if leaf_grads[j] is None else leaf_grads[j] + g

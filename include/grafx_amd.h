@@ -8,9 +8,15 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (HBM) unless marked "host";
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
- *     nothing synchronises, nothing allocates (callers pass workspaces whose
- *     size the *_bytes queries return);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     callers pass every workspace (sizes from the *_bytes queries).  ONE
+ *     exception: the first call on a device of any entry point built on the FFT
+ *     tile (fftconv, fir_spectrum, fir_grad, iir_fsm, odd_alias) allocates that
+ *     device's 40 KB twiddle table with hipMalloc, fills it on `stream` and waits
+ *     for it (hipStreamSynchronize) under a process-wide mutex; the table lives
+ *     for the process.  After that first call nothing allocates or synchronises.
+ *     The device is the CURRENT device (hipGetDevice): make the tensors' device
+ *     current before calling (grafx_amd/ops.py does);
  *   - return 0 on success, a negative GFX_E* code on error; never throws;
  *   - signals are fp32; a "row" is one (batch x node) item, channels inside.
  *
