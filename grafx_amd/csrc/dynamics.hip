@@ -303,6 +303,159 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
         dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi);
 }
 
+// ---- the same fused compressor / gate as ONE-SHOT tiles with a decoupled look-back -----------------------------
+// dyn_fused_kernel streams a row per workgroup: a few thousand long-lived streams at scattered addresses, the access
+// shape that tops out at 4.8-5.5 TB/s on this chip where a one-shot copy reaches 6.2-6.6 (profiles/r2/
+// stream2_copy_ceiling.txt).  Here every 1024-sample tile of every row is its own short-lived workgroup (tiles of a row
+// are consecutive block indices, so the chip sweeps memory front to back), and the recursion's carry crosses tiles
+// through a chained scan with look-back:
+//   * the tile scans its samples from a zero state -> local values and its aggregate A_i (state at the tile end);
+//   * it publishes {A_i, tag} as ONE 8-byte sc1 store, then walks back over its predecessors' records, adding
+//     a^(1024 k) x their aggregates until it meets an inclusive state P_j (or the weight drops below 1e-12, or tile 0);
+//   * it publishes its own inclusive state P_i = A_i + a^1024 carry and adds a^(n+1) carry to its local values.
+// Records are 8-byte {value, tag} granules written by one sc1 store and polled with sc1 loads (MI355X_MICROARCH.md
+// "Valid forms": R2 granule); the buffer is zeroed on the stream before the launch.  A workgroup only waits for lower
+// block indices of its own row, which the dispatcher starts first; the poll is bounded all the same (a stuck
+// predecessor yields NaNs, not a hung GPU).
+// Pole powers come from a per-parameter-row table (dyn_pole_table_kernel): fourteen double-precision exp() per thread
+// are fine once per row, not once per tile.
+constexpr int DP_TAB = 80;   // floats per row: a^(4 l) l < 64 | a_step[6] | a_wave | a_N | ap[0..4] | a | 1 - a | trunc
+
+__global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* __restrict__ tab, int64_t rows, int64_t N) {
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;   // 64 threads
+    if (r >= rows) return;
+    OnePole p;
+    onepole_setup(p, z_alpha[r], N, lane);
+    float* t = tab + r * DP_TAB;
+    t[lane] = p.a_lane;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) t[64 + d] = p.a_step[d];
+        t[70] = p.a_wave;
+        t[71] = p.a_N;
+#pragma unroll
+        for (int i = 0; i <= DE; ++i) t[72 + i] = p.ap[i];
+        t[77] = p.a;
+        t[78] = p.one_m_a;
+        t[79] = p.trunc ? 1.0f : 0.0f;
+    }
+}
+
+union DynRec {
+    unsigned long long u;
+    struct { float v; int tag; } s;
+};
+constexpr int DYN_TAG_A = 1, DYN_TAG_P = 2;
+
+__global__ __launch_bounds__(DT) void dyn_lb_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                    const float* __restrict__ log_threshold,
+                                                    const float* __restrict__ log_ratio,
+                                                    const float* __restrict__ log_knee,
+                                                    const float* __restrict__ tab, unsigned long long* __restrict__ recs,
+                                                    DynArgs a, unsigned ntiles) {
+    __shared__ float slots[16];
+    __shared__ float carry_sh;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned r = blockIdx.x / ntiles, tile = blockIdx.x - r * ntiles;
+    const unsigned pr = r % a.prows;
+    const float* tb = tab + (int64_t)pr * DP_TAB;
+    OnePole p;
+    p.a_lane = tb[lane];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) p.a_step[d] = tb[64 + d];
+    p.a_wave = tb[70];
+    p.a_N = tb[71];
+#pragma unroll
+    for (int i = 0; i <= DE; ++i) p.ap[i] = tb[72 + i];
+    p.a = tb[77];
+    p.one_m_a = tb[78];
+    const bool trunc = tb[79] != 0.0f;
+    Knee q;
+    knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
+    const float* x0 = x + drow_off(a.xmap, r, 0);
+    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
+    float* y0 = y + drow_off(a.ymap, r, 0);
+    float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
+    const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
+    const float invC = 1.0f / (float)a.C;
+    const int64_t n = (int64_t)tile * DTILE + DE * t;
+
+    float xa[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, e[DE], u[DE];
+    load4(x0, n, a.L, vx, xa);
+    if (a.C == 2) load4(x1, n, a.L, vx, xb);
+#pragma unroll
+    for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
+    if (trunc) {   // one scan of e[n] - a^N e[n-N] (see dyn_stream)
+        float da[DE], db[DE];
+        load4(x0, n - a.N, a.L, false, da, 0);
+        if (a.C == 2) load4(x1, n - a.N, a.L, false, db, 0);
+#pragma unroll
+        for (int i = 0; i < DE; ++i)
+            e[i] = fmaf(-p.a_N, (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC, e[i]);
+    }
+    float agg = 0.0f;                                   // in: carry 0; out: the tile's aggregate
+    scan_tile(p, e, u, agg, slots, lane, wave);
+
+    unsigned long long* rec = recs + (int64_t)r * ntiles;
+    if (t == 0) {
+        float carry = 0.0f;
+        if (tile > 0) {
+            if (tile + 1 < ntiles) {
+                DynRec me;
+                me.s.v = agg;
+                me.s.tag = DYN_TAG_A;
+                __hip_atomic_store(rec + tile, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float a1024 = p.a_wave * p.a_wave * p.a_wave * p.a_wave;                 // (a^256)^4 = a^DTILE
+            float w = 1.0f;
+            for (int j = (int)tile - 1; j >= 0; --j) {
+                DynRec o;
+                o.u = 0;
+                int spins = 0;
+                do {
+                    o.u = __hip_atomic_load(rec + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (o.s.tag) break;
+                    __builtin_amdgcn_s_sleep(2);
+                } while (++spins < (1 << 22));
+                if (!o.s.tag) {                         // bounded wait: never hang the GPU
+                    carry = __builtin_nanf("");
+                    break;
+                }
+                carry = fmaf(w, o.s.v, carry);
+                if (o.s.tag == DYN_TAG_P) break;
+                w *= a1024;
+                if (w < 1e-12f) break;
+            }
+        }
+        if (tile + 1 < ntiles) {
+            DynRec me;
+            me.s.v = fmaf(p.a_wave * p.a_wave * p.a_wave * p.a_wave, carry, agg);
+            me.s.tag = DYN_TAG_P;
+            __hip_atomic_store(rec + tile, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        carry_sh = carry;
+    }
+    __syncthreads();
+    const float carry = carry_sh;
+    // u at local position m = DE t + i gets a^(m + 1) carry = a_wave^wave * a_lane * ap[i + 1] * carry
+    float wpow = 1.0f;
+    for (int k = 0; k < wave; ++k) wpow *= p.a_wave;
+    const float base = wpow * p.a_lane * carry;
+    float ga[DE], gb[DE];
+#pragma unroll
+    for (int i = 0; i < DE; ++i) {
+        const float ui = fmaf(p.ap[i + 1], base, u[i]);
+        const float env = fmaxf(p.one_m_a * ui, 0.0f);          // relu, envelope.py:48
+        const float G = logf(env + 1e-5f);                      // dynamics.py:394
+        const float g = expf(log_gain(q, G));                   // 402-403
+        ga[i] = g * xa[i];
+        gb[i] = g * xb[i];
+    }
+    store4(y0, n, a.L, vx, ga);
+    if (a.C == 2) store4(y1, n, a.L, vx, gb);
+}
+
 // ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
 // energy: e[r,n] = mean_c x[r,c,n]^2
 __global__ void energy_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, float* __restrict__ e, int64_t R, int64_t L, int C) {
@@ -999,6 +1152,38 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, (hipStream_t)stream, x, y,
                        log_threshold, log_ratio, log_knee, z_alpha, a);
+    return GFX_LAUNCH_OK();
+}
+
+size_t gfx_dynamics_lookback_ws_bytes(int64_t param_rows, int64_t R, int64_t L) {
+    if (param_rows <= 0 || R <= 0 || L <= 0) return 0;
+    const int64_t ntiles = (L + DTILE - 1) / DTILE;
+    return (size_t)param_rows * DP_TAB * sizeof(float) + (size_t)R * ntiles * sizeof(unsigned long long);
+}
+
+int gfx_dynamics_fused_lb_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                              int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate, void* ws,
+                              size_t ws_bytes, void* stream) {
+    if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
+    if (!x || !y || !log_threshold || !log_ratio || !z_alpha || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
+    if (knee < 0 || knee > 2 || (knee != 0 && !log_knee) || iir_len < 1) return GFX_EINVAL;
+    const int64_t ntiles = (L + DTILE - 1) / DTILE;
+    if (R * ntiles > 0x7fffffffLL) return GFX_EINVAL;
+    if (!ws || ws_bytes < gfx_dynamics_lookback_ws_bytes(param_rows, R, L)) return GFX_ENOSPC;
+    DynArgs a;
+    a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
+    a.smoother = 1; a.knee = knee; a.gate = gate;
+    a.prows = (unsigned)param_rows;
+    a.nchunks = 1;
+    a.chunk_tiles = ntiles;
+    hipStream_t st = (hipStream_t)stream;
+    float* tab = (float*)ws;
+    unsigned long long* recs = (unsigned long long*)((char*)ws + (((size_t)param_rows * DP_TAB * sizeof(float) + 7) & ~(size_t)7));
+    if (hipMemsetAsync(recs, 0, (size_t)R * ntiles * sizeof(unsigned long long), st) != hipSuccess) return GFX_ELAUNCH;
+    hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, tab, param_rows, iir_len);
+    hipLaunchKernelGGL(dyn_lb_kernel, dim3((unsigned)(R * ntiles)), dim3(DT), 0, st, x, y, log_threshold, log_ratio,
+                       log_knee, tab, recs, a, (unsigned)ntiles);
     return GFX_LAUNCH_OK();
 }
 

@@ -371,10 +371,19 @@ def _rowvec(p, R):
     return p
 
 
+# Default schedule of dynamics_fused: "rows" (one workgroup streams a row) or "lookback" (one-shot tiles + decoupled
+# look-back).  Measured on MI355X at 8192 stereo rows x 131072: rows 3.49 ms (4.93 TB/s), lookback 4.01 ms (4.29 TB/s;
+# 7.9 vs 4.8 ms with every pole at the clamp): the look-back hop (an sc1 record crossing XCDs) keeps each tile's workgroup
+# alive ~8 us, which costs more than the one-shot access shape gains.  tools/dyn_lookback_check.py reproduces this.
+DYN_SCHEDULE = "rows"
+
+
 @_on_device
 def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None,
-                   param_rows=None):
-    """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows)."""
+                   param_rows=None, schedule=None):
+    """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows).
+    ``schedule``: "rows" (gfx_dynamics_fused_ex_f32) or "lookback" (one-shot tiles, gfx_dynamics_fused_lb_f32)."""
+    schedule = DYN_SCHEDULE if schedule is None else schedule
     _require_gpu(x, out)
     xmap, R, C, L = rowmap(x)
     P = R if param_rows is None else param_rows
@@ -382,6 +391,14 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     ymap = rowmap(out)[0]
     pin = _Pin()
+    if smoother == 1 and schedule == "lookback":
+        ws = torch.empty(lib().gfx_dynamics_lookback_ws_bytes(P, R, L), dtype=torch.uint8, device=x.device)
+        with _timed("dyn_fused_kernel", 8 * R * C * L):
+            check(lib().gfx_dynamics_fused_lb_f32(_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)),
+                                                  pin(_rowvec(log_ratio, P)), pin(_rowvec(log_knee, P)),
+                                                  pin(_rowvec(z_alpha, P)), P, R, C, L, iir_len, KNEES[knee], int(gate),
+                                                  _ptr(ws), ws.numel(), _stream()), "gfx_dynamics_fused_lb_f32")
+        return out
     args = (_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)), pin(_rowvec(log_ratio, P)),
             pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
     with _timed("dyn_fused_kernel", 8 * R * C * L):

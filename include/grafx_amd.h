@@ -218,6 +218,16 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               const float* log_threshold, const float* log_ratio, const float* log_knee,
                               const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
                               int smoother, int64_t iir_len, int knee, int gate, void* stream);
+/* The smoothed (one-pole) configuration as one-shot tiles: every 1024-sample tile of every row is its own workgroup and
+ * the recursion's carry crosses tiles through a chained scan with decoupled look-back (8-byte {value, tag} records in
+ * `ws`) -- the access shape that reaches the chip's copy bandwidth, where the row-per-workgroup kernel behind
+ * gfx_dynamics_fused_ex_f32 is a set of long scattered streams.  Same arguments and results (to rounding);
+ * `ws` of gfx_dynamics_lookback_ws_bytes(param_rows, R, L) bytes is scratch for this call. */
+size_t gfx_dynamics_lookback_ws_bytes(int64_t param_rows, int64_t R, int64_t L);
+int gfx_dynamics_fused_lb_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
+                              const float* log_threshold, const float* log_ratio, const float* log_knee,
+                              const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
+                              int64_t iir_len, int knee, int gate, void* ws, size_t ws_bytes, void* stream);
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);

@@ -206,3 +206,25 @@ def test_cfg3_full_batch_512_rows_repeat_the_checked_rows():
     assert y.shape == (512, 2, Lc)
     d = (y.view(256, 2, 2, Lc) - y2).abs().amax(dim=(0, 2, 3))
     assert (d <= 2e-6 * y2.abs().amax(dim=(1, 2))).all(), d
+
+
+@pytest.mark.parametrize("iir_len", [16383, 300])
+def test_lookback_schedule_of_the_fused_dynamics_equals_the_row_schedule(iir_len):
+    """gfx_dynamics_fused_lb_f32 (one-shot tiles, chained scan with decoupled look-back) against the row-streaming
+    kernel: poles from instant to the clamp at 1 - 1e-5 (long look-back chains, truncation term active), ragged
+    length, mono and stereo, shared parameter rows."""
+    from grafx_amd import ops
+
+    torch.manual_seed(12)
+    for C, Lc in ((2, 131072), (1, 5001)):
+        n, B = 6, 3
+        x = torch.randn(B, n, C, Lc, device="cuda") * torch.linspace(0.05, 1.0, Lc, device="cuda")
+        p = dict(log_threshold=torch.randn(n, 1, device="cuda") - 2, log_ratio=torch.randn(n, 1, device="cuda"),
+                 log_knee=torch.randn(n, 1, device="cuda"),
+                 z_alpha=torch.tensor([[20.0], [9.0], [6.0], [2.0], [0.0], [-3.0]], device="cuda"))
+        for knee, gate in (("quadratic", False), ("hard", True)):
+            kw = dict(smoother=1, iir_len=iir_len, knee=knee, gate=gate, param_rows=n)
+            a = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="rows", **kw)
+            b = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="lookback", **kw)
+            assert torch.isfinite(b).all()
+            assert (a - b).abs().max() <= 5e-6 * a.abs().max(), (C, Lc, knee, gate)
