@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-DST = os.path.join(ROOT, "profiles", "r1")
+DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r2"))
 
 
 def bare(name):
@@ -43,7 +43,7 @@ def counter(dirname, cname):
 def main():
     os.makedirs(DST, exist_ok=True)
     bench = json.loads(open(os.path.join(RAW, "bench.json")).read().strip().splitlines()[-1])
-    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, "bench_r1.json"))
+    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, f"bench_{os.environ.get('GRAFX_ROUND', 'r2')}.json"))
     shutil.copy(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(DST, "bench_under_rocprof.json"))
     stats = glob.glob(os.path.join(RAW, "trace", "**", "*kernel_stats.csv"), recursive=True)
     shutil.copy(stats[0], os.path.join(DST, "rocprofv3_kernel_stats.csv"))
