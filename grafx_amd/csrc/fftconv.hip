@@ -265,6 +265,13 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
     if (lb >= (unsigned)a.nblocks) return;
+#if GFX_CONV_PRIO == 1
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
+#elif GFX_CONV_PRIO == 2
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(3);
+#elif GFX_CONV_PRIO == 3
+    if ((blockIdx.x >> 11) & 1) __builtin_amdgcn_s_setprio(2);
+#endif
     const unsigned ntiles = (unsigned)a.ntiles;
     const unsigned rco = lb / ntiles;
     const int64_t tile = lb - rco * ntiles;
@@ -536,6 +543,9 @@ struct PPArgs {
     unsigned bh;       // rows per filter row: R / hrows; units are ordered (filter row, channel, batch)
 };
 
+#ifndef GFX_CONV_PRIO
+#define GFX_CONV_PRIO 0   // experiment: static wave priority for every other workgroup of fftconv1_kernel
+#endif
 #ifndef GFX_PP_ABLATE
 #define GFX_PP_ABLATE 0   // timing experiments only: 1 no window requests, 2 no stores, 4 no spectrum loads, 8 no compute
 #endif
@@ -886,6 +896,213 @@ __global__ __launch_bounds__(PP_T, 2) void fftconv1pp_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fftconv1h_kernel: the tile arithmetic of fftconv1_kernel with HALF-SIZE LDS exchanges, so that THREE workgroups fit a
+// CU (the production kernel's 73.7 KB exchange image allows two, and two resident tiles leave the vector ALU ~60 % used).
+// Every exchange moves its 32 values per thread in two rounds of 16 through an image of half the size, split along an
+// index that lets every thread read exactly half of what it needs per round:
+//   exchange 1 / 4 (S1 image, 16 of its 32 k1 rows): round s in {0,1} carries rows k1 in [16 s, 16 s + 16) -- the second
+//                 pass's two radix-16 sets;
+//   exchange 2 / 3 (S2 image, 8 of its 16 k2 planes): round 0 carries butterflies j < 256 (the thread's j = t),
+//                 round 1 j >= 256 (its mirror 512 - t).
+// Same LDS instruction count as the full exchanges (8-byte accesses), twice the barriers (15 per tile instead of 7) --
+// round 1 measured a re/im split (twice the instructions AND barriers) at -28 %.  Twiddles: stage 2 and the eight
+// "hi" stage-1 rows live in LDS next to the image (14.8 KB), only lo1[1..3] stay in registers, so that the kernel fits
+// 168 VGPRs.  LDS: 36,864 + 15,104 = 51,968 B per workgroup.
+constexpr int HX_IMG_F2 = 256 * S2_ROW;                 // 4608 float2 = 36,864 B (S1 half: 16 x 272 = 4352 fits too)
+constexpr int HX_TW1_F2 = 7 * 256;                      // hi1[1..7][t]
+constexpr int HX_TW2_F2 = 6 * 16;                       // lo2[1..3][d], hi2[1..3][d]
+constexpr int HX_LDS_BYTES = (HX_IMG_F2 + HX_TW1_F2 + HX_TW2_F2) * 8;
+
+__device__ __forceinline__ int s1h_at(int k1h, int b) { return k1h * S1_ROW + b; }
+__device__ __forceinline__ int s2h_row(int k2h, int k1) { return (k2h * 32 + k1) * S2_ROW; }
+
+struct HxTw {
+    cx lo1[4];             // registers: W_8192^(t i), i < 4
+    const cx* hi1;         // LDS: hi1[(i - 1) * 256 + t] = W_8192^(4 i t), i = 1..7
+    const cx* tw2;         // LDS: lo2[1..3][d], hi2[1..3][d]
+    __device__ __forceinline__ void stage1(TileTw& tw, int t) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw.lo1[i] = lo1[i];
+        tw.hi1[0] = cx{1.0f, 0.0f};
+#pragma unroll
+        for (int i = 1; i < 8; ++i) tw.hi1[i] = hi1[(i - 1) * 256 + t];
+    }
+    __device__ __forceinline__ void stage2(TileTw& tw, int d) const {
+        tw.lo2[0] = tw.hi2[0] = cx{1.0f, 0.0f};
+#pragma unroll
+        for (int i = 1; i < 4; ++i) tw.lo2[i] = tw2[(i - 1) * 16 + d];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) tw.hi2[i] = tw2[(2 + i) * 16 + d];
+    }
+};
+
+// `mid()` runs once the first exchange is done (the 32 window registers are dead, the second pass not yet started):
+// the caller requests the filter spectrum there, so that its 68 registers are not live during the first pass.
+template <typename Mid>
+__device__ __forceinline__ void tile_forward_hx(cx (&v)[32], cx (&w)[2][16], const HxTw& hx, cx* lds, int t, Mid&& mid) {
+    const int kk = t >> 4, d = t & 15;
+    dif<32, false>(v);
+    {
+        TileTw tw;
+        hx.stage1(tw, t);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v[r] = tw.fwd1(v[r], brev(r, 5));
+    }
+    cx u[2][16];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int k1 = brev(r, 5);
+            if ((k1 >> 4) == s) lds[s1h_at(k1 & 15, t)] = v[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) u[s][c] = lds[s1h_at(kk, 16 * c + d)];
+        __syncthreads();
+        if (s == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+            dif<16, false>(u[0]);
+        }
+    }
+    dif<16, false>(u[1]);
+    {
+        TileTw tw;
+        hx.stage2(tw, d);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[s][r] = tw.fwd2(u[s][r], brev(r, 4));
+    }
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {                    // round bf carries planes k2 in [8 bf, 8 bf + 8)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k2 = brev(r, 4);
+                if ((k2 >> 3) == bf) lds[s2h_row(k2 & 7, kk + 16 * s) + d] = u[s][r];
+            }
+        __syncthreads();
+        const int j = bf ? bf_b(t) : bf_a(t);
+        const f4v* row = reinterpret_cast<const f4v*>(lds + s2h_row((j >> 5) & 7, j & 31));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f4v pq = row[q];
+            w[bf][2 * q] = pq.lo;
+            w[bf][2 * q + 1] = pq.hi;
+        }
+        __syncthreads();
+        if (bf == 1) dif<16, false>(w[0]);
+    }
+    dif<16, false>(w[1]);
+}
+
+// the last barrier of tile_forward_hx already separates its reads from the writes below
+__device__ __forceinline__ void tile_inverse_hx(cx (&w)[2][16], cx (&v)[32], const HxTw& hx, cx* lds, int t) {
+    const int kk = t >> 4, d = t & 15;
+    cx u[2][16];
+    TileTw tw2;
+    hx.stage2(tw2, d);
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+        cx p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[k] = w[bf][brev(k, 4)];  // register renaming only
+        dif<16, true>(p);
+        const int j = bf ? bf_b(t) : bf_a(t);
+        f4v* row = reinterpret_cast<f4v*>(lds + s2h_row((j >> 5) & 7, j & 31));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) row[q] = __builtin_shufflevector(p[brev(2 * q, 4)], p[brev(2 * q + 1, 4)], 0, 1, 2, 3);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int k2h = 0; k2h < 8; ++k2h)
+                u[s][8 * bf + k2h] = tw2.inv2(lds[s2h_row(k2h, kk + 16 * s) + d], 8 * bf + k2h);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        dif<16, true>(u[s]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[s1h_at(kk, 16 * brev(r, 4) + d)] = u[s][r];
+        __syncthreads();
+#pragma unroll
+        for (int k1h = 0; k1h < 16; ++k1h) v[16 * s + k1h] = lds[s1h_at(k1h, t)];
+        if (s == 0) __syncthreads();
+    }
+    {
+        TileTw tw;
+        hx.stage1(tw, t);
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) v[k1] = tw.inv1(v[k1], k1);
+    }
+    dif<32, true>(v);
+}
+
+template <bool TEE>
+__global__ __launch_bounds__(TILE_T, 3) void fftconv1h_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
+                                                              float* __restrict__ y, float* __restrict__ xcopy,
+                                                              ConvArgs a, const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
+    const int t = threadIdx.x;
+    const unsigned lb = xcd_logical_block();
+    if (lb >= (unsigned)a.nblocks) return;
+    const unsigned ntiles = (unsigned)a.ntiles;
+    const unsigned rco = lb / ntiles;
+    const int64_t tile = lb - rco * ntiles;
+    const unsigned r = rco / (unsigned)a.Cout;
+    const int c = (int)(rco - r * (unsigned)a.Cout);
+    const float* xrow = x + row_off(a.xmap, r, a.Cin == 1 ? 0 : c);
+    float* yrow = y + row_off(a.ymap, r, c);
+    const rsrc_t H = make_rsrc(Hs + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4, H_TILE_F4 * 16);
+
+    cx* tw1 = lds + HX_IMG_F2;
+    cx* tw2 = tw1 + HX_TW1_F2;
+    HxTw hx;
+    hx.hi1 = tw1;
+    hx.tw2 = tw2;
+    cx v[32], w[2][16];
+    f4v hreg[H_SLOTS];
+    load_window(v, xrow, a.off + tile * a.V - a.O, a.L, t, 1.0f);
+    // twiddle table rows: 0-3 lo1, 4-11 hi1, 12-15 lo2, 16-19 hi2
+    hx.lo1[0] = cx{1.0f, 0.0f};
+#pragma unroll
+    for (int i = 1; i < 4; ++i) hx.lo1[i] = to_cx(twtab[i * TILE_T + t]);
+    cx hi[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) hi[i] = to_cx(twtab[(5 + i) * TILE_T + t]);
+    cx t2 = {0.0f, 0.0f};
+    if (t < HX_TW2_F2) {
+        const int row = t >> 4;
+        t2 = to_cx(twtab[(row < 3 ? 13 + row : 14 + row) * TILE_T + (t & 15)]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tw1[i * 256 + t] = hi[i];
+    if (t < HX_TW2_F2) tw2[t] = t2;
+    if (TEE) store_valid<true>(v, xcopy + row_off(a.cmap, r, c), tile * a.V, a.O, a.L, t);
+    __syncthreads();                                   // twiddle tables visible
+    tile_forward_hx(v, w, hx, lds, t, [&]() {
+#pragma unroll
+        for (int q = 0; q < H_SLOTS; ++q) hreg[q] = buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
+    });
+    for_each_pair(t, hx.lo1[1], [&](int slot, int ia, int ib, cx wk, bool self) {
+        cx xe, xo, ye, yo, za, zb;
+        pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
+        pair_product(xe, xo, hreg[slot], wk, ye, yo);
+        pair_merge(ye, yo, za, zb);
+        NAT(w, ia) = za;
+        if (!self) NAT(w, ib) = zb;
+    });
+    tile_inverse_hx(w, v, hx, lds, t);
+    store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
+}
+
 static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
 
 template <typename K>
@@ -1039,7 +1256,9 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                           gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
                           int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, int schedule,
                           void* stream) {
-    if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PINGPONG) return GFX_EINVAL;
+    if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PINGPONG &&
+        schedule != GFX_SCHED_HALFX)
+        return GFX_EINVAL;
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
     if (xcopy && (off != 0 || Lout != L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
@@ -1100,6 +1319,19 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                                    y, xcopy, pa, tw);
             return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
         }
+    }
+    if (schedule == GFX_SCHED_HALFX && g.nparts != 1) return GFX_EINVAL;
+    if (g.nparts == 1 && schedule == GFX_SCHED_HALFX) {
+        const void* k = xcopy ? reinterpret_cast<const void*>(fftconv1h_kernel<true>)
+                              : reinterpret_cast<const void*>(fftconv1h_kernel<false>);
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES) != hipSuccess) return GFX_ELAUNCH;
+        if (xcopy)
+            hipLaunchKernelGGL(fftconv1h_kernel<true>, dim3(pad8(a.nblocks)), dim3(TILE_T), HX_LDS_BYTES, st, x,
+                               (const float4*)Hs, y, xcopy, a, tw);
+        else
+            hipLaunchKernelGGL(fftconv1h_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), HX_LDS_BYTES, st, x,
+                               (const float4*)Hs, y, xcopy, a, tw);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     if (g.nparts == 1) {
         if (allow_lds(fftconv1_kernel<false>) || allow_lds(fftconv1_kernel<true>)) return GFX_ELAUNCH;

@@ -182,7 +182,7 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
-SCHEDULES = {"auto": 0, "tile": 1, "pingpong": 2}   # GFX_SCHED_* of include/grafx_amd.h
+SCHEDULES = {"auto": 0, "tile": 1, "pingpong": 2, "halfx": 3}   # GFX_SCHED_* of include/grafx_amd.h
 
 
 @_on_device

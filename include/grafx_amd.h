@@ -133,6 +133,7 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
 #define GFX_SCHED_AUTO 0
 #define GFX_SCHED_TILE 1
 #define GFX_SCHED_PINGPONG 2
+#define GFX_SCHED_HALFX 3   /* one tile per workgroup with half-size LDS exchanges: three workgroups per CU */
 int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
                           float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,

@@ -262,6 +262,12 @@ def test_pingpong_schedule_matches_the_oracle_convolution(seed):
         assert torch.equal(tee, x4), what
     y_tile = ops.fftconv(x4, Hs, N, Cf, Lout=Lout, off=off, h_rows=h.shape[0], schedule="tile")
     assert (y - y_tile).abs().max() <= 4e-6 * scale, what
+    # the half-exchange schedule (three workgroups per CU) computes the same tiles as the tile schedule
+    tee2 = None if tee is None else torch.full_like(tee, float("nan"))
+    y_hx = ops.fftconv(x4, Hs, N, Cf, Lout=Lout, off=off, h_rows=h.shape[0], tee=tee2, schedule="halfx")
+    assert (y_hx - y_tile).abs().max() <= 2e-6 * scale, what
+    if tee2 is not None:
+        assert torch.equal(tee2, x4), what
 
 
 @pytest.mark.gpu

@@ -57,7 +57,7 @@ def main():
             print(f"  fftconv1 + tee      {ms:8.3f} ms  {1.5 * gb / ms * 1e3:8.1f} GB/s")
             ms = timeit(lambda: tee.copy_(x), a.iters)
             print(f"  plain copy          {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
-            for sched in ("tile", "pingpong"):
+            for sched in ("tile", "halfx", "pingpong"):
                 ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y, schedule=sched), a.iters)
                 print(f"  fftconv1 {sched:9s}      {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
                 ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y, tee=tee, schedule=sched), a.iters)
