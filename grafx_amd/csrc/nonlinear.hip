@@ -201,3 +201,63 @@ int gfx_waveshaper_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t
 }
 
 }  // extern "C"
+
+// ---- small inverse real DFT (parameter-side front-ends) --------------------------------------------------------------
+// y = irfft(X, n) for short transforms of ANY length n <= 8192 as a direct sum: the zero-phase FIR design
+// (core/fir.py:20-27: n = 2 bins - 1 = 2047, odd) and the surrogate delay's soft impulse (core/delay.py:73-76).  These
+// are per-node front-ends (R x ~1024 bins), where a direct O(n K) sum with the twiddles e^{2 pi i j / n} tabulated
+// in LDS (phase index k m mod n carried incrementally: exact) is a few microseconds per row and replaces the FFT library.
+//   y[(m + roll) mod n] = w[(m + roll) mod n] / n * ( Re X[0] + 2 sum_{0<k<n/2} Re(X[k] e^{2 pi i k m / n})
+//                                                      + [n even] Re X[n/2] (-1)^m )
+namespace gfx {
+
+__global__ __launch_bounds__(256) void irdft_kernel(const float* __restrict__ X, int is_real, float* __restrict__ y,
+                                                    int K, int n, int roll, const float* __restrict__ window) {
+    extern __shared__ float2 tab[];                       // tab[j] = e^{2 pi i j / n}, then the row's spectrum
+    float2* spec = tab + n;
+    const int64_t row = blockIdx.x;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double s, c;                                       // in double: j / n is not exact in float (6e-7 rad at n = 4001)
+        sincospi(2.0 * (double)j / (double)n, &s, &c);
+        tab[j] = make_float2((float)c, (float)s);
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+        spec[k] = is_real ? make_float2(X[row * K + k], 0.0f)
+                          : make_float2(X[(row * K + k) * 2], X[(row * K + k) * 2 + 1]);
+    __syncthreads();
+    const int half = n / 2;
+    const bool even = (n & 1) == 0;
+    const int kmax = even ? half - 1 : half;              // bins with weight 2
+    for (int m = threadIdx.x; m < n; m += blockDim.x) {
+        double acc = 0.0;                                  // thousands of terms: accumulate in double (a tiny kernel)
+        int idx = 0;
+        for (int k = 1; k <= kmax; ++k) {
+            idx += m;
+            if (idx >= n) idx -= n;
+            const float2 w = tab[idx], x = spec[k];
+            acc += (double)x.x * (double)w.x - (double)x.y * (double)w.y;
+        }
+        float v = (float)((double)spec[0].x + 2.0 * acc);
+        if (even) v += (m & 1) ? -spec[half].x : spec[half].x;
+        int o = m + roll;
+        o -= (o >= n) ? n : 0;
+        v /= (float)n;
+        y[row * n + o] = window ? v * window[o] : v;
+    }
+}
+
+}  // namespace gfx
+
+extern "C" int gfx_irdft_f32(const float* X, int is_real, float* y, int64_t rows, int64_t K, int64_t n, int64_t roll,
+                             const float* window, void* stream) {
+    if (!X || !y || rows <= 0 || rows > 0x7fffffffLL || n < 1 || n > 8192 || K != n / 2 + 1 || roll < 0 || roll >= n)
+        return GFX_EINVAL;
+    const size_t lds = (size_t)(n + K) * sizeof(float2);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gfx::irdft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return GFX_ELAUNCH;
+    hipLaunchKernelGGL(gfx::irdft_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, X, is_real, y, (int)K,
+                       (int)n, (int)roll, window);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}

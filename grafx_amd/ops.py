@@ -249,6 +249,29 @@ def fir_direct(x, h, Lout=None, off=0, out=None, h_rows=None):
     return out
 
 
+# ----------------------------------------------------------------------------------------- small inverse real DFT
+IRDFT_MAX_N = 8192
+
+
+@_on_device
+def irdft(X, n, roll=0, window=None):
+    """irfft(X, n) for short transforms (n <= 8192, any n) as a direct sum on the GPU, rolled by ``roll`` and windowed:
+    X (..., n//2 + 1) real or complex64 -> (..., n) float32 (gfx_irdft_f32)."""
+    _require_gpu(window)
+    if not X.is_cuda:
+        _require_gpu(X)
+    K = X.shape[-1]
+    is_real = not X.is_complex()
+    flat = (X if is_real else torch.view_as_real(X.contiguous())).reshape(-1, K, *(() if is_real else (2,))).contiguous()
+    if flat.dtype != torch.float32:
+        raise TypeError(f"irdft: float32 / complex64 input expected, got {X.dtype}")
+    rows = flat.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=X.device)
+    pin = _Pin()
+    check(lib().gfx_irdft_f32(_ptr(flat), int(is_real), _ptr(y), rows, K, n, roll, pin(window), _stream()), "gfx_irdft_f32")
+    return y.view(*X.shape[:-1], n)
+
+
 # ----------------------------------------------------------------------------------------- odd-length aliasing
 _ALIAS_PLANS = {}
 

@@ -5,6 +5,9 @@ with a straight-through gradient.  A (num_taps x N/2) front-end — torch ops on
 import torch
 import torch.nn as nn
 
+from ... import ops
+from ...autograd import needs_grad
+
 
 class NormalizedGradient(torch.autograd.Function):
     """Identity whose backward passes only the direction of the gradient (g / (|g| + 1e-7))."""
@@ -35,7 +38,12 @@ class SurrogateDelay(nn.Module):
             z = NormalizedGradient.apply(z)
         radius = z.abs()
         z = z * torch.tanh(radius) / (radius + 1e-7)
-        soft = torch.fft.irfft((z[:, None] + 1e-7) ** self.arange_sin)   # length 2*(N//2), as upstream
+        spec = (z[:, None] + 1e-7) ** self.arange_sin
+        n = 2 * (spec.shape[-1] - 1)                                      # length 2*(N//2), as upstream
+        if spec.is_cuda and not needs_grad(z) and 1 <= n <= ops.IRDFT_MAX_N:
+            soft = ops.irdft(spec, n)                                     # direct-sum kernel, no FFT library
+        else:
+            soft = torch.fft.irfft(spec)
         irs = self.apply_straight_through(soft) if self.straight_through else soft
         return irs.view(*shape, -1), loss
 

@@ -4,7 +4,19 @@ roll -> window, left to torch on the GPU; the heavy part is the zero-phase convo
 import torch
 import torch.nn as nn
 
+from ... import ops
+from ...autograd import needs_grad
 from .fft_filterbank import TriangularFilterBank
+
+
+def _zerophase_ir(magnitude, fir_len, window):
+    """irfft(magnitude, n=fir_len) rolled to the centre and windowed (core/fir.py:20-27).  Inference on the GPU: the
+    direct-sum kernel gfx_irdft_f32 (any length, no FFT library); with gradients, or beyond its size, torch ops."""
+    if (magnitude.is_cuda and not needs_grad(magnitude) and fir_len <= ops.IRDFT_MAX_N
+            and magnitude.shape[-1] == fir_len // 2 + 1 and magnitude.dtype == torch.float32):
+        return ops.irdft(magnitude, fir_len, roll=fir_len // 2, window=window)
+    ir = torch.roll(torch.fft.irfft(magnitude, n=fir_len), shifts=fir_len // 2, dims=-1)
+    return ir if window is None else ir * window[None, :]
 
 
 def get_window(window_type, window_length, **kwargs):
@@ -19,10 +31,7 @@ def get_window(window_type, window_length, **kwargs):
 
 def log_magnitude_to_zerophase_fir(log_magnitude, fir_len, window=None):
     lead, bins = log_magnitude.shape[:-1], log_magnitude.shape[-1]
-    ir = torch.fft.irfft(torch.exp(log_magnitude.reshape(-1, bins)), n=fir_len)
-    ir = torch.roll(ir, shifts=fir_len // 2, dims=-1)
-    if window is not None:
-        ir = ir * window[None, :]
+    ir = _zerophase_ir(torch.exp(log_magnitude.reshape(-1, bins)), fir_len, window)
     return ir.view(*lead, -1)
 
 
@@ -65,7 +74,5 @@ class ZeroPhaseFilterBankFIR(nn.Module):
         magnitude = torch.exp(log_magnitude.reshape(-1, bins))
         if self.use_filterbank:
             magnitude = torch.sqrt(self.filterbank(magnitude.square()) + self.eps)
-        ir = torch.roll(torch.fft.irfft(magnitude, n=self.fir_len), shifts=self.fir_len // 2, dims=-1)
-        if self.window is not None:
-            ir = ir * self.window[None, :]
+        ir = _zerophase_ir(magnitude, self.fir_len, self.window)
         return ir.view(*lead, -1)

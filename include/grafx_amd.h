@@ -162,6 +162,15 @@ int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, voi
 int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                       const void* plan, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- small inverse real DFT (parameter-side front-ends) ---------------------------------------
+ * y = irfft(X, n) for any n <= 8192 as a direct sum (twiddles tabulated in LDS), K = n/2 + 1 bins per row, X complex
+ * (rows, K, 2) or real (rows, K) when is_real; the result is rotated by `roll` and multiplied by `window` (n, nullable):
+ *   y[row, (m + roll) mod n] = window[(m + roll) mod n] * irfft(X[row], n)[m]
+ * Replaces the FFT-library calls of the zero-phase FIR design (core/fir.py:20-27: irfft, roll, window) and of the
+ * surrogate delay (core/delay.py:73-76). */
+int gfx_irdft_f32(const float* X, int is_real, float* y, int64_t rows, int64_t K, int64_t n, int64_t roll,
+                  const float* window, void* stream);
+
 /* ---- frequency-sampled IIR -------------------------------------------------------------
  * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276
  * (complex64 response of the biquad cascade on the N-point grid, then torch.fft.irfft(n=N)).

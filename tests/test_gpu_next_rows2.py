@@ -230,3 +230,25 @@ def test_stft_reverb_with_fresh_noise_per_forward():
     o.noise_stft = noise.cpu()
     with torch.no_grad():
         assert_close(m(x.cuda(), **pg).cpu(), o(x, **p), 2e-5, "fresh-noise reverb vs oracle with the same noise")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 255, 256, 2047, 2048, 4001, 8191, 8192])
+def test_small_inverse_real_dft_matches_torch_irfft(n):
+    """gfx_irdft_f32 (direct-sum inverse real DFT of any length n <= 8192: the zero-phase FIR design's and the surrogate
+    delay's front-end) against torch.fft.irfft in float64, real and complex spectra, with roll and window."""
+    from grafx_amd import ops
+
+    torch.manual_seed(n)
+    K = n // 2 + 1
+    Xc = torch.randn(3, 2, K, dtype=torch.complex64, device="cuda")
+    Xr = torch.randn(5, K, device="cuda").abs()
+    for X in (Xc, Xr):
+        want = torch.fft.irfft(X.to(torch.complex128), n=n)
+        got = ops.irdft(X, n)
+        assert got.shape == want.shape
+        assert (got.double() - want).abs().max() <= 2e-6 * want.abs().max().clamp_min(1e-12), n
+    w = torch.rand(n, device="cuda") + 0.5
+    r = n // 2
+    want = torch.roll(torch.fft.irfft(Xr.double(), n=n), shifts=r, dims=-1) * w.double()
+    assert (ops.irdft(Xr, n, roll=r, window=w).double() - want).abs().max() <= 2e-6 * want.abs().max().clamp_min(1e-12)
