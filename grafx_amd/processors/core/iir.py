@@ -46,8 +46,9 @@ class IIRFilter(nn.Module):
 
     def _taps(self, Bs, As):
         """(R,Cf,K,3) coefficients -> (R*Cf, N) frequency-sampled taps (iir.py:148-150): the native response +
-        Bluestein kernel up to 4096 taps; beyond that the same formula as torch ops on the GPU (complex64 response as
-        upstream, inverse real FFT in float64 so that the library transform adds no fp32 noise of its own)."""
+        Bluestein kernel up to 4096 taps and the tile's own inverse transform at 8192 / 16384; other lengths: the same
+        response formula as torch ops on the GPU (complex64 as upstream), inverted by the direct-sum kernel up to 8192
+        taps and by the FFT library in float64 beyond."""
         N = self.fsm_fir_len
         if ops.iir_fsm_native(N):  # 1..4096 (Bluestein on the LDS tile), 8192 and 16384 (the tile's own inverse transform)
             return ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
@@ -55,6 +56,8 @@ class IIRFilter(nn.Module):
         d = torch.arange(3, device=Bs.device)
         delays = torch.exp(-1j * ((d[:, None] * k[None, :]).to(Bs.dtype) / N * 2 * torch.pi))
         resp = ((Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)).prod(-2)
+        if N <= ops.IRDFT_MAX_N and resp.dtype == torch.complex64:   # any length up to 8192: direct-sum kernel, no FFT library
+            return ops.irdft(resp.contiguous(), N).reshape(-1, N)
         return torch.fft.irfft(resp.to(torch.complex128), dim=-1, n=N).float().reshape(-1, N)
 
     def fsm_fir(self, Bs, As):
