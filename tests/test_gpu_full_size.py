@@ -46,10 +46,10 @@ def test_headline_console_graph_batch2(lens):
         got, _, gbuf = render_grafx(hip, x.cuda(), dev,
                                     prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda"))
     if lens["fsm_fir_len"] % 2 == 1:  # reference == linear convolution: plain tolerance
-        assert_close(got.cpu(), want, 2e-5, "console output")
+        assert_close(got.cpu(), want, 1e-5, "console output")
         # every intermediate node too (eq outputs, compressor outputs, buses, reverb)
         for lo, hi, name in [(32, 64, "eq"), (64, 96, "compressor"), (96, 101, "mix"), (109, 110, "reverb")]:
-            assert_close(gbuf[:, lo:hi].cpu(), wbuf[:, lo:hi], 2e-5, name)
+            assert_close(gbuf[:, lo:hi].cpu(), wbuf[:, lo:hi], 1e-5, name)
         return
     # reference-default (even) lengths: every convolve() inverts a ~135071-point spectrum on a 135070-point
     # grid in fp32; five such stages in series leave the reference's own fp32 render a few 1e-5
