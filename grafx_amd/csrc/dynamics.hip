@@ -348,16 +348,21 @@ union DynRec {
 };
 constexpr int DYN_TAG_A = 1, DYN_TAG_P = 2;
 
+// CH tiles per workgroup (a chunk of CH * 1024 samples): the chunk is scanned serially from a zero state with its samples
+// and local scan values held in registers, its aggregate published, the look-back done (by then the predecessors'
+// records have long been written: the hop is hidden behind the chunk's own loads and scans), and only then are the
+// carry applied and the outputs computed and stored.  One look-back per CH tiles instead of one per tile.
+template <int CH>
 __global__ __launch_bounds__(DT) void dyn_lb_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                     const float* __restrict__ log_threshold,
                                                     const float* __restrict__ log_ratio,
                                                     const float* __restrict__ log_knee,
                                                     const float* __restrict__ tab, unsigned long long* __restrict__ recs,
-                                                    DynArgs a, unsigned ntiles) {
+                                                    DynArgs a, unsigned nchunks) {
     __shared__ float slots[16];
     __shared__ float carry_sh;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned r = blockIdx.x / ntiles, tile = blockIdx.x - r * ntiles;
+    const unsigned r = blockIdx.x / nchunks, chunk = blockIdx.x - r * nchunks;
     const unsigned pr = r % a.prows;
     const float* tb = tab + (int64_t)pr * DP_TAB;
     OnePole p;
@@ -379,37 +384,49 @@ __global__ __launch_bounds__(DT) void dyn_lb_kernel(const float* __restrict__ x,
     float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
     const float invC = 1.0f / (float)a.C;
-    const int64_t n = (int64_t)tile * DTILE + DE * t;
+    const int64_t n0 = (int64_t)chunk * CH * DTILE + DE * t;
 
-    float xa[DE], xb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, e[DE], u[DE];
-    load4(x0, n, a.L, vx, xa);
-    if (a.C == 2) load4(x1, n, a.L, vx, xb);
+    float xa[CH][DE], xb[CH][DE], u[CH][DE];
 #pragma unroll
-    for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
-    if (trunc) {   // one scan of e[n] - a^N e[n-N] (see dyn_stream)
-        float da[DE], db[DE];
-        load4(x0, n - a.N, a.L, false, da, 0);
-        if (a.C == 2) load4(x1, n - a.N, a.L, false, db, 0);
+    for (int k = 0; k < CH; ++k) {
 #pragma unroll
-        for (int i = 0; i < DE; ++i)
-            e[i] = fmaf(-p.a_N, (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC, e[i]);
+        for (int i = 0; i < DE; ++i) xb[k][i] = 0.0f;
+        load4(x0, n0 + (int64_t)k * DTILE, a.L, vx, xa[k]);
+        if (a.C == 2) load4(x1, n0 + (int64_t)k * DTILE, a.L, vx, xb[k]);
     }
-    float agg = 0.0f;                                   // in: carry 0; out: the tile's aggregate
-    scan_tile(p, e, u, agg, slots, lane, wave);
+    float agg = 0.0f;                                   // running state inside the chunk, from zero
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        float e[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[k][i] * xa[k][i] + xb[k][i] * xb[k][i]) : xa[k][i] * xa[k][i]) * invC;
+        if (trunc) {   // one scan of e[n] - a^N e[n-N] (see dyn_stream)
+            float da[DE], db[DE];
+            load4(x0, n0 + (int64_t)k * DTILE - a.N, a.L, false, da, 0);
+            if (a.C == 2) load4(x1, n0 + (int64_t)k * DTILE - a.N, a.L, false, db, 0);
+#pragma unroll
+            for (int i = 0; i < DE; ++i)
+                e[i] = fmaf(-p.a_N, (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC, e[i]);
+        }
+        scan_tile(p, e, u[k], agg, slots + 8 * (k & 1), lane, wave);
+    }
 
-    unsigned long long* rec = recs + (int64_t)r * ntiles;
+    const float a1024 = p.a_wave * p.a_wave * p.a_wave * p.a_wave;   // a^DTILE
+    float a_chunk = 1.0f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) a_chunk *= a1024;
+    unsigned long long* rec = recs + (int64_t)r * nchunks;
     if (t == 0) {
         float carry = 0.0f;
-        if (tile > 0) {
-            if (tile + 1 < ntiles) {
+        if (chunk > 0) {
+            if (chunk + 1 < nchunks) {
                 DynRec me;
                 me.s.v = agg;
                 me.s.tag = DYN_TAG_A;
-                __hip_atomic_store(rec + tile, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rec + chunk, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const float a1024 = p.a_wave * p.a_wave * p.a_wave * p.a_wave;                 // (a^256)^4 = a^DTILE
             float w = 1.0f;
-            for (int j = (int)tile - 1; j >= 0; --j) {
+            for (int j = (int)chunk - 1; j >= 0; --j) {
                 DynRec o;
                 o.u = 0;
                 int spins = 0;
@@ -424,36 +441,39 @@ __global__ __launch_bounds__(DT) void dyn_lb_kernel(const float* __restrict__ x,
                 }
                 carry = fmaf(w, o.s.v, carry);
                 if (o.s.tag == DYN_TAG_P) break;
-                w *= a1024;
+                w *= a_chunk;
                 if (w < 1e-12f) break;
             }
         }
-        if (tile + 1 < ntiles) {
+        if (chunk + 1 < nchunks) {
             DynRec me;
-            me.s.v = fmaf(p.a_wave * p.a_wave * p.a_wave * p.a_wave, carry, agg);
+            me.s.v = fmaf(a_chunk, carry, agg);
             me.s.tag = DYN_TAG_P;
-            __hip_atomic_store(rec + tile, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + chunk, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         carry_sh = carry;
     }
     __syncthreads();
-    const float carry = carry_sh;
-    // u at local position m = DE t + i gets a^(m + 1) carry = a_wave^wave * a_lane * ap[i + 1] * carry
+    // u at chunk position m = DTILE k + DE t + i gets a^(m + 1) carry = a1024^k * a_wave^wave * a_lane * ap[i + 1] * carry
     float wpow = 1.0f;
     for (int k = 0; k < wave; ++k) wpow *= p.a_wave;
-    const float base = wpow * p.a_lane * carry;
-    float ga[DE], gb[DE];
+    float base = wpow * p.a_lane * carry_sh;
 #pragma unroll
-    for (int i = 0; i < DE; ++i) {
-        const float ui = fmaf(p.ap[i + 1], base, u[i]);
-        const float env = fmaxf(p.one_m_a * ui, 0.0f);          // relu, envelope.py:48
-        const float G = logf(env + 1e-5f);                      // dynamics.py:394
-        const float g = expf(log_gain(q, G));                   // 402-403
-        ga[i] = g * xa[i];
-        gb[i] = g * xb[i];
+    for (int k = 0; k < CH; ++k) {
+        float ga[DE], gb[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            const float ui = fmaf(p.ap[i + 1], base, u[k][i]);
+            const float env = fmaxf(p.one_m_a * ui, 0.0f);          // relu, envelope.py:48
+            const float G = logf(env + 1e-5f);                      // dynamics.py:394
+            const float g = expf(log_gain(q, G));                   // 402-403
+            ga[i] = g * xa[k][i];
+            gb[i] = g * xb[k][i];
+        }
+        store4(y0, n0 + (int64_t)k * DTILE, a.L, vx, ga);
+        if (a.C == 2) store4(y1, n0 + (int64_t)k * DTILE, a.L, vx, gb);
+        base *= a1024;
     }
-    store4(y0, n, a.L, vx, ga);
-    if (a.C == 2) store4(y1, n, a.L, vx, gb);
 }
 
 // ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
@@ -1155,10 +1175,14 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     return GFX_LAUNCH_OK();
 }
 
+#ifndef GFX_DYN_CH
+#define GFX_DYN_CH 4    // tiles per look-back workgroup (2: 3.46 ms, 4: 3.37 ms, 8: 6.2 ms (194 VGPRs), 16: 11.5 ms at the headline shape; rows: 3.49)
+#endif
+
 size_t gfx_dynamics_lookback_ws_bytes(int64_t param_rows, int64_t R, int64_t L) {
     if (param_rows <= 0 || R <= 0 || L <= 0) return 0;
-    const int64_t ntiles = (L + DTILE - 1) / DTILE;
-    return (size_t)param_rows * DP_TAB * sizeof(float) + (size_t)R * ntiles * sizeof(unsigned long long);
+    const int64_t nchunks = (L + GFX_DYN_CH * DTILE - 1) / (GFX_DYN_CH * DTILE);
+    return (size_t)param_rows * DP_TAB * sizeof(float) + (size_t)R * nchunks * sizeof(unsigned long long);
 }
 
 int gfx_dynamics_fused_lb_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
@@ -1168,22 +1192,22 @@ int gfx_dynamics_fused_lb_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
     if (!x || !y || !log_threshold || !log_ratio || !z_alpha || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
     if (knee < 0 || knee > 2 || (knee != 0 && !log_knee) || iir_len < 1) return GFX_EINVAL;
-    const int64_t ntiles = (L + DTILE - 1) / DTILE;
-    if (R * ntiles > 0x7fffffffLL) return GFX_EINVAL;
+    const int64_t nchunks = (L + GFX_DYN_CH * DTILE - 1) / (GFX_DYN_CH * DTILE);
+    if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
     if (!ws || ws_bytes < gfx_dynamics_lookback_ws_bytes(param_rows, R, L)) return GFX_ENOSPC;
     DynArgs a;
     a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = 1; a.knee = knee; a.gate = gate;
     a.prows = (unsigned)param_rows;
     a.nchunks = 1;
-    a.chunk_tiles = ntiles;
+    a.chunk_tiles = GFX_DYN_CH;
     hipStream_t st = (hipStream_t)stream;
     float* tab = (float*)ws;
-    unsigned long long* recs = (unsigned long long*)((char*)ws + (((size_t)param_rows * DP_TAB * sizeof(float) + 7) & ~(size_t)7));
-    if (hipMemsetAsync(recs, 0, (size_t)R * ntiles * sizeof(unsigned long long), st) != hipSuccess) return GFX_ELAUNCH;
+    unsigned long long* recs = (unsigned long long*)((char*)ws + (size_t)param_rows * DP_TAB * sizeof(float));
+    if (hipMemsetAsync(recs, 0, (size_t)R * nchunks * sizeof(unsigned long long), st) != hipSuccess) return GFX_ELAUNCH;
     hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, tab, param_rows, iir_len);
-    hipLaunchKernelGGL(dyn_lb_kernel, dim3((unsigned)(R * ntiles)), dim3(DT), 0, st, x, y, log_threshold, log_ratio,
-                       log_knee, tab, recs, a, (unsigned)ntiles);
+    hipLaunchKernelGGL(dyn_lb_kernel<GFX_DYN_CH>, dim3((unsigned)(R * nchunks)), dim3(DT), 0, st, x, y, log_threshold,
+                       log_ratio, log_knee, tab, recs, a, (unsigned)nchunks);
     return GFX_LAUNCH_OK();
 }
 

@@ -394,10 +394,11 @@ def _rowvec(p, R):
     return p
 
 
-# Default schedule of dynamics_fused: "rows" (one workgroup streams a row) or "lookback" (one-shot tiles + decoupled
-# look-back).  Measured on MI355X at 8192 stereo rows x 131072: rows 3.49 ms (4.93 TB/s), lookback 4.01 ms (4.29 TB/s;
-# 7.9 vs 4.8 ms with every pole at the clamp): the look-back hop (an sc1 record crossing XCDs) keeps each tile's workgroup
-# alive ~8 us, which costs more than the one-shot access shape gains.  tools/dyn_lookback_check.py reproduces this.
+# Default schedule of dynamics_fused: "rows" (one workgroup streams a row) or "lookback" (chunks of four 1024-sample tiles
+# as one-shot workgroups + decoupled look-back).  Measured on MI355X at 8192 stereo rows x 131072: rows 3.49 ms
+# (4.93 TB/s), lookback 3.37 ms (5.1 TB/s) for fast poles but 5.3 vs 4.7 ms with every pole at the clamp (truncation
+# re-reads + a 32-link chain); one tile per workgroup (a look-back hop per tile) 4.0 ms.  The host cannot know the poles
+# without a synchronisation, so the default stays "rows".  tools/dyn_lookback_check.py reproduces this.
 DYN_SCHEDULE = "rows"
 
 
