@@ -15,7 +15,9 @@
 //   rows     : per row k1 one tile: forward, multiply by the chirp's spectrum (thread layout, precomputed), inverse
 //   cols_inv : conjugate twiddle, C-point inverse DFT, then the chirp / weights of the next step
 // all in place on one NFFT-point complex buffer per signal row.  fp32 throughout; the chirps are evaluated once per P
-// in double with the phase reduced exactly (k^2 mod 2P in integers).  C <= 32, i.e. P <= 174,763.
+// in double with the phase reduced exactly (k^2 mod 2P in integers).  C <= 32 covers P <= 174,763; up to P <= 699,051
+// (10 s of audio at 48 kHz plus the filter) an OUTER radix-4 level splits the 2^20-point transform into four 2^18-point
+// ones (czt_outer_*: 4-point DFT over the quarters + twiddle W_N^(n' k3), in place).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -28,8 +30,8 @@ namespace gfx {
 constexpr int CZT_MAXC = 32;
 
 struct CztGeom {
-    int64_t P, Q, K, NFFT;
-    int C;
+    int64_t P, Q, K, NFFT;   // NFFT = S * C * 8192
+    int C, S;                // C <= 32 columns per sub-transform; S = 1, or 4 sub-transforms under an outer radix-4 level
 };
 
 static inline bool czt_geom(int64_t P, CztGeom& g) {
@@ -40,9 +42,14 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
     const int64_t need = P + g.K - 1;
     int C = 1;
     while ((int64_t)C * TILE_M < need) C *= 2;
-    if (C > CZT_MAXC) return false;
+    g.S = 1;
+    if (C > CZT_MAXC) {
+        if (C > 4 * CZT_MAXC) return false;
+        g.S = 4;
+        C = CZT_MAXC;
+    }
     g.C = C;
-    g.NFFT = (int64_t)C * TILE_M;
+    g.NFFT = (int64_t)g.S * C * TILE_M;
     return true;
 }
 
@@ -74,8 +81,9 @@ template <int C, int MODE>
 __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ cP,
                                                           float2* __restrict__ buf, CztGeom g) {
     const int n2 = blockIdx.x * 256 + threadIdx.x;          // column 0..8191
-    const int64_t row = blockIdx.y;
-    float2* b = buf + row * g.NFFT;
+    const int64_t row = blockIdx.y;                        // signal row * S + sub-transform
+    const int64_t NS = g.NFFT / g.S;                       // points of one sub-transform
+    float2* b = buf + row * NS;
     cx v[C];
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
         v[n1] = e;
     }
     dif<C, false>(v);
-    const float ihn = 2.0f / (float)g.NFFT;
+    const float ihn = 2.0f / (float)NS;
     constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(TILE_T, 2) void czt_rows_kernel(float2* __restrict_
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const int64_t tile = blockIdx.x;                    // row * C + k1
-    const int k1 = (int)(tile % C);
+    const int k1 = (int)(tile % C);                       // C here = tiles per signal row = S * C
     cx* b = reinterpret_cast<cx*>(buf) + tile * TILE_M;
     TileTw tw;
     tile_twiddles(tw, twtab, t);
@@ -145,8 +153,9 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ 
                                                           int64_t ldy, int64_t lo, int64_t len, CztGeom g) {
     const int n2 = blockIdx.x * 256 + threadIdx.x;
     const int64_t row = blockIdx.y;
-    float2* b = buf + row * g.NFFT;
-    const float ihn = 2.0f / (float)g.NFFT;
+    const int64_t NS = g.NFFT / g.S;
+    float2* b = buf + row * NS;
+    const float ihn = 2.0f / (float)NS;
     cx v[C];
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
@@ -155,11 +164,93 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ 
     }
     dif<C, true>(v);
     constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
-    const float sc = 1.0f / (float)g.NFFT;
+    const float sc = 1.0f / (float)NS;
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
         const int64_t i = (int64_t)n1 * TILE_M + n2;
         const cx e = v[brev(n1, LOGC)] * sc;
+        if (MODE == 2) {                                   // plain inverse of a sub-transform (outer level follows)
+            b[i] = make_float2(e.x, e.y);
+        } else if (MODE == 0) {
+            cx o = {0.0f, 0.0f};
+            if (i < g.K) {
+                const float wk = (i == 0 || i == g.K - 1) ? 1.0f : 2.0f;
+                o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
+            }
+            b[i] = make_float2(o.x, o.y);
+        } else {
+            if (i >= lo && i < lo + len) {
+                const cx c = to_cx(cQ[i]);
+                y[row * ldy + (i - lo)] = (e.x * c.x - e.y * c.y) / (float)g.Q;
+            }
+        }
+    }
+}
+
+// ---- outer radix-4 level (S = 4): NFFT = 4 NS, n = n3 NS + n', k = k3 + 4 k' ---------------------------------------
+//   forward:  sub[k3][n'] = ( sum_n3 x[n3 NS + n'] W_4^(n3 k3) ) W_NFFT^(n' k3)      then four NS-point transforms
+//   inverse:  x[n3 NS + n'] = (1/4) sum_k3 ( sub[k3][n'] conj W_NFFT^(n' k3) ) W_4^(-n3 k3)
+// in place (a thread owns the four positions n' + n3 NS).  Input / output modes as in the column kernels.
+__device__ __forceinline__ cx outer_twiddle(int64_t np, int k3, int64_t NFFT, bool conj) {
+    // W_NFFT^(np k3): np k3 < 3 * 2^18 is exact in float, and so is the quotient by the power of two NFFT
+    float s, c;
+    sincospif(2.0f * (float)(np * k3) / (float)NFFT, &s, &c);
+    return cx{c, conj ? s : -s};
+}
+
+template <int MODE>   // 0: real z times cP; 1: complex buffer; 2 / 3: chirp sequences bP / bQ (plan)
+__global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ cP,
+                                                           float2* __restrict__ buf, CztGeom g) {
+    const int64_t NS = g.NFFT / 4;
+    const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = blockIdx.y;
+    float2* b = buf + row * g.NFFT;
+    cx v[4];
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) {
+        const int64_t i = n3 * NS + np;
+        cx e = {0.0f, 0.0f};
+        if (MODE == 0) {
+            if (i < g.P) e = to_cx(cP[i]) * z[row * g.P + i];
+        } else if (MODE == 1) {
+            e = to_cx(b[i]);
+        } else {
+            const int64_t lo = MODE == 2 ? g.P - 1 : g.K - 1, hi = MODE == 2 ? g.K - 1 : g.Q - 1;
+            const int64_t den = MODE == 2 ? g.P : g.Q;
+            const double sign = MODE == 2 ? 1.0 : -1.0;
+            if (i <= hi) e = to_cx(chirp_d(i, den, sign));
+            else if (i >= g.NFFT - lo) e = to_cx(chirp_d(g.NFFT - i, den, sign));
+        }
+        v[n3] = e;
+    }
+    dif<4, false>(v);                                     // result for k3 at v[brev(k3, 2)]
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const cx e = v[brev(k3, 2)];
+        const cx o = k3 == 0 ? e : cmul(e, outer_twiddle(np, k3, g.NFFT, false));
+        b[k3 * NS + np] = make_float2(o.x, o.y);
+    }
+}
+
+template <int MODE>   // 0: next step's input (times cP w_k cQ for k < K, zero beyond); 1: real output slice
+__global__ __launch_bounds__(256) void czt_outer_inv_kernel(float2* __restrict__ buf, const float2* __restrict__ cP,
+                                                           const float2* __restrict__ cQ, float* __restrict__ y,
+                                                           int64_t ldy, int64_t lo, int64_t len, CztGeom g) {
+    const int64_t NS = g.NFFT / 4;
+    const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = blockIdx.y;
+    float2* b = buf + row * g.NFFT;
+    cx v[4];
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const cx e = to_cx(b[k3 * NS + np]);
+        v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle(np, k3, g.NFFT, true));
+    }
+    dif<4, true>(v);
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) {
+        const int64_t i = n3 * NS + np;
+        const cx e = v[brev(n3, 2)] * 0.25f;
         if (MODE == 0) {
             cx o = {0.0f, 0.0f};
             if (i < g.K) {
@@ -178,7 +269,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ 
 
 template <int MODE>
 static void launch_cols_fwd(const CztGeom& g, const float* z, const float2* cP, float2* buf, int64_t rows, hipStream_t st) {
-    const dim3 grid(TILE_M / 256, (unsigned)rows), blk(256);
+    const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);   // one "row" per sub-transform
     switch (g.C) {
         case 1: hipLaunchKernelGGL((czt_cols_fwd_kernel<1, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
         case 2: hipLaunchKernelGGL((czt_cols_fwd_kernel<2, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
@@ -192,7 +283,7 @@ static void launch_cols_fwd(const CztGeom& g, const float* z, const float2* cP, 
 template <int MODE>
 static void launch_cols_inv(const CztGeom& g, float2* buf, const float2* cP, const float2* cQ, float* y, int64_t ldy,
                             int64_t lo, int64_t len, int64_t rows, hipStream_t st) {
-    const dim3 grid(TILE_M / 256, (unsigned)rows), blk(256);
+    const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);
     switch (g.C) {
         case 1: hipLaunchKernelGGL((czt_cols_inv_kernel<1, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
         case 2: hipLaunchKernelGGL((czt_cols_inv_kernel<2, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
@@ -240,19 +331,29 @@ int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, voi
     hipLaunchKernelGGL(czt_chirp_table_kernel, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, cP, g.P, g.P, -1.0f);
     hipLaunchKernelGGL(czt_chirp_table_kernel, dim3((unsigned)((g.Q + 255) / 256)), dim3(256), 0, st, cQ, g.Q, g.Q, 1.0f);
     float2* buf = (float2*)ws;
-    launch_cols_fwd<2>(g, nullptr, nullptr, buf, 1, st);
-    hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)g.C), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
-                       (const float2*)nullptr, sP, g.C, tw);
-    launch_cols_fwd<3>(g, nullptr, nullptr, buf, 1, st);
-    hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)g.C), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
-                       (const float2*)nullptr, sQ, g.C, tw);
+    const int ctot = g.S * g.C;
+    const dim3 og((unsigned)(g.NFFT / 4 / 256), 1);
+    if (g.S == 1) launch_cols_fwd<2>(g, nullptr, nullptr, buf, 1, st);
+    else {
+        hipLaunchKernelGGL(czt_outer_fwd_kernel<2>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g);
+        launch_cols_fwd<1>(g, nullptr, nullptr, buf, 1, st);
+    }
+    hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)ctot), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
+                       (const float2*)nullptr, sP, ctot, tw);
+    if (g.S == 1) launch_cols_fwd<3>(g, nullptr, nullptr, buf, 1, st);
+    else {
+        hipLaunchKernelGGL(czt_outer_fwd_kernel<3>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g);
+        launch_cols_fwd<1>(g, nullptr, nullptr, buf, 1, st);
+    }
+    hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)ctot), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
+                       (const float2*)nullptr, sQ, ctot, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
 int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                       const void* plan, void* ws, size_t ws_bytes, void* stream) {
     CztGeom g;
-    if (!z || !y || !plan || rows <= 0 || rows > 65535 || !czt_geom(P, g)) return GFX_EINVAL;
+    if (!z || !y || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
     if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
     if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(float2)) return GFX_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
@@ -263,15 +364,34 @@ int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t
     const float2* sP = cQ + g.Q;
     const float2* sQ = sP + g.NFFT;
     float2* buf = (float2*)ws;
-    const unsigned tiles = (unsigned)(rows * g.C);
-    launch_cols_fwd<0>(g, z, cP, buf, rows, st);
-    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sP, (float2*)nullptr,
-                       g.C, tw);
-    launch_cols_inv<0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    const int ctot = g.S * g.C;
+    const unsigned tiles = (unsigned)(rows * ctot);
+    if (g.S == 1) {
+        launch_cols_fwd<0>(g, z, cP, buf, rows, st);
+        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sP, (float2*)nullptr,
+                           ctot, tw);
+        launch_cols_inv<0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+        launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
+        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sQ, (float2*)nullptr,
+                           ctot, tw);
+        launch_cols_inv<1>(g, buf, cP, cQ, y, ldy, lo, len, rows, st);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    }
+    // outer radix-4 level around four 2^18-point transforms per row
+    const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)rows);
+    hipLaunchKernelGGL(czt_outer_fwd_kernel<0>, og, dim3(256), 0, st, z, cP, buf, g);
     launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sQ, (float2*)nullptr,
-                       g.C, tw);
-    launch_cols_inv<1>(g, buf, cP, cQ, y, ldy, lo, len, rows, st);
+    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sP, (float2*)nullptr, ctot,
+                       tw);
+    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    hipLaunchKernelGGL(czt_outer_inv_kernel<0>, og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0, (int64_t)0,
+                       (int64_t)0, g);
+    hipLaunchKernelGGL(czt_outer_fwd_kernel<1>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g);
+    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
+    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sQ, (float2*)nullptr, ctot,
+                       tw);
+    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    hipLaunchKernelGGL(czt_outer_inv_kernel<1>, og, dim3(256), 0, st, buf, cP, cQ, y, ldy, lo, len, g);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

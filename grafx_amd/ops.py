@@ -277,7 +277,7 @@ _ALIAS_PLANS = {}
 
 
 def odd_alias_supported(P):
-    """Whether gfx_odd_alias_f32 handles a linear convolution of odd length P (3 <= P <= 174,763)."""
+    """Whether gfx_odd_alias_f32 handles a linear convolution of odd length P (3 <= P <= 699,051)."""
     return lib().gfx_odd_alias_plan_bytes(P) > 0
 
 
@@ -285,7 +285,7 @@ def odd_alias_supported(P):
 def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
     full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (2 MB of
-    workspace per row at P ~ 135 k)."""
+    workspace per row at P ~ 135 k, 8 MB beyond 174,763)."""
     _require_gpu(z)
     P = z.shape[-1]
     Q = P - 1
@@ -300,7 +300,8 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
-    chunk = min(rows, rows_per_chunk)
+    per_row = lib().gfx_odd_alias_workspace_bytes(1, P)
+    chunk = max(1, min(rows, rows_per_chunk, (1 << 30) // per_row))   # at most 1 GB of workspace
     ws = torch.empty(lib().gfx_odd_alias_workspace_bytes(chunk, P), dtype=torch.uint8, device=z.device)
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)

@@ -56,7 +56,7 @@ def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
     (convolution.py:123-126): two chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, fp32, no FFT library).
 
     Three cases still go through the device FFT library in float64: gradients (autograd of the aliasing step),
-    P > 174,763 (a 2^18-point transform no longer covers 1.5 P; e.g. 10 s of audio) and ``precise=True`` -- the
+    P > 699,051 (a 2^20-point transform no longer covers 1.5 P) and ``precise=True`` -- the
     energy-envelope smoother of the dynamics processors, whose output feeds log() and a gain curve: there the fp32
     chirp-z noise (~1e-6 of the peak, about twice what the reference's own mixed-radix fp32 FFT leaves) is amplified
     on quiet passages beyond the parity bound (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths)."""
