@@ -9,7 +9,10 @@
 //
 // The inverse real DFT has arbitrary length N <= 4096 (e.g. 4000 = 2^5*5^3, 4001 prime), so it
 // runs as a Bluestein chirp-z transform on the 8192-point LDS FFT tile: one workgroup per
-// (row, filter-channel), 2 tile FFTs each.  The chirp filter spectrum is a per-N "plan".
+// (row, filter-channel), 2 tile FFTs each.  Everything that depends on N alone is a per-N "plan": the chirp filter's
+// spectrum, the chirp itself, and the sample points D[1,k], D[2,k] (evaluated by the same device sincosf the kernel
+// used to call per workgroup, so the taps are bit-identical to the table-free version; the trigonometry and the
+// integer k^2 mod 2N were ~90 % of the kernel's time and most of its 120 KB of code).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -22,6 +25,9 @@
 namespace gfx {
 
 constexpr int FSM_MAX_N = 4096;  // 2N-1 <= 8192
+// plan layout, in float2 units: [0, TILE_M) chirp-filter spectrum in thread layout; [PLAN_CHIRP, +N) e^{+i pi k^2/N};
+// [PLAN_D, +2*(N/2+1)) the pairs (D[1,k], D[2,k]) as one float4 per bin
+constexpr int PLAN_CHIRP = TILE_M, PLAN_D = TILE_M + FSM_MAX_N, PLAN_FLOAT2 = PLAN_D + 2 * (FSM_MAX_N / 2 + 4);
 static inline bool fsm_pow2(int64_t N) { return N == 8192 || N == 16384; }
 
 // exp(+i*pi*k^2/N) (sign = +1) or exp(-i*pi*k^2/N) (sign = -1); k^2 reduced mod 2N in integers
@@ -31,6 +37,8 @@ __device__ __forceinline__ float2 chirp(int k, int N, float sign) {
     sincospif((float)r / (float)N, &s, &c);
     return make_float2(c, sign * s);
 }
+
+__device__ __forceinline__ void sample_points(int k, int N, float2& d1, float2& d2);
 
 __global__ __launch_bounds__(TILE_T, 2) void bluestein_plan_kernel(float2* __restrict__ plan, int N,
                                                                    const float2* __restrict__ twtab) {
@@ -48,6 +56,12 @@ __global__ __launch_bounds__(TILE_T, 2) void bluestein_plan_kernel(float2* __res
     tile_forward(v, w, tw, lds, t);
 #pragma unroll
     for (int q = 0; q < 32; ++q) reinterpret_cast<cx*>(plan)[q * TILE_T + t] = w[q >> 4][q & 15];
+    for (int k = t; k < N; k += TILE_T) plan[PLAN_CHIRP + k] = chirp(k, N, 1.0f);
+    for (int k = t; k <= N / 2; k += TILE_T) {
+        float2 d1, d2;
+        sample_points(k, N, d1, d2);
+        reinterpret_cast<float4*>(plan + PLAN_D)[k] = make_float4(d1.x, d1.y, d2.x, d2.y);
+    }
 }
 
 // complex division, scaled like torch's vectorised complex64 kernel (divide through by max(|c|,|d|))
@@ -58,16 +72,21 @@ __device__ __forceinline__ float2 cdiv(float2 n, float2 d) {
     return make_float2((a * c + b * e) * den, (b * c - a * e) * den);
 }
 
-// cascade response at bin k (0 <= k <= N/2), reference arithmetic (see header)
-__device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, const float* __restrict__ A, int K,
-                                                   int k, int N) {
+// D[1,k], D[2,k] at bin k, reference arithmetic (see header)
+__device__ __forceinline__ void sample_points(int k, int N, float2& d1, float2& d2) {
     const float pi32 = 3.14159274101257324219f;
     const float ph1 = ((float)k / (float)N) * 2.0f * pi32;
     const float ph2 = ((float)(2 * k) / (float)N) * 2.0f * pi32;
     float s1, c1, s2, c2;
     sincosf(ph1, &s1, &c1);
     sincosf(ph2, &s2, &c2);
-    const float2 d1 = make_float2(c1, -s1), d2 = make_float2(c2, -s2);
+    d1 = make_float2(c1, -s1);
+    d2 = make_float2(c2, -s2);
+}
+
+// cascade response from the sample points (0 <= k <= N/2)
+__device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, const float* __restrict__ A, int K,
+                                                   float2 d1, float2 d2) {
     float2 H = make_float2(1.0f, 0.0f);
     for (int i = 0; i < K; ++i) {
         const float b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
@@ -99,7 +118,10 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         const int k = t + 256 * a;
-        if (k <= half) lds[k] = to_cx(cascade_response(B, A, K, k, N));
+        if (k <= half) {
+            const float4 d = reinterpret_cast<const float4*>(plan + PLAN_D)[k];
+            lds[k] = to_cx(cascade_response(B, A, K, make_float2(d.x, d.y), make_float2(d.z, d.w)));
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
             cx Hk = lds[upper ? N - k : k];
             if (upper) Hk.y = -Hk.y;
             if (k == 0 || (even && k == half)) Hk.y = 0.0f;
-            e = cmul(Hk, to_cx(chirp(k, N, 1.0f)));
+            e = cmul(Hk, to_cx(plan[PLAN_CHIRP + k]));
         }
         v[a] = e;
     }
@@ -127,7 +149,7 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
     for (int a = 0; a < 32; ++a) {
         const int n = t + 256 * a;
         if (n < N) {
-            const float2 c = chirp(n, N, 1.0f);
+            const float2 c = plan[PLAN_CHIRP + n];
             const cx e = v[brev(a, 5)];
             out[n] = (e.x * c.x - e.y * c.y) * sc;
         }
@@ -155,7 +177,9 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_pow2_kernel(const float* __
     auto Y = [&](int bin) -> cx {   // tile bin 0..M of the 16384-point spectrum
         if (bin % stride) return cx{0.0f, 0.0f};
         const int k = bin / stride;
-        cx r = to_cx(cascade_response(B, A, K, k, N));
+        float2 d1, d2;
+        sample_points(k, N, d1, d2);
+        cx r = to_cx(cascade_response(B, A, K, d1, d2));
         if (k == 0 || k == N / 2) r.y = 0.0f;   // a c2r transform ignores the imaginary parts of DC and Nyquist
         return r;
     };
@@ -305,7 +329,7 @@ using namespace gfx;
 extern "C" {
 
 int gfx_iir_fsm_native(int64_t N) { return (N >= 1 && N <= FSM_MAX_N) || fsm_pow2(N); }
-size_t gfx_iir_fsm_plan_bytes(int64_t N) { return (N < 1 || N > FSM_MAX_N) ? 0 : (size_t)TILE_M * sizeof(float2); }
+size_t gfx_iir_fsm_plan_bytes(int64_t N) { return (N < 1 || N > FSM_MAX_N) ? 0 : (size_t)PLAN_FLOAT2 * sizeof(float2); }
 
 int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream) {
     if (!plan || N < 1 || N > FSM_MAX_N) return GFX_EINVAL;
