@@ -219,6 +219,10 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
     }
 }
 
+}  // namespace gfx
+#include "fftconv_wide.hpp"
+namespace gfx {
+
 #define NAT(arr, i) arr[(i) >> 4][brev((i) & 15, 4)]
 
 // ------------------------------------------------------------------------------------------------
@@ -265,6 +269,12 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
     if (lb >= (unsigned)a.nblocks) return;
+#ifdef GFX_STAGGER
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < GFX_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #if GFX_CONV_PRIO == 1
     if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
 #elif GFX_CONV_PRIO == 2
@@ -1126,6 +1136,28 @@ int64_t gfx_fftconv_part_len(int64_t N, int64_t Lout) {
     return (TILE_F - Lout) & ~int64_t(1);
 }
 
+// experiment builds (-DGFX_W_STAMP): a 4 MB device buffer the wide kernel writes its phase timestamps into
+static void* gfx_dbg_stamp_buffer() {
+#ifdef GFX_W_STAMP
+    static void* p = nullptr;
+    if (!p && hipMalloc(&p, 4 << 20) != hipSuccess) p = nullptr;
+    return p;
+#else
+    return nullptr;
+#endif
+}
+#ifdef GFX_W_STAMP
+int gfx_dbg_stamp_read(void* host, size_t bytes) {
+    void* p = gfx_dbg_stamp_buffer();
+    if (!p || bytes > (4u << 20)) return GFX_EINVAL;
+    return hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+#endif
+
+size_t gfx_fftconv_wide_ws_bytes(int64_t h_rows, int64_t C_f) {
+    return (h_rows <= 0 || C_f <= 0) ? 0 : (size_t)h_rows * C_f * wide::W_H_F4 * 16;
+}
+
 size_t gfx_fir_spectrum_bytes(int64_t RCf, int64_t N) { return gfx_fir_spectrum_bytes_ex(RCf, N, 0); }
 
 size_t gfx_fir_spectrum_bytes_ex(int64_t RCf, int64_t N, int64_t part_len) {
@@ -1257,7 +1289,7 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                           int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, int schedule,
                           void* stream) {
     if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PINGPONG &&
-        schedule != GFX_SCHED_HALFX)
+        schedule != GFX_SCHED_HALFX && schedule != GFX_SCHED_WIDE)
         return GFX_EINVAL;
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
@@ -1289,6 +1321,27 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     const float2* tw = tile_twiddle_table(st);
     if (!tw) return GFX_ELAUNCH;
 
+    if (schedule == GFX_SCHED_WIDE) {
+        // 512-thread tile: the spectra are first rewritten into its thread layout (workspace: gfx_fftconv_wide_ws_bytes)
+        const int64_t nf = h_rows * C_f;
+        if (!wide::applicable(g, L, Lout, off, N) || part_len != 0 || !ws || ws_bytes < (size_t)nf * wide::W_H_F4 * 16 ||
+            nf > 0x7fffffffLL)
+            return GFX_EINVAL;
+        const float2* tww = wide::tile512_twiddle_table(st);
+        if (!tww) return GFX_ELAUNCH;
+        const void* k = xcopy ? reinterpret_cast<const void*>(wide::fftconv1w_kernel<true>)
+                              : reinterpret_cast<const void*>(wide::fftconv1w_kernel<false>);
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, wide::W_LDS_BYTES) != hipSuccess)
+            return GFX_ELAUNCH;
+        hipLaunchKernelGGL(wide::hconv_kernel, dim3((unsigned)nf), dim3(wide::WT), 0, st, (const float4*)Hs, (float4*)ws);
+        if (xcopy)
+            hipLaunchKernelGGL(wide::fftconv1w_kernel<true>, dim3(pad8(a.nblocks)), dim3(wide::WT), wide::W_LDS_BYTES, st, x,
+                               (const float4*)ws, y, xcopy, a, tww);
+        else
+            hipLaunchKernelGGL(wide::fftconv1w_kernel<false>, dim3(pad8(a.nblocks)), dim3(wide::WT), wide::W_LDS_BYTES, st, x,
+                               (const float4*)ws, y, (float*)gfx_dbg_stamp_buffer(), a, tww);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    }
     if (schedule == GFX_SCHED_PINGPONG && !(g.nparts == 1 && pp_applicable(R, h_rows, N, part_len))) return GFX_EINVAL;
     if (g.nparts == 1 && schedule != GFX_SCHED_TILE && pp_applicable(R, h_rows, N, part_len)) {
         PPArgs pa;

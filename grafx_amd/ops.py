@@ -182,7 +182,7 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
-SCHEDULES = {"auto": 0, "tile": 1, "pingpong": 2, "halfx": 3}   # GFX_SCHED_* of include/grafx_amd.h
+SCHEDULES = {"auto": 0, "tile": 1, "pingpong": 2, "halfx": 3, "wide": 4}   # GFX_SCHED_* of include/grafx_amd.h
 
 
 @_on_device
@@ -209,8 +209,10 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
     if Hs.numel() != lib().gfx_fir_spectrum_bytes_ex(h_rows * Cf, N, part_len):
         raise ValueError(f"filter spectra hold {Hs.numel()} bytes, expected {h_rows} x {Cf} filters of {N} taps")
     nbytes = lib().gfx_fftconv_workspace_bytes_ex(R, Cin, L, Lout, off, N, part_len)
+    if schedule == "wide":
+        nbytes = lib().gfx_fftconv_wide_ws_bytes(h_rows, Cf)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    name = "xspec+macinv_kernels" if nbytes else ("fftconv1_kernel" if lib().gfx_fftconv_nparts(N) == 1 else "winmac_kernel")
+    name = "xspec+macinv_kernels" if nbytes and schedule != "wide" else ("fftconv1_kernel" if lib().gfx_fftconv_nparts(N) == 1 else "winmac_kernel")
     cmap = RowMap(1, 0, 0, 0)
     if tee is not None:
         cmap, Rc, Cc, Lc = rowmap(tee)

@@ -134,6 +134,10 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
 #define GFX_SCHED_TILE 1
 #define GFX_SCHED_PINGPONG 2
 #define GFX_SCHED_HALFX 3   /* one tile per workgroup with half-size LDS exchanges: three workgroups per CU */
+#define GFX_SCHED_WIDE 4    /* one tile per 512-thread workgroup, 16 points per thread: four waves per SIMD.  Plain causal
+                             * geometry only (one partition, off = 0, even L and Lout); `ws` must hold
+                             * gfx_fftconv_wide_ws_bytes(h_rows, C_f) bytes (the spectra in the wide thread layout). */
+size_t gfx_fftconv_wide_ws_bytes(int64_t h_rows, int64_t C_f);
 int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
                           float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,

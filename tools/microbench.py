@@ -57,7 +57,7 @@ def main():
             print(f"  fftconv1 + tee      {ms:8.3f} ms  {1.5 * gb / ms * 1e3:8.1f} GB/s")
             ms = timeit(lambda: tee.copy_(x), a.iters)
             print(f"  plain copy          {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
-            for sched in ("tile", "halfx", "pingpong"):
+            for sched in ("tile", "wide", "halfx", "pingpong"):
                 ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y, schedule=sched), a.iters)
                 print(f"  fftconv1 {sched:9s}      {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
                 ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y, tee=tee, schedule=sched), a.iters)
@@ -78,8 +78,9 @@ def main():
                                         ("buffer out", buf.narrow(1, 32, n), None, x4),
                                         ("buffer out + tee", buf.narrow(1, 32, n), buf.narrow(1, 0, n), x4),
                                         ("buffer in/out", buf.narrow(1, 64, n), None, buf.narrow(1, 32, n))):
-                ms = timeit(lambda: ops.fftconv(xin, Hs, 4001, 1, out=out, tee=tee, h_rows=n), a.iters)
-                print(f"  fftconv1 {name:32s} {ms:8.3f} ms  {(1.5 if tee is not None else 1.0) * gb / ms * 1e3:8.1f} GB/s")
+                for sched in ("tile", "wide"):
+                    ms = timeit(lambda: ops.fftconv(xin, Hs, 4001, 1, out=out, tee=tee, h_rows=n, schedule=sched), a.iters)
+                    print(f"  fftconv1 {sched:5s} {name:32s} {ms:8.3f} ms  {(1.5 if tee is not None else 1.0) * gb / ms * 1e3:8.1f} GB/s")
         if a.what in ("eqcold",):  # the tee launch back to back vs. after other traffic (as inside a render step)
             B, n, V = R // 32, 32, 111
             eq = P.ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=4001).to(dev)
