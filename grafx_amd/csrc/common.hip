@@ -20,7 +20,9 @@ __global__ void tile_twiddle_table_kernel(float2* __restrict__ table) {
     else { num = (t & 15) * 4 * (row - 16); den = 256.0; }
     double s, c;
     sincospi(2.0 * (double)num / den, &s, &c);
-    table[row * TILE_T + t] = make_float2((float)c, (float)(-s));
+    const float2 v = make_float2((float)c, (float)(-s));
+    table[row * TILE_T + t] = v;
+    table[TW_ROWS * TILE_T + (row >> 1) * 2 * TILE_T + 2 * t + (row & 1)] = v;   // the float4-pair copy
 }
 
 const float2* tile_twiddle_table(hipStream_t stream) {
@@ -31,7 +33,7 @@ const float2* tile_twiddle_table(hipStream_t stream) {
     std::lock_guard<std::mutex> lock(mu);
     if (!tables[dev]) {
         float2* p = nullptr;
-        if (hipMalloc(&p, sizeof(float2) * TW_ROWS * TILE_T) != hipSuccess) return nullptr;
+        if (hipMalloc(&p, sizeof(float2) * TW_TABLE_F2) != hipSuccess) return nullptr;
         hipLaunchKernelGGL(tile_twiddle_table_kernel, dim3(TW_ROWS), dim3(TILE_T), 0, stream, p);
         // make the table visible to every stream before anyone else can use it
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {

@@ -297,14 +297,28 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     TileTw tw;
     cx v[32], w[2][16];
     f4v hreg[H_SLOTS];
+#ifdef GFX_T_STAMP
+    // experiment: phase timestamps (100 MHz wall clock) of every 64th workgroup into `xcopy` (non-tee launches only)
+    unsigned long long stamp[8];
+#define T_STAMP(i) stamp[i] = __builtin_amdgcn_s_memrealtime()
+#define T_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define T_STAMP(i)
+#define T_DRAIN()
+#endif
+    T_STAMP(0);
     load_window(v, xrow, a.off + tile * a.V - a.O, a.L, t, 1.0f);
     tile_twiddles(tw, twtab, t);
 #pragma unroll
     for (int q = 0; q < H_SLOTS; ++q) hreg[q] = buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
     __builtin_amdgcn_sched_barrier(0);
+    T_STAMP(1);
+    T_DRAIN();
+    T_STAMP(2);
     // off == 0 here: the window's valid part is x[tile*V, tile*V + V) itself
     if (TEE) store_valid<true>(v, xcopy + row_off(a.cmap, r, c), tile * a.V, a.O, a.L, t);
     tile_forward(v, w, tw, lds, t);
+    T_STAMP(3);
     for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool self) {
         cx xe, xo, ye, yo, za, zb;
         pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
@@ -313,10 +327,22 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
         NAT(w, ia) = za;
         if (!self) NAT(w, ib) = zb;
     });
+    T_STAMP(4);
     // no barrier here: the inverse starts by writing S2 rows j = t and 512 - t, the very rows (and the only rows)
     // this thread read at the end of the forward transform -- nobody else touches them in between
     tile_inverse(w, v, tw, lds, t);
+    T_STAMP(5);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
+    T_STAMP(6);
+    T_DRAIN();
+    T_STAMP(7);
+#ifdef GFX_T_STAMP
+    if (!TEE && xcopy && t == 0 && (lb & 63) == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(xcopy) + (lb >> 6) * 12;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = stamp[q];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,7 +1164,7 @@ int64_t gfx_fftconv_part_len(int64_t N, int64_t Lout) {
 
 // experiment builds (-DGFX_W_STAMP): a 4 MB device buffer the wide kernel writes its phase timestamps into
 static void* gfx_dbg_stamp_buffer() {
-#ifdef GFX_W_STAMP
+#if defined(GFX_W_STAMP) || defined(GFX_T_STAMP)
     static void* p = nullptr;
     if (!p && hipMalloc(&p, 4 << 20) != hipSuccess) p = nullptr;
     return p;
@@ -1146,7 +1172,7 @@ static void* gfx_dbg_stamp_buffer() {
     return nullptr;
 #endif
 }
-#ifdef GFX_W_STAMP
+#if defined(GFX_W_STAMP) || defined(GFX_T_STAMP)
 int gfx_dbg_stamp_read(void* host, size_t bytes) {
     void* p = gfx_dbg_stamp_buffer();
     if (!p || bytes > (4u << 20)) return GFX_EINVAL;
@@ -1393,7 +1419,7 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                                (const float4*)Hs, y, xcopy, a, tw);
         else
             hipLaunchKernelGGL(fftconv1_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
-                               (const float4*)Hs, y, xcopy, a, tw);
+                               (const float4*)Hs, y, (float*)gfx_dbg_stamp_buffer(), a, tw);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     if (g.ntiles == 1) {

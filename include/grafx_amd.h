@@ -12,7 +12,7 @@
  *     callers pass every workspace (sizes from the *_bytes queries).  ONE
  *     exception: the first call on a device of any entry point built on the FFT
  *     tile (fftconv, fir_spectrum, fir_grad, iir_fsm, odd_alias) allocates that
- *     device's 40 KB twiddle table with hipMalloc, fills it on `stream` and waits
+ *     device's 80 KB twiddle table with hipMalloc, fills it on `stream` and waits
  *     for it (hipStreamSynchronize) under a process-wide mutex; the table lives
  *     for the process.  After that first call nothing allocates or synchronises.
  *     The device is the CURRENT device (hipGetDevice): make the tensors' device
