@@ -190,6 +190,9 @@ struct DynArgs {
 // Tiles [t_lo, t_hi) of the row are produced.  The smoother is a truncated FIR (N taps), so a chunk that does not
 // start at the row start is exact if its scans start N samples early from a zero state: tiles [t_warm, t_lo) are
 // scanned without producing output, and samples before `s0 = t_warm * DTILE` count as zero for both scans.
+#ifndef GFX_DYN_MATH
+#define GFX_DYN_MATH 0
+#endif
 template <bool TRUNC>
 __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
                                            const float* x1, float* y0, float* y1, float* slots, int t,
@@ -259,8 +262,16 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
         float ga[DE], gb[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
+#if GFX_DYN_MATH == 2   // experiment: no transcendental functions at all (timing only)
+            const float G = env[i] + 1e-5f;
+            const float g = log_gain(q, G);
+#elif GFX_DYN_MATH == 1  // experiment: hardware log2 / exp2 (v_log_f32, v_exp_f32)
+            const float G = __logf(env[i] + 1e-5f);
+            const float g = __expf(log_gain(q, G));
+#else
             const float G = logf(env[i] + 1e-5f);            // dynamics.py:394
             const float g = expf(log_gain(q, G));            // 402-403
+#endif
             ga[i] = g * xa[i];
             gb[i] = g * xb[i];
         }
