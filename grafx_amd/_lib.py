@@ -52,6 +52,10 @@ SIGNATURES = {
                                               ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, vp]),
     "gfx_dynamics_fused_ex_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                  ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, vp]),
+    "gfx_dynamics_fused_u1_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                                 ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, f32p, vp]),
+    "gfx_dynamics_bwd_u1_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                               ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp]),
     "gfx_dynamics_lookback_ws_bytes": (sz, [i64, i64, i64]),
     "gfx_dynamics_fused_lb_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64, i64,
                                                  ctypes.c_int, ctypes.c_int, vp, sz, vp]),

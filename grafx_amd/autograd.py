@@ -412,18 +412,26 @@ class DynamicsFn(torch.autograd.Function):
     three 16384-tap FFT convolutions."""
 
     @staticmethod
-    def forward(ctx, x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate):
+    def forward(ctx, x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, u1=None):
+        # u1: the smoother's un-truncated scan of this very input, kept by an earlier forward pass (the stage-wise
+        # backward of render_grafx hands over what the inference render stored); None: produced / recomputed here
         four = x.ndim == 4  # a strided (B,n,C,L) view of the signal buffer is read in place
         if x.stride(-1) != 1 or not (four or x.is_contiguous()):
             x = x.contiguous()
+        rows = x.shape[0] * x.shape[1] if four else x.shape[0]
         if tape_only_active():  # the output of this node is the processor's output: its values are not read (see tape_only)
-            rows = x.shape[0] * x.shape[1] if four else x.shape[0]
             y = torch.empty((rows, x.shape[-2], x.shape[-1]), dtype=torch.float32, device=x.device)
         else:
-            y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
-                                   smoother=int(smoother), iir_len=iir_len, knee=knee, gate=gate)
+            if smoother and u1 is None:
+                u1 = torch.empty((rows, x.shape[-1]), dtype=torch.float32, device=x.device)
+                y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
+                                       smoother=1, iir_len=iir_len, knee=knee, gate=gate, u1_out=u1)
+            else:
+                y = ops.dynamics_fused(x, log_threshold, log_ratio, log_knee if knee != "hard" else None, z_alpha,
+                                       smoother=int(smoother), iir_len=iir_len, knee=knee, gate=gate)
         ctx.save_for_backward(x, log_threshold, log_ratio, log_knee, z_alpha)
         ctx.cfg = (smoother, iir_len, knee, gate)
+        ctx.u1 = u1 if smoother else None
         return y.view(x.shape) if four else y
 
     @staticmethod
@@ -436,7 +444,8 @@ class DynamicsFn(torch.autograd.Function):
         if smoother:  # two fused passes over the rows (forward, then backward in time) + the pole-gradient reduction
             sink = _sink_for(x)
             gx, gp, da = ops.dynamics_bwd(x, gy, log_threshold, log_ratio, lk, z_alpha, iir_len, knee, gate,
-                                          out=sink, pole=ctx.needs_input_grad[4])
+                                          out=sink, pole=ctx.needs_input_grad[4], u1=ctx.u1)
+            ctx.u1 = None
             gz = None
             if da is not None:  # chain rule through a = min(sigmoid(z), 1 - 1e-5)
                 sig = torch.sigmoid(z_alpha.reshape(-1))
@@ -449,7 +458,7 @@ class DynamicsFn(torch.autograd.Function):
             gz = None
         like = lambda t, col: None if t is None else gp[:, col].reshape(t.shape)  # noqa: E731
         return (gx, like(log_threshold, 0), like(log_ratio, 1), like(log_knee if knee != "hard" else None, 2), gz,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def truncated_one_pole(u, z_alpha, iir_len, exact=False):

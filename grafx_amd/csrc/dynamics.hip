@@ -193,12 +193,16 @@ struct DynArgs {
 #ifndef GFX_DYN_MATH
 #define GFX_DYN_MATH 0
 #endif
+// u1row (training forward, whole rows only): also store (1-a) x the UN-truncated scan of the energy, which is what the
+// backward pass needs (gfx_dynamics_bwd_u1_f32) -- one extra 4-byte store per sample here instead of a pass over x there.
 template <bool TRUNC>
 __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
                                            const float* x1, float* y0, float* y1, float* slots, int t,
-                                           int64_t t_warm, int64_t t_lo, int64_t t_hi) {
+                                           int64_t t_warm, int64_t t_lo, int64_t t_hi, float* u1row = nullptr) {
     const int lane = t & 63, wave = t >> 6;
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
+    const bool vu = (a.L % 4) == 0;
+    float carry_u = 0.0f;
     const float invC = 1.0f / (float)a.C;
     float carry = 0.0f, carry2 = 0.0f;
     const int64_t s0 = t_warm * DTILE;
@@ -241,6 +245,13 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
         }
         if (a.smoother == 1) {
             float u[DE];
+            if (TRUNC && u1row) {   // the un-truncated scan, for the backward pass only (uniform branch)
+                float uf[DE], raw[DE];
+                scan_tile(p, e, uf, carry_u, slots + 8 * (tile & 1) + 4, lane, wave);
+#pragma unroll
+                for (int i = 0; i < DE; ++i) raw[i] = p.one_m_a * uf[i];
+                store4(u1row, n, a.L, vu, raw);
+            }
             if (TRUNC) {
                 // ONE scan of e[n] - a^N e[n-N]: the scan is linear, and subtracting before accumulating keeps the
                 // truncation exact where U[n] - a^N U[n-N] would cancel (short filters, poles near one)
@@ -253,6 +264,12 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
             }
             scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
             if (tile < t_lo) continue;  // warm-up tile: only the scan state matters (uniform branch)
+            if (!TRUNC && u1row) {
+                float raw[DE];
+#pragma unroll
+                for (int i = 0; i < DE; ++i) raw[i] = p.one_m_a * u[i];
+                store4(u1row, n, a.L, vu, raw);
+            }
 #pragma unroll
             for (int i = 0; i < DE; ++i) env[i] = fmaxf(p.one_m_a * u[i], 0.0f);  // relu, envelope.py:48
         } else {
@@ -287,7 +304,8 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
                                                        const float* __restrict__ log_threshold,
                                                        const float* __restrict__ log_ratio,
                                                        const float* __restrict__ log_knee,
-                                                       const float* __restrict__ z_alpha, DynArgs a) {
+                                                       const float* __restrict__ z_alpha, DynArgs a,
+                                                       float* __restrict__ u1) {
     __shared__ float slots[16];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x / a.nchunks;
@@ -308,10 +326,11 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
     // warm-up: N taps of history (none without a smoother), whole tiles, not before the row start
     const int64_t warm_tiles = a.smoother == 1 ? (a.N + DTILE - 1) / DTILE : 0;
     const int64_t t_warm = t_lo > warm_tiles ? t_lo - warm_tiles : 0;
+    float* u1row = u1 ? u1 + r * a.L : nullptr;   // (launched with nchunks = 1 then)
     if (p.trunc)
-        dyn_stream<true>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi);
+        dyn_stream<true>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi, u1row);
     else
-        dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi);
+        dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi, u1row);
 }
 
 // ---- the same fused compressor / gate as ONE-SHOT tiles with a decoupled look-back -----------------------------
@@ -1030,6 +1049,210 @@ __global__ __launch_bounds__(DT) void dyn_bwd_b_kernel(const float* __restrict__
     }
 }
 
+// ---- the same backward in fewer bytes (round 2): pass A' only scans the energy (x -> u1: no gy, no denv), and pass C --
+// pass B with the gain computer's derivatives folded in -- recomputes denv where it needs it from (x, gy, u1):
+//   A' reads 8 B and writes 4 B per stereo sample; C reads 20 B (x, gy, u1) and writes 8 B: 40 B instead of 56 B.
+// For rows whose truncation term is live, C also needs denv N samples later for its second scan and recomputes it from
+// a second set of loads there.
+__device__ __forceinline__ void dyn_bwd_u1_stream(const DynArgs& a, const OnePole& p, const float* x0, const float* x1,
+                                                  float* u1, float* slots, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    const bool vx = vec_ok(x0) && vec_ok(x1), vo = (a.L % 4) == 0;
+    const float invC = 1.0f / (float)a.C;
+    float carry = 0.0f;
+    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    float nxa[DE], nxb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+    load4(x0, (int64_t)DE * t, a.L, vx, nxa);
+    if (a.C == 2) load4(x1, (int64_t)DE * t, a.L, vx, nxb);
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int64_t n = tile * DTILE + DE * t;
+        float xa[DE], xb[DE], e[DE], u[DE], raw[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            xa[i] = nxa[i];
+            xb[i] = nxb[i];
+        }
+        if (tile + 1 < ntiles) {
+            load4(x0, n + DTILE, a.L, vx, nxa);
+            if (a.C == 2) load4(x1, n + DTILE, a.L, vx, nxb);
+        }
+#pragma unroll
+        for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
+        scan_tile(p, e, u, carry, slots + 8 * (tile & 1), lane, wave);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) raw[i] = p.one_m_a * u[i];
+        store4(u1, n, a.L, vo, raw);
+    }
+}
+
+__global__ __launch_bounds__(DT) void dyn_bwd_u1_kernel(const float* __restrict__ x, const float* __restrict__ z_alpha,
+                                                        float* __restrict__ u1, DynArgs a) {
+    __shared__ float slots[16];
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    OnePole p;
+    onepole_setup(p, z_alpha[r], a.N, t & 63);
+    dyn_bwd_u1_stream(a, p, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0), u1 + r * a.L, slots, t);
+}
+
+// dL/d(smoothed energy) at four (reversed-walk) positions from the samples, output gradients and scan values there;
+// also returns the gain and, when `acc` is given, adds the parameter-gradient terms (as pass A did).
+__device__ __forceinline__ void dyn_denv4(const DynArgs& a, const Knee& q, const float (&xa)[DE], const float (&xb)[DE],
+                                          const float (&ga)[DE], const float (&gb)[DE], const float (&lin)[DE],
+                                          float (&dv)[DE], float (&gn)[DE], float* acc) {
+#pragma unroll
+    for (int i = 0; i < DE; ++i) {
+        const float env = fmaxf(lin[i], 0.0f);
+        const float G = logf(env + 1e-5f);
+        gn[i] = expf(log_gain(q, G));
+        const float dgain = a.C == 2 ? (ga[i] * xa[i] + gb[i] * xb[i]) : ga[i] * xa[i];
+        const float dg = dgain * gn[i];
+        const KneeGrad k = log_gain_grad(q, G);
+        dv[i] = lin[i] > 0.0f ? dg * k.dG / (env + 1e-5f) : 0.0f;
+        if (acc) {   // samples outside the row have x = gy = 0, hence dg = 0
+            acc[0] += dg * k.dT;
+            acc[1] += dg * k.dlr;
+            acc[2] += dg * k.dlk;
+        }
+    }
+}
+
+template <bool TRUNC, bool POLE>
+__device__ __forceinline__ void dyn_bwd_c_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
+                                                 const float* x1, const float* g0, const float* g1, const float* u1,
+                                                 float* o0, float* o1, float* slots, int t, float& pole,
+                                                 float (&acc)[3]) {
+    const int lane = t & 63, wave = t >> 6;
+    const bool al = (a.L % 4) == 0;  // reversed float4 groups stay 16-byte aligned only then
+    const bool vx = al && vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = al;
+    const bool vgx = al && vec_ok(o0) && vec_ok(o1);
+    const float k2 = 2.0f / (float)a.C;
+    const float pole_c2 = p.a_N - p.one_m_a * (float)a.N * (p.a_N / p.a);
+    float carry = 0.0f, carry2 = 0.0f;
+    const int64_t ntiles = (a.L + DTILE - 1) / DTILE;
+    // software prefetch of the next tile's operands (the scan's barrier would otherwise fence the loads)
+    float nu[DE], nxa[DE], nga[DE], nxb[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, ngb[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+    rload4(u1, (int64_t)DE * t, a.L, vo, nu);
+    rload4(x0, (int64_t)DE * t, a.L, vx, nxa);
+    rload4(g0, (int64_t)DE * t, a.L, vx, nga);
+    if (a.C == 2) {
+        rload4(x1, (int64_t)DE * t, a.L, vx, nxb);
+        rload4(g1, (int64_t)DE * t, a.L, vx, ngb);
+    }
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int64_t j = tile * DTILE + DE * t;
+        float uu[DE], xa[DE], ga[DE], xb[DE], gb[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            uu[i] = nu[i];
+            xa[i] = nxa[i];
+            ga[i] = nga[i];
+            xb[i] = nxb[i];
+            gb[i] = ngb[i];
+        }
+        if (tile + 1 < ntiles) {
+            rload4(u1, j + DTILE, a.L, vo, nu);
+            rload4(x0, j + DTILE, a.L, vx, nxa);
+            rload4(g0, j + DTILE, a.L, vx, nga);
+            if (a.C == 2) {
+                rload4(x1, j + DTILE, a.L, vx, nxb);
+                rload4(g1, j + DTILE, a.L, vx, ngb);
+            }
+        }
+        float un[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (TRUNC) rload4(u1, j + a.N, a.L, false, un);
+        float lin[DE], d[DE], gn[DE], u[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) lin[i] = TRUNC ? fmaf(-p.a_N, un[i], uu[i]) : uu[i];
+        dyn_denv4(a, q, xa, xb, ga, gb, lin, d, gn, acc);
+        scan_tile(p, d, u, carry, slots + 8 * (tile & 1), lane, wave);
+        if (TRUNC) {
+            // denv at the walk position j - N (N samples later in time), recomputed from its own operands; its lagged scan
+            // value is u1 at (j - N) + N = j, i.e. uu
+            float u_l[DE], xa2[DE], ga2[DE], xb2[DE] = {0.0f, 0.0f, 0.0f, 0.0f}, gb2[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+            rload4(u1, j - a.N, a.L, false, u_l);
+            rload4(x0, j - a.N, a.L, false, xa2);
+            rload4(g0, j - a.N, a.L, false, ga2);
+            if (a.C == 2) {
+                rload4(x1, j - a.N, a.L, false, xb2);
+                rload4(g1, j - a.N, a.L, false, gb2);
+            }
+            float lin2[DE], d2[DE], gn2[DE], u2[DE];
+#pragma unroll
+            for (int i = 0; i < DE; ++i) lin2[i] = fmaf(-p.a_N, uu[i], u_l[i]);
+            dyn_denv4(a, q, xa2, xb2, ga2, gb2, lin2, d2, gn2, nullptr);
+            scan_tile(p, d2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
+        }
+        if (POLE) {
+            const int64_t below = a.L - 1 - j - DE;  // sample under this thread's four
+            const float um = (below >= 0 && below < a.L) ? u1[below] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                const float prev = i + 1 < DE ? uu[i + 1] : um;
+                pole += p.one_m_a * u[i] * prev - d[i] * uu[i];
+                if (TRUNC) pole = fmaf(pole_c2 * d[i], un[i], pole);
+            }
+        }
+        float oa[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) oa[i] = fmaf(gn[i], ga[i], k2 * p.one_m_a * u[i] * xa[i]);
+        rstore4(o0, j, a.L, vgx, oa);
+        if (a.C == 2) {
+            float ob[DE];
+#pragma unroll
+            for (int i = 0; i < DE; ++i) ob[i] = fmaf(gn[i], gb[i], k2 * p.one_m_a * u[i] * xb[i]);
+            rstore4(o1, j, a.L, vgx, ob);
+        }
+    }
+}
+
+__global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       gfx_rowmap_t gmap, const float* __restrict__ log_threshold,
+                                                       const float* __restrict__ log_ratio,
+                                                       const float* __restrict__ log_knee,
+                                                       const float* __restrict__ z_alpha, const float* __restrict__ u1,
+                                                       float* __restrict__ dalpha, float* __restrict__ gparams,
+                                                       float* __restrict__ gx, DynArgs a) {
+    __shared__ float slots[16];
+    __shared__ float red[4][4];
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    OnePole p;
+    onepole_setup(p, z_alpha[r], a.N, t & 63);
+    const float* x0 = x + drow_off(a.xmap, r, 0);
+    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
+    const float* g0 = gy + drow_off(gmap, r, 0);
+    const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
+    float* o0 = gx + drow_off(a.ymap, r, 0);
+    float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
+    Knee q;
+    knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, a.knee, a.gate);
+    float pole = 0.0f, acc[3] = {0.0f, 0.0f, 0.0f};
+    const float* ur = u1 + r * a.L;
+    if (dalpha) {
+        if (p.trunc)
+            dyn_bwd_c_stream<true, true>(a, p, q, x0, x1, g0, g1, ur, o0, o1, slots, t, pole, acc);
+        else
+            dyn_bwd_c_stream<false, true>(a, p, q, x0, x1, g0, g1, ur, o0, o1, slots, t, pole, acc);
+    } else if (p.trunc) {
+        dyn_bwd_c_stream<true, false>(a, p, q, x0, x1, g0, g1, ur, o0, o1, slots, t, pole, acc);
+    } else {
+        dyn_bwd_c_stream<false, false>(a, p, q, x0, x1, g0, g1, ur, o0, o1, slots, t, pole, acc);
+    }
+    float v4[4] = {acc[0], acc[1], acc[2], pole};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = v4[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((t & 63) == 0) red[k][t >> 6] = v;
+    }
+    __syncthreads();
+    if (t < 3) gparams[3 * r + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
+    if (t == 3 && dalpha) dalpha[r] = (red[3][0] + red[3][1] + red[3][2] + red[3][3]) / p.one_m_a;  // u1 = (1-a) U
+}
+
 // One pass over (x, gy, env): gain = exp(g(log(env + 1e-5))),  dgain = sum_c gy x,  dg = dgain * gain,
 //   denv = dg * dg/dG / (env + 1e-5),   gparams[r] += sum_n dg * (dg/dT, dg/dlog_ratio, dg/dlog_knee).
 __global__ __launch_bounds__(256) void dyn_gain_bwd_kernel(const float* __restrict__ x, gfx_rowmap_t xmap,
@@ -1161,7 +1384,16 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
                               int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
                               void* stream) {
+    return gfx_dynamics_fused_u1_f32(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L,
+                                     smoother, iir_len, knee, gate, nullptr, stream);
+}
+
+int gfx_dynamics_fused_u1_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                              int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                              float* u1, void* stream) {
     if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
+    if (u1 && smoother != 1) return GFX_EINVAL;
     if (!x || !y || !log_threshold || !log_ratio || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
     if (knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
     if (smoother != 0 && smoother != 1) return GFX_EINVAL;
@@ -1177,12 +1409,12 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     const int64_t ntiles = (L + DTILE - 1) / DTILE;
     const int64_t warm = smoother == 1 ? (iir_len + DTILE - 1) / DTILE : 0;
     int64_t nchunks = 1;
-    while (R * nchunks < 2048 && nchunks < 16 && ntiles / (2 * nchunks) >= (warm > 4 ? warm : 4)) nchunks *= 2;
+    while (!u1 && R * nchunks < 2048 && nchunks < 16 && ntiles / (2 * nchunks) >= (warm > 4 ? warm : 4)) nchunks *= 2;
     a.nchunks = (int)nchunks;
     a.chunk_tiles = (ntiles + nchunks - 1) / nchunks;
     if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, (hipStream_t)stream, x, y,
-                       log_threshold, log_ratio, log_knee, z_alpha, a);
+                       log_threshold, log_ratio, log_knee, z_alpha, a, u1);
     return GFX_LAUNCH_OK();
 }
 
@@ -1281,7 +1513,10 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                          float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* dalpha,
                          void* stream) {
-    if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !denv || !u1) return GFX_EINVAL;
+    if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !u1) return GFX_EINVAL;
+#ifdef GFX_DYN_BWD_AB
+    if (!denv) return GFX_EINVAL;
+#endif
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
         return GFX_EINVAL;
     if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0 || gxmap.inner <= 0) return GFX_EINVAL;
@@ -1289,10 +1524,33 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
     a.xmap = xmap; a.ymap = gxmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
     hipStream_t st = (hipStream_t)stream;
+#ifdef GFX_DYN_BWD_AB   // round 1's two passes (A writes denv and u1, B reads them back), kept for A/B timing
     hipLaunchKernelGGL(dyn_bwd_a_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
                        log_knee, z_alpha, denv, u1, gparams, a);
     hipLaunchKernelGGL(dyn_bwd_b_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
                        log_knee, z_alpha, denv, u1, dalpha, gx, a);
+#else
+    (void)denv;
+    hipLaunchKernelGGL(dyn_bwd_u1_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, z_alpha, u1, a);
+    hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
+                       log_knee, z_alpha, u1, dalpha, gparams, gx, a);
+#endif
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_dynamics_bwd_u1_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                            const float* log_threshold, const float* log_ratio, const float* log_knee,
+                            const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                            float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* stream) {
+    if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !u1) return GFX_EINVAL;
+    if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
+        return GFX_EINVAL;
+    if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0 || gxmap.inner <= 0) return GFX_EINVAL;
+    DynArgs a;
+    a.xmap = xmap; a.ymap = gxmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
+    a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
+    hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, x, gy, gmap, log_threshold,
+                       log_ratio, log_knee, z_alpha, u1, dalpha, gparams, gx, a);
     return GFX_LAUNCH_OK();
 }
 

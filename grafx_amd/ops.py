@@ -407,10 +407,14 @@ DYN_SCHEDULE = "rows"
 
 @_on_device
 def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None,
-                   param_rows=None, schedule=None):
+                   param_rows=None, schedule=None, u1_out=None):
     """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows).
-    ``schedule``: "rows" (gfx_dynamics_fused_ex_f32) or "lookback" (one-shot tiles, gfx_dynamics_fused_lb_f32)."""
+    ``schedule``: "rows" (gfx_dynamics_fused_ex_f32) or "lookback" (one-shot tiles, gfx_dynamics_fused_lb_f32).
+    ``u1_out``: optional (R, L) tensor that receives the smoother's un-truncated scan for :func:`dynamics_bwd` (the
+    training forward; smoother = 1 only)."""
     schedule = DYN_SCHEDULE if schedule is None else schedule
+    if u1_out is not None:
+        schedule = "rows"
     _require_gpu(x, out)
     xmap, R, C, L = rowmap(x)
     P = R if param_rows is None else param_rows
@@ -426,10 +430,16 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
                                                   pin(_rowvec(z_alpha, P)), P, R, C, L, iir_len, KNEES[knee], int(gate),
                                                   _ptr(ws), ws.numel(), _stream()), "gfx_dynamics_fused_lb_f32")
         return out
+    if u1_out is not None:
+        _require_gpu(u1_out)
+        _expect(u1_out, (R, L), "dynamics_fused: u1_out")
+        if not u1_out.is_contiguous() or smoother != 1:
+            raise ValueError("dynamics_fused: u1_out must be contiguous and needs the one-pole smoother")
     args = (_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)), pin(_rowvec(log_ratio, P)),
-            pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate), _stream())
-    with _timed("dyn_fused_kernel", 8 * R * C * L):
-        check(lib().gfx_dynamics_fused_ex_f32(*args), "gfx_dynamics_fused_ex_f32")
+            pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate),
+            _ptr(u1_out), _stream())
+    with _timed("dyn_fused_kernel", 8 * R * C * L + (4 * R * L if u1_out is not None else 0)):
+        check(lib().gfx_dynamics_fused_u1_f32(*args), "gfx_dynamics_fused_u1_f32")
     return out
 
 
@@ -453,10 +463,11 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
 
 
 @_on_device
-def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True):
+def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True, u1=None):
     """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), dalpha (R) or None).
     ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view).  ``dalpha`` is the gradient with
-    respect to the clamped pole a = min(sigmoid(z_alpha), 1 - 1e-5); the caller applies the chain rule to z_alpha."""
+    respect to the clamped pole a = min(sigmoid(z_alpha), 1 - 1e-5); the caller applies the chain rule to z_alpha.
+    ``u1``: the scan kept by the forward pass (``dynamics_fused(..., u1_out=)``); without it the scan is recomputed."""
     _require_gpu(x, gy, out)
     xmap, R, C, L = rowmap(x)
     gmap, Rg, Cg, Lg = rowmap(gy)
@@ -464,12 +475,20 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
         raise ValueError(f"dynamics_bwd: gradient / output shapes do not match the input {tuple(x.shape)}")
     gx = torch.empty((R, C, L), dtype=torch.float32, device=x.device) if out is None else out
     gp = torch.empty((R, 3), dtype=torch.float32, device=x.device)
-    denv, u1 = (torch.empty((R, L), dtype=torch.float32, device=x.device) for _ in range(2))
     da = torch.empty(R, dtype=torch.float32, device=x.device) if pole else None
     pin = _Pin()
+    if u1 is not None:
+        _require_gpu(u1)
+        _expect(u1, (R, L), "dynamics_bwd: u1")
+        check(lib().gfx_dynamics_bwd_u1_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
+                                            pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)), pin(_rowvec(z_alpha, R)),
+                                            R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp),
+                                            pin(u1), _ptr(da), _stream()), "gfx_dynamics_bwd_u1_f32")
+        return gx, gp, da
+    u1 = torch.empty((R, L), dtype=torch.float32, device=x.device)
     check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
                                      pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)), pin(_rowvec(z_alpha, R)),
-                                     R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), _ptr(denv),
+                                     R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), None,
                                      _ptr(u1), _ptr(da), _stream()), "gfx_dynamics_bwd_f32")
     return gx, gp, da
 

@@ -39,12 +39,16 @@ class _Dynamics(BufferIO, nn.Module):
 
     accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
     accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
+    accepts_aux = True            # _aux=(dict, key): the training render's per-stage store (see forward)
 
-    def render_into(self, x4, out4, _shared_rows=None, **params):
-        return self.forward(x4, _out=out4, _shared_rows=_shared_rows, **params)
+    def render_into(self, x4, out4, _shared_rows=None, _aux=None, **params):
+        return self.forward(x4, _out=out4, _shared_rows=_shared_rows, _aux=_aux, **params)
 
     def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None,
-                _out=None, _shared_rows=None):
+                _out=None, _shared_rows=None, _aux=None):
+        """``_aux = (store, key)`` (render_grafx's training path): the tape-free forward render leaves the smoother's scan
+        in ``store[key]`` and the stage-wise backward, which re-traces this call on the same rows, hands it to the
+        autograd node, so that the backward does not have to scan the input again."""
         if _shared_rows is not None and (needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                                     z_alpha_post) or self.gain_smoother is not None
                                          or self.energy_smoother == "ballistics"
@@ -55,7 +59,9 @@ class _Dynamics(BufferIO, nn.Module):
                 expand_shared(t, reps) for t in (log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post))
             _shared_rows = None
         if needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
-            y = self._forward_differentiable(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post)
+            kept = None if _aux is None else _aux[0].pop(_aux[1], None)
+            y = self._forward_differentiable(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post,
+                                             u1=kept)
             if _out is None:
                 return y
             _out.copy_(y.view(_out.shape))
@@ -67,9 +73,13 @@ class _Dynamics(BufferIO, nn.Module):
             self.energy_smoother is None or (self.energy_smoother == "iir" and not reference_aliases(L, self.iir_len, self.flashfftconv))
         )
         if fusable:  # one pass: energy -> one-pole -> log -> knee -> exp -> multiply
+            u1 = None
+            if _aux is not None and self.energy_smoother == "iir":
+                rows = input_signals.shape[0] * (input_signals.shape[1] if input_signals.ndim == 4 else 1)
+                u1 = _aux[0][_aux[1]] = torch.empty((rows, L), dtype=torch.float32, device=input_signals.device)
             return ops.dynamics_fused(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                       smoother=int(self.energy_smoother == "iir"), iir_len=self.iir_len,
-                                      knee=self.knee, gate=self._gate, out=_out, param_rows=_shared_rows)
+                                      knee=self.knee, gate=self._gate, out=_out, param_rows=_shared_rows, u1_out=u1)
         if _out is not None:  # unfused configurations: run on flattened rows, then copy into the buffer slice
             y = self.forward(input_signals.reshape(-1, *input_signals.shape[2:]), log_threshold, log_ratio, log_knee,
                              z_alpha_pre, z_alpha_post)
@@ -87,13 +97,13 @@ class _Dynamics(BufferIO, nn.Module):
         gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
         return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post))
 
-    def _forward_differentiable(self, x, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post):
+    def _forward_differentiable(self, x, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post, u1=None):
         """dynamics.py:390-405: one native autograd node when there is no gain smoother and the energy smoother is
         the (non-aliasing) one-pole or absent; otherwise torch ops around the native (differentiable) smoothers."""
         if self.gain_smoother is None and (self.energy_smoother is None or (
                 self.energy_smoother == "iir" and not reference_aliases(x.shape[-1], self.iir_len, self.flashfftconv))):
             return diff.DynamicsFn.apply(x, log_threshold, log_ratio, log_knee, z_alpha_pre,
-                                         self.energy_smoother == "iir", self.iir_len, self.knee, self._gate)
+                                         self.energy_smoother == "iir", self.iir_len, self.knee, self._gate, u1)
         x = x.reshape(-1, *x.shape[-2:])
         energy = x.square().mean(-2)
         if self.energy_smoother is not None:
@@ -161,9 +171,10 @@ class ApproxCompressor(Compressor):
         super().__init__(energy_smoother="iir", gain_smoother=None, knee="quadratic", iir_len=iir_len,
                          flashfftconv=flashfftconv, max_input_len=max_input_len)
 
-    def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None, _shared_rows=None):
+    def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None, _shared_rows=None,
+                _aux=None):
         return super().forward(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre=z_alpha, _out=_out,
-                               _shared_rows=_shared_rows)
+                               _shared_rows=_shared_rows, _aux=_aux)
 
     def parameter_size(self):
         return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}

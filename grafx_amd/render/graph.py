@@ -194,9 +194,11 @@ def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
     return True
 
 
-def _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters):
+def _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters, aux=None):
     """render_grafx for HIP processors: every stage reads and writes the (B, V, C, L) signal buffer in place
-    (no clone / index_select / reshape copies), routing sums run as one gather-sum kernel."""
+    (no clone / index_select / reshape copies), routing sums run as one gather-sum kernel.
+    ``aux``: a dict (training path) in which processors with ``accepts_aux`` keep per-stage by-products of the forward
+    pass that their backward needs (key: the stage's order); the stage-wise backward hands it back to them."""
     from .. import ops
 
     squeeze = input_signals.ndim == 3
@@ -315,6 +317,8 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             state, event = prepared[i]
             main.wait_event(event)
             extra["_prepared"] = state
+        if aux is not None and plan is None and getattr(proc, "accepts_aux", False):
+            extra["_aux"] = (aux, i)   # (a gathered input is a temporary: the backward re-gathers it, same values)
         proc.render_into(x_view, out_view, **extra, **params, **common_i)
         if prepared is None:  # the first processor stage is on its way: now design the later ones underneath it
             prepared = prepare_later_stages(i)
@@ -367,8 +371,9 @@ class _BufferRenderFn(torch.autograd.Function):
         processors, render_data, p_spec, c_spec = meta
         params = _unflatten_tree(p_spec, leaves)
         common = None if c_spec is None else _unflatten_tree(c_spec, leaves)
+        ctx.aux = {}
         with torch.no_grad():
-            _, _, buf = _render_buffer_io(processors, input_signals, params, render_data, common)
+            _, _, buf = _render_buffer_io(processors, input_signals, params, render_data, common, aux=ctx.aux)
         ctx.meta = meta
         ctx.squeeze = input_signals.ndim == 3
         ctx.n_src = input_signals.shape[0 if ctx.squeeze else 1]
@@ -477,6 +482,8 @@ class _BufferRenderFn(torch.autograd.Function):
                     # a user subclass that post-processes super().forward(); so they are enabled for the exact types
                     # only (type(), not isinstance()).
                     trusted = type(processors[node_type]) in _tape_safe_types()
+                    if trusted and i in ctx.aux and getattr(processors[node_type], "accepts_aux", False):
+                        extra["_aux"] = (ctx.aux, i)   # what the forward render kept for this stage
                     with diff.tape_only(trusted):  # only the stage's tape is wanted here, not its output values
                         y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y

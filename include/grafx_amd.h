@@ -279,6 +279,19 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                          float* gx, gfx_rowmap_t gxmap, float* gparams, float* denv, float* u1, float* dalpha,
                          void* stream);
+/* The same backward when the forward pass has kept the scan: gfx_dynamics_fused_u1_f32 is gfx_dynamics_fused_ex_f32 that
+ * also stores u1 (R, L) = (1-a) x the un-truncated one-pole scan of the energy (whole rows, one extra 4-byte store per
+ * sample), and gfx_dynamics_bwd_u1_f32 is the second pass of gfx_dynamics_bwd_f32 alone, reading that u1.  Since round 2
+ * gfx_dynamics_bwd_f32 itself runs as "scan x into u1" + that pass (the gain computer's derivatives are recomputed where
+ * they are needed instead of being written out and read back); its `denv` workspace is no longer used and may be NULL. */
+int gfx_dynamics_fused_u1_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
+                              const float* log_threshold, const float* log_ratio, const float* log_knee,
+                              const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L, int smoother,
+                              int64_t iir_len, int knee, int gate, float* u1, void* stream);
+int gfx_dynamics_bwd_u1_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                            const float* log_threshold, const float* log_ratio, const float* log_knee,
+                            const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                            float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* stream);
 /* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
  * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,
