@@ -114,7 +114,7 @@ extern "C" int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64
                                          const int64_t* unique_src, const int64_t* dest_mask, int64_t U, float* out,
                                          int64_t out_sb, int64_t out_sv, int64_t out_sc, int64_t B, int64_t J,
                                          int64_t C, int64_t L, void* stream) {
-    if (!buf || !unique_src || !dest_mask || !out || B <= 0 || J <= 0 || J > 8 || C <= 0 || L <= 0 || U <= 0)
+    if (!buf || !unique_src || !dest_mask || !out || B <= 0 || J <= 0 || J > 32 || C <= 0 || L <= 0 || U <= 0)
         return GFX_EINVAL;
     if (B > 65535 || C > 65535) return GFX_EINVAL;
     const bool aligned = (((uintptr_t)buf | (uintptr_t)out) & 15) == 0 && (L % 4 == 0) &&
@@ -122,9 +122,16 @@ extern "C" int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64
     if (!aligned) return GFX_EINVAL;  // callers fall back to gfx_gather_sum_f32
     int64_t bx = (L / 4 + 255) / 256;
     if (bx > 512) bx = 512;
-    hipLaunchKernelGGL(gfx::gather_sum_fanout_kernel<8>, dim3((unsigned)bx, (unsigned)C, (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, buf, buf_sb, buf_sv, buf_sc, unique_src, dest_mask, (int)U, out, out_sb,
-                       out_sv, out_sc, (int)J, L / 4);
+    // up to 8 destinations: the forward routing sums (many strips -> a few buses); up to 32: their adjoints (a few bus
+    // gradients -> every strip), 32 accumulators = 128 VGPRs
+    if (J <= 8)
+        hipLaunchKernelGGL(gfx::gather_sum_fanout_kernel<8>, dim3((unsigned)bx, (unsigned)C, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, buf, buf_sb, buf_sv, buf_sc, unique_src, dest_mask, (int)U, out, out_sb,
+                           out_sv, out_sc, (int)J, L / 4);
+    else
+        hipLaunchKernelGGL(gfx::gather_sum_fanout_kernel<32>, dim3((unsigned)bx, (unsigned)C, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, buf, buf_sb, buf_sv, buf_sc, unique_src, dest_mask, (int)U, out, out_sb,
+                           out_sv, out_sc, (int)J, L / 4);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

@@ -753,7 +753,7 @@ def gather_sum(buf, src_idx, seg_ptr, out):
 
 @_on_device
 def gather_sum_fanout(buf, unique_src, dest_mask, out):
-    """Fan-out form of :func:`gather_sum`: source rows read once, up to 8 destinations (bit mask per source)."""
+    """Fan-out form of :func:`gather_sum`: source rows read once, up to 32 destinations (bit mask per source)."""
     _require_gpu(buf, out)
     B, _, C, L = buf.shape
     J = out.shape[1]

@@ -73,7 +73,9 @@ def _gather_plan(step, device):
 
 def _transposed_plan(step, plan, device):
     """The adjoint of a gather plan: for every distinct source row, the list of destination slots it fed.
-    -> (unique source rows (list), dst_idx tensor, seg_ptr tensor, contiguous?)"""
+    -> (unique source rows (list), dst_idx tensor, seg_ptr tensor, contiguous?, fan) -- fan = (slot indices, per-slot bit
+    mask over the unique source rows) when there are at most 32 of them: the adjoint then reads every slot's gradient once
+    (gfx_gather_sum_fanout_f32) instead of once per source row."""
     cache = step.__dict__.setdefault("_plans_T", {})
     key = (device.type, device.index)
     if key not in cache:
@@ -87,8 +89,18 @@ def _transposed_plan(step, plan, device):
         for u in uniq:
             dst.extend(by_src[u])
             ptr.append(len(dst))
+        fan = None
+        if len(uniq) <= 32:
+            masks = {}
+            for k, u in enumerate(uniq):
+                for j in by_src[u]:
+                    masks[j] = masks.get(j, 0) | (1 << k)
+            slots = sorted(masks)
+            fan = (torch.tensor(slots, dtype=torch.long, device=device),
+                   torch.tensor([masks[j] for j in slots], dtype=torch.long, device=device))
         cache[key] = (uniq, torch.tensor(dst, dtype=torch.long, device=device),
-                      torch.tensor(ptr, dtype=torch.long, device=device), uniq == list(range(uniq[0], uniq[0] + len(uniq))))
+                      torch.tensor(ptr, dtype=torch.long, device=device),
+                      uniq == list(range(uniq[0], uniq[0] + len(uniq))), fan)
     return cache[key]
 
 
@@ -513,12 +525,14 @@ class _BufferRenderFn(torch.autograd.Function):
             else:
                 # adjoint of the gather-sum: every source row collects the gradients of the slots it fed --
                 # the same gather-sum kernel with the transposed plan
-                uniq, dst_idx, ptr, contiguous = _transposed_plan(step, plan, dev)
+                uniq, dst_idx, ptr, contiguous, fan = _transposed_plan(step, plan, dev)
                 if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]):
                     g_src = gbuf.narrow(1, uniq[0], len(uniq))  # first contribution: gather straight into the rows
                 else:
                     g_src = torch.empty(B, len(uniq), C, L, device=dev)
-                g_src = ops.gather_sum(g_in if g_in.stride(-1) == 1 else g_in.contiguous(), dst_idx, ptr, g_src)
+                g_in = g_in if g_in.stride(-1) == 1 else g_in.contiguous()
+                if fan is None or not ops.gather_sum_fanout(g_in, fan[0], fan[1], g_src):
+                    g_src = ops.gather_sum(g_in, dst_idx, ptr, g_src)
                 if contiguous:
                     accumulate(uniq[0], uniq[0] + len(uniq), g_src)
                 else:

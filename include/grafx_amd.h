@@ -337,7 +337,8 @@ int gfx_gather_sum_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t
                        const int64_t* src_idx, const int64_t* seg_ptr,
                        float* out, int64_t out_sb, int64_t out_sv, int64_t out_sc,
                        int64_t B, int64_t J, int64_t C, int64_t L, void* stream);
-/* Same result for fan-out routing (one source feeding several of the J <= 8 destinations): every
+/* Same result for fan-out routing (one source feeding several of the J <= 32 destinations; more than 8 is the shape of
+ * a routing sum's adjoint: a few bus gradients onto every strip): every
  * distinct source row unique_src[u] is read once and added to the destinations whose bit is set in
  * dest_mask[u].  Needs 16-byte aligned rows (returns GFX_EINVAL otherwise: use gfx_gather_sum_f32). */
 int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t buf_sc,
