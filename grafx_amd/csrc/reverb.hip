@@ -44,6 +44,27 @@ __global__ void istft_basis_kernel(const float* __restrict__ window, float* __re
     basis[i] = v;
 }
 
+// Half basis behind the full one (same buffer): hb[k][p][n], n < NC = roundup(n_fft/2 + 1, 16), p = 0: (1|2)/N cos(2 pi k n / N),
+// p = 1: -(1|2)/N sin(2 pi k n / N), NOT windowed.  Columns n and N - n of the inverse real DFT share these products
+// (cos is even in n, sin odd), so frame[n] = w[n] (C + S), frame[N-n] = w[N-n] (C - S): half the matrix multiply.
+__host__ __device__ inline int64_t half_cols(int64_t n_fft) { return ((n_fft / 2 + 1) + 15) / 16 * 16; }
+__global__ void istft_half_basis_kernel(float* __restrict__ hb, int n_fft, int NC) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = n_fft / 2 + 1;
+    if (i >= (int64_t)K * 2 * NC) return;
+    const int n = (int)(i % NC), p = (int)((i / NC) & 1), k = (int)(i / (2 * NC));
+    float v = 0.0f;
+    if (n <= n_fft / 2) {
+        const bool edge = (k == 0 || k == n_fft / 2);
+        const int r = (int)(((int64_t)k * n) % n_fft);
+        float sn, cs;
+        sincospif(2.0f * (float)r / (float)n_fft, &sn, &cs);
+        const float wgt = (edge ? 1.0f : 2.0f) / (float)n_fft;
+        v = p ? (edge ? 0.0f : -wgt * sn) : wgt * cs;
+    }
+    hb[i] = v;
+}
+
 __device__ __forceinline__ float softplus_t(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
 
 struct IstftArgs {
@@ -201,6 +222,116 @@ __global__ __launch_bounds__(256) void istft_frames_tiled_kernel(const float* __
         }
 }
 
+// The tiled kernel on the half basis (n_fft <= 384): per k-step of 4 bins a wave multiplies the real parts into its C tiles
+// and the imaginary parts into its S tiles, then writes frame[n] = w[n] (C + S) and frame[N-n] = w[N-n] (C - S):
+// 26 column tiles x 49 k-steps instead of 24 x 97.
+__global__ __launch_bounds__(256) void istft_frames_half_kernel(const float* __restrict__ noise_stft,
+                                                                const float* __restrict__ init_lm,
+                                                                const float* __restrict__ delta_lm,
+                                                                const float* __restrict__ gain_env,
+                                                                const float* __restrict__ hb,
+                                                                const float* __restrict__ window,
+                                                                float* __restrict__ frames, IstftArgs a) {
+    __shared__ float As[2][IST_KC * IST_AROW];
+    __shared__ float slope_s[256];   // -softplus(delta) per bin: the same for all 64 frames of the tile (K <= 193)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rc = blockIdx.y;
+    const int c = (int)(rc & 1);
+    const int m0 = blockIdx.x * 64;
+    const float* H0 = init_lm + rc * a.K;
+    const float* Hd = delta_lm + rc * a.K;
+    const int fm = tid & 63, m = m0 + fm;
+    const bool m_ok = m < a.T;
+    const float mf = (float)m;
+    const float genv = (gain_env && m_ok) ? gain_env[rc * a.T + m] : 0.0f;
+    if (tid < a.K) slope_s[tid] = -softplus_t(Hd[tid]);
+    __syncthreads();
+    const int NC = (int)half_cols(a.n_fft), ntile = NC / 16;
+    // wave w: row tiles 2 (w & 1), +1 (32 of the 64 frames) x one half of the column tiles (7 + 6 of 13 at n_fft = 384):
+    // 2 x 7 x {C, S} = 28 accumulator tiles = 112 registers, so that two workgroups fit a CU
+    constexpr int HCT = 7;
+    const int rt0 = 2 * (wave & 1);
+    const int ct0 = (wave >> 1) * ((ntile + 1) / 2);
+    const int nct = (wave >> 1) ? ntile - ct0 : ct0 + (ntile + 1) / 2 > ntile ? ntile : (ntile + 1) / 2;
+
+    f32x4 accC[2][HCT], accS[2][HCT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < HCT; ++ct) accC[rt][ct] = accS[rt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int kq = lane >> 4, li = lane & 15;
+    const int colw = ct0 * 16 + li;
+    const int nchunks = (2 * a.K + IST_KC - 1) / IST_KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        float* A = As[ch & 1];
+        const int kk0 = ch * IST_KC;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = (kk0 >> 1) + (tid >> 6) * 4 + q;
+            float re = 0.0f, im = 0.0f;
+            if (m_ok && k < a.K) {
+                float lm = __fadd_rn(H0[k], __fmul_rn(slope_s[k], mf));
+                if (gain_env) lm = __fadd_rn(lm, genv);
+                const float mask = expf(lm / 8.0f);
+                const float2 nz = *reinterpret_cast<const float2*>(noise_stft + (rc >> 1) * a.nstride + (((int64_t)c * a.K + k) * a.T + m) * 2);
+                re = nz.x * mask;
+                im = nz.y * mask;
+            }
+            const int kkl = 2 * ((tid >> 6) * 4 + q);
+            A[kkl * IST_AROW + fm] = re;
+            A[(kkl + 1) * IST_AROW + fm] = im;
+        }
+        __syncthreads();  // chunk ch visible; the other buffer is free again two barriers later
+#pragma unroll
+        for (int ks = 0; ks < IST_KC / 8; ++ks) {   // 4 bins per step
+            const int bl = ks * 4 + kq;              // bin within the chunk
+            const int k = (kk0 >> 1) + bl;
+            float are[2], aim[2], bc[HCT], bs[HCT];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                are[rt] = A[(2 * bl) * IST_AROW + 16 * (rt0 + rt) + li];
+                aim[rt] = A[(2 * bl + 1) * IST_AROW + 16 * (rt0 + rt) + li];
+            }
+            const float* brow = hb + (int64_t)k * 2 * NC + colw;
+#pragma unroll
+            for (int ct = 0; ct < HCT; ++ct) {
+                const bool ok = k < a.K && ct < nct;
+                bc[ct] = ok ? brow[16 * ct] : 0.0f;
+                bs[ct] = ok ? brow[NC + 16 * ct] : 0.0f;
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < HCT; ++ct)
+                    if (ct < nct) {   // (wave-uniform)
+                        accC[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(are[rt], bc[ct], accC[rt][ct], 0, 0, 0);
+                        accS[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[rt], bs[ct], accS[rt][ct], 0, 0, 0);
+                    }
+        }
+    }
+    const int half = a.n_fft / 2;
+#pragma unroll
+    for (int ct = 0; ct < HCT; ++ct) {
+        const int n = colw + 16 * ct;
+        if (ct < nct && n <= half) {
+            const float wn = window[n], wm = window[(a.n_fft - n) % a.n_fft];
+            const bool mirror = n > 0 && n < half;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mm = m0 + 16 * (rt0 + rt) + kq * 4 + q;
+                    if (mm < a.T) {
+                        float* fr = frames + (rc * a.T + mm) * a.n_fft;
+                        fr[n] = wn * (accC[rt][ct][q] + accS[rt][ct][q]);
+                        if (mirror) fr[a.n_fft - n] = wm * (accC[rt][ct][q] - accS[rt][ct][q]);
+                    }
+                }
+        }
+    }
+}
+
 // overlap-add + envelope division + trim (centre) + optional ms->lr + energy.
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
                                                         float* __restrict__ ir, float* __restrict__ energy, IstftArgs a,
@@ -316,7 +447,7 @@ int gfx_noise_shaping_ir_f32(const float* noise, int64_t noise_stride, const flo
 
 size_t gfx_istft_basis_bytes(int64_t n_fft) {
     if (n_fft < 2 || (n_fft & 1)) return 0;
-    return (size_t)kpad_of(n_fft) * n_fft * sizeof(float);
+    return ((size_t)kpad_of(n_fft) * n_fft + (size_t)(n_fft / 2 + 1) * 2 * half_cols(n_fft)) * sizeof(float);
 }
 
 int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* stream) {
@@ -324,6 +455,9 @@ int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* 
     const int64_t total = kpad_of(n_fft) * n_fft;
     hipLaunchKernelGGL(istft_basis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        window, basis, (int)n_fft, (int)kpad_of(n_fft));
+    const int64_t htotal = (n_fft / 2 + 1) * 2 * half_cols(n_fft);
+    hipLaunchKernelGGL(istft_half_basis_kernel, dim3((unsigned)((htotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       basis + total, (int)n_fft, (int)half_cols(n_fft));
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
@@ -364,8 +498,13 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
     if (hipMemsetAsync(row_gain, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
     if (n_fft <= 384) {
         dim3 g1((unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
+#ifdef GFX_ISTFT_FULL   // round 1's full-matrix form, kept for A/B timing
         hipLaunchKernelGGL(istft_frames_tiled_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude,
                            delta_log_magnitude, gain_env_log_magnitude, basis, (float*)ws, a);
+#else
+        hipLaunchKernelGGL(istft_frames_half_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude,
+                           delta_log_magnitude, gain_env_log_magnitude, basis + kpad_of(n_fft) * n_fft, window, (float*)ws, a);
+#endif
     } else {
         dim3 g1((unsigned)((n_fft + 127) / 128), (unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
         hipLaunchKernelGGL(istft_frames_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude,
