@@ -275,7 +275,8 @@ def irdft(X, n, roll=0, window=None):
 
 
 # ----------------------------------------------------------------------------------------- odd-length aliasing
-_ALIAS_PLANS = {}
+_ALIAS_PLANS = {}          # (P, device) -> plan, most recently used last; at most _ALIAS_PLANS_MAX entries (up to 25 MB each)
+_ALIAS_PLANS_MAX = 8
 
 
 def odd_alias_supported(P):
@@ -293,12 +294,16 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
     Q = P - 1
     length = Q - lo if length is None else length
     key = (P, z.device.type, z.device.index)
-    plan = _ALIAS_PLANS.get(key)
+    plan = _ALIAS_PLANS.pop(key, None)
+    if plan is not None:
+        _ALIAS_PLANS[key] = plan   # back in as the most recent
     if plan is None:
         plan = torch.empty(lib().gfx_odd_alias_plan_bytes(P), dtype=torch.uint8, device=z.device)
         w1 = torch.empty(lib().gfx_odd_alias_workspace_bytes(1, P), dtype=torch.uint8, device=z.device)
         check(lib().gfx_odd_alias_plan_f32(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), "gfx_odd_alias_plan_f32")
         _ALIAS_PLANS[key] = plan
+        while len(_ALIAS_PLANS) > _ALIAS_PLANS_MAX:
+            _ALIAS_PLANS.pop(next(iter(_ALIAS_PLANS)))
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
