@@ -5,6 +5,7 @@
 # into profiles/r2/ (GRAFX_ROUND).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_raw
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_cfg2 $OUT/trace_cfg3   # one run per directory
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
