@@ -21,9 +21,10 @@ class IIRFilter(nn.Module):
         if flashfftconv:  # same precondition as upstream (iir.py:110-112)
             assert fsm_fir_len % 2 == 0
             assert fsm_max_input_len % 2 == 0
+        self.order = order
         if backend == "fsm":
-            if order != 2:
-                raise NotImplementedError("the HIP FSM kernel evaluates second-order sections (order=2)")
+            # order != 2 (no processor of the package uses it): the sampled response is formed by torch ops on the GPU, as
+            # upstream (iir.py:147-150 with delays = arange(order + 1)); the taps then take the native convolution
             if fsm_regularization:
                 assert False  # upstream: iir.py:122-123
             self.conv = FIRConvolution(mode="causal", flashfftconv=flashfftconv, max_input_len=fsm_max_input_len)
@@ -50,10 +51,10 @@ class IIRFilter(nn.Module):
         response formula as torch ops on the GPU (complex64 as upstream), inverted by the direct-sum kernel up to 8192
         taps and by the FFT library in float64 beyond."""
         N = self.fsm_fir_len
-        if ops.iir_fsm_native(N):  # 1..4096 (Bluestein on the LDS tile), 8192 and 16384 (the tile's own inverse transform)
+        if Bs.shape[-1] == 3 and ops.iir_fsm_native(N):  # 1..4096 (Bluestein on the LDS tile), 8192 and 16384 (tile inverse)
             return ops.iir_fsm_fir(Bs, As, N, self._plan(Bs.device))
         k = torch.arange(N // 2 + 1, device=Bs.device)
-        d = torch.arange(3, device=Bs.device)
+        d = torch.arange(Bs.shape[-1], device=Bs.device)
         delays = torch.exp(-1j * ((d[:, None] * k[None, :]).to(Bs.dtype) / N * 2 * torch.pi))
         resp = ((Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)).prod(-2)
         if N <= ops.IRDFT_MAX_N and resp.dtype == torch.complex64:   # any length up to 8192: direct-sum kernel, no FFT library
@@ -113,7 +114,7 @@ class IIRFilter(nn.Module):
             tee = None
         if needs_grad(input_signal, Bs, As):  # training path: torch front-end + native conv fwd/bwd
             # a strided (B,n,C,L) view goes through as it is (the native convolution reads it in place)
-            if self.fsm_fir_len <= self.FSM_NATIVE_MAX:  # native taps, written-out backward
+            if self.fsm_fir_len <= self.FSM_NATIVE_MAX and Bs.shape[-1] == 3:  # native taps, written-out backward
                 h = diff.FsmFirFn.apply(Bs, As, self.fsm_fir_len, self._plan(Bs.device))
             else:
                 h = diff.fsm_fir(Bs, As, self.fsm_fir_len)

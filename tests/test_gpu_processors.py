@@ -218,3 +218,32 @@ def test_iir_fsm_native_taps_for_power_of_two_lengths_above_4096(N, K):
     ref64 = lti.iir_fsm_fir(Bs.double(), As.double(), N)
     assert fir.shape == ref.shape == (R, Cf, N)
     assert_parity(fir, ref, ref64.float(), TOL, f"fsm taps N={N} K={K}")
+
+
+@pytest.mark.parametrize("order,N", [(1, 512), (3, 513), (4, 1000)])
+def test_iir_fsm_other_orders(order, N):
+    """IIRFilter(order != 2, backend="fsm") (core/iir.py:96-152 with delays = arange(order + 1); no processor of the package
+    uses it): response by torch ops on the GPU, taps by the direct-sum inverse DFT, convolution native -- vs the oracle,
+    forward and gradients."""
+    from grafx_amd.processors import IIRFilter
+    from oracle import lti
+
+    torch.manual_seed(10 * order + N)
+    R, Cf, K, L = 3, 1, 2, 3000
+    Bs = 0.3 * torch.randn(R, Cf, K, order + 1)
+    As = 0.1 * torch.randn(R, Cf, K, order + 1)
+    As[..., 0] = 1.0
+    x = torch.randn(R, 2, L)
+    flt = IIRFilter(order=order, backend="fsm", flashfftconv=False, fsm_fir_len=N)
+    h_ref = lti.iir_fsm_fir(Bs, As, N)
+    y_ref = lti.convolve(x, h_ref, "causal")
+    with torch.no_grad():
+        y = flt(x.cuda(), Bs.cuda(), As.cuda()).cpu()
+    assert_close(y, y_ref, TOL, f"fsm order {order}")
+    Bg, Ag, xg = Bs.cuda().requires_grad_(), As.cuda().requires_grad_(), x.cuda().requires_grad_()
+    w = torch.randn(R, 2, L)
+    (flt(xg, Bg, Ag) * w.cuda()).sum().backward()
+    Br, Ar, xr = Bs.clone().requires_grad_(), As.clone().requires_grad_(), x.clone().requires_grad_()
+    (lti.convolve(xr, lti.iir_fsm_fir(Br, Ar, N), "causal") * w).sum().backward()
+    for got, want, name in ((Bg.grad, Br.grad, "dBs"), (Ag.grad, Ar.grad, "dAs"), (xg.grad, xr.grad, "dx")):
+        assert_close(got.cpu(), want, 5e-4, f"fsm order {order} {name}")
