@@ -1,5 +1,5 @@
 import sys, torch, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from grafx_amd import ops
 torch.manual_seed(0)
 def timeit(fn, iters=5):
