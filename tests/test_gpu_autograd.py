@@ -252,3 +252,31 @@ def test_fsm_taps_backward_matches_torch_autograd(N):
     want = torch.autograd.grad((h64 * w.double()).sum(), (B64, A64))
     for g, wv, name in zip(got, want, ("Bs", "As")):
         assert (g - wv.float()).abs().max() <= 2e-4 * wv.abs().max(), f"{name}: {(g - wv.float()).abs().max().item():.3e}"
+
+
+@pytest.mark.gpu
+def test_compressor_backward_with_and_without_the_kept_scan_agree():
+    """gfx_dynamics_bwd_f32 (scan x again, then the backward-in-time pass) and gfx_dynamics_bwd_u1_f32 (the same pass on
+    the scan gfx_dynamics_fused_u1_f32 kept in the forward) are the same arithmetic: identical gradients, bit for bit,
+    including rows with a live truncation term; the forward that keeps the scan returns the plain forward's output."""
+    import torch
+
+    from grafx_amd import ops
+
+    torch.manual_seed(11)
+    R, C, L, N = 6, 2, 5000, 300
+    x = 0.5 * torch.randn(R, C, L, device="cuda")
+    gy = torch.randn(R, C, L, device="cuda")
+    lt, lr, lk = torch.randn(R, 1, device="cuda") - 3, torch.randn(R, 1, device="cuda"), torch.randn(R, 1, device="cuda")
+    z = torch.tensor([[20.0], [6.0], [3.0], [0.0], [-2.0], [1.0]], device="cuda")   # clamp, live truncation, fast poles
+    for knee in ("quadratic", "hard"):
+        lkk = None if knee == "hard" else lk
+        y0 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False)
+        u1 = torch.empty(R, L, device="cuda")
+        y1 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False, u1_out=u1)
+        assert torch.equal(y0, y1)
+        a = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False)
+        b = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False, u1=u1)
+        for ta, tb, name in zip(a, b, ("gx", "gparams", "dalpha")):
+            assert torch.equal(ta, tb), name
+        assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all() and torch.isfinite(a[2]).all()
