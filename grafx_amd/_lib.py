@@ -26,7 +26,6 @@ SIGNATURES = {
     "gfx_fftconv_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_fftconv_ex_f32": (ctypes.c_int, [f32p, RowMap, vp, i64, i64, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_fftconv_sched_f32": (ctypes.c_int, [f32p, RowMap, vp, i64, i64, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, ctypes.c_int, vp]),
-    "gfx_fftconv_wide_ws_bytes": (sz, [i64, i64]),
     "gfx_fir_direct_max_taps": (i64, []),
     "gfx_fir_direct_f32": (ctypes.c_int, [f32p, RowMap, f32p, i64, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp]),
     "gfx_fftconv_part_len": (i64, [i64, i64]),
@@ -56,9 +55,9 @@ SIGNATURES = {
                                                  ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, f32p, vp]),
     "gfx_dynamics_bwd_u1_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp]),
-    "gfx_dynamics_lookback_ws_bytes": (sz, [i64, i64, i64]),
-    "gfx_dynamics_fused_lb_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64, i64,
-                                                 ctypes.c_int, ctypes.c_int, vp, sz, vp]),
+    "gfx_dynamics_ws_bytes": (sz, [i64]),
+    "gfx_dynamics_fused_ws_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                                 ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, f32p, vp, sz, vp]),
     "gfx_ballistics_bwd_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, vp]),
     "gfx_dyn_gain_bwd_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, ctypes.c_int,
                                             ctypes.c_int, f32p, f32p, f32p, vp]),

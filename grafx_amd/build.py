@@ -13,7 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libgrafx_amd.so")
+# GRAFX_AMD_LIB: use (and build) another copy of the library instead of the default one -- how the A/B tools select a
+# variant without ever overwriting the live library (tools/ab.sh, tools/build_variant.sh)
+LIB = os.environ.get("GRAFX_AMD_LIB") or os.path.join(LIBDIR, "libgrafx_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -pragma-unroll-threshold: the FFT tile passes are `#pragma unroll` loop nests around inline packed-FP32
 # instructions; the default size cap stops unrolling them (and then every twiddle index is a run-time value).
@@ -43,10 +45,12 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = LIBDIR if "GRAFX_AMD_LIB" not in os.environ else os.path.join(LIBDIR, "obj_" + os.path.basename(LIB))
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
         if verbose:

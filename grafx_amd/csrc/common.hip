@@ -5,7 +5,6 @@
 
 #include "../../include/grafx_amd.h"
 #include "fft_tile.hpp"
-#include "fft_tile512.hpp"
 
 namespace gfx {
 
@@ -45,44 +44,7 @@ const float2* tile_twiddle_table(hipStream_t stream) {
     return tables[dev];
 }
 
-namespace wide {
 
-__global__ void tile512_twiddle_table_kernel(float2* __restrict__ table) {
-    const int t = threadIdx.x;
-    const int row = blockIdx.x;
-    const int b = t >> 1, h = t & 1, d = t & 15;
-    long long num;
-    double den;
-    if (row < 4) { num = (long long)b * (h + 2 * row); den = 8192.0; }
-    else if (row < 8) { num = (long long)b * 8 * (row - 4); den = 8192.0; }
-    else if (row < 12) { num = d * (row - 8); den = 256.0; }
-    else if (row < 16) { num = d * 4 * (row - 12); den = 256.0; }
-    else { num = j_of(t); den = 8192.0; }
-    double s, c;
-    sincospi(2.0 * (double)num / den, &s, &c);
-    table[row * WT + t] = make_float2((float)c, (float)(-s));
-}
-
-const float2* tile512_twiddle_table(hipStream_t stream) {
-    static std::mutex mu;
-    static float2* tables[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!tables[dev]) {
-        float2* p = nullptr;
-        if (hipMalloc(&p, sizeof(float2) * W_TW_ROWS * WT) != hipSuccess) return nullptr;
-        hipLaunchKernelGGL(tile512_twiddle_table_kernel, dim3(W_TW_ROWS), dim3(WT), 0, stream, p);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
-            hipFree(p);
-            return nullptr;
-        }
-        tables[dev] = p;
-    }
-    return tables[dev];
-}
-
-}  // namespace wide
 
 }  // namespace gfx
 

@@ -32,6 +32,10 @@ namespace gfx {
 constexpr int DT = 256;            // threads per workgroup
 constexpr int DE = 4;              // samples per thread per tile
 constexpr int DTILE = DT * DE;     // 1024 samples per tile
+// per-parameter-row pole table (dyn_pole_table_kernel), floats per row:
+//   a^(4 l) l < 64 | a_step[6] | a_wave | a_N | ap[0..4] | a | 1 - a | trunc | one-shot | H | pad
+constexpr int DP_TAB = 84;
+constexpr int DP_ONESHOT = 80, DP_HIST = 81;
 
 __device__ __forceinline__ int64_t drow_off(const gfx_rowmap_t& m, int64_t r, int c) {
     const unsigned inner = (unsigned)m.inner, rr = (unsigned)r;  // both fit 32 bits (launchers check)
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
                                                        const float* __restrict__ log_ratio,
                                                        const float* __restrict__ log_knee,
                                                        const float* __restrict__ z_alpha, DynArgs a,
-                                                       float* __restrict__ u1) {
+                                                       float* __restrict__ u1, const float* __restrict__ oneshot_tab) {
     __shared__ float slots[16];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x / a.nchunks;
@@ -313,6 +317,8 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
     OnePole p;
     p.trunc = false;
     const unsigned pr = (unsigned)r % a.prows;
+    // rows the one-shot grid takes (dyn_oneshot_kernel, same pole table, complementary test) are not produced here
+    if (oneshot_tab && oneshot_tab[(size_t)pr * DP_TAB + DP_ONESHOT] != 0.0f) return;
     if (a.smoother == 1) onepole_setup(p, z_alpha[pr], a.N, t & 63);
     Knee q;
     knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
@@ -333,23 +339,21 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
         dyn_stream<false>(a, p, q, x0, x1, y0, y1, slots, t, t_warm, t_lo, t_hi, u1row);
 }
 
-// ---- the same fused compressor / gate as ONE-SHOT tiles with a decoupled look-back -----------------------------
+// ---- the same fused compressor / gate as dependency-free ONE-SHOT tiles ---------------------------------------------
 // dyn_fused_kernel streams a row per workgroup: a few thousand long-lived streams at scattered addresses, the access
 // shape that tops out at 4.8-5.5 TB/s on this chip where a one-shot copy reaches 6.2-6.6 (profiles/r2/
 // stream2_copy_ceiling.txt).  Here every 1024-sample tile of every row is its own short-lived workgroup (tiles of a row
-// are consecutive block indices, so the chip sweeps memory front to back), and the recursion's carry crosses tiles
-// through a chained scan with look-back:
-//   * the tile scans its samples from a zero state -> local values and its aggregate A_i (state at the tile end);
-//   * it publishes {A_i, tag} as ONE 8-byte sc1 store, then walks back over its predecessors' records, adding
-//     a^(1024 k) x their aggregates until it meets an inclusive state P_j (or the weight drops below 1e-12, or tile 0);
-//   * it publishes its own inclusive state P_i = A_i + a^1024 carry and adds a^(n+1) carry to its local values.
-// Records are 8-byte {value, tag} granules written by one sc1 store and polled with sc1 loads (MI355X_MICROARCH.md
-// "Valid forms": R2 granule); the buffer is zeroed on the stream before the launch.  A workgroup only waits for lower
-// block indices of its own row, which the dispatcher starts first; the poll is bounded all the same (a stuck
-// predecessor yields NaNs, not a hung GPU).
-// Pole powers come from a per-parameter-row table (dyn_pole_table_kernel): fourteen double-precision exp() per thread
-// are fine once per row, not once per tile.
-constexpr int DP_TAB = 80;   // floats per row: a^(4 l) l < 64 | a_step[6] | a_wave | a_N | ap[0..4] | a | 1 - a | trunc
+// on consecutive logical block indices of one XCD, so the chip sweeps memory front to back) and NO state crosses tiles:
+// the smoother is a FIR, h[k] = (1-a) a^k, so the scan state entering a tile is the weighted sum of the H most recent
+// energies before it, u[s-1] = sum_{k<H} a^k e[s-1-k], with H the number of taps above 1e-12.  A tile re-reads those H
+// samples (thread t takes taps 4t .. 4t+3 as one predicated 16-byte load per channel) and reduces them in the same LDS
+// hop that carries the scan across its four waves: one barrier per tile, as in the row kernel.
+// Which rows qualify is decided ON THE DEVICE from the pole table (no host synchronisation): a row is taken here when its
+// truncation term is dead (a^N <= 1e-12) and H <= DYN_OS_HMAX; every other row leaves this grid at once and is produced
+// by dyn_fused_kernel, launched over the same rows with the complementary test.
+#ifndef GFX_DYN_OS_HMAX
+#define GFX_DYN_OS_HMAX 256   // taps of history a one-shot tile may re-read (tile: 1024 samples)
+#endif
 
 __global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* __restrict__ tab, int64_t rows, int64_t N) {
     const int64_t r = blockIdx.x;
@@ -369,43 +373,38 @@ __global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* 
         t[77] = p.a;
         t[78] = p.one_m_a;
         t[79] = p.trunc ? 1.0f : 0.0f;
+        // taps above 1e-12: H = ceil(log 1e-12 / log a); the row is one-shot material when the N-tap truncation is
+        // beyond that (so H <= N and the truncation term is dead) and the history fits the re-read budget
+        const double la = log((double)p.a);
+        const double h = ceil(-27.631021115928547 / la);
+        const bool os = h <= (double)GFX_DYN_OS_HMAX && h <= (double)N;
+        t[DP_ONESHOT] = os ? 1.0f : 0.0f;
+        t[DP_HIST] = os ? (float)h : 0.0f;
+        t[82] = t[83] = 0.0f;
     }
 }
 
-union DynRec {
-    unsigned long long u;
-    struct { float v; int tag; } s;
-};
-constexpr int DYN_TAG_A = 1, DYN_TAG_P = 2;
-
-// CH tiles per workgroup (a chunk of CH * 1024 samples): the chunk is scanned serially from a zero state with its samples
-// and local scan values held in registers, its aggregate published, the look-back done (by then the predecessors'
-// records have long been written: the hop is hidden behind the chunk's own loads and scans), and only then are the
-// carry applied and the outputs computed and stored.  One look-back per CH tiles instead of one per tile.
-template <int CH>
-__global__ __launch_bounds__(DT) void dyn_lb_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                    const float* __restrict__ log_threshold,
-                                                    const float* __restrict__ log_ratio,
-                                                    const float* __restrict__ log_knee,
-                                                    const float* __restrict__ tab, unsigned long long* __restrict__ recs,
-                                                    DynArgs a, unsigned nchunks) {
-    __shared__ float slots[16];
-    __shared__ float carry_sh;
+__global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ log_threshold,
+                                                         const float* __restrict__ log_ratio,
+                                                         const float* __restrict__ log_knee,
+                                                         const float* __restrict__ tab, DynArgs a, unsigned ntiles,
+                                                         unsigned nblocks, float* __restrict__ u1) {
+    __shared__ float slots[8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned r = blockIdx.x / nchunks, chunk = blockIdx.x - r * nchunks;
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (a tile's history is its neighbour's data)
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (b >= nblocks) return;
+    const unsigned r = b / ntiles;
+    const unsigned tile = b - r * ntiles;
     const unsigned pr = r % a.prows;
-    const float* tb = tab + (int64_t)pr * DP_TAB;
-    OnePole p;
-    p.a_lane = tb[lane];
-#pragma unroll
-    for (int d = 0; d < 6; ++d) p.a_step[d] = tb[64 + d];
-    p.a_wave = tb[70];
-    p.a_N = tb[71];
-#pragma unroll
-    for (int i = 0; i <= DE; ++i) p.ap[i] = tb[72 + i];
-    p.a = tb[77];
-    p.one_m_a = tb[78];
-    const bool trunc = tb[79] != 0.0f;
+    const float* tb = tab + (size_t)pr * DP_TAB;
+    if (tb[DP_ONESHOT] == 0.0f) return;          // produced by dyn_fused_kernel (uniform)
+    const int H = (int)tb[DP_HIST];
+    const float a1 = tb[77], one_m_a = tb[78], a_wave = tb[70];
+    const float ap1 = tb[73], ap2 = tb[74], ap3 = tb[75], ap4 = tb[76];
+    const float a_lane = tb[lane];
     Knee q;
     knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
     const float* x0 = x + drow_off(a.xmap, r, 0);
@@ -414,96 +413,90 @@ __global__ __launch_bounds__(DT) void dyn_lb_kernel(const float* __restrict__ x,
     float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
     const float invC = 1.0f / (float)a.C;
-    const int64_t n0 = (int64_t)chunk * CH * DTILE + DE * t;
+    const int64_t s = (int64_t)tile * DTILE;     // first sample of the tile
+    const int64_t n = s + DE * t;
 
-    float xa[CH][DE], xb[CH][DE], u[CH][DE];
+    float xa[DE], xb[DE], ha[DE], hb[DE];
+    load4(x0, n, a.L, vx, xa);
+    if (a.C == 2) load4(x1, n, a.L, vx, xb);
+    else {
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-#pragma unroll
-        for (int i = 0; i < DE; ++i) xb[k][i] = 0.0f;
-        load4(x0, n0 + (int64_t)k * DTILE, a.L, vx, xa[k]);
-        if (a.C == 2) load4(x1, n0 + (int64_t)k * DTILE, a.L, vx, xb[k]);
+        for (int i = 0; i < DE; ++i) xb[i] = 0.0f;
     }
-    float agg = 0.0f;                                   // running state inside the chunk, from zero
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        float e[DE];
-#pragma unroll
-        for (int i = 0; i < DE; ++i) e[i] = (a.C == 2 ? (xa[k][i] * xa[k][i] + xb[k][i] * xb[k][i]) : xa[k][i] * xa[k][i]) * invC;
-        if (trunc) {   // one scan of e[n] - a^N e[n-N] (see dyn_stream)
-            float da[DE], db[DE];
-            load4(x0, n0 + (int64_t)k * DTILE - a.N, a.L, false, da, 0);
-            if (a.C == 2) load4(x1, n0 + (int64_t)k * DTILE - a.N, a.L, false, db, 0);
-#pragma unroll
-            for (int i = 0; i < DE; ++i)
-                e[i] = fmaf(-p.a_N, (a.C == 2 ? (da[i] * da[i] + db[i] * db[i]) : da[i] * da[i]) * invC, e[i]);
-        }
-        scan_tile(p, e, u[k], agg, slots + 8 * (k & 1), lane, wave);
+    // history taps 4t .. 4t+3 = samples s-4(t+1) .. s-4t-1 (tile 0 has none; s is a multiple of 1024 otherwise)
+    const bool hist = tile != 0 && DE * t < H;
+    const bool hwave = tile != 0 && DE * 64 * wave < H;     // does this wave hold any live tap (uniform)
+    if (hist) {
+        load4(x0, s - DE * (t + 1), a.L, vx, ha);
+        if (a.C == 2) load4(x1, s - DE * (t + 1), a.L, vx, hb);
     }
-
-    const float a1024 = p.a_wave * p.a_wave * p.a_wave * p.a_wave;   // a^DTILE
-    float a_chunk = 1.0f;
+    float e[DE], loc[DE];
+    float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) a_chunk *= a1024;
-    unsigned long long* rec = recs + (int64_t)r * nchunks;
-    if (t == 0) {
-        float carry = 0.0f;
-        if (chunk > 0) {
-            if (chunk + 1 < nchunks) {
-                DynRec me;
-                me.s.v = agg;
-                me.s.tag = DYN_TAG_A;
-                __hip_atomic_store(rec + chunk, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < DE; ++i) {
+        e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
+        acc = fmaf(a1, acc, e[i]);
+        loc[i] = acc;
+    }
+    // inclusive scan of the thread totals inside the wave
+    float inc = acc;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        const float up = __shfl_up(inc, 1 << d, 64);
+        if (lane >= (1 << d)) inc = fmaf(tb[64 + d], up, inc);
+    }
+    if (lane == 63) slots[wave] = inc;
+    float excl = __shfl_up(inc, 1, 64);
+    if (lane == 0) excl = 0.0f;
+    // this wave's share of the entering state: sum over its live taps of a^k e[s-1-k], k = 4t + (3 - i)
+    if (hwave) {
+        float hs = 0.0f;
+        if (hist) {
+            // Horner over the four taps, oldest first: ((e0 a + e1) a + e2) a + e3 = sum_i e_i a^(3-i)
+            float w = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                const float eh = (a.C == 2 ? (ha[i] * ha[i] + hb[i] * hb[i]) : ha[i] * ha[i]) * invC;
+                w = fmaf(a1, w, eh);
             }
-            float w = 1.0f;
-            for (int j = (int)chunk - 1; j >= 0; --j) {
-                DynRec o;
-                o.u = 0;
-                int spins = 0;
-                do {
-                    o.u = __hip_atomic_load(rec + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (o.s.tag) break;
-                    __builtin_amdgcn_s_sleep(2);
-                } while (++spins < (1 << 22));
-                if (!o.s.tag) {                         // bounded wait: never hang the GPU
-                    carry = __builtin_nanf("");
-                    break;
-                }
-                carry = fmaf(w, o.s.v, carry);
-                if (o.s.tag == DYN_TAG_P) break;
-                w *= a_chunk;
-                if (w < 1e-12f) break;
-            }
+            hs = w * a_lane;                      // x a^(4 lane); the wave's own a^(256 wave) is applied below
         }
-        if (chunk + 1 < nchunks) {
-            DynRec me;
-            me.s.v = fmaf(a_chunk, carry, agg);
-            me.s.tag = DYN_TAG_P;
-            __hip_atomic_store(rec + chunk, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        carry_sh = carry;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hs += __shfl_xor(hs, d, 64);
+        if (lane == 0) slots[4 + wave] = hs;
+    } else if (lane == 0) {
+        slots[4 + wave] = 0.0f;
     }
     __syncthreads();
-    // u at chunk position m = DTILE k + DE t + i gets a^(m + 1) carry = a1024^k * a_wave^wave * a_lane * ap[i + 1] * carry
-    float wpow = 1.0f;
-    for (int k = 0; k < wave; ++k) wpow *= p.a_wave;
-    float base = wpow * p.a_lane * carry_sh;
+    // entering state of the tile, then of this wave
+    float state = 0.0f, aw = 1.0f;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        float ga[DE], gb[DE];
-#pragma unroll
-        for (int i = 0; i < DE; ++i) {
-            const float ui = fmaf(p.ap[i + 1], base, u[k][i]);
-            const float env = fmaxf(p.one_m_a * ui, 0.0f);          // relu, envelope.py:48
-            const float G = logf(env + 1e-5f);                      // dynamics.py:394
-            const float g = expf(log_gain(q, G));                   // 402-403
-            ga[i] = g * xa[k][i];
-            gb[i] = g * xb[k][i];
-        }
-        store4(y0, n0 + (int64_t)k * DTILE, a.L, vx, ga);
-        if (a.C == 2) store4(y1, n0 + (int64_t)k * DTILE, a.L, vx, gb);
-        base *= a1024;
+    for (int w = 0; w < DT / 64; ++w) {
+        state = fmaf(aw, slots[4 + w], state);
+        aw *= a_wave;
     }
+    float entering = state;
+#pragma unroll
+    for (int w = 0; w < DT / 64; ++w) {
+        if (w == wave) entering = state;
+        state = fmaf(a_wave, state, slots[w]);
+    }
+    const float pre = fmaf(a_lane, entering, excl);   // u just before this thread's first sample
+    const float apk[DE] = {ap1, ap2, ap3, ap4};
+    float ga[DE], gb[DE], raw[DE];
+#pragma unroll
+    for (int i = 0; i < DE; ++i) {
+        const float u = fmaf(apk[i], pre, loc[i]);
+        raw[i] = one_m_a * u;
+        const float env = fmaxf(raw[i], 0.0f);                // relu, envelope.py:48
+        const float G = logf(env + 1e-5f);                    // dynamics.py:394
+        const float g = expf(log_gain(q, G));                 // 402-403
+        ga[i] = g * xa[i];
+        gb[i] = g * xb[i];
+    }
+    if (u1) store4(u1 + (int64_t)r * a.L, n, a.L, (a.L % 4) == 0, raw);
+    store4(y0, n, a.L, vx, ga);
+    if (a.C == 2) store4(y1, n, a.L, vx, gb);
 }
 
 // ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
@@ -1392,6 +1385,18 @@ int gfx_dynamics_fused_u1_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
                               int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
                               float* u1, void* stream) {
+    return gfx_dynamics_fused_ws_f32(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L,
+                                     smoother, iir_len, knee, gate, u1, nullptr, 0, stream);
+}
+
+size_t gfx_dynamics_ws_bytes(int64_t param_rows) {
+    return param_rows <= 0 ? 0 : (size_t)param_rows * DP_TAB * sizeof(float);
+}
+
+int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                              int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                              float* u1, void* ws, size_t ws_bytes, void* stream) {
     if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
     if (u1 && smoother != 1) return GFX_EINVAL;
     if (!x || !y || !log_threshold || !log_ratio || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
@@ -1399,58 +1404,37 @@ int gfx_dynamics_fused_u1_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     if (smoother != 0 && smoother != 1) return GFX_EINVAL;
     if (smoother == 1 && (!z_alpha || iir_len < 1)) return GFX_EINVAL;
     if (R > 0x7fffffffLL) return GFX_EINVAL;
+    if (ws && ws_bytes < gfx_dynamics_ws_bytes(param_rows)) return GFX_ENOSPC;
     DynArgs a;
     a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = smoother; a.knee = knee; a.gate = gate;
     a.prows = (unsigned)param_rows;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t ntiles = (L + DTILE - 1) / DTILE;
+    // With a workspace and a smoother: the pole table, then the dependency-free one-shot grid for the rows whose
+    // history fits (decided per row on the device), then the row kernel for the others (same table, complementary test).
+    const float* tab = nullptr;
+    if (ws && smoother == 1 && ntiles > 1 && R * ntiles <= 0x7ffffff0LL) {
+        float* t = (float*)ws;
+        hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, t, param_rows, iir_len);
+        const unsigned nblocks = (unsigned)(R * ntiles);
+        a.nchunks = 1;
+        a.chunk_tiles = 1;
+        hipLaunchKernelGGL(dyn_oneshot_kernel, dim3((nblocks + 7u) & ~7u), dim3(DT), 0, st, x, y, log_threshold, log_ratio,
+                           log_knee, (const float*)t, a, (unsigned)ntiles, nblocks, u1);
+        tab = t;
+    }
     // Few rows: one workgroup per row walks the whole length serially (~2 us per tile) and the launch is bound by
     // that latency, not by bandwidth.  Split every row into time chunks then; a chunk re-scans N samples of history
     // (exact, the smoother is an N-tap FIR), so chunks are kept at least as long as that history.
-    const int64_t ntiles = (L + DTILE - 1) / DTILE;
     const int64_t warm = smoother == 1 ? (iir_len + DTILE - 1) / DTILE : 0;
     int64_t nchunks = 1;
     while (!u1 && R * nchunks < 2048 && nchunks < 16 && ntiles / (2 * nchunks) >= (warm > 4 ? warm : 4)) nchunks *= 2;
     a.nchunks = (int)nchunks;
     a.chunk_tiles = (ntiles + nchunks - 1) / nchunks;
     if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
-    hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, (hipStream_t)stream, x, y,
-                       log_threshold, log_ratio, log_knee, z_alpha, a, u1);
-    return GFX_LAUNCH_OK();
-}
-
-#ifndef GFX_DYN_CH
-#define GFX_DYN_CH 4    // tiles per look-back workgroup (2: 3.46 ms, 4: 3.37 ms, 8: 6.2 ms (194 VGPRs), 16: 11.5 ms at the headline shape; rows: 3.49)
-#endif
-
-size_t gfx_dynamics_lookback_ws_bytes(int64_t param_rows, int64_t R, int64_t L) {
-    if (param_rows <= 0 || R <= 0 || L <= 0) return 0;
-    const int64_t nchunks = (L + GFX_DYN_CH * DTILE - 1) / (GFX_DYN_CH * DTILE);
-    return (size_t)param_rows * DP_TAB * sizeof(float) + (size_t)R * nchunks * sizeof(unsigned long long);
-}
-
-int gfx_dynamics_fused_lb_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
-                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
-                              int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate, void* ws,
-                              size_t ws_bytes, void* stream) {
-    if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
-    if (!x || !y || !log_threshold || !log_ratio || !z_alpha || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
-    if (knee < 0 || knee > 2 || (knee != 0 && !log_knee) || iir_len < 1) return GFX_EINVAL;
-    const int64_t nchunks = (L + GFX_DYN_CH * DTILE - 1) / (GFX_DYN_CH * DTILE);
-    if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
-    if (!ws || ws_bytes < gfx_dynamics_lookback_ws_bytes(param_rows, R, L)) return GFX_ENOSPC;
-    DynArgs a;
-    a.xmap = xmap; a.ymap = ymap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
-    a.smoother = 1; a.knee = knee; a.gate = gate;
-    a.prows = (unsigned)param_rows;
-    a.nchunks = 1;
-    a.chunk_tiles = GFX_DYN_CH;
-    hipStream_t st = (hipStream_t)stream;
-    float* tab = (float*)ws;
-    unsigned long long* recs = (unsigned long long*)((char*)ws + (size_t)param_rows * DP_TAB * sizeof(float));
-    if (hipMemsetAsync(recs, 0, (size_t)R * nchunks * sizeof(unsigned long long), st) != hipSuccess) return GFX_ELAUNCH;
-    hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, tab, param_rows, iir_len);
-    hipLaunchKernelGGL(dyn_lb_kernel<GFX_DYN_CH>, dim3((unsigned)(R * nchunks)), dim3(DT), 0, st, x, y, log_threshold,
-                       log_ratio, log_knee, tab, recs, a, (unsigned)nchunks);
+    hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, st, x, y,
+                       log_threshold, log_ratio, log_knee, z_alpha, a, u1, tab);
     return GFX_LAUNCH_OK();
 }
 

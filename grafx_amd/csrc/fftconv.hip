@@ -219,9 +219,6 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
     }
 }
 
-}  // namespace gfx
-#include "fftconv_wide.hpp"
-namespace gfx {
 
 #define NAT(arr, i) arr[(i) >> 4][brev((i) & 15, 4)]
 
@@ -269,19 +266,6 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
     if (lb >= (unsigned)a.nblocks) return;
-#ifdef GFX_STAGGER
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll
-        for (int i = 0; i < GFX_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#if GFX_CONV_PRIO == 1
-    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
-#elif GFX_CONV_PRIO == 2
-    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(3);
-#elif GFX_CONV_PRIO == 3
-    if ((blockIdx.x >> 11) & 1) __builtin_amdgcn_s_setprio(2);
-#endif
     const unsigned ntiles = (unsigned)a.ntiles;
     const unsigned rco = lb / ntiles;
     const int64_t tile = lb - rco * ntiles;
@@ -297,28 +281,14 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     TileTw tw;
     cx v[32], w[2][16];
     f4v hreg[H_SLOTS];
-#ifdef GFX_T_STAMP
-    // experiment: phase timestamps (100 MHz wall clock) of every 64th workgroup into `xcopy` (non-tee launches only)
-    unsigned long long stamp[8];
-#define T_STAMP(i) stamp[i] = __builtin_amdgcn_s_memrealtime()
-#define T_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define T_STAMP(i)
-#define T_DRAIN()
-#endif
-    T_STAMP(0);
     load_window(v, xrow, a.off + tile * a.V - a.O, a.L, t, 1.0f);
     tile_twiddles(tw, twtab, t);
 #pragma unroll
     for (int q = 0; q < H_SLOTS; ++q) hreg[q] = buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
     __builtin_amdgcn_sched_barrier(0);
-    T_STAMP(1);
-    T_DRAIN();
-    T_STAMP(2);
     // off == 0 here: the window's valid part is x[tile*V, tile*V + V) itself
     if (TEE) store_valid<true>(v, xcopy + row_off(a.cmap, r, c), tile * a.V, a.O, a.L, t);
     tile_forward(v, w, tw, lds, t);
-    T_STAMP(3);
     for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx wk, bool self) {
         cx xe, xo, ye, yo, za, zb;
         pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
@@ -327,22 +297,10 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
         NAT(w, ia) = za;
         if (!self) NAT(w, ib) = zb;
     });
-    T_STAMP(4);
     // no barrier here: the inverse starts by writing S2 rows j = t and 512 - t, the very rows (and the only rows)
     // this thread read at the end of the forward transform -- nobody else touches them in between
     tile_inverse(w, v, tw, lds, t);
-    T_STAMP(5);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
-    T_STAMP(6);
-    T_DRAIN();
-    T_STAMP(7);
-#ifdef GFX_T_STAMP
-    if (!TEE && xcopy && t == 0 && (lb & 63) == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(xcopy) + (lb >> 6) * 12;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = stamp[q];
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,595 +507,6 @@ __global__ __launch_bounds__(TILE_T, 2) void corr1_kernel(const float* __restric
     store_valid(v, gh + ((int64_t)r * a.Cout + c) * a.N, 0, 0, a.N, t);
 }
 
-// ------------------------------------------------------------------------------------------------
-// fftconv1pp_kernel: the same tile arithmetic as fftconv1_kernel, organised for large launches as ONE persistent
-// 512-thread workgroup per CU whose two halves (4 waves each, one per SIMD) work half a tile apart ("ping-pong"):
-//
-//   * every half-period one half runs the FIRST part of a tile (window -> registers, input copy, forward passes 1-3,
-//     spectral product: role X) while the other runs the SECOND part of the previous tile (inverse passes, output
-//     stores: role Y), then the roles swap.  Nine barriers per half-period order the four LDS exchanges of the two
-//     halves (X: 1, 2; Y: 3, 4) on ONE shared exchange image, so that in every interval one half moves data through
-//     the LDS while the other issues packed-FP32 arithmetic: the LDS round trips of one half hide under the
-//     arithmetic of the other by construction instead of by the chance alignment of two independent workgroups.
-//   * the 64 KB the second exchange image used to take is a circular buffer of the input row ("ring").  Windows
-//     arrive by LDS-DMA (buffer_load_dword ... lds: no VGPRs, no wait), requested one tile ahead by the half that has
-//     just lifted its window into registers.  Consecutive windows of a row overlap by O samples and the ring keeps
-//     them: every input sample crosses HBM -> LDS exactly once, the overlap is never re-read.
-//   * a workgroup walks (filter row, channel, batch) units in filter-major order, so its filter spectrum (68 VGPRs)
-//     and twiddles (32 VGPRs) are loaded once and stay in registers; nothing but the window stream and the output
-//     stores touches the vector-memory queue in steady state.
-//
-// Geometry: O = N - 1 rounded up to 512 samples (V = 16384 - O a multiple of 512), so that a window starts on a ring
-// row (256 complex values) and a DMA chunk (64 samples = 256 B) never straddles the ring's wrap-around.
-constexpr int PP_T = 512;
-constexpr int PP_LDS_BYTES = TILE_LDS_BYTES + TILE_F * 4;   // exchange image + ring = 139,264 B -> one workgroup per CU
-constexpr int PP_CHUNK = 256;                                // samples per window-request chunk (16 B per lane)
-
-struct PPArgs {
-    ConvArgs a;        // with the ping-pong geometry (O, V, ntiles)
-    unsigned units;    // R * Cout (row, output channel) pairs
-    unsigned bh;       // rows per filter row: R / hrows; units are ordered (filter row, channel, batch)
-};
-
-#ifndef GFX_CONV_PRIO
-#define GFX_CONV_PRIO 0   // experiment: static wave priority for every other workgroup of fftconv1_kernel
-#endif
-#ifndef GFX_PP_ABLATE
-#define GFX_PP_ABLATE 0   // timing experiments only: 1 no window requests, 2 no stores, 4 no spectrum loads, 8 no compute
-#endif
-#ifndef GFX_PP_EXP
-#define GFX_PP_EXP 0      // timing experiments: 1 head into fresh registers (store WAR), 2 drop the i9 barrier (WRONG results)
-#endif
-#define LDSP(p) reinterpret_cast<__attribute__((address_space(3))) void*>((__attribute__((address_space(3))) char*)(p))
-
-// Barrier that orders LDS traffic only: pending global stores and LDS-DMA loads stay in flight across it.  Written as
-// inline asm (with the LDS wait it needs) because a compiler-visible fence or barrier makes hipcc drain the
-// vector-memory queue -- it treats in-flight LDS-DMA as LDS writes the barrier must publish.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-// s_waitcnt vmcnt(N) through the builtin (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14), so
-// that hipcc's own wait bookkeeping sees it: after an inline-asm wait it still believes earlier loads are pending and
-// sprinkles vmcnt(0) over the loop, each of which drains the window requests and stores in flight.
-template <int N>
-__device__ __forceinline__ void wait_vmem_le() {
-    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void wait_vmem() { wait_vmem_le<0>(); }
-
-struct PPTile {          // where tile `s` of the workgroup's stream lives (all wave-uniform)
-    unsigned r, tile, hidx;
-    int c;
-};
-
-__device__ __forceinline__ PPTile pp_decode(const PPArgs& pa, unsigned u0, unsigned s) {
-    const unsigned ntiles = (unsigned)pa.a.ntiles;
-    const unsigned un = s / ntiles;
-    PPTile q;
-    q.tile = s - un * ntiles;
-    const unsigned u = u0 + un;
-    const unsigned b = u % pa.bh, fc = u / pa.bh;
-    const unsigned j = fc / (unsigned)pa.a.Cout;
-    q.c = (int)(fc - j * (unsigned)pa.a.Cout);
-    q.r = b * pa.a.hrows + j;
-    q.hidx = j * (unsigned)pa.a.Cf + (pa.a.Cf == 1 ? 0u : (unsigned)q.c);
-    return q;
-}
-
-// One LDS-DMA instruction: lane l fetches the dword at (descriptor base + voff + soff) into LDS at lds_addr + 4 l.
-// Inline asm, so that hipcc does not know about it: for a builtin LDS-DMA it makes every later LDS read and every
-// barrier of the wave wait for the transfer (vmcnt(0)), which is exactly the latency this kernel is built to hide.
-// The waves that issue requests wait for them explicitly (wait_vmem) before the barrier that opens the next half-period.
-using i32x4 = int __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 dma_rsrc(const void* base, int64_t bytes) {
-    const uint64_t p = reinterpret_cast<uint64_t>(base);
-    const int64_t nb = bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes);
-    return i32x4{(int)__builtin_amdgcn_readfirstlane((uint32_t)p), (int)__builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xffffu),
-                 (int)__builtin_amdgcn_readfirstlane((uint32_t)nb), 0x00020000};
-}
-#define GFX_DMA_ASM(insn)                                                                                     \
-    unsigned keep;                                                                                            \
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" insn " %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep)                                                                                \
-                 : "v"(voff), "s"(rs), "s"(lds_addr), "s"(soff)                                               \
-                 : "memory")
-// s_nop 4: the scalar operands may have just been written by a VALU instruction (v_readfirstlane, or v_readlane of a
-// spilled SGPR); s_nop 0: M0 write -> LDS-DMA read.  M0 is saved and restored around the instruction.
-__device__ __forceinline__ void dma_dword(i32x4 rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
-    GFX_DMA_ASM("buffer_load_dword");
-}
-__device__ __forceinline__ void dma_dwordx4(i32x4 rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
-    GFX_DMA_ASM("buffer_load_dwordx4");
-}
-#undef GFX_DMA_ASM
-
-// Request the part of tile q's window that the ring does not hold yet: everything for the first tile of a row, the V new
-// samples otherwise, in chunks of 256 samples (1 KB); chunk k of the request goes to wave slot k % nslots.  Interior
-// chunks are one 16-byte-per-lane transfer with a scalar offset (only 4-byte alignment is needed on the global side);
-// chunks that touch the row's ends are four dword transfers with per-lane offsets, and the buffer range check supplies
-// the zeros (LDS-DMA writes a zero for a lane whose offset fails the check: tools/ubench/lds_dma.hip).
-__device__ __forceinline__ void pp_request(const float* __restrict__ x, uint32_t ring_lds, const PPArgs& pa,
-                                           const PPTile& q, int slot, int nslots, int lane) {
-    const ConvArgs& a = pa.a;
-    const float* xrow = x + row_off(a.xmap, q.r, a.Cin == 1 ? 0 : q.c);
-    const i32x4 rs = dma_rsrc(xrow, a.L * 4);
-    const int vch = (int)(a.V / PP_CHUNK);
-    const int nch = q.tile == 0 ? TILE_F / PP_CHUNK : vch;
-    // first source sample and first ring chunk of the request
-    const int64_t n_first = q.tile == 0 ? a.off - a.O : a.off + (int64_t)q.tile * a.V;
-    const int rc_first = q.tile == 0 ? 0 : (int)(((int64_t)(q.tile - 1) * vch) & (TILE_F / PP_CHUNK - 1));
-    for (int k = slot; k < nch; k += nslots) {
-        const int64_t n0 = n_first + (int64_t)k * PP_CHUNK;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(
-            ring_lds + (uint32_t)(((rc_first + k) & (TILE_F / PP_CHUNK - 1)) * (PP_CHUNK * 4)));
-        if (n0 >= 0 && n0 + PP_CHUNK <= a.L) {
-            dma_dwordx4(rs, dst, 16u * (uint32_t)lane, __builtin_amdgcn_readfirstlane((uint32_t)(4 * n0)));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t n = n0 + 64 * j + lane;
-                dma_dword(rs, dst + 256u * j, (n >= 0 && n < a.L) ? (uint32_t)(4 * n) : OOB, 0u);
-            }
-        }
-    }
-}
-
-// Twiddles of the ping-pong kernel live in LDS (rows lo1[1..3], hi1[1..7] of the per-device table: 10 x 256 values; and
-// lo2[1..3], hi2[1..3] for d = 0..15): a segment reads the handful it needs right before using them, so no twiddle
-// register survives a barrier, and nothing but window requests and stores enters the vector-memory queue.
-constexpr int PP_TW1_F2 = 10 * 256;
-constexpr int PP_TW2_F2 = 6 * 16;
-constexpr int PP_LDS_TOTAL = PP_LDS_BYTES + (PP_TW1_F2 + PP_TW2_F2) * 8;   // 160,512 B of the CU's 163,840
-
-__device__ __forceinline__ void pp_tw1(TileTw& tw, const cx* tw1, int t) {
-    tw.lo1[0] = tw.hi1[0] = cx{1.0f, 0.0f};
-#pragma unroll
-    for (int i = 1; i < 4; ++i) tw.lo1[i] = tw1[(i - 1) * 256 + t];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) tw.hi1[i] = tw1[(2 + i) * 256 + t];
-}
-__device__ __forceinline__ void pp_tw2(TileTw& tw, const cx* tw2, int d) {
-    tw.lo2[0] = tw.hi2[0] = cx{1.0f, 0.0f};
-#pragma unroll
-    for (int i = 1; i < 4; ++i) tw.lo2[i] = tw2[(i - 1) * 16 + d];
-#pragma unroll
-    for (int i = 1; i < 4; ++i) tw.hi2[i] = tw2[(2 + i) * 16 + d];
-}
-
-template <bool TEE>
-__global__ __launch_bounds__(PP_T, 2) void fftconv1pp_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
-                                                             float* __restrict__ y, float* __restrict__ xcopy, PPArgs pa,
-                                                             const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) cx lds[];
-    float* ring = reinterpret_cast<float*>(lds + TILE_LDS_F2);
-    const cx* ringc = reinterpret_cast<const cx*>(ring);
-    cx* tw1 = lds + TILE_LDS_F2 + TILE_M;
-    cx* tw2 = tw1 + PP_TW1_F2;
-    const ConvArgs& a = pa.a;
-    const int tid = threadIdx.x;
-    const int t = tid & 255, lane = tid & 63;
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int wih = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // wave within the half
-    const unsigned G = gridDim.x, wg = blockIdx.x;
-    const unsigned u0 = (unsigned)((uint64_t)wg * pa.units / G), u1 = (unsigned)((uint64_t)(wg + 1) * pa.units / G);
-    const unsigned S = (u1 - u0) * (unsigned)a.ntiles;   // tiles in this workgroup's stream
-    if (S == 0) return;
-    const int vrows = (int)(a.V / 512);                  // ring rows (256 complex) a window start advances per tile
-
-    // twiddle tables -> LDS (table rows: 0-3 lo1, 4-11 hi1, 12-15 lo2, 16-19 hi2; rows 0, 4, 12, 16 are all ones)
-    for (int i = tid; i < PP_TW1_F2; i += PP_T) {
-        const int row = i >> 8;
-        tw1[i] = to_cx(twtab[(row < 3 ? 1 + row : 2 + row) * TILE_T + (i & 255)]);
-    }
-    if (tid < PP_TW2_F2) {
-        const int row = tid >> 4;
-        tw2[tid] = to_cx(twtab[(row < 3 ? 13 + row : 14 + row) * TILE_T + (tid & 15)]);
-    }
-
-    const int kk = t >> 4, d = t & 15;
-    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDSP(ring));   // LDS byte address
-
-    // Loop-carried registers of a half: `v` = the head of its next tile (window lifted from the ring, first radix pass and
-    // its twiddles done, ready for exchange 1); `pz` = its tile after the spectral product and the first inverse pass,
-    // ready for exchange 3.  Only one of the two is live at a period boundary.
-    // One 64-VGPR array carries both (as far as the compiler can tell, two arrays would both be live at the loop header).
-    cx st[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) st[q] = cx{0.0f, 0.0f};
-    PPTile cur = pp_decode(pa, u0, 0);                   // the tile this half is working on
-
-    // window -> registers, input copy, first forward pass (role Y', last interval; and the prologue for tile 0)
-    auto head = [&](const PPTile& q, bool live) {
-        const int a0 = (int)((q.tile * (unsigned)vrows) & 31u);               // ring row of the window's first sample
-#pragma unroll
-        for (int i = 0; i < 32; ++i) st[i] = ringc[(((i + a0) & 31) << 8) + t];
-        if (TEE && live && !(GFX_PP_ABLATE & 2))
-            store_valid<true>(st, xcopy + row_off(a.cmap, q.r, q.c), (int64_t)q.tile * a.V, a.O, a.L, t);
-        dif<32, false>(st);
-        TileTw tw;
-        pp_tw1(tw, tw1, t);
-#pragma unroll
-        for (int r = 0; r < 32; ++r) st[r] = tw.fwd1(st[r], brev(r, 5));
-    };
-
-    // All workgroups start together and do identical work, so left alone they stay in phase: every CU would request its
-    // window, and store its tile, at the same moment -- bursts of 12 MB that the memory system serves while the whole
-    // chip waits, then idles while the whole chip computes.  Spread the phases over one tile period once, at the start
-    // (the relative phases persist: every workgroup runs at the same pace).
-#ifndef GFX_PP_STAGGER
-#define GFX_PP_STAGGER 200   // cycles per phase step, 64 steps
-#endif
-    {
-        const unsigned steps = ((wg * 0x9E3779B1u) >> 26) * (GFX_PP_STAGGER / 64 + 1);   // 0..63 phase steps
-        for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(1);                // 64 cycles each
-    }
-
-    // prologue: the first window, requested by all eight waves; half 0 lifts it
-    pp_request(x, ring_lds, pa, cur, half * 4 + wih, 8, lane);
-    wait_vmem();
-    lds_barrier();
-    if (half == 0) head(cur, true);
-
-    // Period p: one half runs role X' on tile p (exchanges 1 and 2, last forward pass, spectral product, first inverse
-    // pass); the other runs role Y' (exchanges 3 and 4 and the last inverse pass of tile p-1, its output stores, then the
-    // head of tile p+1).  The four exchanges take turns on the one exchange image (3, 1, 4, 2: intervals i1..i8); from
-    // i8 on role Y' is done with the LDS image and runs its store-heavy tail + head against role X's arithmetic-only
-    // product stretch.  Tiles outside the stream (role Y' tail at p = 0, role X' at p = S, heads past the end) run the
-    // arithmetic on whatever the registers hold and skip only their memory side effects.
-    for (unsigned p = 0; p <= S; ++p) {
-        if ((int)(p & 1) == half) {
-            // ------------------------------------------------------------------------ role X': tile p (cur), v ready
-            cx u[2][16], w[2][16];
-            // the tile's filter spectrum (L2-resident; used after i8).  Fetched per tile rather than kept across the loop: 68
-            // VGPRs held through both roles push the allocator into scratch, and a scratch reload is a vector-memory
-            // load that waits behind everything in flight.
-            f4v hreg[H_SLOTS];
-            {
-                const rsrc_t H = make_rsrc(Hs + (int64_t)cur.hidx * H_TILE_F4, H_TILE_F4 * 16);
-#pragma unroll
-                for (int q = 0; q < H_SLOTS; ++q)
-                    hreg[q] = (GFX_PP_ABLATE & 4) ? f4v{1.0f, 0.0f, 0.5f, 0.0f} : buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
-            }
-            lds_barrier();                                                    // i1 (other half: W3, window request)
-            lds_barrier();                                                    // i2 (other half: R3)
-            lds_barrier();                                                    // i3: W1
-#pragma unroll
-            for (int r = 0; r < 32; ++r) lds[s1_at(brev(r, 5), t)] = st[r];
-            lds_barrier();                                                    // i4: R1, first radix-16 set
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) u[s][c] = lds[s1_at(kk + 16 * s, 16 * c + d)];
-            dif<16, false>(u[0]);
-            lds_barrier();                                                    // i5 (other half: W4)
-            dif<16, false>(u[1]);
-            {
-                TileTw tw;
-                pp_tw2(tw, tw2, d);
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) u[s][r] = tw.fwd2(u[s][r], brev(r, 4));
-            }
-            lds_barrier();                                                    // i6 (other half: R4)
-            lds_barrier();                                                    // i7: W2
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lds[s2_row(brev(r, 4), kk + 16 * s) + d] = u[s][r];
-            lds_barrier();                                                    // i8: R2, last forward pass
-#pragma unroll
-            for (int bf = 0; bf < 2; ++bf) {
-                const int j = bf ? bf_b(t) : bf_a(t);
-                const f4v* row = reinterpret_cast<const f4v*>(lds + s2_row(j >> 5, j & 31));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f4v pq = row[q];
-                    w[bf][2 * q] = pq.lo;
-                    w[bf][2 * q + 1] = pq.hi;
-                }
-            }
-            dif<16, false>(w[0]);
-            dif<16, false>(w[1]);
-            if (!(GFX_PP_EXP & 2)) lds_barrier();                             // i9 (other half: next window has landed)
-            // take delivery of the spectrum HERE, on every path: the product below sits in two lane-divergent blocks that a
-            // wave may skip, and hipcc would otherwise carry "loads may be pending" into the other role and guard its
-            // registers with vmcnt waits -- each of which drains the window request in flight
-#pragma unroll
-            for (int q = 0; q < H_SLOTS; ++q) asm volatile("" : "+v"(hreg[q]));
-            for_each_pair(t, tw1[t], [&](int slot, int ia, int ib, cx wk, bool self) {
-                cx xe, xo, ye, yo, za, zb;
-                pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
-                pair_product(xe, xo, hreg[slot], wk, ye, yo);
-                pair_merge(ye, yo, za, zb);
-                NAT(w, ia) = za;
-                if (!self) NAT(w, ib) = zb;
-            });
-#pragma unroll
-            for (int bf = 0; bf < 2; ++bf) {
-                cx pz[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) pz[k] = w[bf][brev(k, 4)];      // register renaming only
-                dif<16, true>(pz);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) st[bf * 16 + k] = pz[k];
-            }
-        } else {
-            // ------------------------------------------------------------------------ role Y': tail of tile p-1, head of p+1
-            const bool tail = p >= 1, more = p + 1 < S;
-            cx u[2][16];
-            lds_barrier();                                                    // i1: W3; the ring can take window p+1
-#pragma unroll
-            for (int bf = 0; bf < 2; ++bf) {
-                const int j = bf ? bf_b(t) : bf_a(t);
-                f4v* row = reinterpret_cast<f4v*>(lds + s2_row(j >> 5, j & 31));
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    row[q] = __builtin_shufflevector(st[bf * 16 + brev(2 * q, 4)], st[bf * 16 + brev(2 * q + 1, 4)], 0, 1, 2, 3);
-            }
-            const PPTile nxt = pp_decode(pa, u0, more ? p + 1 : S - 1);
-            if (!(GFX_PP_ABLATE & 1) && more) pp_request(x, ring_lds, pa, nxt, wih, 4, lane);
-            lds_barrier();                                                    // i2: R3, first inverse radix-16 set
-            {
-                TileTw tw;
-                pp_tw2(tw, tw2, d);
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) u[s][k2] = tw.inv2(lds[s2_row(k2, kk + 16 * s) + d], k2);
-            }
-            dif<16, true>(u[0]);
-            lds_barrier();                                                    // i3 (other half: W1)
-            dif<16, true>(u[1]);
-            lds_barrier();                                                    // i4 (other half: R1)
-            lds_barrier();                                                    // i5: W4
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lds[s1_at(kk + 16 * s, 16 * brev(r, 4) + d)] = u[s][r];
-            lds_barrier();                                                    // i6: R4
-            {
-                TileTw tw;
-                pp_tw1(tw, tw1, t);
-#pragma unroll
-                for (int k1 = 0; k1 < 32; ++k1) st[k1] = tw.inv1(lds[s1_at(k1, t)], k1);
-            }
-            lds_barrier();                                                    // i7 (other half: W2): last inverse pass
-            dif<32, true>(st);
-            lds_barrier();                                                    // i8 (other half: R2 ...): output stores
-            if (tail && !(GFX_PP_ABLATE & 2))
-                store_valid(st, y + row_off(a.ymap, cur.r, cur.c), (int64_t)cur.tile * a.V, a.O, a.Lout, t);
-            // This half requested window p+1 itself (i1) and has since issued only these output stores (32 buffer stores,
-            // plus a single-sample store on odd row ends): the vector-memory queue completes in order, so "at most 32
-            // outstanding" means the request has landed, without waiting for the stores.  (p = 0: nothing was stored.)
-            if (GFX_PP_EXP & 4) {}                                             // timing experiment: no wait at all
-            else if (tail && !(GFX_PP_ABLATE & 2)) wait_vmem_le<32>();
-            else wait_vmem();
-            if (!(GFX_PP_EXP & 2)) lds_barrier();                             // i9: window p+1 is in the ring: head
-            cur = nxt;
-            if (GFX_PP_EXP & 1) {
-                cx keep[32];
-#pragma unroll
-                for (int q = 0; q < 32; ++q) keep[q] = st[q];
-                head(cur, more);
-#pragma unroll
-                for (int q = 0; q < 32; ++q) asm volatile("" : "+v"(keep[q]));   // the store sources stay untouched until here
-            } else {
-                head(cur, more);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// fftconv1h_kernel: the tile arithmetic of fftconv1_kernel with HALF-SIZE LDS exchanges, so that THREE workgroups fit a
-// CU (the production kernel's 73.7 KB exchange image allows two, and two resident tiles leave the vector ALU ~60 % used).
-// Every exchange moves its 32 values per thread in two rounds of 16 through an image of half the size, split along an
-// index that lets every thread read exactly half of what it needs per round:
-//   exchange 1 / 4 (S1 image, 16 of its 32 k1 rows): round s in {0,1} carries rows k1 in [16 s, 16 s + 16) -- the second
-//                 pass's two radix-16 sets;
-//   exchange 2 / 3 (S2 image, 8 of its 16 k2 planes): round 0 carries butterflies j < 256 (the thread's j = t),
-//                 round 1 j >= 256 (its mirror 512 - t).
-// Same LDS instruction count as the full exchanges (8-byte accesses), twice the barriers (15 per tile instead of 7) --
-// round 1 measured a re/im split (twice the instructions AND barriers) at -28 %.  Twiddles: stage 2 and the eight
-// "hi" stage-1 rows live in LDS next to the image (14.8 KB), only lo1[1..3] stay in registers, so that the kernel fits
-// 168 VGPRs.  LDS: 36,864 + 15,104 = 51,968 B per workgroup.
-constexpr int HX_IMG_F2 = 256 * S2_ROW;                 // 4608 float2 = 36,864 B (S1 half: 16 x 272 = 4352 fits too)
-constexpr int HX_TW1_F2 = 7 * 256;                      // hi1[1..7][t]
-constexpr int HX_TW2_F2 = 6 * 16;                       // lo2[1..3][d], hi2[1..3][d]
-constexpr int HX_LDS_BYTES = (HX_IMG_F2 + HX_TW1_F2 + HX_TW2_F2) * 8;
-
-__device__ __forceinline__ int s1h_at(int k1h, int b) { return k1h * S1_ROW + b; }
-__device__ __forceinline__ int s2h_row(int k2h, int k1) { return (k2h * 32 + k1) * S2_ROW; }
-
-struct HxTw {
-    cx lo1[4];             // registers: W_8192^(t i), i < 4
-    const cx* hi1;         // LDS: hi1[(i - 1) * 256 + t] = W_8192^(4 i t), i = 1..7
-    const cx* tw2;         // LDS: lo2[1..3][d], hi2[1..3][d]
-    __device__ __forceinline__ void stage1(TileTw& tw, int t) const {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tw.lo1[i] = lo1[i];
-        tw.hi1[0] = cx{1.0f, 0.0f};
-#pragma unroll
-        for (int i = 1; i < 8; ++i) tw.hi1[i] = hi1[(i - 1) * 256 + t];
-    }
-    __device__ __forceinline__ void stage2(TileTw& tw, int d) const {
-        tw.lo2[0] = tw.hi2[0] = cx{1.0f, 0.0f};
-#pragma unroll
-        for (int i = 1; i < 4; ++i) tw.lo2[i] = tw2[(i - 1) * 16 + d];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) tw.hi2[i] = tw2[(2 + i) * 16 + d];
-    }
-};
-
-// `mid()` runs once the first exchange is done (the 32 window registers are dead, the second pass not yet started):
-// the caller requests the filter spectrum there, so that its 68 registers are not live during the first pass.
-template <typename Mid>
-__device__ __forceinline__ void tile_forward_hx(cx (&v)[32], cx (&w)[2][16], const HxTw& hx, cx* lds, int t, Mid&& mid) {
-    const int kk = t >> 4, d = t & 15;
-    dif<32, false>(v);
-    {
-        TileTw tw;
-        hx.stage1(tw, t);
-#pragma unroll
-        for (int r = 0; r < 32; ++r) v[r] = tw.fwd1(v[r], brev(r, 5));
-    }
-    cx u[2][16];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int k1 = brev(r, 5);
-            if ((k1 >> 4) == s) lds[s1h_at(k1 & 15, t)] = v[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) u[s][c] = lds[s1h_at(kk, 16 * c + d)];
-        __syncthreads();
-        if (s == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            mid();
-            __builtin_amdgcn_sched_barrier(0);
-            dif<16, false>(u[0]);
-        }
-    }
-    dif<16, false>(u[1]);
-    {
-        TileTw tw;
-        hx.stage2(tw, d);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u[s][r] = tw.fwd2(u[s][r], brev(r, 4));
-    }
-#pragma unroll
-    for (int bf = 0; bf < 2; ++bf) {                    // round bf carries planes k2 in [8 bf, 8 bf + 8)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k2 = brev(r, 4);
-                if ((k2 >> 3) == bf) lds[s2h_row(k2 & 7, kk + 16 * s) + d] = u[s][r];
-            }
-        __syncthreads();
-        const int j = bf ? bf_b(t) : bf_a(t);
-        const f4v* row = reinterpret_cast<const f4v*>(lds + s2h_row((j >> 5) & 7, j & 31));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f4v pq = row[q];
-            w[bf][2 * q] = pq.lo;
-            w[bf][2 * q + 1] = pq.hi;
-        }
-        __syncthreads();
-        if (bf == 1) dif<16, false>(w[0]);
-    }
-    dif<16, false>(w[1]);
-}
-
-// the last barrier of tile_forward_hx already separates its reads from the writes below
-__device__ __forceinline__ void tile_inverse_hx(cx (&w)[2][16], cx (&v)[32], const HxTw& hx, cx* lds, int t) {
-    const int kk = t >> 4, d = t & 15;
-    cx u[2][16];
-    TileTw tw2;
-    hx.stage2(tw2, d);
-#pragma unroll
-    for (int bf = 0; bf < 2; ++bf) {
-        cx p[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) p[k] = w[bf][brev(k, 4)];  // register renaming only
-        dif<16, true>(p);
-        const int j = bf ? bf_b(t) : bf_a(t);
-        f4v* row = reinterpret_cast<f4v*>(lds + s2h_row((j >> 5) & 7, j & 31));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) row[q] = __builtin_shufflevector(p[brev(2 * q, 4)], p[brev(2 * q + 1, 4)], 0, 1, 2, 3);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int k2h = 0; k2h < 8; ++k2h)
-                u[s][8 * bf + k2h] = tw2.inv2(lds[s2h_row(k2h, kk + 16 * s) + d], 8 * bf + k2h);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        dif<16, true>(u[s]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lds[s1h_at(kk, 16 * brev(r, 4) + d)] = u[s][r];
-        __syncthreads();
-#pragma unroll
-        for (int k1h = 0; k1h < 16; ++k1h) v[16 * s + k1h] = lds[s1h_at(k1h, t)];
-        if (s == 0) __syncthreads();
-    }
-    {
-        TileTw tw;
-        hx.stage1(tw, t);
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) v[k1] = tw.inv1(v[k1], k1);
-    }
-    dif<32, true>(v);
-}
-
-template <bool TEE>
-__global__ __launch_bounds__(TILE_T, 3) void fftconv1h_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
-                                                              float* __restrict__ y, float* __restrict__ xcopy,
-                                                              ConvArgs a, const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) cx lds[];
-    const int t = threadIdx.x;
-    const unsigned lb = xcd_logical_block();
-    if (lb >= (unsigned)a.nblocks) return;
-    const unsigned ntiles = (unsigned)a.ntiles;
-    const unsigned rco = lb / ntiles;
-    const int64_t tile = lb - rco * ntiles;
-    const unsigned r = rco / (unsigned)a.Cout;
-    const int c = (int)(rco - r * (unsigned)a.Cout);
-    const float* xrow = x + row_off(a.xmap, r, a.Cin == 1 ? 0 : c);
-    float* yrow = y + row_off(a.ymap, r, c);
-    const rsrc_t H = make_rsrc(Hs + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * H_TILE_F4, H_TILE_F4 * 16);
-
-    cx* tw1 = lds + HX_IMG_F2;
-    cx* tw2 = tw1 + HX_TW1_F2;
-    HxTw hx;
-    hx.hi1 = tw1;
-    hx.tw2 = tw2;
-    cx v[32], w[2][16];
-    f4v hreg[H_SLOTS];
-    load_window(v, xrow, a.off + tile * a.V - a.O, a.L, t, 1.0f);
-    // twiddle table rows: 0-3 lo1, 4-11 hi1, 12-15 lo2, 16-19 hi2
-    hx.lo1[0] = cx{1.0f, 0.0f};
-#pragma unroll
-    for (int i = 1; i < 4; ++i) hx.lo1[i] = to_cx(twtab[i * TILE_T + t]);
-    cx hi[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) hi[i] = to_cx(twtab[(5 + i) * TILE_T + t]);
-    cx t2 = {0.0f, 0.0f};
-    if (t < HX_TW2_F2) {
-        const int row = t >> 4;
-        t2 = to_cx(twtab[(row < 3 ? 13 + row : 14 + row) * TILE_T + (t & 15)]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) tw1[i * 256 + t] = hi[i];
-    if (t < HX_TW2_F2) tw2[t] = t2;
-    if (TEE) store_valid<true>(v, xcopy + row_off(a.cmap, r, c), tile * a.V, a.O, a.L, t);
-    __syncthreads();                                   // twiddle tables visible
-    tile_forward_hx(v, w, hx, lds, t, [&]() {
-#pragma unroll
-        for (int q = 0; q < H_SLOTS; ++q) hreg[q] = buf_load_f4(H, 16u * (uint32_t)t, 4096u * q);
-    });
-    for_each_pair(t, hx.lo1[1], [&](int slot, int ia, int ib, cx wk, bool self) {
-        cx xe, xo, ye, yo, za, zb;
-        pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
-        pair_product(xe, xo, hreg[slot], wk, ye, yo);
-        pair_merge(ye, yo, za, zb);
-        NAT(w, ia) = za;
-        if (!self) NAT(w, ib) = zb;
-    });
-    tile_inverse_hx(w, v, hx, lds, t);
-    store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
-}
 
 static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
 
@@ -1162,27 +531,6 @@ int64_t gfx_fftconv_part_len(int64_t N, int64_t Lout) {
     return (TILE_F - Lout) & ~int64_t(1);
 }
 
-// experiment builds (-DGFX_W_STAMP): a 4 MB device buffer the wide kernel writes its phase timestamps into
-static void* gfx_dbg_stamp_buffer() {
-#if defined(GFX_W_STAMP) || defined(GFX_T_STAMP)
-    static void* p = nullptr;
-    if (!p && hipMalloc(&p, 4 << 20) != hipSuccess) p = nullptr;
-    return p;
-#else
-    return nullptr;
-#endif
-}
-#if defined(GFX_W_STAMP) || defined(GFX_T_STAMP)
-int gfx_dbg_stamp_read(void* host, size_t bytes) {
-    void* p = gfx_dbg_stamp_buffer();
-    if (!p || bytes > (4u << 20)) return GFX_EINVAL;
-    return hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-}
-#endif
-
-size_t gfx_fftconv_wide_ws_bytes(int64_t h_rows, int64_t C_f) {
-    return (h_rows <= 0 || C_f <= 0) ? 0 : (size_t)h_rows * C_f * wide::W_H_F4 * 16;
-}
 
 size_t gfx_fir_spectrum_bytes(int64_t RCf, int64_t N) { return gfx_fir_spectrum_bytes_ex(RCf, N, 0); }
 
@@ -1292,31 +640,12 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
                                  ws_bytes, GFX_SCHED_AUTO, stream);
 }
 
-// Ping-pong schedule: worth it once every CU gets a long stream of tiles (it runs ONE workgroup per CU, and a unit --
-// a (row, channel) pair -- is walked serially by its workgroup).
-static bool pp_applicable(int64_t R, int64_t h_rows, int64_t N, int64_t part_len) {
-    return N <= TILE_M + 1 && part_len == 0 && R % h_rows == 0;
-}
-
-static int device_cus() {
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!cus[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
 
 int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len, float* y,
                           gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
                           int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, int schedule,
                           void* stream) {
-    if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PINGPONG &&
-        schedule != GFX_SCHED_HALFX && schedule != GFX_SCHED_WIDE)
-        return GFX_EINVAL;
+    if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PIPE) return GFX_EINVAL;
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
     if (xcopy && (off != 0 || Lout != L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
@@ -1347,71 +676,6 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     const float2* tw = tile_twiddle_table(st);
     if (!tw) return GFX_ELAUNCH;
 
-    if (schedule == GFX_SCHED_WIDE) {
-        // 512-thread tile: the spectra are first rewritten into its thread layout (workspace: gfx_fftconv_wide_ws_bytes)
-        const int64_t nf = h_rows * C_f;
-        if (!wide::applicable(g, L, Lout, off, N) || part_len != 0 || !ws || ws_bytes < (size_t)nf * wide::W_H_F4 * 16 ||
-            nf > 0x7fffffffLL)
-            return GFX_EINVAL;
-        const float2* tww = wide::tile512_twiddle_table(st);
-        if (!tww) return GFX_ELAUNCH;
-        const void* k = xcopy ? reinterpret_cast<const void*>(wide::fftconv1w_kernel<true>)
-                              : reinterpret_cast<const void*>(wide::fftconv1w_kernel<false>);
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, wide::W_LDS_BYTES) != hipSuccess)
-            return GFX_ELAUNCH;
-        hipLaunchKernelGGL(wide::hconv_kernel, dim3((unsigned)nf), dim3(wide::WT), 0, st, (const float4*)Hs, (float4*)ws);
-        if (xcopy)
-            hipLaunchKernelGGL(wide::fftconv1w_kernel<true>, dim3(pad8(a.nblocks)), dim3(wide::WT), wide::W_LDS_BYTES, st, x,
-                               (const float4*)ws, y, xcopy, a, tww);
-        else
-            hipLaunchKernelGGL(wide::fftconv1w_kernel<false>, dim3(pad8(a.nblocks)), dim3(wide::WT), wide::W_LDS_BYTES, st, x,
-                               (const float4*)ws, y, (float*)gfx_dbg_stamp_buffer(), a, tww);
-        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-    }
-    if (schedule == GFX_SCHED_PINGPONG && !(g.nparts == 1 && pp_applicable(R, h_rows, N, part_len))) return GFX_EINVAL;
-    if (g.nparts == 1 && schedule != GFX_SCHED_TILE && pp_applicable(R, h_rows, N, part_len)) {
-        PPArgs pa;
-        pa.a = a;
-        pa.a.O = ((N - 1) + 511) & ~int64_t(511);
-        pa.a.V = TILE_F - pa.a.O;
-        pa.a.hop = pa.a.V;
-        pa.a.ntiles = (Lout + pa.a.V - 1) / pa.a.V;
-        const int64_t units = R * a.Cout;
-        const int cus = device_cus();
-        if (cus <= 0) return GFX_ELAUNCH;
-        // AUTO never picks it on this hardware generation: measured on MI355X (profiles/r2/pingpong_ablation.md) the
-        // one-tile-per-workgroup kernel is faster at every size (5.1 vs 7.0 ms at 8192 stereo rows), so the ping-pong
-        // schedule runs only when asked for by name
-        if (units <= 0x7fffffffLL / (pa.a.ntiles + 1) && schedule == GFX_SCHED_PINGPONG) {
-            pa.units = (unsigned)units;
-            pa.bh = (unsigned)(R / h_rows);
-            const unsigned grid = (unsigned)(units < cus ? units : cus);
-            const void* k = xcopy ? reinterpret_cast<const void*>(fftconv1pp_kernel<true>)
-                                  : reinterpret_cast<const void*>(fftconv1pp_kernel<false>);
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
-                return GFX_ELAUNCH;
-            if (xcopy)
-                hipLaunchKernelGGL(fftconv1pp_kernel<true>, dim3(grid), dim3(PP_T), PP_LDS_TOTAL, st, x, (const float4*)Hs,
-                                   y, xcopy, pa, tw);
-            else
-                hipLaunchKernelGGL(fftconv1pp_kernel<false>, dim3(grid), dim3(PP_T), PP_LDS_TOTAL, st, x, (const float4*)Hs,
-                                   y, xcopy, pa, tw);
-            return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-        }
-    }
-    if (schedule == GFX_SCHED_HALFX && g.nparts != 1) return GFX_EINVAL;
-    if (g.nparts == 1 && schedule == GFX_SCHED_HALFX) {
-        const void* k = xcopy ? reinterpret_cast<const void*>(fftconv1h_kernel<true>)
-                              : reinterpret_cast<const void*>(fftconv1h_kernel<false>);
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES) != hipSuccess) return GFX_ELAUNCH;
-        if (xcopy)
-            hipLaunchKernelGGL(fftconv1h_kernel<true>, dim3(pad8(a.nblocks)), dim3(TILE_T), HX_LDS_BYTES, st, x,
-                               (const float4*)Hs, y, xcopy, a, tw);
-        else
-            hipLaunchKernelGGL(fftconv1h_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), HX_LDS_BYTES, st, x,
-                               (const float4*)Hs, y, xcopy, a, tw);
-        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-    }
     if (g.nparts == 1) {
         if (allow_lds(fftconv1_kernel<false>) || allow_lds(fftconv1_kernel<true>)) return GFX_ELAUNCH;
         if (xcopy)
@@ -1419,7 +683,7 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                                (const float4*)Hs, y, xcopy, a, tw);
         else
             hipLaunchKernelGGL(fftconv1_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
-                               (const float4*)Hs, y, (float*)gfx_dbg_stamp_buffer(), a, tw);
+                               (const float4*)Hs, y, (float*)nullptr, a, tw);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     if (g.ntiles == 1) {

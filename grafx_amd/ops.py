@@ -182,7 +182,7 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
-SCHEDULES = {"auto": 0, "tile": 1, "pingpong": 2, "halfx": 3, "wide": 4}   # GFX_SCHED_* of include/grafx_amd.h
+SCHEDULES = {"auto": 0, "tile": 1, "pipe": 2}   # GFX_SCHED_* of include/grafx_amd.h
 
 
 @_on_device
@@ -193,8 +193,8 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
     ``tee``: optional tensor shaped like ``x`` that receives a copy of ``x`` from the same kernel.
     ``h_rows``: number of filters in ``Hs`` when fewer than the signal rows (rows are batch-major, so
     ``h_rows = nodes`` shares one filter per node across the batch); default: one filter per row.
-    ``schedule``: "auto" (the library picks), "tile" (one tile per workgroup) or "pingpong" (persistent ping-pong
-    workgroups, for N <= 8193 and rows % h_rows == 0); see gfx_fftconv_sched_f32.
+    ``schedule``: "auto" (the library picks), "tile" (one tile per workgroup, compiler-scheduled) or "pipe" (the
+    hand-scheduled persistent kernel, N <= 8193); see gfx_fftconv_sched_f32.
     """
     _require_gpu(x, out, tee)
     xmap, R, Cin, L = rowmap(x)
@@ -209,10 +209,8 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
     if Hs.numel() != lib().gfx_fir_spectrum_bytes_ex(h_rows * Cf, N, part_len):
         raise ValueError(f"filter spectra hold {Hs.numel()} bytes, expected {h_rows} x {Cf} filters of {N} taps")
     nbytes = lib().gfx_fftconv_workspace_bytes_ex(R, Cin, L, Lout, off, N, part_len)
-    if schedule == "wide":
-        nbytes = lib().gfx_fftconv_wide_ws_bytes(h_rows, Cf)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    name = "xspec+macinv_kernels" if nbytes and schedule != "wide" else ("fftconv1_kernel" if lib().gfx_fftconv_nparts(N) == 1 else "winmac_kernel")
+    name = "xspec+macinv_kernels" if nbytes else ("fftconv1_kernel" if lib().gfx_fftconv_nparts(N) == 1 else "winmac_kernel")
     cmap = RowMap(1, 0, 0, 0)
     if tee is not None:
         cmap, Rc, Cc, Lc = rowmap(tee)
@@ -264,11 +262,15 @@ def irdft(X, n, roll=0, window=None):
         _require_gpu(X)
     K = X.shape[-1]
     is_real = not X.is_complex()
-    flat = (X if is_real else torch.view_as_real(X.contiguous())).reshape(-1, K, *(() if is_real else (2,))).contiguous()
-    if flat.dtype != torch.float32:
+    if X.dtype not in (torch.float32, torch.complex64):
         raise TypeError(f"irdft: float32 / complex64 input expected, got {X.dtype}")
+    if window is not None and (window.dtype != torch.float32 or window.numel() != n):
+        raise ValueError(f"irdft: the window must hold {n} float32 values, got {tuple(window.shape)} {window.dtype}")
+    flat = (X if is_real else torch.view_as_real(X.contiguous())).reshape(-1, K, *(() if is_real else (2,))).contiguous()
     rows = flat.shape[0]
     y = torch.empty((rows, n), dtype=torch.float32, device=X.device)
+    if rows == 0:        # an empty shard (gather_outputs / shard_batch produce them): torch.fft.irfft returned empty too
+        return y.view(*X.shape[:-1], n)
     pin = _Pin()
     check(lib().gfx_irdft_f32(_ptr(flat), int(is_real), _ptr(y), rows, K, n, roll, pin(window), _stream()), "gfx_irdft_f32")
     return y.view(*X.shape[:-1], n)
@@ -298,12 +300,19 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
     if plan is not None:
         _ALIAS_PLANS[key] = plan   # back in as the most recent
     if plan is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a plan built during capture would live in the graph's private pool and be rebuilt on every replay
+            raise RuntimeError(f"odd_alias: no plan for P={P} yet; run the call once outside the HIP-graph capture")
         plan = torch.empty(lib().gfx_odd_alias_plan_bytes(P), dtype=torch.uint8, device=z.device)
         w1 = torch.empty(lib().gfx_odd_alias_workspace_bytes(1, P), dtype=torch.uint8, device=z.device)
         check(lib().gfx_odd_alias_plan_f32(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), "gfx_odd_alias_plan_f32")
+        torch.cuda.current_stream(z.device).synchronize()   # the cached plan is complete before any stream can pick it up
         _ALIAS_PLANS[key] = plan
         while len(_ALIAS_PLANS) > _ALIAS_PLANS_MAX:
-            _ALIAS_PLANS.pop(next(iter(_ALIAS_PLANS)))
+            old = _ALIAS_PLANS.pop(next(iter(_ALIAS_PLANS)))
+            torch.cuda.synchronize(old.device)               # nobody on any stream still reads the evicted plan
+            del old
+    plan.record_stream(torch.cuda.current_stream(z.device))
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
@@ -402,24 +411,22 @@ def _rowvec(p, R):
     return p
 
 
-# Default schedule of dynamics_fused: "rows" (one workgroup streams a row) or "lookback" (chunks of four 1024-sample tiles
-# as one-shot workgroups + decoupled look-back).  Measured on MI355X at 8192 stereo rows x 131072: rows 3.49 ms
-# (4.93 TB/s), lookback 3.37 ms (5.1 TB/s) for fast poles but 5.3 vs 4.7 ms with every pole at the clamp (truncation
-# re-reads + a 32-link chain); one tile per workgroup (a look-back hop per tile) 4.0 ms.  The host cannot know the poles
-# without a synchronisation, so the default stays "rows".  tools/dyn_lookback_check.py reproduces this.
-DYN_SCHEDULE = "rows"
+# Default schedule of dynamics_fused: "oneshot" hands the library a workspace, with which the smoothed configuration runs
+# as dependency-free 1024-sample tiles for every row whose smoother memory is short (decided per row on the device,
+# gfx_dynamics_fused_ws_f32) and as one workgroup per row for the others; "rows" forces one workgroup per row.
+DYN_SCHEDULE = "oneshot"
 
 
 @_on_device
 def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None,
                    param_rows=None, schedule=None, u1_out=None):
     """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows).
-    ``schedule``: "rows" (gfx_dynamics_fused_ex_f32) or "lookback" (one-shot tiles, gfx_dynamics_fused_lb_f32).
+    ``schedule``: "oneshot" (default) or "rows", see above.
     ``u1_out``: optional (R, L) tensor that receives the smoother's un-truncated scan for :func:`dynamics_bwd` (the
     training forward; smoother = 1 only)."""
     schedule = DYN_SCHEDULE if schedule is None else schedule
-    if u1_out is not None:
-        schedule = "rows"
+    if schedule not in ("oneshot", "rows"):
+        raise ValueError(f"dynamics_fused: unknown schedule {schedule!r}")
     _require_gpu(x, out)
     xmap, R, C, L = rowmap(x)
     P = R if param_rows is None else param_rows
@@ -427,24 +434,19 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     ymap = rowmap(out)[0]
     pin = _Pin()
-    if smoother == 1 and schedule == "lookback":
-        ws = torch.empty(lib().gfx_dynamics_lookback_ws_bytes(P, R, L), dtype=torch.uint8, device=x.device)
-        with _timed("dyn_fused_kernel", 8 * R * C * L):
-            check(lib().gfx_dynamics_fused_lb_f32(_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)),
-                                                  pin(_rowvec(log_ratio, P)), pin(_rowvec(log_knee, P)),
-                                                  pin(_rowvec(z_alpha, P)), P, R, C, L, iir_len, KNEES[knee], int(gate),
-                                                  _ptr(ws), ws.numel(), _stream()), "gfx_dynamics_fused_lb_f32")
-        return out
     if u1_out is not None:
         _require_gpu(u1_out)
         _expect(u1_out, (R, L), "dynamics_fused: u1_out")
         if not u1_out.is_contiguous() or smoother != 1:
             raise ValueError("dynamics_fused: u1_out must be contiguous and needs the one-pole smoother")
+    ws = None
+    if smoother == 1 and schedule == "oneshot":
+        ws = torch.empty(lib().gfx_dynamics_ws_bytes(P), dtype=torch.uint8, device=x.device)
     args = (_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)), pin(_rowvec(log_ratio, P)),
             pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate),
-            _ptr(u1_out), _stream())
+            _ptr(u1_out), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     with _timed("dyn_fused_kernel", 8 * R * C * L + (4 * R * L if u1_out is not None else 0)):
-        check(lib().gfx_dynamics_fused_u1_f32(*args), "gfx_dynamics_fused_u1_f32")
+        check(lib().gfx_dynamics_fused_ws_f32(*args), "gfx_dynamics_fused_ws_f32")
     return out
 
 

@@ -9,12 +9,14 @@ for odd P it inverts a P-point spectrum on a (P-1)-point grid
 * even P  -> the result IS the linear convolution: one pass of the HIP
   overlap-save kernels (gfx_fftconv_f32), reading x once and writing y once;
 * odd P   -> the HIP kernels produce the full linear convolution z (length P) and
-  the reference's aliasing ``irfft(rfft(z))`` is applied on top with the device
-  FFT library (compatibility path, library FFT — see DESIGN.md §quirk).
+  the reference's aliasing ``irfft_{P-1}(rfft_P(z))`` is applied on top, natively as two
+  chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32; the float64 FFT-library
+  route remains for gradients, P > 699,051 and the dynamics envelope -- DESIGN.md §2).
 
 ``set_exact_convolution(True)`` opts out of the quirk (true linear convolution
 for every length; deviates from the reference when P is odd).
 """
+import contextlib
 import contextvars
 import warnings
 
@@ -39,6 +41,18 @@ def set_exact_convolution(flag=True):
 
 def exact_convolution():
     return _EXACT.get()
+
+
+@contextlib.contextmanager
+def exact_convolution_scope(flag):
+    """Run a block under a given setting whatever thread it runs on: the render's autograd node records the caller's
+    setting in forward and re-traces its stages under it in backward, which the autograd engine runs on its own worker
+    thread (a thread that does not inherit the caller's context)."""
+    token = _EXACT.set(bool(flag))
+    try:
+        yield
+    finally:
+        _EXACT.reset(token)
 
 
 def reference_aliases(lx, lh, exact=False):

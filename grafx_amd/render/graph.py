@@ -21,6 +21,12 @@ from .core import (
 )
 
 
+# Training forward: keep the dynamics stages' smoother scan (R x L floats per stage) for their backward instead of
+# re-scanning the input there (-4 % step time at the console graph, +4.8 GB at 256 graphs).  Set to False to trade the
+# memory back for the recompute pass.
+KEEP_SMOOTHER_SCAN = True
+
+
 def _gather_plan(step, device):
     """(src_idx, seg_ptr, n_out) for gfx_gather_sum_f32, or None when the step is a plain slice read.
 
@@ -329,8 +335,11 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             state, event = prepared[i]
             main.wait_event(event)
             extra["_prepared"] = state
-        if aux is not None and plan is None and getattr(proc, "accepts_aux", False):
-            extra["_aux"] = (aux, i)   # (a gathered input is a temporary: the backward re-gathers it, same values)
+        if (aux is not None and plan is None and KEEP_SMOOTHER_SCAN and getattr(proc, "accepts_aux", False)
+                and type(proc) in _tape_safe_types()):
+            # only for the exact library types whose backward consumes it (see `trusted` in the backward); a gathered
+            # input is a temporary: the backward re-gathers it, same values
+            extra["_aux"] = (aux, i)
         proc.render_into(x_view, out_view, **extra, **params, **common_i)
         if prepared is None:  # the first processor stage is on its way: now design the later ones underneath it
             prepared = prepare_later_stages(i)
@@ -387,6 +396,11 @@ class _BufferRenderFn(torch.autograd.Function):
         with torch.no_grad():
             _, _, buf = _render_buffer_io(processors, input_signals, params, render_data, common, aux=ctx.aux)
         ctx.meta = meta
+        # the backward re-traces the stages on the autograd engine's worker thread, which does not see the caller's
+        # context-local set_exact_convolution(): carry the setting the forward ran under
+        from ..processors.core.convolution import exact_convolution
+
+        ctx.exact = exact_convolution()
         ctx.squeeze = input_signals.ndim == 3
         ctx.n_src = input_signals.shape[0 if ctx.squeeze else 1]
         ctx.save_for_backward(buf, *leaves)
@@ -400,6 +414,13 @@ class _BufferRenderFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out_rows, g_buf):
+        from ..processors.core.convolution import exact_convolution_scope
+
+        with exact_convolution_scope(ctx.exact):
+            return _BufferRenderFn._backward(ctx, g_out_rows, g_buf)
+
+    @staticmethod
+    def _backward(ctx, g_out_rows, g_buf):
         from .. import autograd as diff
         from .. import ops
 

@@ -118,26 +118,16 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
                        int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                        void* ws, size_t ws_bytes, void* stream);
 
-/* gfx_fftconv_ex_f32 with an explicit kernel schedule for filters of N <= 8193 taps (same results to rounding, the
- * tile boundaries differ):
- *   GFX_SCHED_TILE      one 16384-sample tile per 256-thread workgroup (fftconv1_kernel): spreads small problems
- *                       over the whole chip.
- *   GFX_SCHED_PINGPONG  one persistent 512-thread workgroup per CU; its two halves run half a tile apart so the LDS
- *                       exchanges of one hide under the arithmetic of the other; input windows arrive by LDS-DMA
- *                       through a ring that keeps the overlap between consecutive windows (every sample is read from
- *                       HBM once), filter spectrum and twiddles stay in registers (fftconv1pp_kernel).  Needs
- *                       R % h_rows == 0 and part_len == 0; GFX_EINVAL otherwise.
- *   GFX_SCHED_AUTO      what gfx_fftconv_f32 / _tee_f32 / _ex_f32 use: currently always one tile per workgroup, which
- *                       measures faster than the ping-pong schedule at every size on MI355X
- *                       (profiles/r2/pingpong_ablation.md). */
+/* gfx_fftconv_ex_f32 with an explicit kernel schedule for filters of N <= 8193 taps (same results to rounding):
+ *   GFX_SCHED_TILE  one 16384-sample tile per 256-thread workgroup (fftconv1_kernel, compiler-scheduled).
+ *   GFX_SCHED_PIPE  the hand-scheduled persistent form of the same tile (generated gfx950 assembly, explicit register
+ *                   allocation: the next tile's window, the filter spectrum and the output stores are interleaved
+ *                   with the arithmetic of the running tile).  GFX_EINVAL where it does not apply.
+ *   GFX_SCHED_AUTO  what gfx_fftconv_f32 / _tee_f32 / _ex_f32 use: the faster of the two for the shape at hand.
+ * (Round-2 experiments -- ping-pong, half-size exchanges, 512-thread tile -- live in tools/experiments/r2_schedules.) */
 #define GFX_SCHED_AUTO 0
 #define GFX_SCHED_TILE 1
-#define GFX_SCHED_PINGPONG 2
-#define GFX_SCHED_HALFX 3   /* one tile per workgroup with half-size LDS exchanges: three workgroups per CU */
-#define GFX_SCHED_WIDE 4    /* one tile per 512-thread workgroup, 16 points per thread: four waves per SIMD.  Plain causal
-                             * geometry only (one partition, off = 0, even L and Lout); `ws` must hold
-                             * gfx_fftconv_wide_ws_bytes(h_rows, C_f) bytes (the spectra in the wide thread layout). */
-size_t gfx_fftconv_wide_ws_bytes(int64_t h_rows, int64_t C_f);
+#define GFX_SCHED_PIPE 2
 int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
                           float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
@@ -232,16 +222,20 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               const float* log_threshold, const float* log_ratio, const float* log_knee,
                               const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
                               int smoother, int64_t iir_len, int knee, int gate, void* stream);
-/* The smoothed (one-pole) configuration as one-shot tiles: every 1024-sample tile of every row is its own workgroup and
- * the recursion's carry crosses tiles through a chained scan with decoupled look-back (8-byte {value, tag} records in
- * `ws`) -- the access shape that reaches the chip's copy bandwidth, where the row-per-workgroup kernel behind
- * gfx_dynamics_fused_ex_f32 is a set of long scattered streams.  Same arguments and results (to rounding);
- * `ws` of gfx_dynamics_lookback_ws_bytes(param_rows, R, L) bytes is scratch for this call. */
-size_t gfx_dynamics_lookback_ws_bytes(int64_t param_rows, int64_t R, int64_t L);
-int gfx_dynamics_fused_lb_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
+/* The same with a workspace of gfx_dynamics_ws_bytes(param_rows) bytes (scratch for this call; may be NULL, which is
+ * gfx_dynamics_fused_ex_f32) and an optional `u1` (R, L): the un-truncated smoother scan (1 - a) * U, kept for
+ * gfx_dynamics_bwd_u1_f32.  With a workspace the smoothed configuration runs as dependency-free one-shot tiles: every
+ * 1024-sample tile of every row is its own workgroup, which re-reads the H = ceil(log 1e-12 / log a) most recent
+ * samples before the tile to rebuild the smoother state (exact to 1e-12 of the peak energy: the smoother is a FIR with
+ * taps (1 - a) a^k) -- the access shape of a plain copy, where one workgroup per row is a set of long scattered
+ * streams.  Rows whose history does not fit (H > 256, or a live a^N truncation term) are picked out on the device from
+ * a per-row pole table and produced by the row kernel in the same call; no host synchronisation. */
+size_t gfx_dynamics_ws_bytes(int64_t param_rows);
+int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
                               const float* log_threshold, const float* log_ratio, const float* log_knee,
                               const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
-                              int64_t iir_len, int knee, int gate, void* ws, size_t ws_bytes, void* stream);
+                              int smoother, int64_t iir_len, int knee, int gate, float* u1,
+                              void* ws, size_t ws_bytes, void* stream);
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);

@@ -208,23 +208,50 @@ def test_cfg3_full_batch_512_rows_repeat_the_checked_rows():
     assert (d <= 2e-6 * y2.abs().amax(dim=(1, 2))).all(), d
 
 
-@pytest.mark.parametrize("iir_len", [16383, 300])
-def test_lookback_schedule_of_the_fused_dynamics_equals_the_row_schedule(iir_len):
-    """gfx_dynamics_fused_lb_f32 (one-shot tiles, chained scan with decoupled look-back) against the row-streaming
-    kernel: poles from instant to the clamp at 1 - 1e-5 (long look-back chains, truncation term active), ragged
-    length, mono and stereo, shared parameter rows."""
+@pytest.mark.parametrize("iir_len", [16383, 300, 40])
+def test_oneshot_schedule_of_the_fused_dynamics_equals_the_row_schedule(iir_len):
+    """gfx_dynamics_fused_ws_f32 (dependency-free one-shot tiles that re-read their smoother history, chosen per row on
+    the device) against the row-streaming kernel: poles from instant to the clamp at 1 - 1e-5 in ONE call, so that rows
+    taken by the one-shot grid and rows left to the row kernel (long memory, or a live truncation term at short
+    iir_len) sit side by side; ragged length, mono and stereo, shared parameter rows, and the kept scan `u1`."""
     from grafx_amd import ops
 
     torch.manual_seed(12)
-    for C, Lc in ((2, 131072), (1, 5001)):
-        n, B = 6, 3
+    for C, Lc in ((2, 131072), (1, 5001), (2, 1024), (2, 1028)):
+        n, B = 8, 3
         x = torch.randn(B, n, C, Lc, device="cuda") * torch.linspace(0.05, 1.0, Lc, device="cuda")
         p = dict(log_threshold=torch.randn(n, 1, device="cuda") - 2, log_ratio=torch.randn(n, 1, device="cuda"),
                  log_knee=torch.randn(n, 1, device="cuda"),
-                 z_alpha=torch.tensor([[20.0], [9.0], [6.0], [2.0], [0.0], [-3.0]], device="cuda"))
+                 z_alpha=torch.tensor([[20.0], [9.0], [6.0], [2.3], [2.0], [0.0], [-3.0], [-12.0]], device="cuda"))
         for knee, gate in (("quadratic", False), ("hard", True)):
             kw = dict(smoother=1, iir_len=iir_len, knee=knee, gate=gate, param_rows=n)
-            a = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="rows", **kw)
-            b = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="lookback", **kw)
-            assert torch.isfinite(b).all()
+            ua = torch.empty(B * n, Lc, device="cuda")
+            ub = torch.full((B * n, Lc), float("nan"), device="cuda")
+            a = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="rows", u1_out=ua, **kw)
+            b = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="oneshot", u1_out=ub, **kw)
+            c = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="oneshot", **kw)
+            assert torch.isfinite(b).all() and torch.isfinite(ub).all()
             assert (a - b).abs().max() <= 5e-6 * a.abs().max(), (C, Lc, knee, gate)
+            assert torch.equal(b, c)
+            assert (ua - ub).abs().max() <= 5e-6 * ua.abs().max(), (C, Lc, knee, gate)
+
+
+def test_oneshot_dynamics_matches_the_oracle_on_a_loud_to_silent_signal():
+    """The one-shot tiles drop smoother taps below 1e-12: a passage 120 dB down right after a loud one is where a
+    dropped tail would show.  Compared with the CPU oracle (the reference's FFT convolution with the 16383-tap FIR)."""
+    import oracle
+    from grafx_amd.processors import Compressor
+
+    torch.manual_seed(3)
+    Lc = 40960
+    x = torch.randn(6, 2, Lc)
+    x[:, :, 20000:] *= 1e-6
+    m = Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).cuda()
+    o = oracle.OracleCompressor(energy_smoother="iir", iir_len=16383)
+    p = dict(log_threshold=torch.randn(6, 1) - 3, log_ratio=torch.randn(6, 1), log_knee=torch.randn(6, 1),
+             z_alpha_pre=torch.tensor([[2.0], [1.0], [0.0], [-1.0], [-4.0], [3.0]]))
+    with torch.no_grad():
+        want = o(x.double(), **{k: v.double() for k, v in p.items()}).float()
+        got = m(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
+    for sl in (slice(0, 20000), slice(20000, Lc)):
+        assert (got[..., sl] - want[..., sl]).abs().max() <= 1e-5 * want[..., sl].abs().max()

@@ -6,10 +6,10 @@ OUT=$R/gpurun_out/clock
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in $1; do
-  cp $R/grafx_amd/lib/$v.so $R/grafx_amd/lib/libgrafx_amd.so
+  export GRAFX_AMD_LIB=$R/grafx_amd/lib/$v.so   # the variant is selected by name, the live library is not touched
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/$v -- python3 $R/tools/microbench.py eqbuf --rows 8192 --iters 3 > $OUT/$v.log 2>&1
 done
-cp $R/grafx_amd/lib/A.so $R/grafx_amd/lib/libgrafx_amd.so
+unset GRAFX_AMD_LIB
 python3 - <<PY
 import csv, glob, collections, re, os
 for v in "$1".split():

@@ -57,7 +57,7 @@ def main():
             print(f"  fftconv1 + tee      {ms:8.3f} ms  {1.5 * gb / ms * 1e3:8.1f} GB/s")
             ms = timeit(lambda: tee.copy_(x), a.iters)
             print(f"  plain copy          {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
-            for sched in ("tile", "wide", "halfx", "pingpong"):
+            for sched in ("tile", "pipe"):
                 ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y, schedule=sched), a.iters)
                 print(f"  fftconv1 {sched:9s}      {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
                 ms = timeit(lambda: ops.fftconv(x, Hs, 4001, 1, out=y, tee=tee, schedule=sched), a.iters)
@@ -78,7 +78,7 @@ def main():
                                         ("buffer out", buf.narrow(1, 32, n), None, x4),
                                         ("buffer out + tee", buf.narrow(1, 32, n), buf.narrow(1, 0, n), x4),
                                         ("buffer in/out", buf.narrow(1, 64, n), None, buf.narrow(1, 32, n))):
-                for sched in ("tile", "wide"):
+                for sched in ("tile", "pipe"):
                     ms = timeit(lambda: ops.fftconv(xin, Hs, 4001, 1, out=out, tee=tee, h_rows=n, schedule=sched), a.iters)
                     print(f"  fftconv1 {sched:5s} {name:32s} {ms:8.3f} ms  {(1.5 if tee is not None else 1.0) * gb / ms * 1e3:8.1f} GB/s")
         if a.what in ("eqcold",):  # the tee launch back to back vs. after other traffic (as inside a render step)
@@ -169,8 +169,16 @@ def main():
         if a.what in ("comp", "all"):
             cp = P.Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).to(dev)
             p = {k: 0.1 * torch.randn(R, 1, device=dev) for k in cp.parameter_size()}
-            ms = timeit(lambda: cp.render_into(x.view(1, R, 2, L), y.view(1, R, 2, L), **p), a.iters)
-            print(f"comp    R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            for label, z in (("poles sigmoid(0.1 randn)", p["z_alpha_pre"]), ("poles 0.88 (H = 218)", torch.full((R, 1), 2.0, device=dev)),
+                             ("poles 0.95 (row kernel)", torch.full((R, 1), 3.0, device=dev)),
+                             ("poles at the clamp", torch.full((R, 1), 20.0, device=dev)),
+                             ("half fast, half at the clamp", torch.where(torch.arange(R, device=dev)[:, None] % 2 == 0, 0.0, 20.0))):
+                for sched in ("rows", "oneshot"):
+                    ops.DYN_SCHEDULE = sched
+                    q = dict(p, z_alpha_pre=z)
+                    ms = timeit(lambda: cp.render_into(x.view(1, R, 2, L), y.view(1, R, 2, L), **q), a.iters)
+                    print(f"comp {sched:8s} {label:30s} R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            ops.DYN_SCHEDULE = "oneshot"
         if a.what in ("reverb", "all"):
             Rr = max(R // 8, 1)
             rv = P.STFTMaskedNoiseReverb(ir_len=60001, flashfftconv=False).to(dev)
