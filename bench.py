@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); a one-float4-per-thr
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="graphs (cfg4) or rows (cfg2/cfg3) per GPU")
     ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--config", choices=["cfg4", "cfg2", "cfg3"], default="cfg4",
@@ -50,6 +50,9 @@ def parse_args(argv=None):
                     help="CPU plumbing check: pass-through processors on CPU tensors (launch, sharding, barriers, JSON)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the cfg2 / cfg3 measurements (BASELINE configs[1] / configs[2]) that the default single-GPU "
+                         "run appends to the line as `secondary`")
     ap.add_argument("--reference-default-lengths", action="store_true",
                     help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
                          "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
@@ -152,8 +155,13 @@ def dry_processors():
     import torch.nn as nn
 
     class Pass(nn.Module):
-        def forward(self, input_signals, **params):
-            return input_signals
+        """y = x * (1 + mean(p)): a pass-through at p = 0 whose one parameter per node still receives a gradient, so
+        that the dry run exercises the training leg (backward + flat all-reduce) as well."""
+
+        def forward(self, input_signals, p=None, **params):
+            if p is None or not p.requires_grad:
+                return input_signals
+            return input_signals * (1.0 + p.reshape(p.shape[0], -1).mean(-1).view(-1, 1, 1))
 
         def parameter_size(self):
             return {"p": 1}
@@ -247,7 +255,7 @@ def roofline_from_profile(prof, steps, elapsed, B, L):
     total_ms, avg_ms, avg_bytes, n = stats[name]
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         pmc = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
         if not os.path.exists(pmc):  # PMC bytes come from a separate rocprofv3 --pmc pass of this same command
             continue
@@ -299,6 +307,10 @@ def run_rank(args):
             dist.all_reduce(warm)
             dist.barrier()
             torch.cuda.synchronize()
+
+    if dist is not None:  # one line per rank in the log: which backend carries the collectives and how many ranks it sees
+        print(f"[bench] rank {rank}/{world}: torch.distributed backend={dist.get_backend()} "
+              f"world_size={dist.get_world_size()} device={dev}", file=sys.stderr, flush=True)
 
     def sync():
         if not args.dry:
@@ -401,12 +413,21 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     roof = roofline_from_profile(prof, args.steps, elapsed, B, L) if prof else None
 
     train = None
-    if not (args.no_train or args.dry or args.capture):
+    if not (args.no_train or args.capture):
         del y
         try:
             train = train_leg(args, torch, dist, dev, world, procs, params, x, rd_dev, L, sync, fence)
         except Exception as e:  # the headline line must survive a failure of the secondary measurement
             train = {"error": f"{type(e).__name__}: {e}"}
+
+    secondary = None
+    if world == 1 and not (args.no_secondary or args.dry or args.capture or args.reference_default_lengths
+                           or args.reference_default_args):
+        x = None  # (the closure `step` is done with it) release the 8.6 GB batch before the other workloads allocate
+        try:
+            secondary = secondary_leg(torch, dev, sync)
+        except Exception as e:  # never lose the headline line to a secondary measurement
+            secondary = {"error": f"{type(e).__name__}: {e}"}
 
     if rank != 0:
         return None
@@ -449,6 +470,8 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
                              "frac_of_hbm_peak": graph_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if train is not None:
         out["training"] = train
+    if secondary is not None:
+        out["secondary"] = secondary
     if world == 1 and not args.no_cpu_baseline and not args.dry:
         out["cpu_baseline"] = cpu_baseline_console(G, render_data, params_cpu, L)
     return out
@@ -462,8 +485,9 @@ def train_leg(args, torch, dist, dev, world, procs, params, x, rd_dev, L, sync, 
     from grafx_amd.parallel import all_reduce_gradients
     from grafx_amd.render import render_grafx
 
-    torch.cuda.empty_cache()
-    torch.cuda.reset_peak_memory_stats()
+    if not args.dry:
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
     Bt = min(args.train_batch, x.shape[0])
     tparams = nn.ParameterDict({t: nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in d.items()})
                                 for t, d in params.items()})
@@ -485,32 +509,38 @@ def train_leg(args, torch, dist, dev, world, procs, params, x, rd_dev, L, sync, 
     sync()
     dt = time.perf_counter() - t1
     fence()
+    grad_sync = None
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # after the all-reduce every rank must hold the same gradients: compare them rank by rank (a few KB)
+        flat = torch.cat([p.grad.reshape(-1) for p in plist if p.grad is not None])
+        every = [torch.zeros_like(flat) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, flat)
+        grad_sync = {"ranks": len(every), "grad_abs_sum": float(flat.abs().sum()),
+                     "max_abs_diff_across_ranks": float(max((e - every[0]).abs().max() for e in every))}
     return {"what": "forward + backward + flat all-reduce of shared-parameter gradients", "batch_per_gpu": Bt,
             "steps": args.train_steps, "ms_per_step": dt / args.train_steps * 1e3,
             "value": world * Bt * L * args.train_steps / dt, "unit": "audio samples/s",
-            "grad_floats": sum(p.numel() for p in plist), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}
+            "grad_floats": sum(p.grad.numel() for p in plist if p.grad is not None), "grad_sync": grad_sync,
+            "peak_mem_GiB": None if args.dry else torch.cuda.max_memory_allocated() / 2**30}
 
 
-def bench_processor(args, torch, dist, dev, world, rank, sync, fence):
-    """BASELINE configs[1] / configs[2]: one processor call over a resident batch of rows."""
-    if args.dry:
-        raise SystemExit("--dry only applies to the console graph")
+def processor_case(cfg, torch, dev, rank, batch=None, length=None):
+    """BASELINE configs[1] / configs[2] as (step function, rows, channels, length, description)."""
     from grafx_amd.processors import ParametricEqualizer, STFTMaskedNoiseReverb
 
     torch.manual_seed(1000 + rank)
-    if args.config == "cfg2":
-        R, C, L = args.batch or 1024, 1, args.length or 480000
+    if cfg == "cfg2":
+        R, C, L = batch or 1024, 1, length or 480000
         proc = ParametricEqualizer(num_filters=6, processor_channel="mono", flashfftconv=False,
                                    fsm_fir_len=LENS["fsm_fir_len"]).to(dev)
         p = {k: torch.randn(R, 1, 6, device=dev) for k in ("w0", "q_inv", "log_gain")}
         what = (f"BASELINE configs[1]: ParametricEqualizer(num_filters=6, mono, fsm_fir_len={LENS['fsm_fir_len']}) on "
                 f"{R} x {C} x {L}, parameters randn (std 1)")
     else:
-        R, C, L = args.batch or 512, 2, args.length or 240000
+        R, C, L = batch or 512, 2, length or 240000
         proc = STFTMaskedNoiseReverb(ir_len=LENS["ir_len"], flashfftconv=False).to(dev)
         p = {k: torch.randn(R, 2, 193, device=dev) for k in ("init_log_magnitude", "delta_log_magnitude")}
         what = (f"BASELINE configs[2]: STFTMaskedNoiseReverb(ir_len={LENS['ir_len']}, pseudo_midside) on {R} x {C} x {L}, "
@@ -521,6 +551,49 @@ def bench_processor(args, torch, dist, dev, world, rank, sync, fence):
         with torch.no_grad():
             return proc(x, **p)
 
+    return step, R, C, L, what
+
+
+def call_roofline(R, C, L, ms_per_step):
+    call_bytes = 8 * R * C * L  # read x once, write y once
+    gbps = call_bytes / (ms_per_step * 1e-3) / 1e9
+    return {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
+
+
+def secondary_leg(torch, dev, sync, steps=10, warmup=3):
+    """BASELINE configs[1] and configs[2] on this GPU, a few milliseconds each, appended to the headline line so that the
+    driver's own run records them: ms per call, the call's algorithmic-bytes roofline and the dominant kernel's."""
+    from grafx_amd import ops
+
+    out = {}
+    for cfg in ("cfg2", "cfg3"):
+        torch.cuda.empty_cache()
+        step, R, C, L, what = processor_case(cfg, torch, dev, 0)
+        for _ in range(warmup):
+            y = step()
+        sync()
+        with ops.profiling() as prof:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = step()
+            sync()
+            elapsed = time.perf_counter() - t0
+        assert torch.isfinite(y).all(), f"{cfg}: non-finite samples"
+        ms = elapsed / steps * 1e3
+        roof = roofline_from_profile(prof, steps, elapsed, R, L)
+        out[cfg] = {"workload": what, "steps": steps, "warmup": warmup, "ms_per_step": ms,
+                    "value": R * C * L * steps / elapsed, "unit": "channel-samples/s",
+                    "call_roofline": call_roofline(R, C, L, ms), "roofline": roof}
+        del step, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_processor(args, torch, dist, dev, world, rank, sync, fence):
+    """BASELINE configs[1] / configs[2]: one processor call over a resident batch of rows."""
+    if args.dry:
+        raise SystemExit("--dry only applies to the console graph")
+    step, R, C, L, what = processor_case(args.config, torch, dev, rank, args.batch, args.length)
     step()
     sync()
     y, elapsed, per_rank, prof = _timed_region(args, torch, dist, dev, step, sync, fence, profile=True)
@@ -529,7 +602,6 @@ def bench_processor(args, torch, dist, dev, world, rank, sync, fence):
     if rank != 0:
         return None
     ms_per_step = elapsed / args.steps * 1e3
-    call_bytes = 8 * R * C * L  # read x once, write y once
     out = {
         "metric": "channel-samples/sec through one processor call (all GPUs)",
         "value": world * R * C * L * args.steps / elapsed, "unit": "channel-samples/s", "n_gpus": world,
@@ -540,9 +612,7 @@ def bench_processor(args, torch, dist, dev, world, rank, sync, fence):
         "world_size": world if dist is None else dist.get_world_size(),
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         "roofline": roof,
-        "call_roofline": {"algorithmic_bytes_per_call": call_bytes,
-                          "achieved_GBps": call_bytes / (ms_per_step * 1e-3) / 1e9,
-                          "frac_of_hbm_peak": call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "call_roofline": call_roofline(R, C, L, ms_per_step),
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_proc(args.config, L)

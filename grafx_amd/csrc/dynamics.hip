@@ -155,6 +155,29 @@ __device__ __forceinline__ float log_gain(const Knee& q, float G) {
     return -q.er * softplusf(q.k * (-d)) / q.k;                                                // 709-721
 }
 
+// Hardware log2 / exp2 forms (v_log_f32, v_exp_f32) for the forward kernels: the one-shot tiles run at copy speed once the
+// arithmetic is out of the way -- with the library logf / expf they take 3.46 ms where the grid moving the same bytes takes
+// 2.72 (8192 stereo rows, profiles/r3/dyn_oneshot_ablation.txt) -- and the row kernel uses the same forms so that a row
+// gives the same samples whichever kernel produces it.  Accuracy: the
+// envelope is >= 1e-5, so log() sees no denormals and is good to ~1e-7 absolute; exp(g) is good to (2 + |g| log2 e) ulp,
+// i.e. a relative 6e-8 |g| on a GAIN that is itself e^g: large |g| means a proportionally small output.
+struct FastMath {
+    static __device__ __forceinline__ float log(float v) { return __logf(v); }
+    static __device__ __forceinline__ float exp(float v) { return __expf(v); }
+    // softplus, torch threshold 20; below -15 log1p(e^v) = e^v to fp32 (and 1 + e^v would round to 1)
+    static __device__ __forceinline__ float softplus(float v) {
+        return v > 20.0f ? v : (v < -15.0f ? __expf(v) : __logf(1.0f + __expf(v)));
+    }
+};
+
+template <typename M>
+__device__ __forceinline__ float log_gain_m(const Knee& q, float G) {
+    if (q.kind != 2) return log_gain(q, G);       // hard / quadratic knees: no transcendental
+    const float d = G - q.T;
+    if (!q.gate) return (q.invR - 1.0f) * M::softplus(q.k * d) / q.k;      // dynamics.py:478-489
+    return -q.er * M::softplus(q.k * (-d)) / q.k;                            // 709-721
+}
+
 // ---- loads / stores of 4 consecutive samples with bounds -----------------------------------------
 // samples [n, n+4) of a row, zero outside [lo, L)
 __device__ __forceinline__ void load4(const float* __restrict__ row, int64_t n, int64_t L, bool vec, float (&v)[DE],
@@ -194,9 +217,6 @@ struct DynArgs {
 // Tiles [t_lo, t_hi) of the row are produced.  The smoother is a truncated FIR (N taps), so a chunk that does not
 // start at the row start is exact if its scans start N samples early from a zero state: tiles [t_warm, t_lo) are
 // scanned without producing output, and samples before `s0 = t_warm * DTILE` count as zero for both scans.
-#ifndef GFX_DYN_MATH
-#define GFX_DYN_MATH 0
-#endif
 // u1row (training forward, whole rows only): also store (1-a) x the UN-truncated scan of the energy, which is what the
 // backward pass needs (gfx_dynamics_bwd_u1_f32) -- one extra 4-byte store per sample here instead of a pass over x there.
 template <bool TRUNC>
@@ -283,16 +303,8 @@ __device__ __forceinline__ void dyn_stream(const DynArgs& a, const OnePole& p, c
         float ga[DE], gb[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
-#if GFX_DYN_MATH == 2   // experiment: no transcendental functions at all (timing only)
-            const float G = env[i] + 1e-5f;
-            const float g = log_gain(q, G);
-#elif GFX_DYN_MATH == 1  // experiment: hardware log2 / exp2 (v_log_f32, v_exp_f32)
-            const float G = __logf(env[i] + 1e-5f);
-            const float g = __expf(log_gain(q, G));
-#else
-            const float G = logf(env[i] + 1e-5f);            // dynamics.py:394
-            const float g = expf(log_gain(q, G));            // 402-403
-#endif
+            const float G = FastMath::log(env[i] + 1e-5f);                  // dynamics.py:394
+            const float g = FastMath::exp(log_gain_m<FastMath>(q, G));      // 402-403
             ga[i] = g * xa[i];
             gb[i] = g * xb[i];
         }
@@ -342,12 +354,12 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
 // ---- the same fused compressor / gate as dependency-free ONE-SHOT tiles ---------------------------------------------
 // dyn_fused_kernel streams a row per workgroup: a few thousand long-lived streams at scattered addresses, the access
 // shape that tops out at 4.8-5.5 TB/s on this chip where a one-shot copy reaches 6.2-6.6 (profiles/r2/
-// stream2_copy_ceiling.txt).  Here every 1024-sample tile of every row is its own short-lived workgroup (tiles of a row
-// on consecutive logical block indices of one XCD, so the chip sweeps memory front to back) and NO state crosses tiles:
-// the smoother is a FIR, h[k] = (1-a) a^k, so the scan state entering a tile is the weighted sum of the H most recent
-// energies before it, u[s-1] = sum_{k<H} a^k e[s-1-k], with H the number of taps above 1e-12.  A tile re-reads those H
-// samples (thread t takes taps 4t .. 4t+3 as one predicated 16-byte load per channel) and reduces them in the same LDS
-// hop that carries the scan across its four waves: one barrier per tile, as in the row kernel.
+// stream2_copy_ceiling.txt).  Here every 512-sample tile of every row belongs to one WAVE of a short-lived workgroup
+// (four consecutive tiles per workgroup, workgroups of a row on consecutive logical block indices of one XCD, so the
+// chip sweeps memory front to back) and NO state crosses tiles: the smoother is a FIR, h[k] = (1-a) a^k, so the scan
+// state entering a tile is the weighted sum of the H most recent energies before it, u[s-1] = sum_{k<H} a^k e[s-1-k],
+// with H the number of taps above 1e-12.  A tile re-reads those H samples (lane l takes taps 4l .. 4l+3 as one
+// predicated 16-byte load per channel) and reduces them with six shuffles: no LDS, no barrier.
 // Which rows qualify is decided ON THE DEVICE from the pole table (no host synchronisation): a row is taken here when its
 // truncation term is dead (a^N <= 1e-12) and H <= DYN_OS_HMAX; every other row leaves this grid at once and is produced
 // by dyn_fused_kernel, launched over the same rows with the complementary test.
@@ -384,119 +396,126 @@ __global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* 
     }
 }
 
+constexpr int OS_SUB = 2;                  // 256-sample sub-tiles per wave tile (1: 5.1, 2: 6.0, 4: 5.6 TB/s -- profiles/r3/dyn_oneshot_ablation.txt)
+constexpr int OS_WTILE = 64 * DE * OS_SUB; // 512 samples per wave (a multiple of 256: the history offsets assume it)
+constexpr int OS_GTILE = OS_WTILE * (DT / 64);   // 2048 samples per workgroup
+
+// One WAVE per 512-sample tile, four tiles per workgroup, no LDS and no barrier: the wave scans two 256-sample
+// sub-tiles (each lane 4 consecutive samples, 6 shuffle steps per sub-tile), chains them through one scalar carry, and
+// gets the state entering its tile from the history dot product (lanes 4 l < H, one predicated 16-byte load per channel).
 __global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ log_threshold,
                                                          const float* __restrict__ log_ratio,
                                                          const float* __restrict__ log_knee,
-                                                         const float* __restrict__ tab, DynArgs a, unsigned ntiles,
+                                                         const float* __restrict__ tab, DynArgs a, unsigned ngroups,
                                                          unsigned nblocks, float* __restrict__ u1) {
-    __shared__ float slots[8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (a tile's history is its neighbour's data)
     const unsigned per_xcd = gridDim.x >> 3;
     const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (b >= nblocks) return;
-    const unsigned r = b / ntiles;
-    const unsigned tile = b - r * ntiles;
+    const unsigned r = b / ngroups;
+    const unsigned grp = b - r * ngroups;
     const unsigned pr = r % a.prows;
     const float* tb = tab + (size_t)pr * DP_TAB;
     if (tb[DP_ONESHOT] == 0.0f) return;          // produced by dyn_fused_kernel (uniform)
-    const int H = (int)tb[DP_HIST];
-    const float a1 = tb[77], one_m_a = tb[78], a_wave = tb[70];
-    const float ap1 = tb[73], ap2 = tb[74], ap3 = tb[75], ap4 = tb[76];
-    const float a_lane = tb[lane];
-    Knee q;
-    knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
+    const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;     // first sample of this wave's tile
+    if (s >= a.L) return;
     const float* x0 = x + drow_off(a.xmap, r, 0);
     const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
     float* y0 = y + drow_off(a.ymap, r, 0);
     float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
-    const float invC = 1.0f / (float)a.C;
-    const int64_t s = (int64_t)tile * DTILE;     // first sample of the tile
-    const int64_t n = s + DE * t;
+    const bool stereo = a.C == 2;
+    const int64_t n0 = s + DE * lane;
 
-    float xa[DE], xb[DE], ha[DE], hb[DE];
-    load4(x0, n, a.L, vx, xa);
-    if (a.C == 2) load4(x1, n, a.L, vx, xb);
-    else {
+    float xa[OS_SUB][DE], xb[OS_SUB][DE], ha[DE], hb[DE];
 #pragma unroll
-        for (int i = 0; i < DE; ++i) xb[i] = 0.0f;
+    for (int k = 0; k < OS_SUB; ++k) {
+        load4(x0, n0 + 256 * k, a.L, vx, xa[k]);
+        if (stereo) load4(x1, n0 + 256 * k, a.L, vx, xb[k]);
+        else {
+#pragma unroll
+            for (int i = 0; i < DE; ++i) xb[k][i] = 0.0f;
+        }
     }
-    // history taps 4t .. 4t+3 = samples s-4(t+1) .. s-4t-1 (tile 0 has none; s is a multiple of 1024 otherwise)
-    const bool hist = tile != 0 && DE * t < H;
-    const bool hwave = tile != 0 && DE * 64 * wave < H;     // does this wave hold any live tap (uniform)
+    // history taps 4 l .. 4 l + 3 = samples s - 4 (l + 1) .. s - 4 l - 1 (none before the row start; s is a multiple of 1024)
+    const int H = (int)tb[DP_HIST];
+    const bool hist = s != 0 && DE * lane < H;
     if (hist) {
-        load4(x0, s - DE * (t + 1), a.L, vx, ha);
-        if (a.C == 2) load4(x1, s - DE * (t + 1), a.L, vx, hb);
+        load4(x0, s - DE * (lane + 1), a.L, vx, ha);
+        if (stereo) load4(x1, s - DE * (lane + 1), a.L, vx, hb);
     }
-    float e[DE], loc[DE];
-    float acc = 0.0f;
+    const float a1 = tb[77], one_m_a = tb[78], a_sub = tb[70];          // a, 1 - a, a^256
+    const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};              // a^1 .. a^4
+    const float a_lane = tb[lane];                                       // a^(4 lane)
+    float a_step[6];
 #pragma unroll
-    for (int i = 0; i < DE; ++i) {
-        e[i] = (a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) : xa[i] * xa[i]) * invC;
-        acc = fmaf(a1, acc, e[i]);
-        loc[i] = acc;
-    }
-    // inclusive scan of the thread totals inside the wave
-    float inc = acc;
+    for (int d = 0; d < 6; ++d) a_step[d] = tb[64 + d];
+    Knee q;
+    knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
+    const float invC = 1.0f / (float)a.C;
+
+    // the four sub-tiles' local and in-wave scans do not depend on each other
+    float loc[OS_SUB][DE], excl[OS_SUB], total[OS_SUB];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) {
-        const float up = __shfl_up(inc, 1 << d, 64);
-        if (lane >= (1 << d)) inc = fmaf(tb[64 + d], up, inc);
+    for (int k = 0; k < OS_SUB; ++k) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            const float e = (stereo ? (xa[k][i] * xa[k][i] + xb[k][i] * xb[k][i]) : xa[k][i] * xa[k][i]) * invC;
+            acc = fmaf(a1, acc, e);
+            loc[k][i] = acc;
+        }
+        float inc = acc;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const float up = __shfl_up(inc, 1 << d, 64);
+            if (lane >= (1 << d)) inc = fmaf(a_step[d], up, inc);
+        }
+        const float ex = __shfl_up(inc, 1, 64);
+        excl[k] = lane == 0 ? 0.0f : ex;
+        total[k] = __shfl(inc, 63, 64);          // the sub-tile's aggregate, uniform
     }
-    if (lane == 63) slots[wave] = inc;
-    float excl = __shfl_up(inc, 1, 64);
-    if (lane == 0) excl = 0.0f;
-    // this wave's share of the entering state: sum over its live taps of a^k e[s-1-k], k = 4t + (3 - i)
-    if (hwave) {
+    // state entering the tile: sum over the live taps of a^k e[s-1-k], k = 4 lane + (3 - i)
+    float carry = 0.0f;
+    if (s != 0 && H > 0) {                        // uniform
         float hs = 0.0f;
         if (hist) {
-            // Horner over the four taps, oldest first: ((e0 a + e1) a + e2) a + e3 = sum_i e_i a^(3-i)
-            float w = 0.0f;
+            float w = 0.0f;                       // Horner, oldest first: ((e0 a + e1) a + e2) a + e3
 #pragma unroll
             for (int i = 0; i < DE; ++i) {
-                const float eh = (a.C == 2 ? (ha[i] * ha[i] + hb[i] * hb[i]) : ha[i] * ha[i]) * invC;
+                const float eh = (stereo ? (ha[i] * ha[i] + hb[i] * hb[i]) : ha[i] * ha[i]) * invC;
                 w = fmaf(a1, w, eh);
             }
-            hs = w * a_lane;                      // x a^(4 lane); the wave's own a^(256 wave) is applied below
+            hs = w * a_lane;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) hs += __shfl_xor(hs, d, 64);
-        if (lane == 0) slots[4 + wave] = hs;
-    } else if (lane == 0) {
-        slots[4 + wave] = 0.0f;
+        carry = hs;
     }
-    __syncthreads();
-    // entering state of the tile, then of this wave
-    float state = 0.0f, aw = 1.0f;
+    float* u1row = u1 ? u1 + (int64_t)r * a.L : nullptr;
+    const bool vu = (a.L % 4) == 0;
 #pragma unroll
-    for (int w = 0; w < DT / 64; ++w) {
-        state = fmaf(aw, slots[4 + w], state);
-        aw *= a_wave;
-    }
-    float entering = state;
+    for (int k = 0; k < OS_SUB; ++k) {
+        const float pre = fmaf(a_lane, carry, excl[k]);   // u just before this lane's first sample of sub-tile k
+        carry = fmaf(a_sub, carry, total[k]);
+        float ga[DE], gb[DE], raw[DE];
 #pragma unroll
-    for (int w = 0; w < DT / 64; ++w) {
-        if (w == wave) entering = state;
-        state = fmaf(a_wave, state, slots[w]);
+        for (int i = 0; i < DE; ++i) {
+            const float u = fmaf(apk[i], pre, loc[k][i]);
+            raw[i] = one_m_a * u;
+            const float env = fmaxf(raw[i], 0.0f);                       // relu, envelope.py:48
+            const float G = FastMath::log(env + 1e-5f);                  // dynamics.py:394
+            const float g = FastMath::exp(log_gain_m<FastMath>(q, G));   // 402-403
+            ga[i] = g * xa[k][i];
+            gb[i] = g * xb[k][i];
+        }
+        const int64_t n = n0 + 256 * k;
+        if (u1row) store4(u1row, n, a.L, vu, raw);
+        store4(y0, n, a.L, vx, ga);
+        if (stereo) store4(y1, n, a.L, vx, gb);
     }
-    const float pre = fmaf(a_lane, entering, excl);   // u just before this thread's first sample
-    const float apk[DE] = {ap1, ap2, ap3, ap4};
-    float ga[DE], gb[DE], raw[DE];
-#pragma unroll
-    for (int i = 0; i < DE; ++i) {
-        const float u = fmaf(apk[i], pre, loc[i]);
-        raw[i] = one_m_a * u;
-        const float env = fmaxf(raw[i], 0.0f);                // relu, envelope.py:48
-        const float G = logf(env + 1e-5f);                    // dynamics.py:394
-        const float g = expf(log_gain(q, G));                 // 402-403
-        ga[i] = g * xa[i];
-        gb[i] = g * xb[i];
-    }
-    if (u1) store4(u1 + (int64_t)r * a.L, n, a.L, (a.L % 4) == 0, raw);
-    store4(y0, n, a.L, vx, ga);
-    if (a.C == 2) store4(y1, n, a.L, vx, gb);
 }
 
 // ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
@@ -1414,14 +1433,15 @@ int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     // With a workspace and a smoother: the pole table, then the dependency-free one-shot grid for the rows whose
     // history fits (decided per row on the device), then the row kernel for the others (same table, complementary test).
     const float* tab = nullptr;
-    if (ws && smoother == 1 && ntiles > 1 && R * ntiles <= 0x7ffffff0LL) {
+    const int64_t ngroups = (L + OS_GTILE - 1) / OS_GTILE;
+    if (ws && smoother == 1 && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL) {
         float* t = (float*)ws;
         hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, t, param_rows, iir_len);
-        const unsigned nblocks = (unsigned)(R * ntiles);
+        const unsigned nblocks = (unsigned)(R * ngroups);
         a.nchunks = 1;
         a.chunk_tiles = 1;
         hipLaunchKernelGGL(dyn_oneshot_kernel, dim3((nblocks + 7u) & ~7u), dim3(DT), 0, st, x, y, log_threshold, log_ratio,
-                           log_knee, (const float*)t, a, (unsigned)ntiles, nblocks, u1);
+                           log_knee, (const float*)t, a, (unsigned)ngroups, nblocks, u1);
         tab = t;
     }
     // Few rows: one workgroup per row walks the whole length serially (~2 us per tile) and the launch is bound by

@@ -31,6 +31,14 @@ def test_bench_gpus_2_launches_two_ranks():
     assert out["scaling"] == "weak" and out["steps"] == 2 and out["warmup"] == 1
     assert abs(out["ms_per_step"] - max(out["per_rank_ms_per_step"])) < 1e-9  # the job's time is the MAX over ranks
     assert "dry" in out
+    # the training leg runs in the dry mode too: backward through the render + ONE flat all-reduce; every rank renders a
+    # different shard (seeded by rank), so equal gradients afterwards mean the reduction really happened
+    tr = out["training"]
+    assert "error" not in tr, tr
+    assert tr["grad_floats"] > 0 and tr["grad_sync"]["ranks"] == 2
+    assert tr["grad_sync"]["grad_abs_sum"] > 0 and tr["grad_sync"]["max_abs_diff_across_ranks"] == 0.0
+    # each rank reports the process group it joined (what a SCALE log will show for RCCL)
+    assert res.stderr.count("torch.distributed backend=gloo world_size=2") == 2, res.stderr[-2000:]
 
 
 def test_bench_single_rank_dry():

@@ -305,8 +305,8 @@ def test_fsm_taps_backward_matches_torch_autograd(N):
 @pytest.mark.gpu
 def test_compressor_backward_with_and_without_the_kept_scan_agree():
     """gfx_dynamics_bwd_f32 (scan x again, then the backward-in-time pass) and gfx_dynamics_bwd_u1_f32 (the same pass on
-    the scan gfx_dynamics_fused_u1_f32 kept in the forward) are the same arithmetic: identical gradients, bit for bit,
-    including rows with a live truncation term; the forward that keeps the scan returns the plain forward's output."""
+    the scan kept in the forward) are the same arithmetic: identical gradients, bit for bit with the row schedule (to rounding
+    with the one-shot tiles), including rows with a live truncation term; the forward that keeps the scan returns the plain forward's output."""
     import torch
 
     from grafx_amd import ops
@@ -319,12 +319,16 @@ def test_compressor_backward_with_and_without_the_kept_scan_agree():
     z = torch.tensor([[20.0], [6.0], [3.0], [0.0], [-2.0], [1.0]], device="cuda")   # clamp, live truncation, fast poles
     for knee in ("quadratic", "hard"):
         lkk = None if knee == "hard" else lk
-        y0 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False)
-        u1 = torch.empty(R, L, device="cuda")
-        y1 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False, u1_out=u1)
-        assert torch.equal(y0, y1)
         a = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False)
-        b = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False, u1=u1)
-        for ta, tb, name in zip(a, b, ("gx", "gparams", "dalpha")):
-            assert torch.equal(ta, tb), name
         assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all() and torch.isfinite(a[2]).all()
+        for sched in ("rows", "oneshot"):
+            y0 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False, schedule=sched)
+            u1 = torch.empty(R, L, device="cuda")
+            y1 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False, u1_out=u1, schedule=sched)
+            assert torch.equal(y0, y1)
+            b = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False, u1=u1)
+            for ta, tb, name in zip(a, b, ("gx", "gparams", "dalpha")):
+                if sched == "rows":     # the row kernel keeps exactly the scan the backward would recompute
+                    assert torch.equal(ta, tb), name
+                else:                   # one-shot tiles rebuild the state from a history dot product: same to rounding
+                    assert (ta - tb).abs().max() <= 2e-5 * ta.abs().max().clamp_min(1e-12), (name, sched)

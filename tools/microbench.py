@@ -179,6 +179,15 @@ def main():
                     ms = timeit(lambda: cp.render_into(x.view(1, R, 2, L), y.view(1, R, 2, L), **q), a.iters)
                     print(f"comp {sched:8s} {label:30s} R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
             ops.DYN_SCHEDULE = "oneshot"
+        if a.what in ("comp1",):   # one-shot vs row schedule at the headline poles, plus the copy the same bytes make
+            cp = P.Compressor(energy_smoother="iir", iir_len=16383, flashfftconv=False).to(dev)
+            p = {k: 0.1 * torch.randn(R, 1, device=dev) for k in cp.parameter_size()}
+            for sched in ("rows", "oneshot", "rows", "oneshot"):
+                ops.DYN_SCHEDULE = sched
+                ms = timeit(lambda: cp.render_into(x.view(1, R, 2, L), y.view(1, R, 2, L), **p), a.iters)
+                print(f"comp {sched:8s} R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
+            ms = timeit(lambda: y.copy_(x), a.iters)
+            print(f"torch copy    R={R} {ms:8.3f} ms  {gb / ms * 1e3:8.1f} GB/s")
         if a.what in ("reverb", "all"):
             Rr = max(R // 8, 1)
             rv = P.STFTMaskedNoiseReverb(ir_len=60001, flashfftconv=False).to(dev)
