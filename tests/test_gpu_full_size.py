@@ -232,7 +232,7 @@ def test_oneshot_schedule_of_the_fused_dynamics_equals_the_row_schedule(iir_len)
             c = ops.dynamics_fused(x, p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"], schedule="oneshot", **kw)
             assert torch.isfinite(b).all() and torch.isfinite(ub).all()
             assert (a - b).abs().max() <= 5e-6 * a.abs().max(), (C, Lc, knee, gate)
-            assert (b - c).abs().max() <= 2e-6 * a.abs().max()   # (without `u1` few long-memory rows run time-chunked)
+            assert (b - c).abs().max() <= 1e-5 * a.abs().max()   # (without `u1` few long-memory rows run time-chunked)
             assert (ua - ub).abs().max() <= 5e-6 * ua.abs().max(), (C, Lc, knee, gate)
 
 
