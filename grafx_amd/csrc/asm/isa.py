@@ -28,6 +28,8 @@ class R:
         self.kind, self.idx, self.n = kind, int(idx), int(n)
 
     def __repr__(self):
+        if self.kind in ("vcc", "exec"):
+            return self.kind
         if self.n == 1:
             return f"{self.kind}{self.idx}"
         return f"{self.kind}[{self.idx}:{self.idx + self.n - 1}]"
@@ -100,9 +102,9 @@ def _fmt_mods(m, keys):
 
 
 def render_inst(i):
-    op, m = i.op, i.mods
     if isinstance(i, Label):
         return f"{i.name}:"
+    op, m = i.op, i.mods
     c = f"  ; {i.comment}" if i.comment else ""
     if op.startswith("v_pk_"):
         ops = ", ".join(map(repr, (i.dst,) + i.src))
@@ -137,6 +139,8 @@ def render_inst(i):
         return "\ts_waitcnt " + " ".join(parts) + c
     if op.startswith("s_load_dword"):
         return f"\t{op} {i.dst!r}, {i.src[0]!r}, {hex(m.get('offset', 0))}" + c
+    if op == ";touch":
+        return "\t; (registers needed from here on: " + ", ".join(map(repr, i.src)) + ")"
     if op in ("s_barrier", "s_endpgm"):
         return f"\t{op}" + c
     if op in ("s_nop", "s_setprio", "s_sleep"):
@@ -415,8 +419,9 @@ class Emulator:
                 if bad.any():
                     raise EmuError(f"wave {w.wid} pc {w.pc}: LDS read of data written by another wave in the same barrier "
                                    f"interval (missing s_barrier) -- {render_inst(i).strip()}")
+                fresh = self.lds_repoch[idx] != self.epoch          # first read of this dword in this interval
+                self.lds_rwave[idx] = np.where(fresh | (self.lds_rwave[idx] == w.wid), w.wid, -2)
                 self.lds_repoch[idx] = self.epoch
-                self.lds_rwave[idx] = np.where(self.lds_rwave[idx] == -1, w.wid, np.where(self.lds_rwave[idx] == w.wid, w.wid, -2))
             vals = np.zeros(WAVE, dtype=np.uint32)
             vals[w.exec] = self.lds[idx]
             self.wrv(w, i.dst, d, vals)
@@ -497,7 +502,8 @@ class Emulator:
             self.wr64s(w, i.dst, r)
             w.scc = int(r != 0)
         elif op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32", "s_mul_i32", "s_mul_hi_u32", "s_lshl_b32",
-                    "s_lshr_b32", "s_and_b32", "s_or_b32", "s_min_u32", "s_max_u32", "s_andn2_b32", "s_ashr_i32", "s_xor_b32"):
+                    "s_lshr_b32", "s_and_b32", "s_or_b32", "s_min_u32", "s_max_u32", "s_andn2_b32", "s_ashr_i32", "s_xor_b32",
+                    "s_max_i32", "s_min_i32"):
             a, b = int(self.rds(w, i.src[0])), int(self.rds(w, i.src[1]))
             if op == "s_add_u32":
                 r = a + b
@@ -537,6 +543,11 @@ class Emulator:
             elif op == "s_xor_b32":
                 r = a ^ b
                 w.scc = int(r != 0)
+            elif op in ("s_max_i32", "s_min_i32"):
+                sa = a - (1 << 32) if a >> 31 else a
+                sb = b - (1 << 32) if b >> 31 else b
+                r = max(sa, sb) if op == "s_max_i32" else min(sa, sb)
+                w.scc = int((sa >= sb) if op == "s_max_i32" else (sa <= sb))
             elif op == "s_min_u32":
                 r = min(a, b)
                 w.scc = int(a <= b)
@@ -574,8 +585,10 @@ class Emulator:
             self._issue(w, "lgkm", [("s", i.dst.idx + d) for d in range(nd)])
         elif op == "s_waitcnt":
             self._waitcnt(w, m)
-        elif op in ("s_nop", "s_setprio", "s_sleep"):
-            pass
+        elif op in ("s_nop", "s_setprio", "s_sleep", ";touch"):
+            if op == ";touch":
+                for x in i.src:
+                    self._check_ready(w, x, "use of")
         elif op == "s_barrier":
             if w.lgkm and any(len(x) == 0 for x in w.lgkm):
                 raise EmuError(f"wave {w.wid} pc {w.pc}: s_barrier with LDS writes still outstanding (needs s_waitcnt lgkmcnt(0))")

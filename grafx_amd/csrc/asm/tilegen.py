@@ -110,11 +110,12 @@ def _match_const(idx32, inv):
 
 
 class TileGen(Emit):
-    def __init__(self, sgpr_const_tw, sgpr_one_neg=None):
-        """sgpr_const_tw: dict j -> SGPR pair holding P_j; sgpr_one_neg: SGPR pair (1.0, -1.0)"""
+    def __init__(self, sgpr_const_tw, sgpr_one_neg=None, sgpr_c2=None):
+        """sgpr_const_tw: dict j -> SGPR pair holding P_j; sgpr_one_neg: SGPR pair (1.0, -1.0); sgpr_c2: (-2.0, 2.0)"""
         super().__init__()
         self.ctw = sgpr_const_tw
         self.one_neg = sgpr_one_neg
+        self.c2 = sgpr_c2
 
     def cmul_const(self, d, a, idx32, inv, tmp=None):
         """d = a * W_32^(+-idx32) for a general (non-trivial) constant twiddle: two packed instructions"""
@@ -151,32 +152,34 @@ class TileGen(Emit):
         self.cmul_const(d, a, k, inv, tmp)
 
     # ---- in-register radix-2 DIF DFT of n = 16 or 32 points; result for frequency k ends up at vals[brev(k)] ----------
+    # Every butterfly is IN PLACE, so a value never changes its register (the register map of a whole tile is static):
+    #   trivial twiddle (1):   A' = A + B ;  B' = A' - 2 B                      (= A - B, one rounding more than a - b)
+    #   twiddle -+i:           A' = A + B ;  B' = (A' - 2 B) * (-+i)            (one packed FMA with op_sel / neg)
+    #   general twiddle:       T = A - B ; A' = A + B ; B' = T * w              (T: the caller's scratch pair)
     def dif(self, vals, tmp, inv):
-        """vals: list of VGPR pairs (modified: entries are re-bound when a butterfly swaps its temp); tmp: a free pair.
-        Returns the free pair left over."""
         n = len(vals)
+        C2 = self.c2        # SGPR pair (-2.0, 2.0)
         length = n
         while length >= 2:
             half = length // 2
             for base in range(0, n, length):
                 for j in range(half):
-                    ia, ib = base + j, base + j + half
-                    a, b = vals[ia], vals[ib]
+                    a, b = vals[base + j], vals[base + j + half]
                     idx = j * (32 // length)
                     if idx == 0:
-                        self.csub(tmp, a, b)
                         self.cadd(a, a, b)
-                        vals[ib], tmp = tmp, b
-                    elif idx == 8:
-                        (self.sub_mul_pos_i if inv else self.sub_mul_neg_i)(tmp, a, b)
+                        self.add("v_pk_fma_f32", b, (b, C2, a), op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1])
+                    elif idx == 8 and not inv:   # (A - B)(-i) = (A'.y - 2 B.y, 2 B.x - A'.x)
                         self.cadd(a, a, b)
-                        vals[ib], tmp = tmp, b
+                        self.add("v_pk_fma_f32", b, (b, C2, a), op_sel=[1, 0, 1], op_sel_hi=[0, 1, 0], neg_hi=[0, 0, 1])
+                    elif idx == 8:               # (A - B)(+i) = (2 B.y - A'.y, A'.x - 2 B.x)
+                        self.cadd(a, a, b)
+                        self.add("v_pk_fma_f32", b, (b, C2, a), op_sel=[1, 1, 1], op_sel_hi=[0, 0, 0], neg_lo=[0, 0, 1])
                     else:
                         self.csub(tmp, a, b)
                         self.cadd(a, a, b)
                         self.cmul_const(b, tmp, idx, inv)
             length //= 2
-        return tmp
 
     # ---- per-thread twiddles (two-level, as TileTw in fft_tile.hpp) -----------------------------------------------
     def apply_tw(self, e, lo, hi, il, ih, conj, t1, t2):
@@ -205,10 +208,11 @@ def interleave(main, side, first=0.0, last=1.0):
     for idx in range(span):
         # side instruction k goes in front of main instruction lo + idx once idx passes its slot
         while k < len(side) and (k + 0.5) * span / len(side) <= idx:
-            out.append(side[k])
+            out.extend(side[k] if isinstance(side[k], list) else [side[k]])
             k += 1
         out.append(main[lo + idx])
-    out.extend(side[k:])
+    for grp in side[k:]:
+        out.extend(grp if isinstance(grp, list) else [grp])
     out.extend(main[hi:])
     return out
 

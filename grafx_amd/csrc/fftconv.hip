@@ -508,6 +508,115 @@ __global__ __launch_bounds__(TILE_T, 2) void corr1_kernel(const float* __restric
 }
 
 
+// ---- the hand-scheduled persistent kernels (csrc/asm/gen_fftconv_pipe.py) ---------------------------------------
+// Assembled at build time into one gfx950 code object that is embedded here and loaded per device on first use
+// (hipModuleLoadData: no file on disk, nothing to ship besides the library).
+}  // namespace gfx
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "fftconv_pipe_args.inc"
+#include "fftconv_pipe_hsaco.inc"
+namespace gfx {
+
+struct PipeModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[sizeof(kPipeVariants) / sizeof(kPipeVariants[0])] = {};
+    int cus = 0;
+    bool tried = false, ok = false;
+};
+
+static PipeModule* pipe_module() {
+    static std::mutex mu;
+    static PipeModule mods[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    PipeModule& m = mods[dev];
+    if (!m.tried) {
+        m.tried = true;
+        bool ok = hipModuleLoadData(&m.mod, kPipeCodeObject) == hipSuccess;
+        for (size_t i = 0; ok && i < sizeof(kPipeVariants) / sizeof(kPipeVariants[0]); ++i)
+            ok = hipModuleGetFunction(&m.fn[i], m.mod, kPipeVariants[i].name) == hipSuccess;
+        ok = ok && hipDeviceGetAttribute(&m.cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && m.cus >= 8;
+        m.ok = ok;
+        (void)hipGetLastError();
+    }
+    return m.ok ? &m : nullptr;
+}
+
+// q_est = mulhi(n, m) >> sh is floor(n / d) or one less for every 32-bit n (the kernel corrects by one)
+static inline void pipe_magic(uint32_t d, uint32_t& m, uint32_t& sh) {
+    sh = 31u - (uint32_t)__builtin_clz(d);
+    const unsigned __int128 q = ((unsigned __int128)1 << (32 + sh)) / d;
+    m = q > 0xffffffffu ? 0xffffffffu : (uint32_t)q;
+}
+
+// What the persistent kernels cover: one partition, no output offset, even row lengths (stores are whole sample pairs),
+// the same batch-major row grouping on every tensor, byte strides inside 32 bits, and an overlap the build has a variant
+// for.  Everything else runs on fftconv1_kernel.
+static int pipe_variant(const ConvArgs& a, const ConvGeom& g, bool tee, int64_t N) {
+    if (g.nparts != 1 || a.off != 0 || (a.Lout & 1) || (tee && (a.L & 1)) || N > TILE_M + 1) return -1;
+    if (a.L * 4 >= (int64_t(1) << 30) || a.Lout * 4 >= (int64_t(1) << 30)) return -1;
+    if (a.xmap.inner != a.ymap.inner || (tee && a.cmap.inner != a.xmap.inner)) return -1;
+    auto fits = [](const gfx_rowmap_t& mp) {
+        return mp.stride_inner >= 0 && mp.stride_ch >= 0 && mp.stride_outer >= 0 && mp.stride_inner * 4 < (int64_t(1) << 32) &&
+               mp.stride_ch * 4 < (int64_t(1) << 32);
+    };
+    if (!fits(a.xmap) || !fits(a.ymap) || (tee && !fits(a.cmap))) return -1;
+    for (size_t i = 0; i < sizeof(kPipeVariants) / sizeof(kPipeVariants[0]); ++i)
+        if (kPipeVariants[i].tee == tee && (int64_t)kPipeVariants[i].a_lo * 512 == a.O) return (int)i;
+    return -1;
+}
+
+static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* Hs, float* y, float* xcopy,
+                       const ConvArgs& a, const float2* tw, hipStream_t st) {
+    PipeKernArgs k;
+    memset(&k, 0, sizeof(k));
+    auto lo = [](const void* p) { return (uint32_t)reinterpret_cast<uint64_t>(p); };
+    auto hi = [](const void* p) { return (uint32_t)(reinterpret_cast<uint64_t>(p) >> 32); };
+    k.x_lo = lo(x); k.x_hi = hi(x); k.h_lo = lo(Hs); k.h_hi = hi(Hs); k.y_lo = lo(y); k.y_hi = hi(y);
+    k.c_lo = lo(xcopy); k.c_hi = hi(xcopy); k.tw_lo = lo(tw); k.tw_hi = hi(tw);
+    k.L_bytes = (uint32_t)(a.L * 4); k.Lout_bytes = (uint32_t)(a.Lout * 4);
+    k.V_bytes = (uint32_t)(a.V * 4); k.O_bytes = (uint32_t)(a.O * 4);
+    k.ntiles = (uint32_t)a.ntiles; k.nblocks = (uint32_t)a.nblocks;
+    pipe_magic(k.ntiles, k.m_ntiles, k.sh_ntiles);
+    k.inner = (uint32_t)a.xmap.inner;
+    pipe_magic(k.inner, k.m_inner, k.sh_inner);
+    k.hrows = a.hrows;
+    pipe_magic(k.hrows, k.m_hrows, k.sh_hrows);
+    k.cout_shift = a.Cout == 2 ? 1 : 0; k.cout_mask = a.Cout == 2 ? 1 : 0;
+    k.cin_mask = a.Cin == 2 ? 1 : 0; k.cf_mask = a.Cf == 2 ? 1 : 0; k.Cf = (uint32_t)a.Cf;
+    const unsigned grid = (unsigned)(2 * pm->cus) & ~7u;     // two resident workgroups per CU
+    k.per_xcd = (uint32_t)((a.nblocks + 7) / 8); k.wgs_per_xcd = grid / 8;
+    auto strides = [](const gfx_rowmap_t& mp, uint32_t& olo, uint32_t& ohi, uint32_t& in, uint32_t& ch) {
+        const uint64_t o = (uint64_t)mp.stride_outer * 4;
+        olo = (uint32_t)o; ohi = (uint32_t)(o >> 32); in = (uint32_t)(mp.stride_inner * 4); ch = (uint32_t)(mp.stride_ch * 4);
+    };
+    strides(a.xmap, k.xs_outer_lo, k.xs_outer_hi, k.xs_inner, k.xs_ch);
+    strides(a.ymap, k.ys_outer_lo, k.ys_outer_hi, k.ys_inner, k.ys_ch);
+    if (xcopy) strides(a.cmap, k.cs_outer_lo, k.cs_outer_hi, k.cs_inner, k.cs_ch);
+    size_t size = sizeof(k);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(pm->fn[variant], grid, 1, 1, TILE_T, 1, 1, 0, st, nullptr, config) == hipSuccess ? GFX_OK
+                                                                                                              : GFX_ELAUNCH;
+}
+
+// Whether GFX_SCHED_AUTO may pick the persistent kernel for large launches (decided by measurement)
+#ifndef GFX_PIPE_AUTO
+#define GFX_PIPE_AUTO 0
+#endif
+// GFX_SCHED_AUTO: which of the two kernels a launch gets.  GRAFX_FFTCONV_SCHED=tile|pipe overrides (A/B measurements).
+static int auto_schedule() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("GRAFX_FFTCONV_SCHED");
+        cached = e && !strcmp(e, "pipe") ? GFX_SCHED_PIPE : (e && !strcmp(e, "tile") ? GFX_SCHED_TILE : GFX_SCHED_AUTO);
+    }
+    return cached;
+}
+
 static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
 
 template <typename K>
@@ -676,6 +785,16 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     const float2* tw = tile_twiddle_table(st);
     if (!tw) return GFX_ELAUNCH;
 
+    // the persistent hand-scheduled kernel: by name, or by AUTO once a launch is large enough to fill its pipeline
+    PipeModule* pm = pipe_module();   // (loaded on the first call on a device, whatever the schedule: never mid-capture)
+    if (schedule == GFX_SCHED_AUTO && auto_schedule() != GFX_SCHED_AUTO) schedule = auto_schedule();
+    const int pv = pm ? pipe_variant(a, g, xcopy != nullptr, N) : -1;
+    if (schedule == GFX_SCHED_PIPE && pv < 0) {
+        if (auto_schedule() == GFX_SCHED_PIPE) schedule = GFX_SCHED_TILE;   // the override only steers what can be steered
+        else return GFX_EINVAL;
+    }
+    if (schedule == GFX_SCHED_PIPE || (schedule == GFX_SCHED_AUTO && pv >= 0 && GFX_PIPE_AUTO && a.nblocks >= 16 * pm->cus))
+        return launch_pipe(pm, pv, x, Hs, y, xcopy, a, tw, st);
     if (g.nparts == 1) {
         if (allow_lds(fftconv1_kernel<false>) || allow_lds(fftconv1_kernel<true>)) return GFX_ELAUNCH;
         if (xcopy)

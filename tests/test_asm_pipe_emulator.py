@@ -1,0 +1,113 @@
+"""CPU check of the hand-scheduled convolution kernel (grafx_amd/csrc/asm): the generated instruction list is executed by
+the wave-level emulator of `isa.py` -- the same list that is printed as gfx950 assembly -- on small problems, against a
+float64 convolution.  The emulator also rejects a schedule that reads a register before its load was waited for, or
+hands data across waves through LDS without a barrier, so a pass here means the arithmetic, the register map, the
+software pipeline across tiles (prologue, alternating banks, both exits) and the automatic s_waitcnt placement agree.
+
+No GPU involved; the GPU parity tests of the assembled kernel are in tests/test_gpu_fftconv.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _twiddle_table():
+    t = np.arange(256)
+    rows = []
+    for row in range(20):
+        if row < 4:
+            num, den = t * row, 8192.0
+        elif row < 12:
+            num, den = t * 4 * (row - 4), 8192.0
+        elif row < 16:
+            num, den = (t & 15) * (row - 12), 256.0
+        else:
+            num, den = (t & 15) * 4 * (row - 16), 256.0
+        ang = 2 * np.pi * num / den
+        rows.append(np.stack([np.cos(ang), -np.sin(ang)], -1))
+    return np.stack(rows).astype(np.float32)          # [20][256][2]
+
+
+def _spectra(h):
+    """taps (F, N) -> the (He, Ho) thread layout hspec_kernel writes: [F][17][256][4] float32"""
+    import fft_tile_model as model
+
+    out = np.zeros((h.shape[0], 17, 256, 4), np.float32)
+    for f in range(h.shape[0]):
+        He, Ho = model.filter_slots(h[f].astype(np.float64))
+        out[f, :, :, 0], out[f, :, :, 1] = He.real, He.imag
+        out[f, :, :, 2], out[f, :, :, 3] = Ho.real, Ho.imag
+    return out
+
+
+def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0):
+    from grafx_amd.csrc.asm import gen_fftconv_pipe as gen
+    from grafx_amd.csrc.asm.isa import Buffer, Emulator
+
+    rng = np.random.default_rng(seed)
+    O = (N - 1 + 511) & ~511
+    V = 16384 - O
+    a_lo = O // 512
+    Cout = max(C, Cf)
+    R = B * n
+    ntiles = (L + V - 1) // V
+    nblocks = R * Cout * ntiles
+    prog = gen.PipeGen(tee, a_lo).build()
+    # signals live in a (B, nodes, C, L) buffer with more node rows than the stage uses (strided views, as in the render)
+    nodes = n + 3
+    xbuf = rng.standard_normal((B, nodes, C, L)).astype(np.float32)
+    ybuf = np.full((B, nodes, Cout, L), np.nan, np.float32)
+    cbuf = np.full((B, nodes, C, L), np.nan, np.float32)
+    h = (rng.standard_normal((hrows * Cf, N)) / np.sqrt(N)).astype(np.float32)
+    mem = Buffer()
+    xa, ya, ca = mem.alloc(xbuf), mem.alloc(ybuf), mem.alloc(cbuf)
+    ha, ta = mem.alloc(_spectra(h)), mem.alloc(_twiddle_table())
+    x0 = xa + 4 * (1 * C * L)            # the stage reads node rows 1 .. n
+    y0 = ya + 4 * (2 * Cout * L)         # and writes node rows 2 .. n + 1
+    c0 = ca + 4 * (0 * C * L)
+    per_xcd = nblocks if tiles_per_wg is None else tiles_per_wg
+    m = {k: gen.magic(d) for k, d in (("ntiles", ntiles), ("inner", n), ("hrows", hrows))}
+    args = gen.pack_args(
+        x_lo=x0, x_hi=x0 >> 32, h_lo=ha, h_hi=ha >> 32, y_lo=y0, y_hi=y0 >> 32, c_lo=c0, c_hi=c0 >> 32, tw_lo=ta, tw_hi=ta >> 32,
+        L_bytes=4 * L, Lout_bytes=4 * L, V_bytes=4 * V, O_bytes=4 * O, ntiles=ntiles, nblocks=nblocks,
+        m_ntiles=m["ntiles"][0], sh_ntiles=m["ntiles"][1], inner=n, m_inner=m["inner"][0], sh_inner=m["inner"][1],
+        hrows=hrows, m_hrows=m["hrows"][0], sh_hrows=m["hrows"][1], cout_shift=Cout - 1, cout_mask=Cout - 1,
+        cin_mask=0 if C == 1 else 1, cf_mask=0 if Cf == 1 else 1, Cf=Cf, per_xcd=per_xcd, wgs_per_xcd=1,
+        xs_outer_lo=4 * nodes * C * L, xs_inner=4 * C * L, xs_ch=4 * L,
+        ys_outer_lo=4 * nodes * Cout * L, ys_inner=4 * Cout * L, ys_ch=4 * L,
+        cs_outer_lo=4 * nodes * C * L, cs_inner=4 * C * L, cs_ch=4 * L)
+    nwg = min(8, (nblocks + per_xcd - 1) // per_xcd)
+    for wg in range(nwg):
+        Emulator(prog, mem, gen.TILE_LDS_BYTES, kernarg=args, wg_id=wg, rng=np.random.default_rng(100 + wg)).run()
+    y = mem.read_back(ya).reshape(ybuf.shape)[:, 2: 2 + n]
+    cc = mem.read_back(ca).reshape(cbuf.shape)[:, 0: n]
+    x = xbuf[:, 1: 1 + n]
+    want = np.zeros((B, n, Cout, L))
+    for b in range(B):
+        for j in range(n):
+            r = b * n + j
+            for c in range(Cout):
+                hh = h[(r % hrows) * Cf + (c if Cf == 2 else 0)].astype(np.float64)
+                want[b, j, c] = np.convolve(x[b, j, c if C == 2 else 0].astype(np.float64), hh)[:L]
+    untouched = np.concatenate([mem.read_back(ya).reshape(ybuf.shape)[:, :2].ravel(),
+                                mem.read_back(ya).reshape(ybuf.shape)[:, 2 + n:].ravel()])
+    return y, want, cc, x, untouched
+
+
+@pytest.mark.parametrize("tee,C,Cf,L,tiles_per_wg", [(True, 1, 1, 20002, None), (False, 2, 1, 12288 * 2, 2), (True, 2, 2, 9000, 3)])
+def test_pipe_kernel_in_the_emulator(tee, C, Cf, L, tiles_per_wg):
+    B, n, N = 2, 2, 4001
+    y, want, cc, x, untouched = _run(tee, B, n, C, Cf, L, N, hrows=n, tiles_per_wg=tiles_per_wg)
+    assert np.isfinite(y).all()
+    err = np.abs(y - want).max() / np.abs(want).max()
+    assert err < 5e-6, err
+    assert np.isnan(untouched).all()                 # rows of the buffer the stage does not own stay untouched
+    if tee:
+        assert np.array_equal(cc, x)
+    else:
+        assert np.isnan(cc).all()

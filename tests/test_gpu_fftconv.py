@@ -218,3 +218,73 @@ def test_filter_gradient_correlation_matches_float64(L, Lg, N, off, Cx, Cg):
     want4 = reference(view.reshape(-1, Cx, L), g4.reshape(-1, Cg, Lg)).float()
     got4 = ops.fir_grad(view, g4, N, off)
     assert (got4 - want4).abs().max() <= 2e-5 * want4.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GRAFX_FUZZ_PIPE_SEEDS", 24))))
+def test_pipe_schedule_matches_the_oracle_convolution(seed):
+    """The hand-scheduled persistent kernel (gfx_fftconv_sched_f32, GFX_SCHED_PIPE: generated gfx950 assembly, csrc/asm)
+    forced onto small random problems it covers -- taps with a 4096-sample overlap, even lengths around the tile
+    boundaries (V = 12288), one to many tiles per row, fewer tiles than workgroups and more, channel broadcasts, shared
+    filters, strided buffer views and the input copy -- against the oracle and the compiler-built tile kernel."""
+    import random
+
+    import torch
+
+    from grafx_amd import ops
+
+    rng = random.Random(4000 + seed)
+    torch.manual_seed(seed)
+    L = rng.choice([2, 18, 1000, 8192, 12286, 12288, 12290, 16384, 24576, 24578, 40002, 70000, 131072])
+    N = rng.choice([3586, 3587, 4000, 4001, 4096, 4097])
+    Cin, Cf = rng.choice([(1, 1), (2, 1), (1, 2), (2, 2)])
+    B, n = rng.choice([(1, 1), (2, 3), (3, 2), (5, 1), (7, 9)])
+    shared = rng.random() < 0.5
+    buf = torch.randn(B, n + 2, Cin, L, device="cuda")
+    x4 = buf.narrow(1, 1, n)                                  # strided (B, n, C, L) view
+    h = torch.randn(n if shared else B * n, Cf, N, device="cuda") / N ** 0.5
+    Hs = ops.fir_spectrum(h.reshape(-1, N))
+    tee = None
+    if ops.fftconv_can_tee(Cin, Cf, L, L, 0, N) and rng.random() < 0.6:
+        tee = torch.full((B, n, Cin, L), float("nan"), device="cuda")
+    out = torch.full((B, n + 1, max(Cin, Cf), L), float("nan"), device="cuda")
+    ops.fftconv(x4, Hs, N, Cf, out=out.narrow(1, 0, n), h_rows=h.shape[0], tee=tee, schedule="pipe")
+    y = out[:, :n].reshape(B * n, max(Cin, Cf), L)
+    hx = (h.repeat(B, 1, 1) if shared else h).cpu()
+    ref = lti.linear_convolve(x4.reshape(B * n, Cin, L).cpu(), hx, "full")[..., :L]
+    scale = ref.abs().max().clamp_min(1e-6)
+    what = f"L={L} N={N} C={Cin}/{Cf} B={B} n={n} shared={shared} tee={tee is not None}"
+    assert torch.isfinite(y).all(), what
+    assert torch.isnan(out[:, n]).all(), what                # the row behind the stage's rows is not touched
+    assert (y.cpu() - ref).abs().max() <= 2e-5 * scale, what
+    if tee is not None:
+        assert torch.equal(tee, x4), what
+    y_tile = ops.fftconv(x4, Hs, N, Cf, h_rows=h.shape[0], schedule="tile")
+    assert (y - y_tile).abs().max() <= 4e-6 * scale, what
+
+
+@pytest.mark.gpu
+def test_pipe_schedule_headline_shape_against_the_tile_schedule():
+    """The shape the console's first stage launches (32 shared filters, stereo, L = 131072, N = 4001, output and input
+    copy written into strided views of one buffer) at 8 graphs: persistent kernel vs one tile per workgroup, every
+    sample; and what the schedule does not cover is refused by name."""
+    import torch
+
+    from grafx_amd import ops
+
+    torch.manual_seed(5)
+    B, n, L, N = 8, 32, 131072, 4001
+    x4 = torch.randn(B, n, 2, L, device="cuda")
+    h = torch.randn(n, 1, N, device="cuda") / N ** 0.5
+    Hs = ops.fir_spectrum(h.reshape(-1, N))
+    buf = torch.zeros(B, 3 * n, 2, L, device="cuda")
+    ops.fftconv(x4, Hs, N, 1, out=buf.narrow(1, n, n), tee=buf.narrow(1, 0, n), h_rows=n, schedule="pipe")
+    want = ops.fftconv(x4, Hs, N, 1, h_rows=n, schedule="tile")
+    assert torch.equal(buf[:, :n], x4)
+    assert (buf[:, n : 2 * n].reshape(B * n, 2, L) - want).abs().max() <= 4e-6 * want.abs().max()
+    assert (buf[:, 2 * n :] == 0).all()
+    with pytest.raises(RuntimeError):                         # odd length: not covered, refused
+        ops.fftconv(x4[..., :4097], Hs, N, 1, h_rows=n, schedule="pipe")
+    h2 = torch.randn(n, 1, 100, device="cuda")
+    with pytest.raises(RuntimeError):                         # no variant for a 512-sample overlap
+        ops.fftconv(x4, ops.fir_spectrum(h2.reshape(-1, 100)), 100, 1, h_rows=n, schedule="pipe")
