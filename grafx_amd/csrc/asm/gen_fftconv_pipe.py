@@ -23,8 +23,8 @@ import struct
 import sys
 
 from .isa import EXEC, Inst, Label, Lit, R, render, s, v
-from .tilegen import (CONST_TW_J, S1_ROW, S2_ROW, TILE_LDS_BYTES, TileGen, brev, const_tw_values, insert_waitcnt,
-                      interleave)
+from .tilegen import (CONST_TW_J, S1_ROW, S2_ROW, TILE_LDS_BYTES, TileGen, brev, cluster_at, const_tw_values,
+                      insert_waitcnt, interleave)
 
 # ---- kernel arguments: 48 dwords, loaded into s[ARG0 : ARG0 + 48) ---------------------------------------------------
 ARG_NAMES = ["x_lo", "x_hi", "h_lo", "h_hi", "y_lo", "y_hi", "c_lo", "c_hi", "tw_lo", "tw_hi",
@@ -71,9 +71,23 @@ TW_ROWS = {**{i: LO1[i] for i in LO1}, **{4 + i: HI1[i] for i in HI1}, **{12 + i
            **{16 + i: HI2[i] for i in HI2}}                               # table row -> register pair
 H_BASE = 56
 HQ = [v(H_BASE + 4 * q, 4) for q in range(17)]
-BANK_A = [v(124 + 2 * i, 2) for i in range(32)]
-BANK_B = [v(188 + 2 * i, 2) for i in range(32)]
-NUM_VGPR = 252
+
+
+class Bank:
+    """32 complex values of a tile plus the spare pair the FMA butterflies rotate through.  `land`: where loads and LDS
+    reads put logical element i (fixed, contiguous: element pairs form aligned quads); `nat[i]`: register of spectrum
+    bin NAT i between the forward and the inverse transform; `rows[a]`: register of output time row a after the inverse
+    transform -- both static, found by the generator."""
+
+    def __init__(self, base, spare):
+        self.land = [v(base + 2 * i, 2) for i in range(32)]
+        self.spare = spare
+        self.nat = self.free = self.rows = None
+
+
+BANK_A = Bank(124, v(54, 2))
+BANK_B = Bank(188, v(252, 2))
+NUM_VGPR = 254
 
 S_CTW = {j: s(56 + 2 * k, 2) for k, j in enumerate(CONST_TW_J)}    # s[56:63]
 S_ONE_NEG = s(64, 2)
@@ -92,11 +106,39 @@ H_TILE_BYTES = 17 * 256 * 16
 RSRC_FLAGS = 0x00020000
 
 
+# Schedule knobs (tuning and timing-only ablations; the defaults are what the library embeds)
+KNOBS = dict(
+    fwd_window=(0.0, 1.0),    # where in the forward transform the previous tile's stores / the next window's loads go
+    inv_window=(0.0, 1.0),    # where in the inverse transform the tee stores / the next spectrum's loads go
+    ablate="",                  # comma list out of: nostore, nowin, noh, notee  (timing only: results are wrong)
+    prio=0,                     # s_setprio level while a tile's arithmetic runs (0: off)
+    place="spread",             # spread: evenly inside the windows; barrier / after: in clusters before / after the barriers
+    inv_order="tee_first",      # tee_first / h_first / mix: order of the tee stores and the spectrum loads in the inverse
+    codelet="dit",              # dit: radix-2 DIT with fused multiply-adds (3 instructions per general butterfly, values
+                                # rotate through a spare pair); dif: the in-place DIF of fft_tile.hpp (4 instructions)
+)
+
+
 class PipeGen(TileGen):
-    def __init__(self, tee, a_lo, stamps=False):
+    def __init__(self, tee, a_lo, **knobs):
         super().__init__(S_CTW, S_ONE_NEG, S_C2)
-        self.tee, self.a_lo, self.stamps = tee, a_lo, stamps
+        self.tee, self.a_lo = tee, a_lo
+        self.k = dict(KNOBS, **knobs)
+        self.ablate = set(filter(None, self.k["ablate"].split(",")))
         self.uid = 0
+        for bank in (BANK_A, BANK_B):       # where the inverse transform leaves the output rows (static per bank)
+            self.sub()
+            bank.rows, _ = self.dft(bank.land, bank.spare, True)
+            self.sub()
+
+    def dft(self, inputs, free, inv):
+        """DFT of the pairs `inputs` (natural order) -> (out, free): out[k] = pair holding frequency k"""
+        if self.k["codelet"] == "dit":
+            return self.dit(list(inputs), free, inv)
+        vals = list(inputs)
+        self.dif(vals, TMP[0], inv)
+        bits = len(vals).bit_length() - 1
+        return [vals[brev(k, bits)] for k in range(len(vals))], free
 
     def sop(self, op, dst, *src):
         self.add(op, dst, src)
@@ -206,6 +248,14 @@ class PipeGen(TileGen):
         """32 groups: row a of the next window -> bank[a]; rows before the row start (a < S_ALO, first tiles only) get an
         out-of-range offset and read as zero"""
         out = []
+        if "widemem" in self.ablate:     # timing experiment (wrong results): the same bytes as 16-byte accesses
+            for p in range(16):
+                grp = [Inst("s_mov_b32", S_OFF, (Lit(4096 * p),))]
+                if p < 8:
+                    grp += [Inst("s_cmp_gt_u32", None, (S_ALO, Lit(2 * p))), Inst("s_cselect_b32", S_OFF, (S_HUGE, S_OFF))]
+                grp.append(Inst("buffer_load_dwordx4", R("v", bank[2 * p].idx, 4), (V_OFF16, NX_X, S_OFF), {}))
+                out.append(grp)
+            return out
         for a in range(32):
             grp = []
             grp.append(Inst("s_mov_b32", S_OFF, (Lit(2048 * a),)))
@@ -219,6 +269,12 @@ class PipeGen(TileGen):
     def g_stores(self, regs_of_row, desc):
         """stores of the rows a >= a_lo (the tile's valid part): row a <- regs_of_row(a)"""
         out = []
+        if "widemem" in self.ablate:
+            for p in range(self.a_lo // 2, 16):
+                q = R("v", (BANK_A if regs_of_row(31).idx < BANK_B.land[0].idx else BANK_B).land[2 * p].idx, 4)
+                out.append([Inst("s_mov_b32", S_OFF, (Lit(4096 * p),)),
+                            Inst("buffer_store_dwordx4", None, (q, V_OFF16, desc, S_OFF), dict(nt=1))])
+            return out
         for a in range(self.a_lo, 32):
             out.append([Inst("s_mov_b32", S_OFF, (Lit(4096 * (a >> 1)),)),
                         Inst("buffer_store_dwordx2", None, (regs_of_row(a), V_OFF8, desc, S_OFF),
@@ -242,53 +298,50 @@ class PipeGen(TileGen):
         return prev
 
     def fwd_pass1(self, X):
-        t1, t2, t3 = TMP[0], TMP[1], TMP[2]
-        self.dif(X, t1, inv=False)
-        for r in range(32):
-            k1 = brev(r, 5)
-            self.apply_tw(X[r], LO1, HI1, k1 & 3, k1 >> 2, False, t1, t2)
+        t1, t2 = TMP[1], TMP[2]
+        out, _ = self.dft(X.land, X.spare, False)
+        for k1 in range(32):
+            self.apply_tw(out[k1], LO1, HI1, k1 & 3, k1 >> 2, False, t1, t2)
             base, off = (V_OFF8, 8 * S1_ROW * k1) if k1 < 16 else (V_P1HI, 8 * S1_ROW * (k1 - 16))
-            self.add("ds_write_b64", None, (base, X[r]), offset=off)
+            self.add("ds_write_b64", None, (base, out[k1]), offset=off)
 
     def fwd_read1(self, X):
-        # u[s][c] = S1[kk + 16 s][16 c + d] -> X[16 s + c]
+        # u[s][c] = S1[kk + 16 s][16 c + d] -> land[16 s + c]
         for sgrp in range(2):
             for c in range(16):
-                self.add("ds_read_b64", X[16 * sgrp + c], (V_P2,), offset=8 * (16 * sgrp * S1_ROW + 16 * c))
+                self.add("ds_read_b64", X.land[16 * sgrp + c], (V_P2,), offset=8 * (16 * sgrp * S1_ROW + 16 * c))
 
     def fwd_pass2(self, X):
-        t1, t2 = TMP[0], TMP[1]
+        t1, t2 = TMP[1], TMP[2]
+        free = X.spare
         for sgrp in range(2):
-            u = X[16 * sgrp: 16 * sgrp + 16]
-            self.dif(u, t1, inv=False)
-            for r in range(16):
-                k2 = brev(r, 4)
-                self.apply_tw(u[r], LO2, HI2, k2 & 3, k2 >> 2, False, t1, t2)
+            out, free = self.dft(X.land[16 * sgrp: 16 * sgrp + 16], free, False)
+            for k2 in range(16):
+                self.apply_tw(out[k2], LO2, HI2, k2 & 3, k2 >> 2, False, t1, t2)
                 off = 8 * S2_ROW * (k2 * 32 + 16 * sgrp)
                 base = V_P3
                 if k2 >= 8:
                     base, off = V_P3HI, off - 8 * S2_ROW * 8 * 32
-                self.add("ds_write_b64", None, (base, u[r]), offset=off)
+                self.add("ds_write_b64", None, (base, out[k2]), offset=off)
 
     def fwd_read2(self, X):
         # w[bf][2q], w[bf][2q+1] = row_j[q] (float4), j = t (bf 0) and 512 - t (bf 1; thread 0: 256)
         for bf, base in ((0, V_P4A), (1, V_P4B)):
             for q in range(8):
-                quad = R("v", X[16 * bf + 2 * q].idx, 4)
+                quad = R("v", X.land[16 * bf + 2 * q].idx, 4)
                 self.add("ds_read_b128", quad, (base,), offset=16 * q)
 
     def fwd_pass3(self, X):
+        free, nat = X.spare, []
         for bf in range(2):
-            self.dif(X[16 * bf: 16 * bf + 16], TMP[0], inv=False)
-
-    @staticmethod
-    def nat(X, i):
-        return X[16 * (i >> 4) + brev(i & 15, 4)]
+            out, free = self.dft(X.land[16 * bf: 16 * bf + 16], free, False)
+            nat += out
+        X.nat, X.free = nat, free
 
     def pair(self, X, ia, ib, hq, wk_idx, wj, self_pair):
         """one mirrored bin pair (fft_tile.hpp: pair_split / pair_product / pair_merge).  wk = wj * W_32^wk_idx when wj
         is a register pair, else the constant W_32^wk_idx."""
-        za, zb = self.nat(X, ia), self.nat(X, ib)
+        za, zb = X.nat[ia], X.nat[ib]
         xe, xo, who, ye, yo, wk = TMP
         he, ho = hq.sub(0, 2), hq.sub(2, 2)
         self.add_conj(xe, za, zb)
@@ -320,6 +373,9 @@ class PipeGen(TileGen):
             self.pair(X, k3, 16 + (15 - k3), HQ[k3], 2 * k3, wj, False)
         # thread 0 (wave 0, lane 0) owns the two self-mirrored butterflies j = 0 and j = 256
         skip = self.fresh("not_t0")
+        if "not0" in self.ablate:          # timing experiment: what thread 0's extra pairs cost the workgroup
+            self.add("s_mov_b64", EXEC, (Lit(-1),))
+            return
         self.add("s_cmp_eq_u32", None, (S_WAVE0, Lit(0)))
         self.add("s_cbranch_scc1", target=skip)
         self.add("s_mov_b64", EXEC, (Lit(1),))
@@ -333,45 +389,44 @@ class PipeGen(TileGen):
         self.add("s_mov_b64", EXEC, (Lit(-1),))
 
     def inv_pass1(self, X):
-        # p[k] = w[bf][brev4(k)] (a renaming), dif16 inverse, row_j[q] = (p[brev(2q)], p[brev(2q+1)]) = registers (2q, 2q+1)
+        # rows j of S2 get the inverse 16-point transforms over k3 of the two butterfly sets (element e at row_j + 8 e)
+        free = X.free
         for bf, base in ((0, V_P4A), (1, V_P4B)):
-            W = X[16 * bf: 16 * bf + 16]
-            p = [W[brev(k, 4)] for k in range(16)]
-            self.dif(p, TMP[0], inv=True)
-            for q in range(8):
-                assert p[brev(2 * q, 4)] == W[2 * q] and p[brev(2 * q + 1, 4)] == W[2 * q + 1]
-                self.add("ds_write_b128", None, (base, R("v", W[2 * q].idx, 4)), offset=16 * q)
+            out, free = self.dft(X.nat[16 * bf: 16 * bf + 16], free, True)
+            for e in range(16):
+                self.add("ds_write_b64", None, (base, out[e]), offset=8 * e)
 
     def inv_read2(self, X):
-        t1, t2 = TMP[0], TMP[1]
+        t1, t2 = TMP[1], TMP[2]
         for sgrp in range(2):
             for k2 in range(16):
                 off = 8 * S2_ROW * (k2 * 32 + 16 * sgrp)
                 base = V_P3
                 if k2 >= 8:
                     base, off = V_P3HI, off - 8 * S2_ROW * 8 * 32
-                self.add("ds_read_b64", X[16 * sgrp + k2], (base,), offset=off)
+                self.add("ds_read_b64", X.land[16 * sgrp + k2], (base,), offset=off)
         for sgrp in range(2):
             for k2 in range(16):
-                self.apply_tw(X[16 * sgrp + k2], LO2, HI2, k2 & 3, k2 >> 2, True, t1, t2)
+                self.apply_tw(X.land[16 * sgrp + k2], LO2, HI2, k2 & 3, k2 >> 2, True, t1, t2)
 
     def inv_pass2(self, X):
+        free = X.spare
         for sgrp in range(2):
-            u = X[16 * sgrp: 16 * sgrp + 16]
-            self.dif(u, TMP[0], inv=True)
-            for r in range(16):
-                self.add("ds_write_b64", None, (V_P2, u[r]), offset=8 * (16 * sgrp * S1_ROW + 16 * brev(r, 4)))
+            out, free = self.dft(X.land[16 * sgrp: 16 * sgrp + 16], free, True)
+            for c in range(16):
+                self.add("ds_write_b64", None, (V_P2, out[c]), offset=8 * (16 * sgrp * S1_ROW + 16 * c))
 
     def inv_read3(self, X):
-        t1, t2 = TMP[0], TMP[1]
+        t1, t2 = TMP[1], TMP[2]
         for k1 in range(32):
             base, off = (V_OFF8, 8 * S1_ROW * k1) if k1 < 16 else (V_P1HI, 8 * S1_ROW * (k1 - 16))
-            self.add("ds_read_b64", X[k1], (base,), offset=off)
+            self.add("ds_read_b64", X.land[k1], (base,), offset=off)
         for k1 in range(32):
-            self.apply_tw(X[k1], LO1, HI1, k1 & 3, k1 >> 2, True, t1, t2)
+            self.apply_tw(X.land[k1], LO1, HI1, k1 & 3, k1 >> 2, True, t1, t2)
 
     def inv_pass3(self, X):
-        self.dif(X, TMP[0], inv=True)
+        rows, _ = self.dft(X.land, X.spare, True)
+        assert rows == X.rows
 
     # ---- one tile in bank X while bank Y drains / refills -----------------------------------------------------------
     def iteration(self, X, Y, name):
@@ -394,8 +449,9 @@ class PipeGen(TileGen):
         self.fwd_read2(X)
         self.fwd_pass3(X)
         fwd = self.sub()
-        side = self.g_stores(lambda a: Y[brev(a, 5)], ST_Y) + self.g_window_loads(Y)
-        out += interleave(fwd, side, 0.02, 0.90)
+        side = ([] if "nostore" in self.ablate else self.g_stores(lambda a: Y.rows[a], ST_Y)) + \
+               ([] if "nowin" in self.ablate else self.g_window_loads(Y.land))
+        out += self.place(fwd, side, self.k["fwd_window"])
         self.product(X)
         out += self.sub()
         # inverse transform; meanwhile: the next window's valid part is copied out (tee), the next spectrum is requested
@@ -408,9 +464,27 @@ class PipeGen(TileGen):
         self.inv_read3(X)
         self.inv_pass3(X)
         inv = self.sub()
-        side = (self.g_stores(lambda a: Y[a], NX_T) if self.tee else []) + self.g_h_loads()
-        out += interleave(inv, side, 0.02, 0.85)
+        tee_st = self.g_stores(lambda a: Y.land[a], NX_T) if self.tee and "notee" not in self.ablate else []
+        h_ld = [] if "noh" in self.ablate else self.g_h_loads()
+        if self.k["inv_order"] == "h_first":
+            side = h_ld + tee_st
+        elif self.k["inv_order"] == "mix":
+            side, a, b = [], list(tee_st), list(h_ld)
+            while a or b:
+                if a and (not b or len(a) * len(h_ld) >= len(b) * max(len(tee_st), 1)):
+                    side.append(a.pop(0))
+                else:
+                    side.append(b.pop(0))
+        else:
+            side = tee_st + h_ld
+        out += self.place(inv, side, self.k["inv_window"])
         return out
+
+    def place(self, main, side, window):
+        mode = self.k["place"]
+        if mode == "spread":
+            return interleave(main, side, *window)
+        return cluster_at(main, side, lambda i: i.op == "s_barrier", before=(mode == "barrier"))
 
     # ---- whole kernel -----------------------------------------------------------------------------------------------
     def prologue(self):
@@ -482,10 +556,10 @@ class PipeGen(TileGen):
         self.decode(first=True)
         for k in range(4):
             self.mov_lit(CUR_Y.sub(k), 0 if k < 3 else RSRC_FLAGS)
-        for grp in self.g_window_loads(BANK_A):
+        for grp in self.g_window_loads(BANK_A.land):
             self.prog.extend(grp)
         if self.tee:
-            for grp in self.g_stores(lambda a: BANK_A[a], NX_T):
+            for grp in self.g_stores(lambda a: BANK_A.land[a], NX_T):
                 self.prog.extend(grp)
         for grp in self.g_h_loads():
             self.prog.extend(grp)
@@ -493,7 +567,7 @@ class PipeGen(TileGen):
 
     def exit_block(self, X):
         self.sub()
-        for grp in self.g_stores(lambda a: X[brev(a, 5)], CUR_Y):
+        for grp in self.g_stores(lambda a: X.rows[a], CUR_Y):
             self.prog.extend(grp)
         self.add("s_endpgm")
         return self.sub()
@@ -523,7 +597,8 @@ def kernel_name(tee, a_lo):
     return f"gfx_fftconv_pipe_t{int(tee)}_o{a_lo}"
 
 
-VARIANTS = [(False, 8), (True, 8)]      # (tee, a_lo): O = 4096 covers 3586 .. 4097 taps (the equalisers' 4001)
+# (tee, a_lo): overlap O = 512 a_lo covers filters of 512 (a_lo - 1) + 2 .. 512 a_lo + 1 taps; 8 is the equalisers' 4001
+VARIANTS = [(tee, a_lo) for a_lo in (1, 2, 4, 8, 16) for tee in (False, True)]
 
 
 def kernel_text(name, prog):
@@ -590,12 +665,12 @@ def metadata(names):
             "amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\n\t.end_amdgpu_metadata\n")
 
 
-def generate():
+def generate(**knobs):
     txt = '\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.amdhsa_code_object_version 6\n'
     names = []
     for tee, a_lo in VARIANTS:
         name = kernel_name(tee, a_lo)
-        prog = PipeGen(tee, a_lo).build()
+        prog = PipeGen(tee, a_lo, **knobs).build()
         # labels are local to a kernel: make them unique per kernel
         for i in prog:
             if isinstance(i, Label):
@@ -607,7 +682,36 @@ def generate():
     return txt + metadata(names)
 
 
+def main(argv):
+    """gen_fftconv_pipe.py out.s | --hsaco out.hsaco  [knob=value ...]   (knobs: see KNOBS; tuples as a,b)"""
+    import os
+    import subprocess
+    import tempfile
+
+    knobs, pos, hsaco = {}, [], None
+    it = iter(argv)
+    for a in it:
+        if a == "--hsaco":
+            hsaco = next(it)
+        elif "=" in a:
+            k, val = a.split("=", 1)
+            cur = KNOBS[k]
+            knobs[k] = tuple(float(x) for x in val.split(",")) if isinstance(cur, tuple) else type(cur)(val)
+        else:
+            pos.append(a)
+    text = generate(**knobs)
+    if hsaco is None:
+        with open(pos[0] if pos else "/dev/stdout", "w") as f:
+            f.write(text)
+        return
+    llvm = os.environ.get("GRAFX_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "k.s"), "w") as f:
+            f.write(text)
+        subprocess.run([os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
+                        os.path.join(d, "k.s"), "-o", os.path.join(d, "k.o")], check=True)
+        subprocess.run([os.path.join(llvm, "ld.lld"), "-shared", os.path.join(d, "k.o"), "-o", hsaco], check=True)
+
+
 if __name__ == "__main__":
-    out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
-    with open(out, "w") as f:
-        f.write(generate())
+    main(sys.argv[1:])

@@ -181,6 +181,52 @@ class TileGen(Emit):
                         self.cmul_const(b, tmp, idx, inv)
             length //= 2
 
+    # ---- in-register radix-2 DIT DFT with fused multiply-adds ---------------------------------------------------------
+    # A general butterfly (a, b) -> (a + w b, a - w b) is THREE packed instructions: T = a + w b as two FMAs, then
+    # b' = 2 a - T.  The sum lands in a scratch pair and a's old register becomes the scratch of the next butterfly, so
+    # values move between registers -- statically: the generator tracks where every value lives.  Trivial twiddles
+    # (1, -+i) stay in place with two instructions as in `dif`.
+    def dit(self, inputs, free, inv):
+        """DFT of `inputs` (register pairs in NATURAL input order, n = 16 or 32).  Returns (out, free): out[k] = the pair
+        that holds frequency k, free = the pair left over.  Registers used: exactly inputs + [free]."""
+        n = len(inputs)
+        bits = n.bit_length() - 1
+        pos = [inputs[brev(i, bits)] for i in range(n)]
+        C2 = self.c2
+        h = 1
+        while h < n:
+            for base in range(0, n, 2 * h):
+                for j in range(h):
+                    ia, ib = base + j, base + j + h
+                    a, b = pos[ia], pos[ib]
+                    idx = j * (32 // (2 * h))          # w = W_{2h}^j = W_32^idx
+                    if idx == 0:
+                        self.cadd(a, a, b)
+                        self.add("v_pk_fma_f32", b, (b, C2, a), op_sel=[0, 0, 0], op_sel_hi=[1, 0, 1])          # a' - 2 b
+                    elif idx == 8:
+                        # w b = -+i b.  forward (-i): a' = a - i b = (a.x + b.y, a.y - b.x); b' = 2 a - a'
+                        # in place: a' first needs old a for b' -> compute b' = a + i b from (a, b), then a' = 2 a - b'
+                        if not inv:
+                            self.add("v_pk_add_f32", free, (a, b), op_sel=[0, 1], op_sel_hi=[1, 0], neg_hi=[0, 1])   # a - i b
+                        else:
+                            self.add("v_pk_add_f32", free, (a, b), op_sel=[0, 1], op_sel_hi=[1, 0], neg_lo=[0, 1])   # a + i b
+                        self.add("v_pk_fma_f32", b, (a, C2, free), op_sel=[0, 1, 0], op_sel_hi=[1, 1, 1],
+                                 neg_lo=[0, 0, 1], neg_hi=[0, 0, 1])                                                  # 2 a - a'
+                        pos[ia], free = free, a
+                    else:
+                        j_, ir, sr, ii, si = _match_const(idx, inv)
+                        P = self.ctw[j_]
+                        nr = int(sr < 0)
+                        self.add("v_pk_fma_f32", free, (b, P, a), op_sel=[0, ir, 0], op_sel_hi=[1, ir, 1],
+                                 neg_lo=[0, nr, 0], neg_hi=[0, nr, 0])
+                        self.add("v_pk_fma_f32", free, (b, P, free), op_sel=[1, ii, 0], op_sel_hi=[0, ii, 1],
+                                 neg_lo=[0, int(si > 0), 0], neg_hi=[0, int(si < 0), 0])
+                        self.add("v_pk_fma_f32", b, (a, C2, free), op_sel=[0, 1, 0], op_sel_hi=[1, 1, 1],
+                                 neg_lo=[0, 0, 1], neg_hi=[0, 0, 1])
+                        pos[ia], free = free, a
+            h *= 2
+        return pos, free
+
     # ---- per-thread twiddles (two-level, as TileTw in fft_tile.hpp) -----------------------------------------------
     def apply_tw(self, e, lo, hi, il, ih, conj, t1, t2):
         """e *= lo[il] * hi[ih] (conjugated for the inverse); lo / hi: dicts index -> VGPR pair (index 0 = one, absent)"""
@@ -214,6 +260,33 @@ def interleave(main, side, first=0.0, last=1.0):
     for grp in side[k:]:
         out.extend(grp if isinstance(grp, list) else [grp])
     out.extend(main[hi:])
+    return out
+
+
+def cluster_at(main, side, anchors, before=True, weights=None):
+    """Put the groups of `side` in clusters next to the anchor instructions of `main` (predicate `anchors(inst)`), e.g. in
+    front of every s_barrier: a wave that has to wait there anyway can spend the wait in the memory pipeline's queue."""
+    pos = [k for k, i in enumerate(main) if not isinstance(i, Label) and anchors(i)]
+    if not pos or not side:
+        return interleave(main, side)
+    w = weights or [1.0] * len(pos)
+    tot = float(sum(w[:len(pos)]))
+    counts, acc, given = [], 0.0, 0
+    for k in range(len(pos)):
+        acc += w[k] / tot * len(side)
+        c = int(round(acc)) - given
+        counts.append(c)
+        given += c
+    counts[-1] += len(side) - given
+    out, k0, sidx = [], 0, 0
+    for p, c in zip(pos, counts):
+        cut = p if before else p + 1
+        out.extend(main[k0:cut])
+        for grp in side[sidx:sidx + c]:
+            out.extend(grp if isinstance(grp, list) else [grp])
+        sidx += c
+        k0 = cut
+    out.extend(main[k0:])
     return out
 
 

@@ -536,7 +536,10 @@ static PipeModule* pipe_module() {
     PipeModule& m = mods[dev];
     if (!m.tried) {
         m.tried = true;
-        bool ok = hipModuleLoadData(&m.mod, kPipeCodeObject) == hipSuccess;
+        // GRAFX_PIPE_HSACO=<file>: load another build of the same kernels instead of the embedded one (schedule tuning:
+        // `python -m grafx_amd.csrc.asm.gen_fftconv_pipe --hsaco f.hsaco <knobs>` needs no rebuild of the library)
+        const char* alt = getenv("GRAFX_PIPE_HSACO");
+        bool ok = (alt && *alt ? hipModuleLoad(&m.mod, alt) : hipModuleLoadData(&m.mod, kPipeCodeObject)) == hipSuccess;
         for (size_t i = 0; ok && i < sizeof(kPipeVariants) / sizeof(kPipeVariants[0]); ++i)
             ok = hipModuleGetFunction(&m.fn[i], m.mod, kPipeVariants[i].name) == hipSuccess;
         ok = ok && hipDeviceGetAttribute(&m.cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && m.cus >= 8;
@@ -605,7 +608,7 @@ static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* 
 
 // Whether GFX_SCHED_AUTO may pick the persistent kernel for large launches (decided by measurement)
 #ifndef GFX_PIPE_AUTO
-#define GFX_PIPE_AUTO 0
+#define GFX_PIPE_AUTO 1
 #endif
 // GFX_SCHED_AUTO: which of the two kernels a launch gets.  GRAFX_FFTCONV_SCHED=tile|pipe overrides (A/B measurements).
 static int auto_schedule() {

@@ -45,7 +45,7 @@ def _spectra(h):
     return out
 
 
-def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0):
+def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0, **knobs):
     from grafx_amd.csrc.asm import gen_fftconv_pipe as gen
     from grafx_amd.csrc.asm.isa import Buffer, Emulator
 
@@ -57,7 +57,7 @@ def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0):
     R = B * n
     ntiles = (L + V - 1) // V
     nblocks = R * Cout * ntiles
-    prog = gen.PipeGen(tee, a_lo).build()
+    prog = gen.PipeGen(tee, a_lo, **knobs).build()
     # signals live in a (B, nodes, C, L) buffer with more node rows than the stage uses (strided views, as in the render)
     nodes = n + 3
     xbuf = rng.standard_normal((B, nodes, C, L)).astype(np.float32)
@@ -111,3 +111,22 @@ def test_pipe_kernel_in_the_emulator(tee, C, Cf, L, tiles_per_wg):
         assert np.array_equal(cc, x)
     else:
         assert np.isnan(cc).all()
+
+
+@pytest.mark.parametrize("knobs", [dict(place="barrier"), dict(place="after"), dict(fwd_window=(0.0, 1.0), inv_window=(0.0, 1.0))])
+def test_pipe_kernel_schedule_knobs_keep_the_results(knobs):
+    """Where the memory instructions sit is a tuning knob of the generator; the automatic s_waitcnt pass has to keep every
+    placement correct."""
+    y, want, cc, x, _ = _run(True, 1, 3, 2, 1, 12288 + 4096, 4001, hrows=3, tiles_per_wg=4, **knobs)
+    assert np.abs(y - want).max() / np.abs(want).max() < 5e-6
+    assert np.array_equal(cc, x)
+
+
+@pytest.mark.parametrize("N,tee", [(513, True), (8193, False), (1100, False)])
+def test_pipe_kernel_other_overlap_variants(N, tee):
+    """the kernel is generated per overlap (a_lo = O / 512 rows of a tile are not stored): the shortest, the longest and
+    a middle one"""
+    y, want, cc, x, _ = _run(tee, 1, 2, 1, 1, 30000, N, hrows=2, tiles_per_wg=3)
+    assert np.abs(y - want).max() / np.abs(want).max() < 5e-6
+    if tee:
+        assert np.array_equal(cc, x)

@@ -224,7 +224,7 @@ def test_filter_gradient_correlation_matches_float64(L, Lg, N, off, Cx, Cg):
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GRAFX_FUZZ_PIPE_SEEDS", 24))))
 def test_pipe_schedule_matches_the_oracle_convolution(seed):
     """The hand-scheduled persistent kernel (gfx_fftconv_sched_f32, GFX_SCHED_PIPE: generated gfx950 assembly, csrc/asm)
-    forced onto small random problems it covers -- taps with a 4096-sample overlap, even lengths around the tile
+    forced onto small random problems it covers -- tap counts of every overlap it is built for, even lengths around the tile
     boundaries (V = 12288), one to many tiles per row, fewer tiles than workgroups and more, channel broadcasts, shared
     filters, strided buffer views and the input copy -- against the oracle and the compiler-built tile kernel."""
     import random
@@ -236,7 +236,7 @@ def test_pipe_schedule_matches_the_oracle_convolution(seed):
     rng = random.Random(4000 + seed)
     torch.manual_seed(seed)
     L = rng.choice([2, 18, 1000, 8192, 12286, 12288, 12290, 16384, 24576, 24578, 40002, 70000, 131072])
-    N = rng.choice([3586, 3587, 4000, 4001, 4096, 4097])
+    N = rng.choice([2, 100, 513, 514, 1025, 2049, 3586, 4000, 4001, 4096, 4097, 7682, 8192, 8193])   # overlaps 512 .. 8192
     Cin, Cf = rng.choice([(1, 1), (2, 1), (1, 2), (2, 2)])
     B, n = rng.choice([(1, 1), (2, 3), (3, 2), (5, 1), (7, 9)])
     shared = rng.random() < 0.5
@@ -285,6 +285,6 @@ def test_pipe_schedule_headline_shape_against_the_tile_schedule():
     assert (buf[:, 2 * n :] == 0).all()
     with pytest.raises(RuntimeError):                         # odd length: not covered, refused
         ops.fftconv(x4[..., :4097], Hs, N, 1, h_rows=n, schedule="pipe")
-    h2 = torch.randn(n, 1, 100, device="cuda")
-    with pytest.raises(RuntimeError):                         # no variant for a 512-sample overlap
-        ops.fftconv(x4, ops.fir_spectrum(h2.reshape(-1, 100)), 100, 1, h_rows=n, schedule="pipe")
+    h2 = torch.randn(n, 1, 1100, device="cuda")
+    with pytest.raises(RuntimeError):                         # no variant for a 1536-sample overlap
+        ops.fftconv(x4, ops.fir_spectrum(h2.reshape(-1, 1100)), 1100, 1, h_rows=n, schedule="pipe")
