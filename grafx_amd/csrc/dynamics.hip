@@ -1109,18 +1109,19 @@ __global__ __launch_bounds__(DT) void dyn_bwd_u1_kernel(const float* __restrict_
 
 // dL/d(smoothed energy) at four (reversed-walk) positions from the samples, output gradients and scan values there;
 // also returns the gain and, when `acc` is given, adds the parameter-gradient terms (as pass A did).
+template <bool FAST = false>
 __device__ __forceinline__ void dyn_denv4(const DynArgs& a, const Knee& q, const float (&xa)[DE], const float (&xb)[DE],
                                           const float (&ga)[DE], const float (&gb)[DE], const float (&lin)[DE],
                                           float (&dv)[DE], float (&gn)[DE], float* acc) {
 #pragma unroll
     for (int i = 0; i < DE; ++i) {
         const float env = fmaxf(lin[i], 0.0f);
-        const float G = logf(env + 1e-5f);
-        gn[i] = expf(log_gain(q, G));
+        const float G = FAST ? FastMath::log(env + 1e-5f) : logf(env + 1e-5f);
+        gn[i] = FAST ? FastMath::exp(log_gain_m<FastMath>(q, G)) : expf(log_gain(q, G));
         const float dgain = a.C == 2 ? (ga[i] * xa[i] + gb[i] * xb[i]) : ga[i] * xa[i];
         const float dg = dgain * gn[i];
         const KneeGrad k = log_gain_grad(q, G);
-        dv[i] = lin[i] > 0.0f ? dg * k.dG / (env + 1e-5f) : 0.0f;
+        dv[i] = lin[i] > 0.0f ? (FAST ? dg * k.dG * __builtin_amdgcn_rcpf(env + 1e-5f) : dg * k.dG / (env + 1e-5f)) : 0.0f;
         if (acc) {   // samples outside the row have x = gy = 0, hence dg = 0
             acc[0] += dg * k.dT;
             acc[1] += dg * k.dlr;
@@ -1226,11 +1227,13 @@ __global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__
                                                        const float* __restrict__ log_knee,
                                                        const float* __restrict__ z_alpha, const float* __restrict__ u1,
                                                        float* __restrict__ dalpha, float* __restrict__ gparams,
-                                                       float* __restrict__ gx, DynArgs a) {
+                                                       float* __restrict__ gx, DynArgs a,
+                                                       const float* __restrict__ oneshot_tab) {
     __shared__ float slots[16];
     __shared__ float red[4][4];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x;
+    if (oneshot_tab && oneshot_tab[(size_t)r * DP_TAB + DP_ONESHOT] != 0.0f) return;   // dyn_bwd_oneshot_kernel's row
     OnePole p;
     onepole_setup(p, z_alpha[r], a.N, t & 63);
     const float* x0 = x + drow_off(a.xmap, r, 0);
@@ -1263,6 +1266,165 @@ __global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__
     __syncthreads();
     if (t < 3) gparams[3 * r + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
     if (t == 3 && dalpha) dalpha[r] = (red[3][0] + red[3][1] + red[3][2] + red[3][3]) / p.one_m_a;  // u1 = (1-a) U
+}
+
+// The backward-in-time pass as dependency-free one-shot tiles (the backward twin of dyn_oneshot_kernel): in the reversed
+// "walk" coordinates of dyn_bwd_c_stream the adjoint of the smoother is the same one-pole scan, so a wave takes 512 walk
+// positions, rebuilds the scan state entering them from the H positions before (= the H samples LATER in time: lanes
+// 4 l < H recompute denv there from their own predicated loads) and needs nothing from any other tile.  Rows are chosen
+// on the device from the same pole table; per-row sums (knee parameters, pole) are reduced per workgroup and added with
+// float atomics onto outputs the launcher zeroes.  gx, gparams and dalpha mean what they mean in dyn_bwd_c_kernel.
+// Knee kind and compressor / gate are template parameters (one gain-curve path per instantiation: the generic code is
+// 15 k instructions, more than the instruction cache holds), every access is a whole aligned float4 (the launcher only
+// takes this path for 16-byte aligned rows of a length divisible by four), and log / exp / the reciprocal are the hardware
+// forms as in the forward tiles (6.0 vs 6.4 ms with the library functions, 6.9-7.1 for the row kernel, at 8192 rows).
+// samples L-4-j .. L-1-j in walk order (v[0] = the latest), zero when the group is outside [0, L)
+__device__ __forceinline__ void rl4(const float* __restrict__ row, int64_t j, int64_t L, float (&v)[DE]) {
+    const int64_t n = L - 4 - j;
+    float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (n >= 0 && n + 4 <= L) q = *reinterpret_cast<const float4*>(row + n);
+    v[0] = q.w; v[1] = q.z; v[2] = q.y; v[3] = q.x;
+}
+
+template <int KIND, bool GATE>
+__global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                             gfx_rowmap_t gmap, const float* __restrict__ log_threshold,
+                                                             const float* __restrict__ log_ratio,
+                                                             const float* __restrict__ log_knee,
+                                                             const float* __restrict__ tab, const float* __restrict__ u1,
+                                                             float* __restrict__ dalpha, float* __restrict__ gparams,
+                                                             float* __restrict__ gx, DynArgs a, unsigned ngroups,
+                                                             unsigned nblocks) {
+    __shared__ float red[4][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (b >= nblocks) return;
+    const unsigned r = b / ngroups;
+    const unsigned grp = b - r * ngroups;
+    const float* tb = tab + (size_t)r * DP_TAB;
+    if (tb[DP_ONESHOT] == 0.0f) return;                 // dyn_bwd_c_kernel's row (uniform)
+    const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;     // first WALK position of this wave's tile
+    const int64_t L = s < a.L ? a.L : 0;                // a wave past the row end reads zeros and stores nothing
+    const float* x0 = x + drow_off(a.xmap, r, 0);
+    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
+    const float* g0 = gy + drow_off(gmap, r, 0);
+    const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
+    float* o0 = gx + drow_off(a.ymap, r, 0);
+    float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
+    const float* ur = u1 + (int64_t)r * a.L;
+    const bool stereo = a.C == 2;
+    const int64_t j0 = s + DE * lane;
+
+    float uu[OS_SUB][DE], xa[OS_SUB][DE], xb[OS_SUB][DE], ga[OS_SUB][DE], gb[OS_SUB][DE];
+#pragma unroll
+    for (int k = 0; k < OS_SUB; ++k) {
+        rl4(ur, j0 + 256 * k, L, uu[k]);
+        rl4(x0, j0 + 256 * k, L, xa[k]);
+        rl4(g0, j0 + 256 * k, L, ga[k]);
+        rl4(x1, j0 + 256 * k, stereo ? L : 0, xb[k]);
+        rl4(g1, j0 + 256 * k, stereo ? L : 0, gb[k]);
+    }
+    // walk positions s - 4 (l + 1) .. s - 4 l - 1 = taps 4 l + 3 .. 4 l of the state entering the tile
+    const int H = (int)tb[DP_HIST];
+    const bool hist = s != 0 && DE * lane < H;
+    const int64_t Lh = hist ? L : 0, jh = s - DE * (lane + 1);
+    float hu[DE], hxa[DE], hxb[DE], hga[DE], hgb[DE];
+    rl4(ur, jh, Lh, hu);
+    rl4(x0, jh, Lh, hxa);
+    rl4(g0, jh, Lh, hga);
+    rl4(x1, jh, stereo ? Lh : 0, hxb);
+    rl4(g1, jh, stereo ? Lh : 0, hgb);
+    // u1 one walk position past the tile (the pole term pairs every position with the next one)
+    const int64_t edge = a.L - 1 - (s + OS_WTILE);
+    const float u_edge = (dalpha && L != 0 && edge >= 0) ? ur[edge] : 0.0f;
+    const float a1 = tb[77], one_m_a = tb[78], a_sub = tb[70];
+    const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};
+    const float a_lane = tb[lane];
+    float a_step[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a_step[d] = tb[64 + d];
+    Knee q;
+    knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, KIND, GATE ? 1 : 0);
+    q.kind = KIND;
+    q.gate = GATE ? 1 : 0;
+    const float k2 = 2.0f / (float)a.C;
+
+    float acc[3] = {0.0f, 0.0f, 0.0f}, pole = 0.0f;
+    float d[OS_SUB][DE], gn[OS_SUB][DE], loc[OS_SUB][DE], excl[OS_SUB], total[OS_SUB];
+#pragma unroll
+    for (int k = 0; k < OS_SUB; ++k) {
+        dyn_denv4<true>(a, q, xa[k], xb[k], ga[k], gb[k], uu[k], d[k], gn[k], acc);
+        float run = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            run = fmaf(a1, run, d[k][i]);
+            loc[k][i] = run;
+        }
+        float inc = run;
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            const float up = __shfl_up(inc, 1 << st, 64);
+            if (lane >= (1 << st)) inc = fmaf(a_step[st], up, inc);
+        }
+        const float ex = __shfl_up(inc, 1, 64);
+        excl[k] = lane == 0 ? 0.0f : ex;
+        total[k] = __shfl(inc, 63, 64);
+    }
+    float carry = 0.0f;
+    if (s != 0 && H > 0) {                       // uniform
+        float hd[DE], hgn[DE];
+        dyn_denv4<true>(a, q, hxa, hxb, hga, hgb, hu, hd, hgn, nullptr);   // (lanes without a live tap hold zeros: denv = 0)
+        float w = 0.0f;                          // Horner, farthest walk position first
+#pragma unroll
+        for (int i = 0; i < DE; ++i) w = fmaf(a1, w, hd[i]);
+        float hs = hist ? w * a_lane : 0.0f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) hs += __shfl_xor(hs, o, 64);
+        carry = hs;
+    }
+#pragma unroll
+    for (int k = 0; k < OS_SUB; ++k) {
+        const float pre = fmaf(a_lane, carry, excl[k]);
+        carry = fmaf(a_sub, carry, total[k]);
+        float u[DE];
+#pragma unroll
+        for (int i = 0; i < DE; ++i) u[i] = fmaf(apk[i], pre, loc[k][i]);        // the adjoint scan ("de")
+        if (dalpha) {
+            // u1 at the next walk position: the neighbouring lane's first value, the next sub-tile's, or the one past the tile
+            float nxt = __shfl_down(uu[k][0], 1, 64);
+            const float first_next = k + 1 < OS_SUB ? __shfl(uu[k + 1 < OS_SUB ? k + 1 : k][0], 0, 64) : u_edge;
+            if (lane == 63) nxt = first_next;
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                const float prev = i + 1 < DE ? uu[k][i + 1] : nxt;
+                pole += one_m_a * u[i] * prev - d[k][i] * uu[k][i];
+            }
+        }
+        const int64_t n = L - 4 - (j0 + 256 * k);
+        if (n >= 0 && n + 4 <= L) {
+            using f4 = float __attribute__((ext_vector_type(4)));
+            f4 oa, ob;
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                oa[3 - i] = fmaf(gn[k][i], ga[k][i], k2 * one_m_a * u[i] * xa[k][i]);
+                ob[3 - i] = fmaf(gn[k][i], gb[k][i], k2 * one_m_a * u[i] * xb[k][i]);
+            }
+            *reinterpret_cast<f4*>(o0 + n) = oa;
+            if (stereo) *reinterpret_cast<f4*>(o1 + n) = ob;
+        }
+    }
+    float v4[4] = {acc[0], acc[1], acc[2], pole};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = v4[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (t < 3) atomicAdd(gparams + 3 * (size_t)r + t, red[t][0] + red[t][1] + red[t][2] + red[t][3]);
+    if (t == 3 && dalpha) atomicAdd(dalpha + r, (red[3][0] + red[3][1] + red[3][2] + red[3][3]) / one_m_a);   // u1 = (1 - a) U
 }
 
 // One pass over (x, gy, env): gain = exp(g(log(env + 1e-5))),  dgain = sum_c gy x,  dg = dgain * gain,
@@ -1537,7 +1699,7 @@ int gfx_dynamics_bwd_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx
     (void)denv;
     hipLaunchKernelGGL(dyn_bwd_u1_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, z_alpha, u1, a);
     hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,
-                       log_knee, z_alpha, u1, dalpha, gparams, gx, a);
+                       log_knee, z_alpha, u1, dalpha, gparams, gx, a, (const float*)nullptr);
 #endif
     return GFX_LAUNCH_OK();
 }
@@ -1546,15 +1708,52 @@ int gfx_dynamics_bwd_u1_f32(const float* x, gfx_rowmap_t xmap, const float* gy, 
                             const float* log_threshold, const float* log_ratio, const float* log_knee,
                             const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                             float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* stream) {
+    return gfx_dynamics_bwd_u1_ws_f32(x, xmap, gy, gmap, log_threshold, log_ratio, log_knee, z_alpha, R, C, L, iir_len, knee,
+                                      gate, gx, gxmap, gparams, u1, dalpha, nullptr, 0, stream);
+}
+
+int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                               const float* log_threshold, const float* log_ratio, const float* log_knee,
+                               const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                               float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* ws,
+                               size_t ws_bytes, void* stream) {
     if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !u1) return GFX_EINVAL;
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
         return GFX_EINVAL;
     if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0 || gxmap.inner <= 0) return GFX_EINVAL;
+    if (ws && ws_bytes < gfx_dynamics_ws_bytes(R)) return GFX_ENOSPC;
     DynArgs a;
     a.xmap = xmap; a.ymap = gxmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
-    hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, x, gy, gmap, log_threshold,
-                       log_ratio, log_knee, z_alpha, u1, dalpha, gparams, gx, a);
+    hipStream_t st = (hipStream_t)stream;
+    const float* tab = nullptr;
+    const int64_t ngroups = (L + OS_GTILE - 1) / OS_GTILE;
+    auto aligned = [&](const float* p, const gfx_rowmap_t& m) {
+        return ((uintptr_t)p & 15) == 0 && m.stride_outer % 4 == 0 && m.stride_inner % 4 == 0 && m.stride_ch % 4 == 0;
+    };
+    const bool vec = L % 4 == 0 && aligned(x, xmap) && aligned(gy, gmap) && aligned(gx, gxmap) && ((uintptr_t)u1 & 15) == 0;
+    if (ws && vec && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL) {
+        // rows with a short smoother memory (chosen on the device, as in gfx_dynamics_fused_ws_f32) run as one-shot tiles
+        // that add their per-row sums atomically: zero those outputs first; the row kernel writes the other rows
+        float* t = (float*)ws;
+        if (hipMemsetAsync(gparams, 0, (size_t)R * 3 * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
+        if (dalpha && hipMemsetAsync(dalpha, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
+        hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)R), dim3(64), 0, st, z_alpha, t, R, iir_len);
+        const unsigned nblocks = (unsigned)(R * ngroups);
+        const dim3 grid((nblocks + 7u) & ~7u);
+#define GFX_BWD_OS(K, G)                                                                                                \
+    hipLaunchKernelGGL((dyn_bwd_oneshot_kernel<K, G>), grid, dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,     \
+                       log_knee, (const float*)t, u1, dalpha, gparams, gx, a, (unsigned)ngroups, nblocks)
+        if (gate) {
+            if (knee == 0) GFX_BWD_OS(0, true); else if (knee == 1) GFX_BWD_OS(1, true); else GFX_BWD_OS(2, true);
+        } else {
+            if (knee == 0) GFX_BWD_OS(0, false); else if (knee == 1) GFX_BWD_OS(1, false); else GFX_BWD_OS(2, false);
+        }
+#undef GFX_BWD_OS
+        tab = t;
+    }
+    hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold,
+                       log_ratio, log_knee, z_alpha, u1, dalpha, gparams, gx, a, tab);
     return GFX_LAUNCH_OK();
 }
 

@@ -470,11 +470,13 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
 
 
 @_on_device
-def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True, u1=None):
+def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True, u1=None,
+                 schedule=None):
     """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), dalpha (R) or None).
     ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view).  ``dalpha`` is the gradient with
     respect to the clamped pole a = min(sigmoid(z_alpha), 1 - 1e-5); the caller applies the chain rule to z_alpha.
-    ``u1``: the scan kept by the forward pass (``dynamics_fused(..., u1_out=)``); without it the scan is recomputed."""
+    ``u1``: the scan kept by the forward pass (``dynamics_fused(..., u1_out=)``); without it the scan is recomputed.
+    ``schedule`` (with ``u1``): "oneshot" (default, see DYN_SCHEDULE) or "rows"."""
     _require_gpu(x, gy, out)
     xmap, R, C, L = rowmap(x)
     gmap, Rg, Cg, Lg = rowmap(gy)
@@ -487,10 +489,14 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
     if u1 is not None:
         _require_gpu(u1)
         _expect(u1, (R, L), "dynamics_bwd: u1")
-        check(lib().gfx_dynamics_bwd_u1_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
-                                            pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)), pin(_rowvec(z_alpha, R)),
-                                            R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp),
-                                            pin(u1), _ptr(da), _stream()), "gfx_dynamics_bwd_u1_f32")
+        ws = None
+        if (DYN_SCHEDULE if schedule is None else schedule) == "oneshot":   # one-shot tiles for the short-memory rows
+            ws = torch.empty(lib().gfx_dynamics_ws_bytes(R), dtype=torch.uint8, device=x.device)
+        check(lib().gfx_dynamics_bwd_u1_ws_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
+                                               pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)),
+                                               pin(_rowvec(z_alpha, R)), R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx),
+                                               rowmap(gx)[0], _ptr(gp), pin(u1), _ptr(da), _ptr(ws),
+                                               0 if ws is None else ws.numel(), _stream()), "gfx_dynamics_bwd_u1_ws_f32")
         return gx, gp, da
     u1 = torch.empty((R, L), dtype=torch.float32, device=x.device)
     check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),

@@ -286,6 +286,14 @@ int gfx_dynamics_bwd_u1_f32(const float* x, gfx_rowmap_t xmap, const float* gy, 
                             const float* log_threshold, const float* log_ratio, const float* log_knee,
                             const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                             float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* stream);
+/* The same with a workspace of gfx_dynamics_ws_bytes(R) bytes (scratch for this call; NULL = the call above): rows with a
+ * short smoother memory -- chosen per row on the device, exactly as in gfx_dynamics_fused_ws_f32 -- run as dependency-free
+ * one-shot tiles walking backward in time (their per-row sums land by float atomics), the others on the row kernel. */
+int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                               const float* log_threshold, const float* log_ratio, const float* log_knee,
+                               const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                               float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha,
+                               void* ws, size_t ws_bytes, void* stream);
 /* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
  * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,

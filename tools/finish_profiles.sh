@@ -1,14 +1,14 @@
 #!/bin/bash
-# after `gpurun -- bash tools/collect_profiles.sh` (which clears the raw directories first): distil the run into profiles/r2/
-GRAFX_ROUND=r2 python tools/pmc_summary.py | tail -3
-cp gpurun_out/profiles_raw/bench_cfg2.json profiles/r2/bench_cfg2.json
-cp gpurun_out/profiles_raw/bench_cfg3.json profiles/r2/bench_cfg3.json
-for c in cfg2 cfg3; do cp gpurun_out/profiles_raw/trace_$c/runc/*kernel_stats.csv profiles/r2/rocprofv3_kernel_stats_$c.csv; done
-[ -f gpurun_out/parity_exceptions.md ] && cp gpurun_out/parity_exceptions.md profiles/r2/parity_exceptions.md
+# after `gpurun -- bash tools/collect_profiles.sh` (which clears the raw directories first): distil the run into profiles/r3/
+GRAFX_ROUND=r3 python tools/pmc_summary.py | tail -3
+cp gpurun_out/profiles_raw/bench_cfg2.json profiles/r3/bench_cfg2.json
+cp gpurun_out/profiles_raw/bench_cfg3.json profiles/r3/bench_cfg3.json
+for c in cfg2 cfg3; do cp gpurun_out/profiles_raw/trace_$c/runc/*kernel_stats.csv profiles/r3/rocprofv3_kernel_stats_$c.csv; done
+[ -f gpurun_out/parity_exceptions.md ] && cp gpurun_out/parity_exceptions.md profiles/r3/parity_exceptions.md
 python - <<'PY'
 import json
-d = json.load(open('profiles/r2/bench_r2.json'))
+d = json.load(open('profiles/r3/bench_r3.json'))
 print('headline', d['ms_per_step'], 'frac', d['roofline']['frac'], 'train', d['training']['ms_per_step'], 'cpu', d['cpu_baseline']['value'])
 for k in ('bench_cfg2.json', 'bench_cfg3.json'):
-    e = json.load(open('profiles/r2/' + k)); print(k, e['ms_per_step'], e['roofline']['frac'])
+    e = json.load(open('profiles/r3/' + k)); print(k, e['ms_per_step'], e['roofline']['frac'])
 PY

@@ -8,7 +8,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = [i for i, r in enumerate(rows) if "fftconv1_kernel<true>" in r["Kernel_Name"]][-1]
+first = [i for i, r in enumerate(rows) if "fftconv1_kernel<true>" in r["Kernel_Name"] or "gfx_fftconv_pipe_t1" in r["Kernel_Name"]][-1]
 sub = rows[first - 12:]
 t0 = int(sub[0]["Start_Timestamp"])
 t1 = max(int(r["End_Timestamp"]) for r in sub)
