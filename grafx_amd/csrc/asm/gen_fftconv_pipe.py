@@ -679,6 +679,11 @@ def generate(**knobs):
                 i.mods["target"] = i.mods["target"] + "_" + name
         txt += kernel_text(name, prog)
         names.append(name)
+    from . import gen_corr_pipe       # the filter-gradient kernel shares the code object (and most of this generator)
+
+    name, prog = gen_corr_pipe.kernel(**{k: v for k, v in knobs.items() if k == "codelet"})
+    txt += kernel_text(name, prog)
+    names.append(name)
     return txt + metadata(names)
 
 

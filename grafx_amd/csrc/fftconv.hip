@@ -520,9 +520,12 @@ __global__ __launch_bounds__(TILE_T, 2) void corr1_kernel(const float* __restric
 #include "fftconv_pipe_hsaco.inc"
 namespace gfx {
 
+static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
+
 struct PipeModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn[sizeof(kPipeVariants) / sizeof(kPipeVariants[0])] = {};
+    hipFunction_t corr = nullptr;
     int cus = 0;
     bool tried = false, ok = false;
 };
@@ -542,6 +545,7 @@ static PipeModule* pipe_module() {
         bool ok = (alt && *alt ? hipModuleLoad(&m.mod, alt) : hipModuleLoadData(&m.mod, kPipeCodeObject)) == hipSuccess;
         for (size_t i = 0; ok && i < sizeof(kPipeVariants) / sizeof(kPipeVariants[0]); ++i)
             ok = hipModuleGetFunction(&m.fn[i], m.mod, kPipeVariants[i].name) == hipSuccess;
+        ok = ok && hipModuleGetFunction(&m.corr, m.mod, kCorrKernelName) == hipSuccess;
         ok = ok && hipDeviceGetAttribute(&m.cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && m.cus >= 8;
         m.ok = ok;
         (void)hipGetLastError();
@@ -606,6 +610,55 @@ static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* 
                                                                                                               : GFX_ELAUNCH;
 }
 
+// The hand-scheduled form of corr1_kernel (csrc/asm/gen_corr_pipe.py) covers off = 0 with the same row grouping on x and
+// g and byte strides inside 32 bits -- the equaliser's filter gradient; GRAFX_FFTCONV_SCHED=tile keeps corr1_kernel.
+static bool corr_pipe_ok(const CorrArgs& a) {
+    if (a.off != 0 || a.N > TILE_M + 1 || a.xmap.inner != a.gmap.inner) return false;
+    if (a.L * 4 >= (int64_t(1) << 30) || a.Lg * 4 >= (int64_t(1) << 30)) return false;
+    auto fits = [](const gfx_rowmap_t& mp) {
+        return mp.stride_inner >= 0 && mp.stride_ch >= 0 && mp.stride_outer >= 0 && mp.stride_inner * 4 < (int64_t(1) << 32) &&
+               mp.stride_ch * 4 < (int64_t(1) << 32);
+    };
+    return fits(a.xmap) && fits(a.gmap);
+}
+
+static int launch_corr_pipe(PipeModule* pm, const float* x, const float* g, float* gh, const CorrArgs& a, const float2* tw,
+                            hipStream_t st) {
+    CorrKernArgs k;
+    memset(&k, 0, sizeof(k));
+    auto lo = [](const void* p) { return (uint32_t)reinterpret_cast<uint64_t>(p); };
+    auto hi = [](const void* p) { return (uint32_t)(reinterpret_cast<uint64_t>(p) >> 32); };
+    k.x_lo = lo(x); k.x_hi = hi(x); k.g_lo = lo(g); k.g_hi = hi(g); k.o_lo = lo(gh); k.o_hi = hi(gh);
+    k.tw_lo = lo(tw); k.tw_hi = hi(tw);
+    k.L_bytes = (uint32_t)(a.L * 4); k.Lg_bytes = (uint32_t)(a.Lg * 4); k.V_bytes = (uint32_t)(a.V * 4);
+    k.N_even_bytes = (uint32_t)((a.N & ~int64_t(1)) * 4);
+    k.ntiles = (uint32_t)a.ntiles; k.nblocks = (uint32_t)a.nblocks;
+    k.inner = (uint32_t)a.xmap.inner;
+    pipe_magic(k.inner, k.m_inner, k.sh_inner);
+    k.cout_shift = a.Cout == 2 ? 1 : 0; k.cout_mask = a.Cout == 2 ? 1 : 0;
+    k.cx_mask = a.Cx == 2 ? 1 : 0; k.cg_mask = a.Cg == 2 ? 1 : 0;
+    k.out_row_bytes = (uint32_t)(a.N * 4);
+    if (a.N & 1) {       // the last lag is half of a sample pair: stored on its own (row, lane, row offset of that pair)
+        const uint32_t m = (uint32_t)((a.N - 1) / 2);
+        k.tail_row = m >> 8; k.tail_lane = m & 255; k.tail_off = 2048u * (m >> 8);
+    } else {
+        k.tail_row = 255;
+    }
+    const float sc = 1.0f / (4.0f * TILE_M);
+    memcpy(&k.scale, &sc, 4);
+    const unsigned grid = pad8(a.nblocks);
+    k.pad0 = grid / 8;
+    auto strides = [](const gfx_rowmap_t& mp, uint32_t& olo, uint32_t& ohi, uint32_t& in, uint32_t& ch) {
+        const uint64_t o = (uint64_t)mp.stride_outer * 4;
+        olo = (uint32_t)o; ohi = (uint32_t)(o >> 32); in = (uint32_t)(mp.stride_inner * 4); ch = (uint32_t)(mp.stride_ch * 4);
+    };
+    strides(a.xmap, k.xs_outer_lo, k.xs_outer_hi, k.xs_inner, k.xs_ch);
+    strides(a.gmap, k.gs_outer_lo, k.gs_outer_hi, k.gs_inner, k.gs_ch);
+    size_t size = sizeof(k);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(pm->corr, grid, 1, 1, TILE_T, 1, 1, 0, st, nullptr, config) == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
 // Whether GFX_SCHED_AUTO may pick the persistent kernel for large launches (decided by measurement)
 #ifndef GFX_PIPE_AUTO
 #define GFX_PIPE_AUTO 1
@@ -620,7 +673,6 @@ static int auto_schedule() {
     return cached;
 }
 
-static inline unsigned pad8(int64_t n) { return (unsigned)(((n + 7) / 8) * 8); }
 
 template <typename K>
 static int allow_lds(K kernel) {
@@ -724,6 +776,8 @@ int gfx_fir_grad_f32(const float* x, gfx_rowmap_t xmap, const float* g, gfx_rowm
     hipStream_t st = (hipStream_t)stream;
     const float2* tw = tile_twiddle_table(st);
     if (!tw) return GFX_ELAUNCH;
+    PipeModule* pm = pipe_module();
+    if (pm && corr_pipe_ok(a) && auto_schedule() != GFX_SCHED_TILE) return launch_corr_pipe(pm, x, g, gh, a, tw, st);
     if (allow_lds(corr1_kernel)) return GFX_ELAUNCH;
     hipLaunchKernelGGL(corr1_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, g, gh, a, tw);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;

@@ -130,3 +130,57 @@ def test_pipe_kernel_other_overlap_variants(N, tee):
     assert np.abs(y - want).max() / np.abs(want).max() < 5e-6
     if tee:
         assert np.array_equal(cc, x)
+
+
+def _run_corr(B, n, Cx, Cg, L, N, seed=0, **knobs):
+    from grafx_amd.csrc.asm import gen_corr_pipe as gen
+    from grafx_amd.csrc.asm.gen_fftconv_pipe import TILE_LDS_BYTES, magic
+    from grafx_amd.csrc.asm.isa import Buffer, Emulator
+
+    rng = np.random.default_rng(seed)
+    Cout = max(Cx, Cg)
+    R = B * n
+    V = 16384 - (N & ~1)
+    ntiles = (L + V - 1) // V
+    nodes = n + 2
+    xbuf = rng.standard_normal((B, nodes, Cx, L)).astype(np.float32)
+    gbuf = rng.standard_normal((B, nodes, Cg, L)).astype(np.float32)
+    out = np.full((R * Cout, N), np.nan, np.float32)
+    mem = Buffer()
+    xa, ga, oa, ta = mem.alloc(xbuf), mem.alloc(gbuf), mem.alloc(out), mem.alloc(_twiddle_table())
+    x0, g0 = xa + 4 * (1 * Cx * L), ga + 4 * (2 * Cg * L)        # the stage's rows: nodes 1..n of x, 2..n+1 of g
+    prog = gen.CorrGen(**knobs).build()
+    nblocks = R * Cout
+    grid = (nblocks + 7) & ~7
+    m_in = magic(n)
+    tail = N - 1 if N & 1 else None
+    args = gen.pack_args(
+        x_lo=x0, x_hi=x0 >> 32, g_lo=g0, g_hi=g0 >> 32, o_lo=oa, o_hi=oa >> 32, tw_lo=ta, tw_hi=ta >> 32,
+        L_bytes=4 * L, Lg_bytes=4 * L, V_bytes=4 * V, N_even_bytes=4 * (N & ~1), ntiles=ntiles, nblocks=nblocks,
+        inner=n, m_inner=m_in[0], sh_inner=m_in[1], cout_shift=Cout - 1, cout_mask=Cout - 1,
+        cx_mask=0 if Cx == 1 else 1, cg_mask=0 if Cg == 1 else 1, out_row_bytes=4 * N,
+        tail_row=255 if tail is None else (tail // 2) >> 8, tail_lane=0 if tail is None else (tail // 2) & 255,
+        tail_off=0 if tail is None else 2048 * ((tail // 2) >> 8),
+        scale=int(np.float32(1.0 / (4 * 8192)).view(np.uint32)), pad0=grid // 8,
+        xs_outer_lo=4 * nodes * Cx * L, xs_inner=4 * Cx * L, xs_ch=4 * L,
+        gs_outer_lo=4 * nodes * Cg * L, gs_inner=4 * Cg * L, gs_ch=4 * L)
+    for wg in range(grid):
+        Emulator(prog, mem, TILE_LDS_BYTES, kernarg=args, wg_id=wg, rng=np.random.default_rng(7 + wg)).run()
+    got = mem.read_back(oa).reshape(R, Cout, N)
+    want = np.zeros((R, Cout, N))
+    for b in range(B):
+        for j in range(n):
+            for c in range(Cout):
+                xr = xbuf[b, 1 + j, c if Cx == 2 else 0].astype(np.float64)
+                gr = gbuf[b, 2 + j, c if Cg == 2 else 0].astype(np.float64)
+                full = np.correlate(gr, xr, "full")          # full[L - 1 + k] = sum_n g[n + k] x[n] ... lag k of g against x
+                want[b * n + j, c] = full[L - 1: L - 1 + N]
+    return got, want
+
+
+@pytest.mark.parametrize("Cx,Cg,L,N", [(1, 1, 20002, 4001), (2, 1, 13000, 4000), (1, 2, 9000, 513)])
+def test_corr_kernel_in_the_emulator(Cx, Cg, L, N):
+    """gfx_corr_pipe (the filter-gradient correlation, csrc/asm/gen_corr_pipe.py): gh[k] = sum_n g[n] x[n - k]"""
+    got, want = _run_corr(1, 2, Cx, Cg, L, N)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() / np.abs(want).max() < 5e-6
