@@ -14,7 +14,11 @@
  *     tile (fftconv, fir_spectrum, fir_grad, iir_fsm, odd_alias) allocates that
  *     device's 80 KB twiddle table with hipMalloc, fills it on `stream` and waits
  *     for it (hipStreamSynchronize) under a process-wide mutex; the table lives
- *     for the process.  After that first call nothing allocates or synchronises.
+ *     for the process.  The first fftconv / fir_grad call on a device also loads
+ *     the code object of the hand-scheduled kernels (GFX_SCHED_PIPE; gfx950
+ *     assembly embedded in the library, hipModuleLoadData: device memory for its
+ *     ~0.5 MB of code).  After those first calls nothing allocates or
+ *     synchronises (make them outside a stream capture).
  *     The device is the CURRENT device (hipGetDevice): make the tensors' device
  *     current before calling (grafx_amd/ops.py does);
  *   - return 0 on success, a negative GFX_E* code on error; never throws;

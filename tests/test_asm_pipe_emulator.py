@@ -184,3 +184,48 @@ def test_corr_kernel_in_the_emulator(Cx, Cg, L, N):
     got, want = _run_corr(1, 2, Cx, Cg, L, N)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-6
+
+
+def _tiny_launch(prog):
+    """one workgroup, two tiles, of the convolution kernel on `prog`"""
+    from grafx_amd.csrc.asm import gen_fftconv_pipe as gen
+    from grafx_amd.csrc.asm.isa import Buffer, Emulator
+
+    rng = np.random.default_rng(5)
+    L, N, O, V = 12288 * 2, 4001, 4096, 12288
+    x = rng.standard_normal((1, 1, L)).astype(np.float32)
+    y = np.zeros_like(x)
+    h = (rng.standard_normal((1, N)) / 60).astype(np.float32)
+    mem = Buffer()
+    xa, ya, ha, ta = mem.alloc(x), mem.alloc(y), mem.alloc(_spectra(h)), mem.alloc(_twiddle_table())
+    one = gen.magic(1)
+    two = gen.magic(2)
+    args = gen.pack_args(x_lo=xa, x_hi=xa >> 32, h_lo=ha, h_hi=ha >> 32, y_lo=ya, y_hi=ya >> 32, tw_lo=ta, tw_hi=ta >> 32,
+                         L_bytes=4 * L, Lout_bytes=4 * L, V_bytes=4 * V, O_bytes=4 * O, ntiles=2, nblocks=2,
+                         m_ntiles=two[0], sh_ntiles=two[1], inner=1, m_inner=one[0], sh_inner=one[1], hrows=1,
+                         m_hrows=one[0], sh_hrows=one[1], Cf=1, per_xcd=2, wgs_per_xcd=1,
+                         xs_inner=4 * L, xs_ch=4 * L, ys_inner=4 * L, ys_ch=4 * L)
+    Emulator(prog, mem, gen.TILE_LDS_BYTES, kernarg=args, wg_id=0, rng=np.random.default_rng(1)).run()
+    return mem.read_back(ya).reshape(-1), np.convolve(x.reshape(-1).astype(np.float64), h.reshape(-1).astype(np.float64))[:L]
+
+
+def test_the_emulator_rejects_a_schedule_with_a_missing_wait_or_barrier():
+    """The checker has to be able to fail: drop one s_waitcnt that guards a loaded register, or one s_barrier between an
+    LDS write and another wave's read, from the generated program and the emulator must refuse it (and the intact
+    program must pass)."""
+    from grafx_amd.csrc.asm import gen_fftconv_pipe as gen
+    from grafx_amd.csrc.asm.isa import EmuError, Label
+
+    prog = gen.PipeGen(False, 8).build()
+    got, want = _tiny_launch(prog)
+    assert np.abs(got - want).max() / np.abs(want).max() < 5e-6
+    loop = next(i for i, p in enumerate(prog) if isinstance(p, Label) and p.name == ".Lloop")
+    # the first vmcnt wait inside the loop (it guards the window / spectrum registers)
+    k = next(i for i in range(loop, len(prog)) if not isinstance(prog[i], Label) and prog[i].op == "s_waitcnt"
+             and prog[i].mods.get("vmcnt") is not None)
+    with pytest.raises(EmuError, match="outstanding"):
+        _tiny_launch(prog[:k] + prog[k + 1:])
+    # the first barrier of the loop (between the S1 writes of pass 1 and the reads of pass 2)
+    b = next(i for i in range(loop, len(prog)) if not isinstance(prog[i], Label) and prog[i].op == "s_barrier")
+    with pytest.raises(EmuError, match="barrier"):
+        _tiny_launch(prog[:b] + prog[b + 1:])
