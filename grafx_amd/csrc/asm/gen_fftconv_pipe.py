@@ -114,6 +114,7 @@ KNOBS = dict(
     prio=0,                     # s_setprio level while a tile's arithmetic runs (0: off)
     place="spread",             # spread: evenly inside the windows; barrier / after: in clusters before / after the barriers
     inv_order="tee_first",      # tee_first / h_first / mix: order of the tee stores and the spectrum loads in the inverse
+    fake_epilogue=0,            # timing experiment: that many junk VALU instructions + 24 extra stores per tile
     codelet="dit",              # dit: radix-2 DIT with fused multiply-adds (3 instructions per general butterfly, values
                                 # rotate through a spare pair); dif: the in-place DIF of fft_tile.hpp (4 instructions)
 )
@@ -463,6 +464,16 @@ class PipeGen(TileGen):
         self.barrier()
         self.inv_read3(X)
         self.inv_pass3(X)
+        if self.k["fake_epilogue"]:
+            n = int(self.k["fake_epilogue"])
+            for i in range(n):
+                t = TMP[i % 6]
+                if i % 12 == 5:
+                    self.add("v_exp_f32", t.sub(0), (t.sub(0),))
+                else:
+                    self.add("v_pk_fma_f32", t, (t, S_ONE_NEG, t))
+            for grp in self.g_stores(lambda a: X.rows[a], CUR_Y):
+                self.prog.extend(grp)
         inv = self.sub()
         tee_st = self.g_stores(lambda a: Y.land[a], NX_T) if self.tee and "notee" not in self.ablate else []
         h_ld = [] if "noh" in self.ablate else self.g_h_loads()

@@ -183,6 +183,9 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
 
 
 SCHEDULES = {"auto": 0, "tile": 1, "pipe": 2}   # GFX_SCHED_* of include/grafx_amd.h
+# What `schedule="auto"` means to fftconv(): "auto" (the library decides: the persistent hand-scheduled kernel for large
+# launches it covers) or "pipe" (prefer that kernel at every size it covers -- tests and latency experiments).
+FFTCONV_SCHEDULE = "auto"
 
 
 @_on_device
@@ -216,12 +219,15 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
         cmap, Rc, Cc, Lc = rowmap(tee)
         if (Rc, Cc, Lc) != (R, Cin, L):
             raise ValueError(f"tee shape {tuple(tee.shape)} does not match the input {tuple(x.shape)}")
+    def launch(sched):
+        return lib().gfx_fftconv_sched_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R, Cin,
+                                           Cf, L, Lout, off, N, _ptr(ws), nbytes, SCHEDULES[sched], _stream())
+
     with _timed(name, 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)):
-        check(
-            lib().gfx_fftconv_sched_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R, Cin,
-                                        Cf, L, Lout, off, N, _ptr(ws), nbytes, SCHEDULES[schedule], _stream()),
-            "gfx_fftconv_sched_f32",
-        )
+        if schedule == "auto" and FFTCONV_SCHEDULE == "pipe":
+            if launch("pipe") == 0:       # GFX_EINVAL = not covered by the persistent kernel: the library's choice then
+                return out
+        check(launch(schedule), "gfx_fftconv_sched_f32")
     return out
 
 

@@ -32,3 +32,36 @@ def test_captured_render_replays_the_eager_render(batch):
         assert torch.equal(got_buf[:, :-2], want_buf[:, :-2])   # every node before the reverb and the output sum
         assert (got_buf - want_buf).abs().max() <= 2e-6 * want_buf.abs().max()
         assert (got_y - want_y).abs().max() <= 2e-6 * want_y.abs().max()
+
+
+def test_captured_render_with_the_persistent_convolution_kernel():
+    """The hand-scheduled convolution kernel is launched through hipModuleLaunchKernel from a code object loaded at the
+    first call: it has to be capturable into the HIP graph like any other kernel.  (At this size the library would pick
+    the one-tile-per-workgroup kernel; `ops.FFTCONV_SCHEDULE = "pipe"` prefers the persistent one wherever it applies.)"""
+    import bench
+    from grafx_amd import ops
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import CapturedRender, prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    G = bench.console_graph(8, 2)
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    procs = {k: v.cuda() for k, v in bench.hip_processors().items()}
+    torch.manual_seed(4)
+    params = {t: {k: v.detach().cuda() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    x = torch.randn(2, 8, 2, 40000, device="cuda")
+    with torch.no_grad():
+        want_y, _, want_buf = render_grafx(procs, x, params, rd)        # library's choice (tile kernel)
+    ops.FFTCONV_SCHEDULE = "pipe"
+    try:
+        with ops.profiling() as prof:
+            with torch.no_grad():
+                eager_y, _, _ = render_grafx(procs, x, params, rd)
+        assert "fftconv1_kernel" in prof
+        fast = CapturedRender(procs, x, params, rd)
+        got_y, _, got_buf = fast(x, params)
+    finally:
+        ops.FFTCONV_SCHEDULE = "auto"
+    assert (eager_y - want_y).abs().max() <= 4e-6 * want_y.abs().max()
+    assert (got_buf - want_buf).abs().max() <= 4e-6 * want_buf.abs().max()
+    assert (got_y - want_y).abs().max() <= 4e-6 * want_y.abs().max()
