@@ -114,6 +114,8 @@ KNOBS = dict(
     prio=0,                     # s_setprio level while a tile's arithmetic runs (0: off)
     place="spread",             # spread: evenly inside the windows; barrier / after: in clusters before / after the barriers
     inv_order="tee_first",      # tee_first / h_first / mix: order of the tee stores and the spectrum loads in the inverse
+    carry=1,                    # 1: a workgroup walks CONSECUTIVE tiles and copies the window overlap (the last a_lo rows)
+                                # from the running tile's registers into the next window instead of re-reading it
     fake_epilogue=0,            # timing experiment: that many junk VALU instructions + 24 extra stores per tile
     codelet="dit",              # dit: radix-2 DIT with fused multiply-adds (3 instructions per general butterfly, values
                                 # rotate through a spare pair); dif: the in-place DIF of fft_tile.hpp (4 instructions)
@@ -245,10 +247,16 @@ class PipeGen(TileGen):
         self.sop("s_add_u32", S_LB, S_LB, S_STRIDE)
 
     # ---- memory instruction groups (each a short list: the scalar offset, then the access) --------------------------
-    def g_window_loads(self, bank):
+    def g_window_loads(self, bank, carried=False):
         """32 groups: row a of the next window -> bank[a]; rows before the row start (a < S_ALO, first tiles only) get an
-        out-of-range offset and read as zero"""
+        out-of-range offset and read as zero.  `carried`: rows below a_lo come from the previous window's registers
+        (`carry_overlap`), only the rows from a_lo on are loaded."""
         out = []
+        if carried:
+            for a in range(self.a_lo, 32):
+                out.append([Inst("s_mov_b32", S_OFF, (Lit(2048 * a),)),
+                            Inst("buffer_load_dwordx2", bank[a], (V_OFF8, NX_X, S_OFF), {})])
+            return out
         if "widemem" in self.ablate:     # timing experiment (wrong results): the same bytes as 16-byte accesses
             for p in range(16):
                 grp = [Inst("s_mov_b32", S_OFF, (Lit(4096 * p),))]
@@ -450,8 +458,30 @@ class PipeGen(TileGen):
         self.fwd_read2(X)
         self.fwd_pass3(X)
         fwd = self.sub()
-        side = ([] if "nostore" in self.ablate else self.g_stores(lambda a: Y.rows[a], ST_Y)) + \
-               ([] if "nowin" in self.ablate else self.g_window_loads(Y.land))
+        stores = [] if "nostore" in self.ablate else self.g_stores(lambda a: Y.rows[a], ST_Y)
+        if self.k["carry"]:
+            # The next window starts V = 16384 - 512 a_lo samples later: its first a_lo rows are this window's last a_lo
+            # rows, still untouched in X at this point.  The output rows of the previous tile that sit in those
+            # registers of Y leave first, then the rows are copied (or zeroed when the next tile starts a new row).
+            dest = Y.land[: self.a_lo]
+            first = [g for g in stores if g[-1].src[0] in dest]
+            stores = [g for g in stores if g[-1].src[0] not in dest]
+            head = [i for g in first for i in g]
+            zero, done = self.fresh("carry_zero"), self.fresh("carry_done")
+            # (the wait for this window's registers has to sit in front of the branch, not inside one of its arms)
+            head.append(Inst(";touch", None, tuple(X.land) + tuple(dest)))
+            head.append(Inst("s_cmp_lg_u32", None, (S_ALO, Lit(0))))
+            head.append(Inst("s_cbranch_scc1", None, (), dict(target=zero)))
+            for m in range(self.a_lo):
+                src = X.land[32 - self.a_lo + m]
+                head += [Inst("v_mov_b32", dest[m].sub(0), (src.sub(0),)), Inst("v_mov_b32", dest[m].sub(1), (src.sub(1),))]
+            head.append(Inst("s_branch", None, (), dict(target=done)))
+            head.append(Label(zero))
+            for m in range(self.a_lo):
+                head += [Inst("v_mov_b32", dest[m].sub(0), (Lit(0),)), Inst("v_mov_b32", dest[m].sub(1), (Lit(0),))]
+            head.append(Label(done))
+            out += head
+        side = stores + ([] if "nowin" in self.ablate else self.g_window_loads(Y.land, carried=bool(self.k["carry"])))
         out += self.place(fwd, side, self.k["fwd_window"])
         self.product(X)
         out += self.sub()
@@ -545,13 +575,20 @@ class PipeGen(TileGen):
         self.mov_lit(S_GEN_EXEC.sub(1), -1)
         # this workgroup's tiles: logical blocks xcd * per_xcd + w, step wgs_per_xcd, below min((xcd + 1) per_xcd, nblocks)
         self.add("s_waitcnt", lgkmcnt=0)
-        self.sop("s_and_b32", SCR[3], s(2), Lit(7))
-        self.sop("s_lshr_b32", SCR[4], s(2), Lit(3))
-        self.sop("s_mul_i32", SCR[5], SCR[3], A("per_xcd"))
-        self.sop("s_add_u32", S_LB, SCR[5], SCR[4])
-        self.sop("s_add_u32", SCR[5], SCR[5], A("per_xcd"))
-        self.sop("s_min_u32", S_END, SCR[5], A("nblocks"))
-        self.sop("s_mov_b32", S_STRIDE, A("wgs_per_xcd"))
+        if self.k["carry"]:
+            # consecutive tiles: workgroup g takes [g * per_wg, (g + 1) * per_wg) (per_wg arrives in `per_xcd`)
+            self.sop("s_mul_i32", S_LB, s(2), A("per_xcd"))
+            self.sop("s_add_u32", SCR[5], S_LB, A("per_xcd"))
+            self.sop("s_min_u32", S_END, SCR[5], A("nblocks"))
+            self.mov_lit(S_STRIDE, 1)
+        else:
+            self.sop("s_and_b32", SCR[3], s(2), Lit(7))
+            self.sop("s_lshr_b32", SCR[4], s(2), Lit(3))
+            self.sop("s_mul_i32", SCR[5], SCR[3], A("per_xcd"))
+            self.sop("s_add_u32", S_LB, SCR[5], SCR[4])
+            self.sop("s_add_u32", SCR[5], SCR[5], A("per_xcd"))
+            self.sop("s_min_u32", S_END, SCR[5], A("nblocks"))
+            self.sop("s_mov_b32", S_STRIDE, A("wgs_per_xcd"))
         done = ".Lnothing"
         self.add("s_cmp_ge_u32", None, (S_LB, S_END))
         self.add("s_cbranch_scc1", target=done)

@@ -596,7 +596,8 @@ static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* 
     k.cout_shift = a.Cout == 2 ? 1 : 0; k.cout_mask = a.Cout == 2 ? 1 : 0;
     k.cin_mask = a.Cin == 2 ? 1 : 0; k.cf_mask = a.Cf == 2 ? 1 : 0; k.Cf = (uint32_t)a.Cf;
     const unsigned grid = (unsigned)(2 * pm->cus) & ~7u;     // two resident workgroups per CU
-    k.per_xcd = (uint32_t)((a.nblocks + 7) / 8); k.wgs_per_xcd = grid / 8;
+    k.per_xcd = (uint32_t)((a.nblocks + grid - 1) / grid);   // tiles per workgroup: consecutive runs (the overlap is carried in registers)
+    k.wgs_per_xcd = grid / 8;
     auto strides = [](const gfx_rowmap_t& mp, uint32_t& olo, uint32_t& ohi, uint32_t& in, uint32_t& ch) {
         const uint64_t o = (uint64_t)mp.stride_outer * 4;
         olo = (uint32_t)o; ohi = (uint32_t)(o >> 32); in = (uint32_t)(mp.stride_inner * 4); ch = (uint32_t)(mp.stride_ch * 4);

@@ -81,7 +81,7 @@ def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0, **knobs):
         xs_outer_lo=4 * nodes * C * L, xs_inner=4 * C * L, xs_ch=4 * L,
         ys_outer_lo=4 * nodes * Cout * L, ys_inner=4 * Cout * L, ys_ch=4 * L,
         cs_outer_lo=4 * nodes * C * L, cs_inner=4 * C * L, cs_ch=4 * L)
-    nwg = min(8, (nblocks + per_xcd - 1) // per_xcd)
+    nwg = (nblocks + per_xcd - 1) // per_xcd      # consecutive runs of `per_xcd` tiles, one workgroup each
     for wg in range(nwg):
         Emulator(prog, mem, gen.TILE_LDS_BYTES, kernarg=args, wg_id=wg, rng=np.random.default_rng(100 + wg)).run()
     y = mem.read_back(ya).reshape(ybuf.shape)[:, 2: 2 + n]

@@ -3,7 +3,7 @@
 GRAFX_ROUND=r3 python tools/pmc_summary.py | tail -3
 cp gpurun_out/profiles_raw/bench_cfg2.json profiles/r3/bench_cfg2.json
 cp gpurun_out/profiles_raw/bench_cfg3.json profiles/r3/bench_cfg3.json
-for c in cfg2 cfg3; do cp gpurun_out/profiles_raw/trace_$c/runc/*kernel_stats.csv profiles/r3/rocprofv3_kernel_stats_$c.csv; done
+for c in cfg2 cfg3; do cp "$(ls -t gpurun_out/profiles_raw/trace_$c/*/*kernel_stats.csv | head -1)" profiles/r3/rocprofv3_kernel_stats_$c.csv; done
 [ -f gpurun_out/parity_exceptions.md ] && cp gpurun_out/parity_exceptions.md profiles/r3/parity_exceptions.md
 python - <<'PY'
 import json
