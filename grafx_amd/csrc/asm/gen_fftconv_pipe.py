@@ -4,14 +4,16 @@ Same arithmetic and memory layout as the compiler-built kernel -- overlap-save F
 tiles, N <= 8193 taps, replacing convolve() of the reference (processors/core/convolution.py:119-134) for even L + N - 1
 -- with the register allocation and the issue order written out:
 
-  * one persistent 256-thread workgroup per half CU walks its share of the tiles; consecutive tiles of a row are worked
-    on side by side by neighbouring workgroups of one XCD (the window overlaps and filter spectra meet in that L2);
+  * one persistent 256-thread workgroup per half CU walks a run of CONSECUTIVE tiles; the window overlap (the last
+    O / 512 register rows of the running window) is copied into the next window's bank instead of being loaded again,
+    so every input sample crosses HBM once and a tile issues 32 - O / 512 window loads;
   * two register banks of 32 complex values alternate: while tile i is transformed in one bank, the outputs of tile
     i-1 leave the other bank (buffer_store interleaved with the first forward passes) and the window of tile i+1 lands
     in it; the filter spectrum of tile i+1 is requested during the inverse transform of tile i; the per-thread twiddles
     stay in registers for the life of the workgroup;
-  * every butterfly is in place, so the register map is static: 2 x 64 (banks) + 68 (spectrum) + 32 (twiddles) +
-    12 (scratch) + 9 (addresses) VGPRs, no scratch memory, 2 workgroups per CU (73,728 B of LDS each).
+  * radix-2 DIT butterflies with fused multiply-adds (3 instructions; values rotate through a spare pair per bank, the
+    register map stays static): 2 x 66 (banks) + 68 (spectrum) + 32 (twiddles) + 12 (scratch) + 9 (addresses) VGPRs, no
+    scratch memory, 2 workgroups per CU (73,728 B of LDS each).
 
 Variants (kernel name suffix): `t<0|1>` = also store the window's valid part to a second destination (the render's
 source rows), `o<k>` = k = O / 512 leading rows of every tile are overlap (not stored; N - 1 <= 512 k).
