@@ -157,10 +157,36 @@ class LinearConvFn(torch.autograd.Function):
         return gx, gh, None, None, None
 
 
-def convolve(x, h, mode="causal", exact=False, final=False):
+class OddAliasFn(torch.autograd.Function):
+    """y = irfft_{P-1}(rfft_P(z))[..., lo : lo + length] (reference core/convolution.py:123-126) on the chirp-z kernels,
+    its gradient on the transposed pair (gfx_odd_alias_adjoint_f32): no FFT library, no float64."""
+
+    @staticmethod
+    def forward(ctx, z, lo, length):
+        ctx.P, ctx.lo = z.shape[-1], lo
+        return ops.odd_alias(z, lo, length)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        return ops.odd_alias_adjoint(gy, ctx.P, ctx.lo), None, None
+
+
+def odd_alias(z, lo=0, length=None, precise=False):
+    """Differentiable odd-length aliasing; lengths beyond the kernels' range (P > 699,051) and ``precise`` callers (the
+    energy envelope, see processors.core.convolution.odd_length_alias) fall to the FFT library in float64, which
+    differentiates itself."""
+    Q = z.shape[-1] - 1
+    length = Q - lo if length is None else length
+    if not precise and ops.odd_alias_supported(z.shape[-1]):
+        return OddAliasFn.apply(z, lo, length)
+    return torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)[..., lo : lo + length]
+
+
+def convolve(x, h, mode="causal", exact=False, final=False, precise=False):
     """Differentiable twin of processors.core.convolution.convolve (reference core/convolution.py:119-134),
-    including the odd-P aliasing (which is plain torch.fft and differentiates itself).  ``final``: the result is
-    the calling processor's output up to linear operations (see tape_only)."""
+    including the odd-P aliasing (OddAliasFn).  ``final``: the result is the calling processor's output up to linear
+    operations (see tape_only)."""
     from .processors.core.convolution import reference_aliases
 
     flat = x.ndim == 2
@@ -176,13 +202,12 @@ def convolve(x, h, mode="causal", exact=False, final=False):
             y = LinearConvFn.apply(x, h, L + N - 1, 0, final)
     else:
         z = LinearConvFn.apply(x, h, L + N - 1, 0, final)
-        y_pad = torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)  # float64 aliasing, see odd_length_alias
         if mode == "causal":
-            y = y_pad[..., :L]
+            y = odd_alias(z, 0, L, precise)
         elif mode == "zerophase":
-            y = y_pad[..., N // 2 : N // 2 + L]
+            y = odd_alias(z, N // 2, L, precise)
         else:
-            y = y_pad
+            y = odd_alias(z, precise=precise)
     return y.squeeze(1) if flat else y
 
 
@@ -467,7 +492,7 @@ def truncated_one_pole(u, z_alpha, iir_len, exact=False):
 
     if u.ndim == 2 and not reference_aliases(u.shape[-1], iir_len, exact):
         return TruncatedOnePoleFn.apply(u, z_alpha, iir_len)
-    return torch.relu(convolve(u, one_pole_fir(z_alpha, iir_len), "causal", exact=exact))
+    return torch.relu(convolve(u, one_pole_fir(z_alpha, iir_len), "causal", exact=exact, precise=True))
 
 
 class BallisticsFn(torch.autograd.Function):

@@ -53,8 +53,16 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
     return true;
 }
 
-// plan layout (float2 units): cP[P] | cQ[Q] | spectrum of bP [NFFT] | spectrum of bQ [NFFT]
-static inline size_t czt_plan_f2(const CztGeom& g) { return (size_t)(g.P + g.Q + 2 * g.NFFT); }
+// plan layout (float2 units): cP[P] | cQ[Q] | spectra [NFFT] each of bP, bQ (forward) and of bQ, bP placed for the
+// adjoint (same chirps, mirrored support: the adjoint's first transform has Q inputs and K outputs, its second K
+// inputs and P outputs)
+static inline size_t czt_plan_f2(const CztGeom& g) { return (size_t)(g.P + g.Q + 4 * g.NFFT); }
+
+// b[j] = exp(sign i pi j^2 / den) at circular index j mod NFFT for j in [-lo, hi], zero elsewhere
+struct ChirpSeq {
+    int64_t lo, hi, den;
+    double sign;
+};
 
 __device__ __forceinline__ float2 chirp_d(int64_t j, int64_t den, double sign) {   // exp(sign i pi j^2 / den)
     const int64_t r = (j * j) % (2 * den);
@@ -75,11 +83,12 @@ __device__ __forceinline__ cx col_twiddle(int n2, int k1, float inv_half_nfft, b
     return cx{c, conj ? s : -s};
 }
 
-// MODE 0: real rows z (rows x P) times cP;  MODE 1: the complex buffer itself;  MODE 2 / 3: the chirp sequences bP / bQ
-// (plan building: b[j] at circular index j mod NFFT for j in [-(P-1), K-1] resp. [-(K-1), Q-1], zero elsewhere)
+// MODE 0: real rows, z[row, i - lo] tab[i] for lo <= i < lo + len (row stride ldz), zero elsewhere;  MODE 1: the complex
+// buffer itself;  MODE 2: a chirp sequence (plan building)
 template <int C, int MODE>
-__global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ cP,
-                                                          float2* __restrict__ buf, CztGeom g) {
+__global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ tab,
+                                                          float2* __restrict__ buf, CztGeom g, int64_t ldz, int64_t lo,
+                                                          int64_t len, ChirpSeq cs) {
     const int n2 = blockIdx.x * 256 + threadIdx.x;          // column 0..8191
     const int64_t row = blockIdx.y;                        // signal row * S + sub-transform
     const int64_t NS = g.NFFT / g.S;                       // points of one sub-transform
@@ -90,15 +99,12 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
         const int64_t i = (int64_t)n1 * TILE_M + n2;
         cx e = {0.0f, 0.0f};
         if (MODE == 0) {
-            if (i < g.P) e = to_cx(cP[i]) * z[row * g.P + i];
+            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
             e = to_cx(b[i]);
         } else {
-            const int64_t lo = MODE == 2 ? g.P - 1 : g.K - 1, hi = MODE == 2 ? g.K - 1 : g.Q - 1;
-            const int64_t den = MODE == 2 ? g.P : g.Q;
-            const double sign = MODE == 2 ? 1.0 : -1.0;
-            if (i <= hi) e = to_cx(chirp_d(i, den, sign));
-            else if (i >= g.NFFT - lo) e = to_cx(chirp_d(g.NFFT - i, den, sign));
+            if (i <= cs.hi) e = to_cx(chirp_d(i, cs.den, cs.sign));
+            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d(g.NFFT - i, cs.den, cs.sign));
         }
         v[n1] = e;
     }
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(TILE_T, 2) void czt_rows_kernel(float2* __restrict_
 
 // MODE 0 (after the first convolution): buf[k] <- conv[k] cP[k] w_k cQ[k] / NFFT for k < K, zero beyond
 // MODE 1 (after the second):            y[row, n - lo] <- Re(conv[n] cQ[n]) / (NFFT Q)  for lo <= n < lo + len
+// (the adjoint passes cP in cQ's place for MODE 1: its output lives on the P grid, still divided by Q)
 template <int C, int MODE>
 __global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ buf, const float2* __restrict__ cP,
                                                           const float2* __restrict__ cQ, float* __restrict__ y,
@@ -198,9 +205,10 @@ __device__ __forceinline__ cx outer_twiddle(int64_t np, int k3, int64_t NFFT, bo
     return cx{c, conj ? s : -s};
 }
 
-template <int MODE>   // 0: real z times cP; 1: complex buffer; 2 / 3: chirp sequences bP / bQ (plan)
-__global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ cP,
-                                                           float2* __restrict__ buf, CztGeom g) {
+template <int MODE>   // 0: real rows times a chirp table; 1: complex buffer; 2: a chirp sequence (plan)
+__global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ tab,
+                                                           float2* __restrict__ buf, CztGeom g, int64_t ldz, int64_t lo,
+                                                           int64_t len, ChirpSeq cs) {
     const int64_t NS = g.NFFT / 4;
     const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = blockIdx.y;
@@ -211,15 +219,12 @@ __global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restr
         const int64_t i = n3 * NS + np;
         cx e = {0.0f, 0.0f};
         if (MODE == 0) {
-            if (i < g.P) e = to_cx(cP[i]) * z[row * g.P + i];
+            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
             e = to_cx(b[i]);
         } else {
-            const int64_t lo = MODE == 2 ? g.P - 1 : g.K - 1, hi = MODE == 2 ? g.K - 1 : g.Q - 1;
-            const int64_t den = MODE == 2 ? g.P : g.Q;
-            const double sign = MODE == 2 ? 1.0 : -1.0;
-            if (i <= hi) e = to_cx(chirp_d(i, den, sign));
-            else if (i >= g.NFFT - lo) e = to_cx(chirp_d(g.NFFT - i, den, sign));
+            if (i <= cs.hi) e = to_cx(chirp_d(i, cs.den, cs.sign));
+            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d(g.NFFT - i, cs.den, cs.sign));
         }
         v[n3] = e;
     }
@@ -268,15 +273,16 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(float2* __restrict__
 }
 
 template <int MODE>
-static void launch_cols_fwd(const CztGeom& g, const float* z, const float2* cP, float2* buf, int64_t rows, hipStream_t st) {
+static void launch_cols_fwd(const CztGeom& g, const float* z, const float2* cP, float2* buf, int64_t rows, hipStream_t st,
+                            int64_t ldz = 0, int64_t lo = 0, int64_t len = 0, ChirpSeq cs = ChirpSeq{0, 0, 1, 1.0}) {
     const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);   // one "row" per sub-transform
     switch (g.C) {
-        case 1: hipLaunchKernelGGL((czt_cols_fwd_kernel<1, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
-        case 2: hipLaunchKernelGGL((czt_cols_fwd_kernel<2, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
-        case 4: hipLaunchKernelGGL((czt_cols_fwd_kernel<4, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
-        case 8: hipLaunchKernelGGL((czt_cols_fwd_kernel<8, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
-        case 16: hipLaunchKernelGGL((czt_cols_fwd_kernel<16, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
-        default: hipLaunchKernelGGL((czt_cols_fwd_kernel<32, MODE>), grid, blk, 0, st, z, cP, buf, g); break;
+        case 1: hipLaunchKernelGGL((czt_cols_fwd_kernel<1, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+        case 2: hipLaunchKernelGGL((czt_cols_fwd_kernel<2, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+        case 4: hipLaunchKernelGGL((czt_cols_fwd_kernel<4, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+        case 8: hipLaunchKernelGGL((czt_cols_fwd_kernel<8, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+        case 16: hipLaunchKernelGGL((czt_cols_fwd_kernel<16, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+        default: hipLaunchKernelGGL((czt_cols_fwd_kernel<32, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
     }
 }
 
@@ -326,27 +332,66 @@ int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, voi
     if (!tw || !czt_allow_lds(czt_rows_kernel<true>)) return GFX_ELAUNCH;
     float2* cP = (float2*)plan;
     float2* cQ = cP + g.P;
-    float2* sP = cQ + g.Q;
-    float2* sQ = sP + g.NFFT;
+    float2* spec = cQ + g.Q;
     hipLaunchKernelGGL(czt_chirp_table_kernel, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, cP, g.P, g.P, -1.0f);
     hipLaunchKernelGGL(czt_chirp_table_kernel, dim3((unsigned)((g.Q + 255) / 256)), dim3(256), 0, st, cQ, g.Q, g.Q, 1.0f);
     float2* buf = (float2*)ws;
     const int ctot = g.S * g.C;
     const dim3 og((unsigned)(g.NFFT / 4 / 256), 1);
-    if (g.S == 1) launch_cols_fwd<2>(g, nullptr, nullptr, buf, 1, st);
-    else {
-        hipLaunchKernelGGL(czt_outer_fwd_kernel<2>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g);
-        launch_cols_fwd<1>(g, nullptr, nullptr, buf, 1, st);
+    // forward: bP over [-(P-1), K-1], bQ over [-(K-1), Q-1];  adjoint: bQ over [-(Q-1), K-1], bP over [-(K-1), P-1]
+    const ChirpSeq seqs[4] = {{g.P - 1, g.K - 1, g.P, 1.0}, {g.K - 1, g.Q - 1, g.Q, -1.0},
+                              {g.Q - 1, g.K - 1, g.Q, -1.0}, {g.K - 1, g.P - 1, g.P, 1.0}};
+    for (int i = 0; i < 4; ++i) {
+        if (g.S == 1) launch_cols_fwd<2>(g, nullptr, nullptr, buf, 1, st, 0, 0, 0, seqs[i]);
+        else {
+            hipLaunchKernelGGL(czt_outer_fwd_kernel<2>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr,
+                               buf, g, (int64_t)0, (int64_t)0, (int64_t)0, seqs[i]);
+            launch_cols_fwd<1>(g, nullptr, nullptr, buf, 1, st);
+        }
+        hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)ctot), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
+                           (const float2*)nullptr, spec + (int64_t)i * g.NFFT, ctot, tw);
     }
-    hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)ctot), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
-                       (const float2*)nullptr, sP, ctot, tw);
-    if (g.S == 1) launch_cols_fwd<3>(g, nullptr, nullptr, buf, 1, st);
-    else {
-        hipLaunchKernelGGL(czt_outer_fwd_kernel<3>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g);
-        launch_cols_fwd<1>(g, nullptr, nullptr, buf, 1, st);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+// The two chirp-z transforms of one direction: rows of `in` (slice [ilo, ilo + ilen) of the first grid, times tab1) ->
+// convolution with spec1 -> times cP cQ w_k on the K bins -> convolution with spec2 -> Re(. tab2) / Q into the slice
+// [olo, olo + olen) of the second grid.
+static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, int64_t ilen, const float2* tab1,
+                   const float2* spec1, const float2* spec2, const float2* tab2, float* out, int64_t ldo, int64_t olo,
+                   int64_t olen, int64_t rows, const float2* cP, const float2* cQ, float2* buf, hipStream_t st) {
+    const float2* tw = tile_twiddle_table(st);
+    if (!tw || !czt_allow_lds(czt_rows_kernel<false>)) return GFX_ELAUNCH;
+    const int ctot = g.S * g.C;
+    const unsigned tiles = (unsigned)(rows * ctot);
+    const ChirpSeq none{0, 0, 1, 1.0};
+    if (g.S == 1) {
+        launch_cols_fwd<0>(g, in, tab1, buf, rows, st, ldi, ilo, ilen);
+        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec1,
+                           (float2*)nullptr, ctot, tw);
+        launch_cols_inv<0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+        launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
+        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec2,
+                           (float2*)nullptr, ctot, tw);
+        launch_cols_inv<1>(g, buf, cP, tab2, out, ldo, olo, olen, rows, st);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
-    hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)ctot), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
-                       (const float2*)nullptr, sQ, ctot, tw);
+    // outer radix-4 level around four 2^18-point transforms per row
+    const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)rows);
+    hipLaunchKernelGGL(czt_outer_fwd_kernel<0>, og, dim3(256), 0, st, in, tab1, buf, g, ldi, ilo, ilen, none);
+    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
+    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec1, (float2*)nullptr,
+                       ctot, tw);
+    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    hipLaunchKernelGGL(czt_outer_inv_kernel<0>, og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0, (int64_t)0,
+                       (int64_t)0, g);
+    hipLaunchKernelGGL(czt_outer_fwd_kernel<1>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g,
+                       (int64_t)0, (int64_t)0, (int64_t)0, none);
+    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
+    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec2, (float2*)nullptr,
+                       ctot, tw);
+    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    hipLaunchKernelGGL(czt_outer_inv_kernel<1>, og, dim3(256), 0, st, buf, cP, tab2, out, ldo, olo, olen, g);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
@@ -356,43 +401,28 @@ int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t
     if (!z || !y || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
     if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
     if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(float2)) return GFX_ENOSPC;
-    hipStream_t st = (hipStream_t)stream;
-    const float2* tw = tile_twiddle_table(st);
-    if (!tw || !czt_allow_lds(czt_rows_kernel<false>)) return GFX_ELAUNCH;
     const float2* cP = (const float2*)plan;
     const float2* cQ = cP + g.P;
-    const float2* sP = cQ + g.Q;
-    const float2* sQ = sP + g.NFFT;
-    float2* buf = (float2*)ws;
-    const int ctot = g.S * g.C;
-    const unsigned tiles = (unsigned)(rows * ctot);
-    if (g.S == 1) {
-        launch_cols_fwd<0>(g, z, cP, buf, rows, st);
-        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sP, (float2*)nullptr,
-                           ctot, tw);
-        launch_cols_inv<0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-        launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sQ, (float2*)nullptr,
-                           ctot, tw);
-        launch_cols_inv<1>(g, buf, cP, cQ, y, ldy, lo, len, rows, st);
-        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-    }
-    // outer radix-4 level around four 2^18-point transforms per row
-    const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)rows);
-    hipLaunchKernelGGL(czt_outer_fwd_kernel<0>, og, dim3(256), 0, st, z, cP, buf, g);
-    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sP, (float2*)nullptr, ctot,
-                       tw);
-    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-    hipLaunchKernelGGL(czt_outer_inv_kernel<0>, og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0, (int64_t)0,
-                       (int64_t)0, g);
-    hipLaunchKernelGGL(czt_outer_fwd_kernel<1>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g);
-    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, sQ, (float2*)nullptr, ctot,
-                       tw);
-    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-    hipLaunchKernelGGL(czt_outer_inv_kernel<1>, og, dim3(256), 0, st, buf, cP, cQ, y, ldy, lo, len, g);
-    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    const float2* spec = cQ + g.Q;
+    return czt_run(g, z, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, y, ldy, lo, len, rows, cP, cQ, (float2*)ws,
+                   (hipStream_t)stream);
+}
+
+// Transpose of gfx_odd_alias_f32 (the gradient of the aliasing step): with G'[k] = sum_n gy[n] e^{+2 pi i k n / Q},
+//   gz[m] = Re( sum_{k < K} w_k G'[k] e^{-2 pi i k m / P} ) / Q
+// i.e. the same two chirp-z transforms in the other order -- cQ / bQ first (Q inputs, K bins), cP / bP second (P
+// outputs) -- with the chirps' supports mirrored (the plan's third and fourth spectrum).
+int gfx_odd_alias_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows, int64_t P,
+                              const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    CztGeom g;
+    if (!gy || !gz || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
+    if (lo < 0 || len < 1 || lo + len > g.Q || ldg < len) return GFX_EINVAL;
+    if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(float2)) return GFX_ENOSPC;
+    const float2* cP = (const float2*)plan;
+    const float2* cQ = cP + g.P;
+    const float2* spec = cQ + g.Q;
+    return czt_run(g, gy, ldg, lo, len, cQ, spec + 2 * g.NFFT, spec + 3 * g.NFFT, cP, gz, g.P, 0, g.P, rows, cP, cQ,
+                   (float2*)ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

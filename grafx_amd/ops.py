@@ -292,6 +292,36 @@ def odd_alias_supported(P):
     return lib().gfx_odd_alias_plan_bytes(P) > 0
 
 
+def _alias_plan(P, device):
+    """The per-P chirp plan of the aliasing kernels (LRU of _ALIAS_PLANS_MAX, built on first use)."""
+    key = (P, device.type, device.index)
+    plan = _ALIAS_PLANS.pop(key, None)
+    if plan is not None:
+        _ALIAS_PLANS[key] = plan   # back in as the most recent
+    if plan is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a plan built during capture would live in the graph's private pool and be rebuilt on every replay
+            raise RuntimeError(f"odd_alias: no plan for P={P} yet; run the call once outside the HIP-graph capture")
+        plan = torch.empty(lib().gfx_odd_alias_plan_bytes(P), dtype=torch.uint8, device=device)
+        w1 = torch.empty(lib().gfx_odd_alias_workspace_bytes(1, P), dtype=torch.uint8, device=device)
+        check(lib().gfx_odd_alias_plan_f32(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), "gfx_odd_alias_plan_f32")
+        torch.cuda.current_stream(device).synchronize()   # the cached plan is complete before any stream can pick it up
+        _ALIAS_PLANS[key] = plan
+        while len(_ALIAS_PLANS) > _ALIAS_PLANS_MAX:
+            old = _ALIAS_PLANS.pop(next(iter(_ALIAS_PLANS)))
+            torch.cuda.synchronize(old.device)               # nobody on any stream still reads the evicted plan
+            del old
+    plan.record_stream(torch.cuda.current_stream(device))
+    return plan
+
+
+def _alias_chunks(rows, P, rows_per_chunk, device):
+    per_row = lib().gfx_odd_alias_workspace_bytes(1, P)
+    chunk = max(1, min(rows, rows_per_chunk, (1 << 30) // per_row))   # at most 1 GB of workspace
+    ws = torch.empty(lib().gfx_odd_alias_workspace_bytes(chunk, P), dtype=torch.uint8, device=device)
+    return chunk, ws
+
+
 @_on_device
 def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
@@ -301,35 +331,34 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
     P = z.shape[-1]
     Q = P - 1
     length = Q - lo if length is None else length
-    key = (P, z.device.type, z.device.index)
-    plan = _ALIAS_PLANS.pop(key, None)
-    if plan is not None:
-        _ALIAS_PLANS[key] = plan   # back in as the most recent
-    if plan is None:
-        if torch.cuda.is_current_stream_capturing():
-            # a plan built during capture would live in the graph's private pool and be rebuilt on every replay
-            raise RuntimeError(f"odd_alias: no plan for P={P} yet; run the call once outside the HIP-graph capture")
-        plan = torch.empty(lib().gfx_odd_alias_plan_bytes(P), dtype=torch.uint8, device=z.device)
-        w1 = torch.empty(lib().gfx_odd_alias_workspace_bytes(1, P), dtype=torch.uint8, device=z.device)
-        check(lib().gfx_odd_alias_plan_f32(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), "gfx_odd_alias_plan_f32")
-        torch.cuda.current_stream(z.device).synchronize()   # the cached plan is complete before any stream can pick it up
-        _ALIAS_PLANS[key] = plan
-        while len(_ALIAS_PLANS) > _ALIAS_PLANS_MAX:
-            old = _ALIAS_PLANS.pop(next(iter(_ALIAS_PLANS)))
-            torch.cuda.synchronize(old.device)               # nobody on any stream still reads the evicted plan
-            del old
-    plan.record_stream(torch.cuda.current_stream(z.device))
+    plan = _alias_plan(P, z.device)
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
-    per_row = lib().gfx_odd_alias_workspace_bytes(1, P)
-    chunk = max(1, min(rows, rows_per_chunk, (1 << 30) // per_row))   # at most 1 GB of workspace
-    ws = torch.empty(lib().gfx_odd_alias_workspace_bytes(chunk, P), dtype=torch.uint8, device=z.device)
+    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device)
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
         check(lib().gfx_odd_alias_f32(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan),
                                       _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_f32")
     return out.view(*z.shape[:-1], length)
+
+
+@_on_device
+def odd_alias_adjoint(gy, P, lo=0, rows_per_chunk=256):
+    """Transpose of odd_alias: the gradient with respect to z (..., P) given gy (..., length), the gradient with respect
+    to odd_alias(z, lo, length) -- what autograd derives from the reference's rfft / irfft pair."""
+    _require_gpu(gy)
+    length = gy.shape[-1]
+    plan = _alias_plan(P, gy.device)
+    flat = gy.reshape(-1, length).contiguous()
+    rows = flat.shape[0]
+    out = torch.empty((rows, P), dtype=torch.float32, device=gy.device)
+    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, gy.device)
+    for i in range(0, rows, chunk):
+        n = min(chunk, rows - i)
+        check(lib().gfx_odd_alias_adjoint_f32(_ptr(flat[i : i + n]), length, lo, length, _ptr(out[i : i + n]), n, P,
+                                              _ptr(plan), _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_adjoint_f32")
+    return out.view(*gy.shape[:-1], P)
 
 
 # ----------------------------------------------------------------------------------------- IIR (FSM)

@@ -69,8 +69,8 @@ def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for a full linear convolution z of odd length P
     (convolution.py:123-126): two chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, fp32, no FFT library).
 
-    Three cases still go through the device FFT library in float64: gradients (autograd of the aliasing step),
-    P > 699,051 (a 2^20-point transform no longer covers 1.5 P) and ``precise=True`` -- the
+    The gradient is the transposed pair of transforms (autograd.OddAliasFn).  Two cases still go through the device FFT
+    library in float64: P > 699,051 (a 2^20-point transform no longer covers 1.5 P) and ``precise=True`` -- the
     energy-envelope smoother of the dynamics processors, whose output feeds log() and a gain curve: there the fp32
     chirp-z noise (~1e-6 of the peak, about twice what the reference's own mixed-radix fp32 FFT leaves) is amplified
     on quiet passages beyond the parity bound (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths)."""
@@ -79,7 +79,9 @@ def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
     if not precise and not (torch.is_grad_enabled() and z.requires_grad) and ops.odd_alias_supported(z.shape[-1]):
         return ops.odd_alias(z, lo, length)
     if torch.is_grad_enabled() and z.requires_grad:
-        return torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)[..., lo : lo + length]
+        from ... import autograd as diff
+
+        return diff.odd_alias(z, lo, length, precise)
     flat = z.reshape(-1, z.shape[-1])
     out = torch.empty((flat.shape[0], length), dtype=z.dtype, device=z.device)
     for i in range(0, flat.shape[0], rows_per_chunk):

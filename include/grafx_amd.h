@@ -153,12 +153,17 @@ int gfx_fir_direct_f32(const float* x, gfx_rowmap_t xmap, const float* h, int64_
  * default length produces.  gfx_odd_alias_f32 computes y[:, lo : lo + len] from z (rows x P, contiguous) with two
  * chirp-z transforms on the LDS FFT tile (no FFT library, fp32); 3 <= P <= 699,051 odd (NFFT up to 4 x 32 x 8192), rows
  * <= 16383 per call, else the size queries return 0.  `plan` (per P: chirps and their spectra) comes from gfx_odd_alias_plan_f32, which needs a
- * workspace of gfx_odd_alias_workspace_bytes(1, P); the transform needs gfx_odd_alias_workspace_bytes(rows, P). */
+ * workspace of gfx_odd_alias_workspace_bytes(1, P); the transform needs gfx_odd_alias_workspace_bytes(rows, P).
+ * gfx_odd_alias_adjoint_f32 is the transposed map (the gradient the reference gets from differentiating its
+ * rfft / irfft pair): gz (rows x P, contiguous) from gy (rows x len, row stride ldg), the gradient with respect to
+ * y[:, lo : lo + len]; same plan, same workspace size. */
 size_t gfx_odd_alias_plan_bytes(int64_t P);
 size_t gfx_odd_alias_workspace_bytes(int64_t rows, int64_t P);
 int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                       const void* plan, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows, int64_t P,
+                              const void* plan, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- small inverse real DFT (parameter-side front-ends) ---------------------------------------
  * y = irfft(X, n) for any n <= 8192 as a direct sum (twiddles tabulated in LDS), K = n/2 + 1 bins per row, X complex

@@ -38,3 +38,50 @@ def test_odd_alias_limits():
     assert (y.double() - want).abs().max() <= 1e-6
     ones = ops.odd_alias(torch.ones(2, P, device="cuda"))
     assert (ones - P / (P - 1)).abs().max() <= 1e-5   # DC gain of irfft_{P-1} o rfft_P
+
+
+@pytest.mark.parametrize("P", [3, 5, 101, 4001, 10923, 43691, 135071, 147455, 174765, 300001, 699051])
+def test_odd_alias_adjoint_matches_float64_autograd(P):
+    """gfx_odd_alias_adjoint_f32 against torch autograd of the float64 rfft / irfft pair (what the reference's backward
+    computes, core/convolution.py:123-126), whole grid and a slice; and <A z, g> = <z, A^T g> on the native pair."""
+    from grafx_amd import ops
+
+    torch.manual_seed(P + 1)
+    shape = (3, 2) if P < 200000 else (2, 1)
+    z = torch.randn(*shape, P, device="cuda")
+    Q = P - 1
+    for lo, n in ((0, Q), (P // 3, max(1, P // 5))):
+        g = torch.randn(*shape, n, device="cuda")
+        zd = z.double().requires_grad_(True)
+        torch.fft.irfft(torch.fft.rfft(zd))[..., lo : lo + n].backward(g.double())
+        got = ops.odd_alias_adjoint(g, P, lo)
+        assert got.shape == z.shape
+        err = (got.double() - zd.grad).abs().max() / zd.grad.abs().max()
+        assert err <= 3e-6, f"P={P} lo={lo}: {err:.2e}"
+        lhs = (ops.odd_alias(z, lo, n).double() * g.double()).sum()
+        rhs = (z.double() * got.double()).sum()
+        assert abs(lhs - rhs) <= 1e-5 * (z.double().norm() * g.double().norm()), f"P={P}: {lhs} vs {rhs}"
+
+
+def test_convolve_gradient_with_aliasing_is_native():
+    """autograd.convolve at an odd P: gradients equal torch autograd of the reference's expression in float64, and no
+    float64 tensor is created on the way (the aliasing step's backward is OddAliasFn)."""
+    from grafx_amd import autograd as diff
+
+    torch.manual_seed(5)
+    L, N = 8192, 1000      # P = 9191
+    x = torch.randn(3, 2, L, device="cuda", requires_grad=True)
+    h = (torch.randn(3, 2, N, device="cuda") / 30).requires_grad_(True)
+    g = torch.randn(3, 2, L, device="cuda")
+    for mode, lo in (("causal", 0), ("zerophase", N // 2)):
+        x.grad = h.grad = None
+        y = diff.convolve(x, h, mode)
+        assert y.dtype == torch.float32 and type(y.grad_fn).__name__ == "OddAliasFnBackward"
+        y.backward(g)
+        xd, hd = x.detach().double().requires_grad_(True), h.detach().double().requires_grad_(True)
+        P = L + N - 1
+        yd = torch.fft.irfft(torch.fft.rfft(xd, n=P) * torch.fft.rfft(hd, n=P))[..., lo : lo + L]
+        yd.backward(g.double())
+        assert (y.double() - yd).abs().max() <= 1e-5 * yd.abs().max()
+        for a, b in ((x.grad, xd.grad), (h.grad, hd.grad)):
+            assert (a.double() - b).abs().max() <= 2e-5 * b.abs().max()
