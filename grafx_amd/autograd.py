@@ -162,24 +162,24 @@ class OddAliasFn(torch.autograd.Function):
     its gradient on the transposed pair (gfx_odd_alias_adjoint_f32): no FFT library, no float64."""
 
     @staticmethod
-    def forward(ctx, z, lo, length):
-        ctx.P, ctx.lo = z.shape[-1], lo
-        return ops.odd_alias(z, lo, length)
+    def forward(ctx, z, lo, length, precise):
+        ctx.P, ctx.lo, ctx.precise = z.shape[-1], lo, precise
+        return ops.odd_alias(z, lo, length, precise=precise)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        return ops.odd_alias_adjoint(gy, ctx.P, ctx.lo), None, None
+        return ops.odd_alias_adjoint(gy, ctx.P, ctx.lo, precise=ctx.precise), None, None, None
 
 
 def odd_alias(z, lo=0, length=None, precise=False):
-    """Differentiable odd-length aliasing; lengths beyond the kernels' range (P > 699,051) and ``precise`` callers (the
-    energy envelope, see processors.core.convolution.odd_length_alias) fall to the FFT library in float64, which
-    differentiates itself."""
+    """Differentiable odd-length aliasing (``precise``: double-precision transforms, see
+    processors.core.convolution.odd_length_alias); lengths beyond the kernels' range (P > 699,051) fall to the FFT
+    library in float64, which differentiates itself."""
     Q = z.shape[-1] - 1
     length = Q - lo if length is None else length
-    if not precise and ops.odd_alias_supported(z.shape[-1]):
-        return OddAliasFn.apply(z, lo, length)
+    if ops.odd_alias_supported(z.shape[-1]):
+        return OddAliasFn.apply(z, lo, length, bool(precise))
     return torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)[..., lo : lo + length]
 
 

@@ -21,13 +21,33 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 
 #include "../../include/grafx_amd.h"
 #include "fft_tile.hpp"
+#include "fft_tile_f64.hpp"
 
 namespace gfx {
 
 constexpr int CZT_MAXC = 32;
+
+// Working precision of the transforms (the data in and out is fp32 either way): float = the packed-FP32 tile, double =
+// the `precise` form for the energy envelope (fft_tile_f64.hpp).  Tables, spectra and the workspace are T2 per point.
+template <typename T> struct Prec;
+template <> struct Prec<float> {
+    using cxt = cx;
+    using T2 = float2;
+    using Tw = TileTw;
+    static constexpr int lds_bytes = TILE_LDS_BYTES;
+    static __device__ __forceinline__ T2 make(float x, float y) { return make_float2(x, y); }
+};
+template <> struct Prec<double> {
+    using cxt = cxd;
+    using T2 = double2;
+    using Tw = TileTwD;
+    static constexpr int lds_bytes = TILE_LDS_BYTES_F64;
+    static __device__ __forceinline__ T2 make(double x, double y) { return make_double2(x, y); }
+};
 
 struct CztGeom {
     int64_t P, Q, K, NFFT;   // NFFT = S * C * 8192
@@ -64,16 +84,18 @@ struct ChirpSeq {
     double sign;
 };
 
-__device__ __forceinline__ float2 chirp_d(int64_t j, int64_t den, double sign) {   // exp(sign i pi j^2 / den)
+template <typename T>
+__device__ __forceinline__ typename Prec<T>::T2 chirp_d(int64_t j, int64_t den, double sign) {   // exp(sign i pi j^2 / den)
     const int64_t r = (j * j) % (2 * den);
     double s, c;
     sincospi((double)r / (double)den, &s, &c);
-    return make_float2((float)c, (float)(sign * s));
+    return Prec<T>::make((T)c, (T)(sign * s));
 }
 
-__global__ void czt_chirp_table_kernel(float2* __restrict__ tab, int64_t n, int64_t den, float sign) {
+template <typename T>
+__global__ void czt_chirp_table_kernel(typename Prec<T>::T2* __restrict__ tab, int64_t n, int64_t den, float sign) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tab[i] = chirp_d(i, den, sign);
+    if (i < n) tab[i] = chirp_d<T>(i, den, sign);
 }
 
 // W_NFFT^(n2 k1): the argument 2 n2 k1 / NFFT is exact in float (NFFT is a power of two, n2 k1 < 2^18)
@@ -82,55 +104,64 @@ __device__ __forceinline__ cx col_twiddle(int n2, int k1, float inv_half_nfft, b
     sincospif((float)(n2 * k1) * inv_half_nfft, &s, &c);
     return cx{c, conj ? s : -s};
 }
+__device__ __forceinline__ cxd col_twiddle(int n2, int k1, double inv_half_nfft, bool conj) {
+    double s, c;
+    sincospi((double)(n2 * k1) * inv_half_nfft, &s, &c);
+    return cxd{c, conj ? s : -s};
+}
 
 // MODE 0: real rows, z[row, i - lo] tab[i] for lo <= i < lo + len (row stride ldz), zero elsewhere;  MODE 1: the complex
 // buffer itself;  MODE 2: a chirp sequence (plan building)
-template <int C, int MODE>
-__global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ tab,
-                                                          float2* __restrict__ buf, CztGeom g, int64_t ldz, int64_t lo,
-                                                          int64_t len, ChirpSeq cs) {
+template <typename T, int C, int MODE>
+__global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restrict__ z,
+                                                          const typename Prec<T>::T2* __restrict__ tab,
+                                                          typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t ldz,
+                                                          int64_t lo, int64_t len, ChirpSeq cs) {
+    using cx = typename Prec<T>::cxt;
     const int n2 = blockIdx.x * 256 + threadIdx.x;          // column 0..8191
     const int64_t row = blockIdx.y;                        // signal row * S + sub-transform
     const int64_t NS = g.NFFT / g.S;                       // points of one sub-transform
-    float2* b = buf + row * NS;
+    typename Prec<T>::T2* b = buf + row * NS;
     cx v[C];
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
         const int64_t i = (int64_t)n1 * TILE_M + n2;
-        cx e = {0.0f, 0.0f};
+        cx e = {0, 0};
         if (MODE == 0) {
-            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * z[row * ldz + (i - lo)];
+            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * (T)z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
             e = to_cx(b[i]);
         } else {
-            if (i <= cs.hi) e = to_cx(chirp_d(i, cs.den, cs.sign));
-            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d(g.NFFT - i, cs.den, cs.sign));
+            if (i <= cs.hi) e = to_cx(chirp_d<T>(i, cs.den, cs.sign));
+            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d<T>(g.NFFT - i, cs.den, cs.sign));
         }
         v[n1] = e;
     }
     dif<C, false>(v);
-    const float ihn = 2.0f / (float)NS;
+    const T ihn = (T)2 / (T)NS;
     constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[brev(k1, LOGC)];
         const cx o = k1 == 0 ? e : cmul(e, col_twiddle(n2, k1, ihn, false));
-        b[(int64_t)k1 * TILE_M + n2] = make_float2(o.x, o.y);
+        b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
     }
 }
 
 // One tile per (row, k1): forward, times the chirp spectrum, inverse -- in place.  PLAN: forward only, spectrum stored
 // in thread layout.
-template <bool PLAN>
-__global__ __launch_bounds__(TILE_T, 2) void czt_rows_kernel(float2* __restrict__ buf, const float2* __restrict__ spec,
-                                                             float2* __restrict__ spec_out, int C,
-                                                             const float2* __restrict__ twtab) {
-    extern __shared__ __attribute__((aligned(16))) cx lds[];
+template <typename T, bool PLAN>
+__global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kernel(
+    typename Prec<T>::T2* __restrict__ buf, const typename Prec<T>::T2* __restrict__ spec,
+    typename Prec<T>::T2* __restrict__ spec_out, int C, const typename Prec<T>::T2* __restrict__ twtab) {
+    using cx = typename Prec<T>::cxt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cx* lds = reinterpret_cast<cx*>(lds_raw);
     const int t = threadIdx.x;
     const int64_t tile = blockIdx.x;                    // row * C + k1
     const int k1 = (int)(tile % C);                       // C here = tiles per signal row = S * C
     cx* b = reinterpret_cast<cx*>(buf) + tile * TILE_M;
-    TileTw tw;
+    typename Prec<T>::Tw tw;
     tile_twiddles(tw, twtab, t);
     cx v[32], w[2][16];
 #pragma unroll
@@ -154,15 +185,18 @@ __global__ __launch_bounds__(TILE_T, 2) void czt_rows_kernel(float2* __restrict_
 // MODE 0 (after the first convolution): buf[k] <- conv[k] cP[k] w_k cQ[k] / NFFT for k < K, zero beyond
 // MODE 1 (after the second):            y[row, n - lo] <- Re(conv[n] cQ[n]) / (NFFT Q)  for lo <= n < lo + len
 // (the adjoint passes cP in cQ's place for MODE 1: its output lives on the P grid, still divided by Q)
-template <int C, int MODE>
-__global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ buf, const float2* __restrict__ cP,
-                                                          const float2* __restrict__ cQ, float* __restrict__ y,
-                                                          int64_t ldy, int64_t lo, int64_t len, CztGeom g) {
+template <typename T, int C, int MODE>
+__global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2* __restrict__ buf,
+                                                          const typename Prec<T>::T2* __restrict__ cP,
+                                                          const typename Prec<T>::T2* __restrict__ cQ,
+                                                          float* __restrict__ y, int64_t ldy, int64_t lo, int64_t len,
+                                                          CztGeom g) {
+    using cx = typename Prec<T>::cxt;
     const int n2 = blockIdx.x * 256 + threadIdx.x;
     const int64_t row = blockIdx.y;
     const int64_t NS = g.NFFT / g.S;
-    float2* b = buf + row * NS;
-    const float ihn = 2.0f / (float)NS;
+    typename Prec<T>::T2* b = buf + row * NS;
+    const T ihn = (T)2 / (T)NS;
     cx v[C];
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
@@ -171,24 +205,24 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ 
     }
     dif<C, true>(v);
     constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
-    const float sc = 1.0f / (float)NS;
+    const T sc = (T)1 / (T)NS;
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
         const int64_t i = (int64_t)n1 * TILE_M + n2;
         const cx e = v[brev(n1, LOGC)] * sc;
         if (MODE == 2) {                                   // plain inverse of a sub-transform (outer level follows)
-            b[i] = make_float2(e.x, e.y);
+            b[i] = Prec<T>::make(e.x, e.y);
         } else if (MODE == 0) {
-            cx o = {0.0f, 0.0f};
+            cx o = {0, 0};
             if (i < g.K) {
-                const float wk = (i == 0 || i == g.K - 1) ? 1.0f : 2.0f;
+                const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
                 o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
             }
-            b[i] = make_float2(o.x, o.y);
+            b[i] = Prec<T>::make(o.x, o.y);
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);
-                y[row * ldy + (i - lo)] = (e.x * c.x - e.y * c.y) / (float)g.Q;
+                y[row * ldy + (i - lo)] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
             }
         }
     }
@@ -198,33 +232,42 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(float2* __restrict__ 
 //   forward:  sub[k3][n'] = ( sum_n3 x[n3 NS + n'] W_4^(n3 k3) ) W_NFFT^(n' k3)      then four NS-point transforms
 //   inverse:  x[n3 NS + n'] = (1/4) sum_k3 ( sub[k3][n'] conj W_NFFT^(n' k3) ) W_4^(-n3 k3)
 // in place (a thread owns the four positions n' + n3 NS).  Input / output modes as in the column kernels.
-__device__ __forceinline__ cx outer_twiddle(int64_t np, int k3, int64_t NFFT, bool conj) {
+template <typename T>
+__device__ __forceinline__ typename Prec<T>::cxt outer_twiddle(int64_t np, int k3, int64_t NFFT, bool conj) {
     // W_NFFT^(np k3): np k3 < 3 * 2^18 is exact in float, and so is the quotient by the power of two NFFT
-    float s, c;
-    sincospif(2.0f * (float)(np * k3) / (float)NFFT, &s, &c);
-    return cx{c, conj ? s : -s};
+    if constexpr (sizeof(T) == 4) {
+        float s, c;
+        sincospif(2.0f * (float)(np * k3) / (float)NFFT, &s, &c);
+        return cx{c, conj ? s : -s};
+    } else {
+        double s, c;
+        sincospi(2.0 * (double)(np * k3) / (double)NFFT, &s, &c);
+        return cxd{c, conj ? s : -s};
+    }
 }
 
-template <int MODE>   // 0: real rows times a chirp table; 1: complex buffer; 2: a chirp sequence (plan)
-__global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restrict__ z, const float2* __restrict__ tab,
-                                                           float2* __restrict__ buf, CztGeom g, int64_t ldz, int64_t lo,
-                                                           int64_t len, ChirpSeq cs) {
+template <typename T, int MODE>   // 0: real rows times a chirp table; 1: complex buffer; 2: a chirp sequence (plan)
+__global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restrict__ z,
+                                                           const typename Prec<T>::T2* __restrict__ tab,
+                                                           typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t ldz,
+                                                           int64_t lo, int64_t len, ChirpSeq cs) {
+    using cx = typename Prec<T>::cxt;
     const int64_t NS = g.NFFT / 4;
     const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = blockIdx.y;
-    float2* b = buf + row * g.NFFT;
+    typename Prec<T>::T2* b = buf + row * g.NFFT;
     cx v[4];
 #pragma unroll
     for (int n3 = 0; n3 < 4; ++n3) {
         const int64_t i = n3 * NS + np;
-        cx e = {0.0f, 0.0f};
+        cx e = {0, 0};
         if (MODE == 0) {
-            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * z[row * ldz + (i - lo)];
+            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * (T)z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
             e = to_cx(b[i]);
         } else {
-            if (i <= cs.hi) e = to_cx(chirp_d(i, cs.den, cs.sign));
-            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d(g.NFFT - i, cs.den, cs.sign));
+            if (i <= cs.hi) e = to_cx(chirp_d<T>(i, cs.den, cs.sign));
+            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d<T>(g.NFFT - i, cs.den, cs.sign));
         }
         v[n3] = e;
     }
@@ -232,78 +275,216 @@ __global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restr
 #pragma unroll
     for (int k3 = 0; k3 < 4; ++k3) {
         const cx e = v[brev(k3, 2)];
-        const cx o = k3 == 0 ? e : cmul(e, outer_twiddle(np, k3, g.NFFT, false));
-        b[k3 * NS + np] = make_float2(o.x, o.y);
+        const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
+        b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
     }
 }
 
-template <int MODE>   // 0: next step's input (times cP w_k cQ for k < K, zero beyond); 1: real output slice
-__global__ __launch_bounds__(256) void czt_outer_inv_kernel(float2* __restrict__ buf, const float2* __restrict__ cP,
-                                                           const float2* __restrict__ cQ, float* __restrict__ y,
-                                                           int64_t ldy, int64_t lo, int64_t len, CztGeom g) {
+template <typename T, int MODE>   // 0: next step's input (times cP w_k cQ for k < K, zero beyond); 1: real output slice
+__global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2* __restrict__ buf,
+                                                           const typename Prec<T>::T2* __restrict__ cP,
+                                                           const typename Prec<T>::T2* __restrict__ cQ,
+                                                           float* __restrict__ y, int64_t ldy, int64_t lo, int64_t len,
+                                                           CztGeom g) {
+    using cx = typename Prec<T>::cxt;
     const int64_t NS = g.NFFT / 4;
     const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = blockIdx.y;
-    float2* b = buf + row * g.NFFT;
+    typename Prec<T>::T2* b = buf + row * g.NFFT;
     cx v[4];
 #pragma unroll
     for (int k3 = 0; k3 < 4; ++k3) {
         const cx e = to_cx(b[k3 * NS + np]);
-        v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle(np, k3, g.NFFT, true));
+        v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
     }
     dif<4, true>(v);
 #pragma unroll
     for (int n3 = 0; n3 < 4; ++n3) {
         const int64_t i = n3 * NS + np;
-        const cx e = v[brev(n3, 2)] * 0.25f;
+        const cx e = v[brev(n3, 2)] * (T)0.25;
         if (MODE == 0) {
-            cx o = {0.0f, 0.0f};
+            cx o = {0, 0};
             if (i < g.K) {
-                const float wk = (i == 0 || i == g.K - 1) ? 1.0f : 2.0f;
+                const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
                 o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
             }
-            b[i] = make_float2(o.x, o.y);
+            b[i] = Prec<T>::make(o.x, o.y);
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);
-                y[row * ldy + (i - lo)] = (e.x * c.x - e.y * c.y) / (float)g.Q;
+                y[row * ldy + (i - lo)] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
             }
         }
     }
 }
 
-template <int MODE>
-static void launch_cols_fwd(const CztGeom& g, const float* z, const float2* cP, float2* buf, int64_t rows, hipStream_t st,
-                            int64_t ldz = 0, int64_t lo = 0, int64_t len = 0, ChirpSeq cs = ChirpSeq{0, 0, 1, 1.0}) {
+template <typename T, int MODE>
+static void launch_cols_fwd(const CztGeom& g, const float* z, const typename Prec<T>::T2* cP, typename Prec<T>::T2* buf,
+                            int64_t rows, hipStream_t st, int64_t ldz = 0, int64_t lo = 0, int64_t len = 0,
+                            ChirpSeq cs = ChirpSeq{0, 0, 1, 1.0}) {
     const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);   // one "row" per sub-transform
+#define GFX_CF(CC) hipLaunchKernelGGL((czt_cols_fwd_kernel<T, CC, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs)
     switch (g.C) {
-        case 1: hipLaunchKernelGGL((czt_cols_fwd_kernel<1, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
-        case 2: hipLaunchKernelGGL((czt_cols_fwd_kernel<2, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
-        case 4: hipLaunchKernelGGL((czt_cols_fwd_kernel<4, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
-        case 8: hipLaunchKernelGGL((czt_cols_fwd_kernel<8, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
-        case 16: hipLaunchKernelGGL((czt_cols_fwd_kernel<16, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
-        default: hipLaunchKernelGGL((czt_cols_fwd_kernel<32, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+        case 1: GFX_CF(1); break;
+        case 2: GFX_CF(2); break;
+        case 4: GFX_CF(4); break;
+        case 8: GFX_CF(8); break;
+        case 16: GFX_CF(16); break;
+        default: GFX_CF(32); break;
     }
+#undef GFX_CF
 }
 
-template <int MODE>
-static void launch_cols_inv(const CztGeom& g, float2* buf, const float2* cP, const float2* cQ, float* y, int64_t ldy,
-                            int64_t lo, int64_t len, int64_t rows, hipStream_t st) {
+template <typename T, int MODE>
+static void launch_cols_inv(const CztGeom& g, typename Prec<T>::T2* buf, const typename Prec<T>::T2* cP,
+                            const typename Prec<T>::T2* cQ, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows,
+                            hipStream_t st) {
     const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);
+#define GFX_CI(CC) hipLaunchKernelGGL((czt_cols_inv_kernel<T, CC, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g)
     switch (g.C) {
-        case 1: hipLaunchKernelGGL((czt_cols_inv_kernel<1, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
-        case 2: hipLaunchKernelGGL((czt_cols_inv_kernel<2, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
-        case 4: hipLaunchKernelGGL((czt_cols_inv_kernel<4, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
-        case 8: hipLaunchKernelGGL((czt_cols_inv_kernel<8, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
-        case 16: hipLaunchKernelGGL((czt_cols_inv_kernel<16, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
-        default: hipLaunchKernelGGL((czt_cols_inv_kernel<32, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
+        case 1: GFX_CI(1); break;
+        case 2: GFX_CI(2); break;
+        case 4: GFX_CI(4); break;
+        case 8: GFX_CI(8); break;
+        case 16: GFX_CI(16); break;
+        default: GFX_CI(32); break;
     }
+#undef GFX_CI
 }
 
 template <typename K>
-static bool czt_allow_lds(K kernel) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               TILE_LDS_BYTES) == hipSuccess;
+static bool czt_allow_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
+           hipSuccess;
+}
+
+// the double tile's twiddles: TW_ROWS x 256 double2 (rows as in fft_tile.hpp), one table per device
+__global__ void czt_twiddle_table_f64_kernel(double2* __restrict__ table) {
+    const int t = threadIdx.x, row = blockIdx.x;
+    int num;
+    double den;
+    if (row < 4) { num = t * row; den = 8192.0; }
+    else if (row < 12) { num = t * 4 * (row - 4); den = 8192.0; }
+    else if (row < 16) { num = (t & 15) * (row - 12); den = 256.0; }
+    else { num = (t & 15) * 4 * (row - 16); den = 256.0; }
+    double s, c;
+    sincospi(2.0 * (double)num / den, &s, &c);
+    table[row * TILE_T + t] = make_double2(c, -s);
+}
+
+static const double2* tile_twiddle_table_f64(hipStream_t stream) {
+    static std::mutex mu;
+    static double2* tables[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tables[dev]) {
+        double2* p = nullptr;
+        if (hipMalloc(&p, sizeof(double2) * TW_ROWS * TILE_T) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(czt_twiddle_table_f64_kernel, dim3(TW_ROWS), dim3(TILE_T), 0, stream, p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            hipFree(p);
+            return nullptr;
+        }
+        tables[dev] = p;
+    }
+    return tables[dev];
+}
+
+template <typename T> static const typename Prec<T>::T2* czt_twiddles(hipStream_t st);
+template <> const float2* czt_twiddles<float>(hipStream_t st) { return tile_twiddle_table(st); }
+template <> const double2* czt_twiddles<double>(hipStream_t st) { return tile_twiddle_table_f64(st); }
+
+template <typename T>
+static int czt_plan(void* plan, int64_t P, void* ws, size_t ws_bytes, hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    CztGeom g;
+    if (!plan || !czt_geom(P, g)) return GFX_EINVAL;
+    if (!ws || ws_bytes < (size_t)g.NFFT * sizeof(T2)) return GFX_ENOSPC;
+    const T2* tw = czt_twiddles<T>(st);
+    if (!tw || !czt_allow_lds(czt_rows_kernel<T, true>, Prec<T>::lds_bytes)) return GFX_ELAUNCH;
+    T2* cP = (T2*)plan;
+    T2* cQ = cP + g.P;
+    T2* spec = cQ + g.Q;
+    hipLaunchKernelGGL(czt_chirp_table_kernel<T>, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, cP, g.P, g.P, -1.0f);
+    hipLaunchKernelGGL(czt_chirp_table_kernel<T>, dim3((unsigned)((g.Q + 255) / 256)), dim3(256), 0, st, cQ, g.Q, g.Q, 1.0f);
+    T2* buf = (T2*)ws;
+    const int ctot = g.S * g.C;
+    const dim3 og((unsigned)(g.NFFT / 4 / 256), 1);
+    // forward: bP over [-(P-1), K-1], bQ over [-(K-1), Q-1];  adjoint: bQ over [-(Q-1), K-1], bP over [-(K-1), P-1]
+    const ChirpSeq seqs[4] = {{g.P - 1, g.K - 1, g.P, 1.0}, {g.K - 1, g.Q - 1, g.Q, -1.0},
+                              {g.Q - 1, g.K - 1, g.Q, -1.0}, {g.K - 1, g.P - 1, g.P, 1.0}};
+    for (int i = 0; i < 4; ++i) {
+        if (g.S == 1) launch_cols_fwd<T, 2>(g, nullptr, nullptr, buf, 1, st, 0, 0, 0, seqs[i]);
+        else {
+            hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 2>), og, dim3(256), 0, st, (const float*)nullptr, (const T2*)nullptr,
+                               buf, g, (int64_t)0, (int64_t)0, (int64_t)0, seqs[i]);
+            launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, 1, st);
+        }
+        hipLaunchKernelGGL((czt_rows_kernel<T, true>), dim3((unsigned)ctot), dim3(TILE_T), Prec<T>::lds_bytes, st, buf,
+                           (const T2*)nullptr, spec + (int64_t)i * g.NFFT, ctot, tw);
+    }
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+// The two chirp-z transforms of one direction: rows of `in` (slice [ilo, ilo + ilen) of the first grid, times tab1) ->
+// convolution with spec1 -> times cP cQ w_k on the K bins -> convolution with spec2 -> Re(. tab2) / Q into the slice
+// [olo, olo + olen) of the second grid.
+template <typename T>
+static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, int64_t ilen,
+                   const typename Prec<T>::T2* tab1, const typename Prec<T>::T2* spec1, const typename Prec<T>::T2* spec2,
+                   const typename Prec<T>::T2* tab2, float* out, int64_t ldo, int64_t olo, int64_t olen, int64_t rows,
+                   const typename Prec<T>::T2* cP, const typename Prec<T>::T2* cQ, typename Prec<T>::T2* buf, hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    const T2* tw = czt_twiddles<T>(st);
+    constexpr int LDS = Prec<T>::lds_bytes;
+    if (!tw || !czt_allow_lds(czt_rows_kernel<T, false>, LDS)) return GFX_ELAUNCH;
+    const int ctot = g.S * g.C;
+    const unsigned tiles = (unsigned)(rows * ctot);
+    const ChirpSeq none{0, 0, 1, 1.0};
+    if (g.S == 1) {
+        launch_cols_fwd<T, 0>(g, in, tab1, buf, rows, st, ldi, ilo, ilen);
+        hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec1, (T2*)nullptr, ctot, tw);
+        launch_cols_inv<T, 0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+        launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+        hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec2, (T2*)nullptr, ctot, tw);
+        launch_cols_inv<T, 1>(g, buf, cP, tab2, out, ldo, olo, olen, rows, st);
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    }
+    // outer radix-4 level around four 2^18-point transforms per row
+    const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)rows);
+    hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 0>), og, dim3(256), 0, st, in, tab1, buf, g, ldi, ilo, ilen, none);
+    launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec1, (T2*)nullptr, ctot, tw);
+    launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    hipLaunchKernelGGL((czt_outer_inv_kernel<T, 0>), og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0,
+                       (int64_t)0, (int64_t)0, g);
+    hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 1>), og, dim3(256), 0, st, (const float*)nullptr, (const T2*)nullptr, buf, g,
+                       (int64_t)0, (int64_t)0, (int64_t)0, none);
+    launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec2, (T2*)nullptr, ctot, tw);
+    launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    hipLaunchKernelGGL((czt_outer_inv_kernel<T, 1>), og, dim3(256), 0, st, buf, cP, tab2, out, ldo, olo, olen, g);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+template <typename T>
+static int czt_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                     const void* plan, void* ws, size_t ws_bytes, void* stream, bool adjoint) {
+    using T2 = typename Prec<T>::T2;
+    CztGeom g;
+    if (!z || !y || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
+    if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
+    if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(T2)) return GFX_ENOSPC;
+    const T2* cP = (const T2*)plan;
+    const T2* cQ = cP + g.P;
+    const T2* spec = cQ + g.Q;
+    if (!adjoint)   // z (rows x P) -> y[:, lo : lo + len]
+        return czt_run<T>(g, z, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, y, ldy, lo, len, rows, cP, cQ, (T2*)ws,
+                          (hipStream_t)stream);
+    // `z` is the gradient gy (row stride ldy) of y[:, lo : lo + len], `y` the gradient gz (rows x P)
+    return czt_run<T>(g, z, ldy, lo, len, cQ, spec + 2 * g.NFFT, spec + 3 * g.NFFT, cP, y, g.P, 0, g.P, rows, cP, cQ, (T2*)ws,
+                      (hipStream_t)stream);
 }
 
 }  // namespace gfx
@@ -324,88 +505,12 @@ size_t gfx_odd_alias_workspace_bytes(int64_t rows, int64_t P) {
 }
 
 int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream) {
-    CztGeom g;
-    if (!plan || !czt_geom(P, g)) return GFX_EINVAL;
-    if (!ws || ws_bytes < (size_t)g.NFFT * sizeof(float2)) return GFX_ENOSPC;
-    hipStream_t st = (hipStream_t)stream;
-    const float2* tw = tile_twiddle_table(st);
-    if (!tw || !czt_allow_lds(czt_rows_kernel<true>)) return GFX_ELAUNCH;
-    float2* cP = (float2*)plan;
-    float2* cQ = cP + g.P;
-    float2* spec = cQ + g.Q;
-    hipLaunchKernelGGL(czt_chirp_table_kernel, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, cP, g.P, g.P, -1.0f);
-    hipLaunchKernelGGL(czt_chirp_table_kernel, dim3((unsigned)((g.Q + 255) / 256)), dim3(256), 0, st, cQ, g.Q, g.Q, 1.0f);
-    float2* buf = (float2*)ws;
-    const int ctot = g.S * g.C;
-    const dim3 og((unsigned)(g.NFFT / 4 / 256), 1);
-    // forward: bP over [-(P-1), K-1], bQ over [-(K-1), Q-1];  adjoint: bQ over [-(Q-1), K-1], bP over [-(K-1), P-1]
-    const ChirpSeq seqs[4] = {{g.P - 1, g.K - 1, g.P, 1.0}, {g.K - 1, g.Q - 1, g.Q, -1.0},
-                              {g.Q - 1, g.K - 1, g.Q, -1.0}, {g.K - 1, g.P - 1, g.P, 1.0}};
-    for (int i = 0; i < 4; ++i) {
-        if (g.S == 1) launch_cols_fwd<2>(g, nullptr, nullptr, buf, 1, st, 0, 0, 0, seqs[i]);
-        else {
-            hipLaunchKernelGGL(czt_outer_fwd_kernel<2>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr,
-                               buf, g, (int64_t)0, (int64_t)0, (int64_t)0, seqs[i]);
-            launch_cols_fwd<1>(g, nullptr, nullptr, buf, 1, st);
-        }
-        hipLaunchKernelGGL(czt_rows_kernel<true>, dim3((unsigned)ctot), dim3(TILE_T), TILE_LDS_BYTES, st, buf,
-                           (const float2*)nullptr, spec + (int64_t)i * g.NFFT, ctot, tw);
-    }
-    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-}
-
-// The two chirp-z transforms of one direction: rows of `in` (slice [ilo, ilo + ilen) of the first grid, times tab1) ->
-// convolution with spec1 -> times cP cQ w_k on the K bins -> convolution with spec2 -> Re(. tab2) / Q into the slice
-// [olo, olo + olen) of the second grid.
-static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, int64_t ilen, const float2* tab1,
-                   const float2* spec1, const float2* spec2, const float2* tab2, float* out, int64_t ldo, int64_t olo,
-                   int64_t olen, int64_t rows, const float2* cP, const float2* cQ, float2* buf, hipStream_t st) {
-    const float2* tw = tile_twiddle_table(st);
-    if (!tw || !czt_allow_lds(czt_rows_kernel<false>)) return GFX_ELAUNCH;
-    const int ctot = g.S * g.C;
-    const unsigned tiles = (unsigned)(rows * ctot);
-    const ChirpSeq none{0, 0, 1, 1.0};
-    if (g.S == 1) {
-        launch_cols_fwd<0>(g, in, tab1, buf, rows, st, ldi, ilo, ilen);
-        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec1,
-                           (float2*)nullptr, ctot, tw);
-        launch_cols_inv<0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-        launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-        hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec2,
-                           (float2*)nullptr, ctot, tw);
-        launch_cols_inv<1>(g, buf, cP, tab2, out, ldo, olo, olen, rows, st);
-        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
-    }
-    // outer radix-4 level around four 2^18-point transforms per row
-    const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)rows);
-    hipLaunchKernelGGL(czt_outer_fwd_kernel<0>, og, dim3(256), 0, st, in, tab1, buf, g, ldi, ilo, ilen, none);
-    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec1, (float2*)nullptr,
-                       ctot, tw);
-    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-    hipLaunchKernelGGL(czt_outer_inv_kernel<0>, og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0, (int64_t)0,
-                       (int64_t)0, g);
-    hipLaunchKernelGGL(czt_outer_fwd_kernel<1>, og, dim3(256), 0, st, (const float*)nullptr, (const float2*)nullptr, buf, g,
-                       (int64_t)0, (int64_t)0, (int64_t)0, none);
-    launch_cols_fwd<1>(g, nullptr, nullptr, buf, rows, st);
-    hipLaunchKernelGGL(czt_rows_kernel<false>, dim3(tiles), dim3(TILE_T), TILE_LDS_BYTES, st, buf, spec2, (float2*)nullptr,
-                       ctot, tw);
-    launch_cols_inv<2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-    hipLaunchKernelGGL(czt_outer_inv_kernel<1>, og, dim3(256), 0, st, buf, cP, tab2, out, ldo, olo, olen, g);
-    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    return czt_plan<float>(plan, P, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                       const void* plan, void* ws, size_t ws_bytes, void* stream) {
-    CztGeom g;
-    if (!z || !y || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
-    if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
-    if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(float2)) return GFX_ENOSPC;
-    const float2* cP = (const float2*)plan;
-    const float2* cQ = cP + g.P;
-    const float2* spec = cQ + g.Q;
-    return czt_run(g, z, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, y, ldy, lo, len, rows, cP, cQ, (float2*)ws,
-                   (hipStream_t)stream);
+    return czt_alias<float>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream, false);
 }
 
 // Transpose of gfx_odd_alias_f32 (the gradient of the aliasing step): with G'[k] = sum_n gy[n] e^{+2 pi i k n / Q},
@@ -414,15 +519,26 @@ int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t
 // outputs) -- with the chirps' supports mirrored (the plan's third and fourth spectrum).
 int gfx_odd_alias_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows, int64_t P,
                               const void* plan, void* ws, size_t ws_bytes, void* stream) {
-    CztGeom g;
-    if (!gy || !gz || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
-    if (lo < 0 || len < 1 || lo + len > g.Q || ldg < len) return GFX_EINVAL;
-    if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(float2)) return GFX_ENOSPC;
-    const float2* cP = (const float2*)plan;
-    const float2* cQ = cP + g.P;
-    const float2* spec = cQ + g.Q;
-    return czt_run(g, gy, ldg, lo, len, cQ, spec + 2 * g.NFFT, spec + 3 * g.NFFT, cP, gz, g.P, 0, g.P, rows, cP, cQ,
-                   (float2*)ws, (hipStream_t)stream);
+    return czt_alias<float>(gy, gz, ldg, lo, len, rows, P, plan, ws, ws_bytes, stream, true);
+}
+
+// ---- the same with double-precision transforms (fp32 in and out): plan and workspace are twice the size ------------
+size_t gfx_odd_alias_precise_plan_bytes(int64_t P) { return 2 * gfx_odd_alias_plan_bytes(P); }
+
+size_t gfx_odd_alias_precise_workspace_bytes(int64_t rows, int64_t P) { return 2 * gfx_odd_alias_workspace_bytes(rows, P); }
+
+int gfx_odd_alias_precise_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream) {
+    return czt_plan<double>(plan, P, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gfx_odd_alias_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                              const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    return czt_alias<double>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream, false);
+}
+
+int gfx_odd_alias_precise_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows,
+                                      int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    return czt_alias<double>(gy, gz, ldg, lo, len, rows, P, plan, ws, ws_bytes, stream, true);
 }
 
 }  // extern "C"

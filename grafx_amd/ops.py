@@ -283,7 +283,7 @@ def irdft(X, n, roll=0, window=None):
 
 
 # ----------------------------------------------------------------------------------------- odd-length aliasing
-_ALIAS_PLANS = {}          # (P, device) -> plan, most recently used last; at most _ALIAS_PLANS_MAX entries (up to 25 MB each)
+_ALIAS_PLANS = {}          # (P, device) -> plan, most recently used last; at most _ALIAS_PLANS_MAX entries (up to 36 MB each, 72 MB precise)
 _ALIAS_PLANS_MAX = 8
 
 
@@ -292,9 +292,17 @@ def odd_alias_supported(P):
     return lib().gfx_odd_alias_plan_bytes(P) > 0
 
 
-def _alias_plan(P, device):
+def _alias_fns(precise):
+    """(plan_bytes, workspace_bytes, plan, forward, adjoint) of the fp32 or the double-precision transforms."""
+    L, tag = lib(), "gfx_odd_alias_precise_" if precise else "gfx_odd_alias_"
+    return (getattr(L, tag + "plan_bytes"), getattr(L, tag + "workspace_bytes"), getattr(L, tag + "plan_f32"),
+            getattr(L, tag + "f32"), getattr(L, tag + "adjoint_f32"), tag)
+
+
+def _alias_plan(P, device, precise=False):
     """The per-P chirp plan of the aliasing kernels (LRU of _ALIAS_PLANS_MAX, built on first use)."""
-    key = (P, device.type, device.index)
+    plan_bytes, ws_bytes, build, _, _, tag = _alias_fns(precise)
+    key = (P, device.type, device.index, bool(precise))
     plan = _ALIAS_PLANS.pop(key, None)
     if plan is not None:
         _ALIAS_PLANS[key] = plan   # back in as the most recent
@@ -302,9 +310,9 @@ def _alias_plan(P, device):
         if torch.cuda.is_current_stream_capturing():
             # a plan built during capture would live in the graph's private pool and be rebuilt on every replay
             raise RuntimeError(f"odd_alias: no plan for P={P} yet; run the call once outside the HIP-graph capture")
-        plan = torch.empty(lib().gfx_odd_alias_plan_bytes(P), dtype=torch.uint8, device=device)
-        w1 = torch.empty(lib().gfx_odd_alias_workspace_bytes(1, P), dtype=torch.uint8, device=device)
-        check(lib().gfx_odd_alias_plan_f32(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), "gfx_odd_alias_plan_f32")
+        plan = torch.empty(plan_bytes(P), dtype=torch.uint8, device=device)
+        w1 = torch.empty(ws_bytes(1, P), dtype=torch.uint8, device=device)
+        check(build(_ptr(plan), P, _ptr(w1), w1.numel(), _stream()), tag + "plan_f32")
         torch.cuda.current_stream(device).synchronize()   # the cached plan is complete before any stream can pick it up
         _ALIAS_PLANS[key] = plan
         while len(_ALIAS_PLANS) > _ALIAS_PLANS_MAX:
@@ -315,49 +323,52 @@ def _alias_plan(P, device):
     return plan
 
 
-def _alias_chunks(rows, P, rows_per_chunk, device):
-    per_row = lib().gfx_odd_alias_workspace_bytes(1, P)
-    chunk = max(1, min(rows, rows_per_chunk, (1 << 30) // per_row))   # at most 1 GB of workspace
-    ws = torch.empty(lib().gfx_odd_alias_workspace_bytes(chunk, P), dtype=torch.uint8, device=device)
+def _alias_chunks(rows, P, rows_per_chunk, device, precise):
+    ws_bytes = _alias_fns(precise)[1]
+    chunk = max(1, min(rows, rows_per_chunk, (1 << 30) // ws_bytes(1, P)))   # at most 1 GB of workspace
+    ws = torch.empty(ws_bytes(chunk, P), dtype=torch.uint8, device=device)
     return chunk, ws
 
 
 @_on_device
-def odd_alias(z, lo=0, length=None, rows_per_chunk=256):
+def odd_alias(z, lo=0, length=None, rows_per_chunk=256, precise=False):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
     full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (2 MB of
-    workspace per row at P ~ 135 k, 8 MB beyond 174,763)."""
+    workspace per row at P ~ 135 k, 8 MB beyond 174,763).  ``precise``: transforms in double precision (twice the
+    workspace), for results that feed a logarithm -- the energy envelope, core/envelope.py:34-49."""
     _require_gpu(z)
     P = z.shape[-1]
     Q = P - 1
     length = Q - lo if length is None else length
-    plan = _alias_plan(P, z.device)
+    plan = _alias_plan(P, z.device, precise)
+    fwd, tag = _alias_fns(precise)[3], _alias_fns(precise)[5]
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
-    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device)
+    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise)
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
-        check(lib().gfx_odd_alias_f32(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan),
-                                      _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_f32")
+        check(fwd(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
+                  _stream()), tag + "f32")
     return out.view(*z.shape[:-1], length)
 
 
 @_on_device
-def odd_alias_adjoint(gy, P, lo=0, rows_per_chunk=256):
+def odd_alias_adjoint(gy, P, lo=0, rows_per_chunk=256, precise=False):
     """Transpose of odd_alias: the gradient with respect to z (..., P) given gy (..., length), the gradient with respect
     to odd_alias(z, lo, length) -- what autograd derives from the reference's rfft / irfft pair."""
     _require_gpu(gy)
     length = gy.shape[-1]
-    plan = _alias_plan(P, gy.device)
+    plan = _alias_plan(P, gy.device, precise)
+    adj, tag = _alias_fns(precise)[4], _alias_fns(precise)[5]
     flat = gy.reshape(-1, length).contiguous()
     rows = flat.shape[0]
     out = torch.empty((rows, P), dtype=torch.float32, device=gy.device)
-    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, gy.device)
+    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, gy.device, precise)
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
-        check(lib().gfx_odd_alias_adjoint_f32(_ptr(flat[i : i + n]), length, lo, length, _ptr(out[i : i + n]), n, P,
-                                              _ptr(plan), _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_adjoint_f32")
+        check(adj(_ptr(flat[i : i + n]), length, lo, length, _ptr(out[i : i + n]), n, P, _ptr(plan), _ptr(ws), ws.numel(),
+                  _stream()), tag + "adjoint_f32")
     return out.view(*gy.shape[:-1], P)
 
 

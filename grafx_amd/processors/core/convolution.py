@@ -10,8 +10,9 @@ for odd P it inverts a P-point spectrum on a (P-1)-point grid
   overlap-save kernels (gfx_fftconv_f32), reading x once and writing y once;
 * odd P   -> the HIP kernels produce the full linear convolution z (length P) and
   the reference's aliasing ``irfft_{P-1}(rfft_P(z))`` is applied on top, natively as two
-  chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32; the float64 FFT-library
-  route remains for gradients, P > 699,051 and the dynamics envelope -- DESIGN.md §2).
+  chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, its transpose for the gradient,
+  double-precision transforms for the dynamics envelope; the float64 FFT-library route
+  remains only for P > 699,051 -- DESIGN.md §2).
 
 ``set_exact_convolution(True)`` opts out of the quirk (true linear convolution
 for every length; deviates from the reference when P is odd).
@@ -67,21 +68,22 @@ def reference_aliases(lx, lh, exact=False):
 
 def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for a full linear convolution z of odd length P
-    (convolution.py:123-126): two chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, fp32, no FFT library).
+    (convolution.py:123-126): two chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, no FFT library).
 
-    The gradient is the transposed pair of transforms (autograd.OddAliasFn).  Two cases still go through the device FFT
-    library in float64: P > 699,051 (a 2^20-point transform no longer covers 1.5 P) and ``precise=True`` -- the
-    energy-envelope smoother of the dynamics processors, whose output feeds log() and a gain curve: there the fp32
-    chirp-z noise (~1e-6 of the peak, about twice what the reference's own mixed-radix fp32 FFT leaves) is amplified
-    on quiet passages beyond the parity bound (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths)."""
+    The gradient is the transposed pair of transforms (autograd.OddAliasFn).  ``precise=True`` carries the transforms
+    in double precision (gfx_odd_alias_precise_f32) -- for the energy-envelope smoother of the dynamics processors,
+    whose output feeds log() and a gain curve: there the fp32 chirp-z noise (~1e-6 of the peak, about twice what the
+    reference's own mixed-radix fp32 FFT leaves) is amplified on quiet passages beyond the parity bound
+    (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths).  Only P > 699,051 (a 2^20-point transform no
+    longer covers 1.5 P) still goes through the device FFT library, in float64."""
     Q = z.shape[-1] - 1
     length = Q - lo if length is None else length
-    if not precise and not (torch.is_grad_enabled() and z.requires_grad) and ops.odd_alias_supported(z.shape[-1]):
-        return ops.odd_alias(z, lo, length)
     if torch.is_grad_enabled() and z.requires_grad:
         from ... import autograd as diff
 
         return diff.odd_alias(z, lo, length, precise)
+    if ops.odd_alias_supported(z.shape[-1]):
+        return ops.odd_alias(z, lo, length, precise=precise)
     flat = z.reshape(-1, z.shape[-1])
     out = torch.empty((flat.shape[0], length), dtype=z.dtype, device=z.device)
     for i in range(0, flat.shape[0], rows_per_chunk):

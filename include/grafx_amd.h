@@ -164,6 +164,17 @@ int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t
                       const void* plan, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows, int64_t P,
                               const void* plan, void* ws, size_t ws_bytes, void* stream);
+/* The same maps with the transforms carried in double precision (fp32 data in and out, own plan and workspace, both
+ * twice the size): for the energy envelope of the dynamics processors (core/envelope.py:34-49), whose aliased result
+ * feeds log() and a gain curve -- the ~1e-6-of-peak noise floor of an fp32 transform pair is amplified beyond the
+ * parity bound on quiet passages.  Same geometry limits and error codes. */
+size_t gfx_odd_alias_precise_plan_bytes(int64_t P);
+size_t gfx_odd_alias_precise_workspace_bytes(int64_t rows, int64_t P);
+int gfx_odd_alias_precise_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                              const void* plan, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_precise_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows,
+                                      int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- small inverse real DFT (parameter-side front-ends) ---------------------------------------
  * y = irfft(X, n) for any n <= 8192 as a direct sum (twiddles tabulated in LDS), K = n/2 + 1 bins per row, X complex

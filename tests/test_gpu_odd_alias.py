@@ -85,3 +85,31 @@ def test_convolve_gradient_with_aliasing_is_native():
         assert (y.double() - yd).abs().max() <= 1e-5 * yd.abs().max()
         for a, b in ((x.grad, xd.grad), (h.grad, hd.grad)):
             assert (a.double() - b).abs().max() <= 2e-5 * b.abs().max()
+
+
+@pytest.mark.parametrize("P", [3, 101, 4001, 10923, 87383, 147455, 174765, 300001])
+def test_precise_odd_alias_is_float64_accurate(P):
+    """gfx_odd_alias_precise_f32 (double-precision transforms, fp32 in / out): the result is the float64 FFT's rounded to
+    fp32 -- also where the signal is 1e-6 of its peak, which is what the energy envelope needs -- and so is the adjoint."""
+    from grafx_amd import ops
+
+    torch.manual_seed(P + 2)
+    shape = (3, 2) if P < 200000 else (2, 1)
+    z = torch.randn(*shape, P, device="cuda")
+    z[..., P // 2 :] *= 1e-6                       # a quiet passage next to a loud one
+    want = torch.fft.irfft(torch.fft.rfft(z.double()))
+    got = ops.odd_alias(z, precise=True)
+    assert got.dtype == torch.float32
+    tol = 1.5e-7 * want.abs() + 1e-12 * want.abs().max()
+    assert ((got.double() - want).abs() <= tol).all(), f"P={P}: {((got.double() - want).abs() / want.abs().max()).max():.2e}"
+    if P > 4000:   # the fp32 transforms' noise floor on the quiet passage, which the double-precision ones do not have
+        q = slice(P - P // 4, None)
+        plain = ops.odd_alias(z)
+        assert (plain.double() - want)[..., q].abs().max() > 100 * (got.double() - want)[..., q].abs().max()
+    lo, n = P // 3, max(1, P // 5)
+    assert torch.equal(ops.odd_alias(z, lo, n, precise=True), got[..., lo : lo + n])
+    g = torch.randn(*shape, n, device="cuda")
+    zd = z.double().requires_grad_(True)
+    torch.fft.irfft(torch.fft.rfft(zd))[..., lo : lo + n].backward(g.double())
+    adj = ops.odd_alias_adjoint(g, P, lo, precise=True)
+    assert (adj.double() - zd.grad).abs().max() <= 2e-7 * zd.grad.abs().max()
