@@ -110,6 +110,23 @@ __device__ __forceinline__ cxd col_twiddle(int n2, int k1, double inv_half_nfft,
     return cxd{c, conj ? s : -s};
 }
 
+// The column twiddles W_NFFT^(n2 k1), k1 = 0 .. C-1 in turn.  float: one sincospif each (exact argument); double: powers
+// of W^(n2) by repeated multiplication (31 steps lose ~1e-15, and a double sincospi per point would make the column
+// kernels compute-bound).
+template <typename T> struct ColTw;
+template <> struct ColTw<float> {
+    int n2;
+    float ihn;
+    bool conj;
+    __device__ __forceinline__ ColTw(int n2_, float ihn_, bool conj_) : n2(n2_), ihn(ihn_), conj(conj_) {}
+    __device__ __forceinline__ cx at(int k1) { return col_twiddle(n2, k1, ihn, conj); }   // k1 = 1, 2, ... in order
+};
+template <> struct ColTw<double> {
+    cxd w1, w;
+    __device__ __forceinline__ ColTw(int n2, double ihn, bool conj) : w1(col_twiddle(n2, 1, ihn, conj)), w(cxd{1.0, 0.0}) {}
+    __device__ __forceinline__ cxd at(int) { w = cmul(w, w1); return w; }                  // k1 = 1, 2, ... in order
+};
+
 // MODE 0: real rows, z[row, i - lo] tab[i] for lo <= i < lo + len (row stride ldz), zero elsewhere;  MODE 1: the complex
 // buffer itself;  MODE 2: a chirp sequence (plan building)
 template <typename T, int C, int MODE>
@@ -140,10 +157,11 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
     dif<C, false>(v);
     const T ihn = (T)2 / (T)NS;
     constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
+    ColTw<T> tw(n2, ihn, false);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[brev(k1, LOGC)];
-        const cx o = k1 == 0 ? e : cmul(e, col_twiddle(n2, k1, ihn, false));
+        const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
         b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
     }
 }
@@ -184,6 +202,8 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
 
 // MODE 0 (after the first convolution): buf[k] <- conv[k] cP[k] w_k cQ[k] / NFFT for k < K, zero beyond
 // MODE 1 (after the second):            y[row, n - lo] <- Re(conv[n] cQ[n]) / (NFFT Q)  for lo <= n < lo + len
+// MODE 3: MODE 0 and the second convolution's column pass (cols_fwd MODE 1) in one -- the same thread owns the column in
+//         both, so the buffer is read and written once instead of twice
 // (the adjoint passes cP in cQ's place for MODE 1: its output lives on the P grid, still divided by Q)
 template <typename T, int C, int MODE>
 __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2* __restrict__ buf,
@@ -198,14 +218,37 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
     typename Prec<T>::T2* b = buf + row * NS;
     const T ihn = (T)2 / (T)NS;
     cx v[C];
+    ColTw<T> twi(n2, ihn, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
-        v[k1] = k1 == 0 ? e : cmul(e, col_twiddle(n2, k1, ihn, true));
+        v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     dif<C, true>(v);
     constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
     const T sc = (T)1 / (T)NS;
+    if (MODE == 3) {   // the step between the two convolutions (S = 1): MODE 0's values, then cols_fwd's MODE 1 on them
+        cx u[C];
+#pragma unroll
+        for (int n1 = 0; n1 < C; ++n1) {
+            const int64_t i = (int64_t)n1 * TILE_M + n2;
+            cx o = {0, 0};
+            if (i < g.K) {
+                const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
+                o = cmul(cmul(v[brev(n1, LOGC)] * sc, to_cx(cP[i])), to_cx(cQ[i])) * wk;
+            }
+            u[n1] = o;
+        }
+        dif<C, false>(u);
+        ColTw<T> twf(n2, ihn, false);
+#pragma unroll
+        for (int k1 = 0; k1 < C; ++k1) {
+            const cx e = u[brev(k1, LOGC)];
+            const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
+            b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+        }
+        return;
+    }
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
         const int64_t i = (int64_t)n1 * TILE_M + n2;
@@ -298,6 +341,27 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2
         v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
     }
     dif<4, true>(v);
+    if (MODE == 2) {   // MODE 0's values, then czt_outer_fwd_kernel's MODE 1 on them: one pass over the buffer
+        cx u[4];
+#pragma unroll
+        for (int n3 = 0; n3 < 4; ++n3) {
+            const int64_t i = n3 * NS + np;
+            cx o = {0, 0};
+            if (i < g.K) {
+                const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
+                o = cmul(cmul(v[brev(n3, 2)] * (T)0.25, to_cx(cP[i])), to_cx(cQ[i])) * wk;
+            }
+            u[n3] = o;
+        }
+        dif<4, false>(u);
+#pragma unroll
+        for (int k3 = 0; k3 < 4; ++k3) {
+            const cx e = u[brev(k3, 2)];
+            const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
+            b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+        }
+        return;
+    }
 #pragma unroll
     for (int n3 = 0; n3 < 4; ++n3) {
         const int64_t i = n3 * NS + np;
@@ -445,8 +509,7 @@ static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, 
     if (g.S == 1) {
         launch_cols_fwd<T, 0>(g, in, tab1, buf, rows, st, ldi, ilo, ilen);
         hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec1, (T2*)nullptr, ctot, tw);
-        launch_cols_inv<T, 0>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-        launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+        launch_cols_inv<T, 3>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
         hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec2, (T2*)nullptr, ctot, tw);
         launch_cols_inv<T, 1>(g, buf, cP, tab2, out, ldo, olo, olen, rows, st);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
@@ -457,10 +520,8 @@ static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, 
     launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
     hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec1, (T2*)nullptr, ctot, tw);
     launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
-    hipLaunchKernelGGL((czt_outer_inv_kernel<T, 0>), og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0,
+    hipLaunchKernelGGL((czt_outer_inv_kernel<T, 2>), og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0,
                        (int64_t)0, (int64_t)0, g);
-    hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 1>), og, dim3(256), 0, st, (const float*)nullptr, (const T2*)nullptr, buf, g,
-                       (int64_t)0, (int64_t)0, (int64_t)0, none);
     launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
     hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec2, (T2*)nullptr, ctot, tw);
     launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
