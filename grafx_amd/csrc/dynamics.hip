@@ -201,6 +201,27 @@ __device__ __forceinline__ void store4(float* __restrict__ row, int64_t n, int64
     }
 }
 __device__ __forceinline__ bool vec_ok(const float* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// the same for rows known to be 16-byte aligned with L % 4 == 0 and n % 4 == 0: one predicated 16-byte access, no
+// element-wise path (which is most of the code of a kernel that inlines a dozen of these)
+template <bool AL>
+__device__ __forceinline__ void ld4(const float* __restrict__ row, int64_t n, int64_t L, bool vec, float (&v)[DE]) {
+    if (AL) {
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (n >= 0 && n < L) q = *reinterpret_cast<const float4*>(row + n);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        load4(row, n, L, vec, v);
+    }
+}
+template <bool AL>
+__device__ __forceinline__ void st4(float* __restrict__ row, int64_t n, int64_t L, bool vec, const float (&v)[DE]) {
+    if (AL) {
+        using f4 = float __attribute__((ext_vector_type(4)));
+        if (n < L) GFX_NT_STORE(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(row + n));
+    } else {
+        store4(row, n, L, vec, v);
+    }
+}
 
 struct DynArgs {
     gfx_rowmap_t xmap, ymap;
@@ -403,60 +424,56 @@ constexpr int OS_GTILE = OS_WTILE * (DT / 64);   // 2048 samples per workgroup
 // One WAVE per 512-sample tile, four tiles per workgroup, no LDS and no barrier: the wave scans two 256-sample
 // sub-tiles (each lane 4 consecutive samples, 6 shuffle steps per sub-tile), chains them through one scalar carry, and
 // gets the state entering its tile from the history dot product (lanes 4 l < H, one predicated 16-byte load per channel).
-__global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         const float* __restrict__ log_threshold,
-                                                         const float* __restrict__ log_ratio,
-                                                         const float* __restrict__ log_knee,
-                                                         const float* __restrict__ tab, DynArgs a, unsigned ngroups,
-                                                         unsigned nblocks, float* __restrict__ u1) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (a tile's history is its neighbour's data)
-    const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (b >= nblocks) return;
-    const unsigned r = b / ngroups;
-    const unsigned grp = b - r * ngroups;
-    const unsigned pr = r % a.prows;
-    const float* tb = tab + (size_t)pr * DP_TAB;
-    if (tb[DP_ONESHOT] == 0.0f) return;          // produced by dyn_fused_kernel (uniform)
-    const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;     // first sample of this wave's tile
-    if (s >= a.L) return;
-    const float* x0 = x + drow_off(a.xmap, r, 0);
-    const float* x1 = x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0);
-    float* y0 = y + drow_off(a.ymap, r, 0);
-    float* y1 = y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
-    const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
+// One wave tile of one row, in two steps so that a caller walking several rows can have the next row's loads in flight
+// while it works on this one.  os_load: x and the H samples of history before the tile (lanes 4 l < H; none before the row
+// start; s is a multiple of 512).  os_finish: the scans, the gain, the stores of y (and of the scan); returns what it stored.
+struct OsIn {
+    float xa[OS_SUB][DE], xb[OS_SUB][DE], ha[DE], hb[DE];
+};
+
+template <bool AL>
+__device__ __forceinline__ void os_load(const DynArgs& a, const float* __restrict__ x0, const float* __restrict__ x1,
+                                        bool vx, const float* __restrict__ tb, int64_t s, int lane, OsIn& in) {
     const bool stereo = a.C == 2;
     const int64_t n0 = s + DE * lane;
-
-    float xa[OS_SUB][DE], xb[OS_SUB][DE], ha[DE], hb[DE];
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
-        load4(x0, n0 + 256 * k, a.L, vx, xa[k]);
-        if (stereo) load4(x1, n0 + 256 * k, a.L, vx, xb[k]);
+        ld4<AL>(x0, n0 + 256 * k, a.L, vx, in.xa[k]);
+        if (stereo) ld4<AL>(x1, n0 + 256 * k, a.L, vx, in.xb[k]);
         else {
 #pragma unroll
-            for (int i = 0; i < DE; ++i) xb[k][i] = 0.0f;
+            for (int i = 0; i < DE; ++i) in.xb[k][i] = 0.0f;
         }
     }
-    // history taps 4 l .. 4 l + 3 = samples s - 4 (l + 1) .. s - 4 l - 1 (none before the row start; s is a multiple of 1024)
+    // history taps 4 l .. 4 l + 3 = samples s - 4 (l + 1) .. s - 4 l - 1
+    const int H = (int)tb[DP_HIST];
+    if (s != 0 && DE * lane < H) {
+        ld4<AL>(x0, s - DE * (lane + 1), a.L, vx, in.ha);
+        if (stereo) ld4<AL>(x1, s - DE * (lane + 1), a.L, vx, in.hb);
+    }
+}
+
+template <bool AL>
+__device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, float* __restrict__ y0, float* __restrict__ y1,
+                                          bool vx, float* __restrict__ u1row, const float* __restrict__ tb, const Knee& q,
+                                          int64_t s, int lane, float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE]) {
+    const bool stereo = a.C == 2;
+    const int64_t n0 = s + DE * lane;
+    const float (&xa)[OS_SUB][DE] = in.xa;
+    const float (&xb)[OS_SUB][DE] = in.xb;
+    const float (&ha)[DE] = in.ha;
+    const float (&hb)[DE] = in.hb;
     const int H = (int)tb[DP_HIST];
     const bool hist = s != 0 && DE * lane < H;
-    if (hist) {
-        load4(x0, s - DE * (lane + 1), a.L, vx, ha);
-        if (stereo) load4(x1, s - DE * (lane + 1), a.L, vx, hb);
-    }
     const float a1 = tb[77], one_m_a = tb[78], a_sub = tb[70];          // a, 1 - a, a^256
     const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};              // a^1 .. a^4
     const float a_lane = tb[lane];                                       // a^(4 lane)
     float a_step[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) a_step[d] = tb[64 + d];
-    Knee q;
-    knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
     const float invC = 1.0f / (float)a.C;
 
-    // the four sub-tiles' local and in-wave scans do not depend on each other
+    // the sub-tiles' local and in-wave scans do not depend on each other
     float loc[OS_SUB][DE], excl[OS_SUB], total[OS_SUB];
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
@@ -494,13 +511,12 @@ __global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict
         for (int d = 32; d >= 1; d >>= 1) hs += __shfl_xor(hs, d, 64);
         carry = hs;
     }
-    float* u1row = u1 ? u1 + (int64_t)r * a.L : nullptr;
     const bool vu = (a.L % 4) == 0;
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
         const float pre = fmaf(a_lane, carry, excl[k]);   // u just before this lane's first sample of sub-tile k
         carry = fmaf(a_sub, carry, total[k]);
-        float ga[DE], gb[DE], raw[DE];
+        float raw[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
             const float u = fmaf(apk[i], pre, loc[k][i]);
@@ -508,13 +524,170 @@ __global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict
             const float env = fmaxf(raw[i], 0.0f);                       // relu, envelope.py:48
             const float G = FastMath::log(env + 1e-5f);                  // dynamics.py:394
             const float g = FastMath::exp(log_gain_m<FastMath>(q, G));   // 402-403
-            ga[i] = g * xa[k][i];
-            gb[i] = g * xb[k][i];
+            ga[k][i] = g * xa[k][i];
+            gb[k][i] = g * xb[k][i];
         }
         const int64_t n = n0 + 256 * k;
-        if (u1row) store4(u1row, n, a.L, vu, raw);
-        store4(y0, n, a.L, vx, ga);
-        if (stereo) store4(y1, n, a.L, vx, gb);
+        if (u1row) st4<AL>(u1row, n, a.L, vu, raw);
+        st4<AL>(y0, n, a.L, vx, ga[k]);
+        if (stereo) st4<AL>(y1, n, a.L, vx, gb[k]);
+    }
+}
+
+__device__ __forceinline__ void os_tile(const DynArgs& a, const float* __restrict__ x0, const float* __restrict__ x1,
+                                        float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ u1row,
+                                        const float* __restrict__ tb, const Knee& q, int64_t s, int lane,
+                                        float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE]) {
+    const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
+    OsIn in;
+    os_load<false>(a, x0, x1, vx, tb, s, lane, in);
+    os_finish<false>(a, in, y0, y1, vx, u1row, tb, q, s, lane, ga, gb);
+}
+
+__global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ log_threshold,
+                                                         const float* __restrict__ log_ratio,
+                                                         const float* __restrict__ log_knee,
+                                                         const float* __restrict__ tab, DynArgs a, unsigned ngroups,
+                                                         unsigned nblocks, float* __restrict__ u1) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (a tile's history is its neighbour's data)
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (b >= nblocks) return;
+    const unsigned r = b / ngroups;
+    const unsigned grp = b - r * ngroups;
+    const unsigned pr = r % a.prows;
+    const float* tb = tab + (size_t)pr * DP_TAB;
+    if (tb[DP_ONESHOT] == 0.0f) return;          // produced by dyn_fused_kernel (uniform)
+    const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;     // first sample of this wave's tile
+    if (s >= a.L) return;
+    Knee q;
+    knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
+    float ga[OS_SUB][DE], gb[OS_SUB][DE];
+    os_tile(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0), y + drow_off(a.ymap, r, 0),
+            y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0), u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb);
+}
+
+// The one-shot tiles with the ROUTING SUM that follows fused in (render/core.py:36-112: the "mix" stage whose sources are
+// exactly this stage's rows).  The rows of one graph (`inner` consecutive rows, r = g * inner + j) feed the mix
+// destinations; a wave owns one 512-sample tile of ALL rows of its graph, walks them in increasing j -- the summation order
+// of the gather-sum kernels, from 0.0f, so the sums are bit-identical to the separate pass -- producing each row's output
+// as os_tile does and adding it to the accumulators of the destinations it feeds: the mix stage's re-read of every row
+// (its whole traffic but the output rows) disappears.  A destination occupies one of NA accumulators only between its
+// first and its last source (the host colours the live ranges: the console's four buses take turns in one accumulator,
+// the send bus holds the other), and is stored right after its last source -- 32 accumulator registers instead of 16 per
+// destination, which is what keeps five waves per SIMD resident.  sched[j], per row of a graph: bits 0..3 = accumulators
+// the row is added to; byte 1 + a = (destination + 1) to store accumulator a to, and clear it, after this row (0: none).
+// Rows the pole table sends to dyn_fused_kernel have been written by it BEFORE this grid (the launcher orders it so) and
+// are read back here.
+#ifndef GFX_MIX_PF
+#define GFX_MIX_PF 0
+#endif
+struct MixArgs {
+    const int64_t* sched;                 // [inner]
+    float* out;                           // mix destinations: out + g * sb + j * sv + c * sc
+    int64_t sb, sv, sc;
+    int inner;
+};
+
+#ifndef GFX_MIX_WGS
+#define GFX_MIX_WGS 3   // workgroups per CU the register budget is held to (168 VGPRs; two rows ahead need 171 unconstrained)
+#endif
+template <int NA, bool STEREO, int KIND, bool GATE>   // knee kind and compressor / gate at compile time: a wave runs the
+// row body `inner` times, and with every gain curve inlined it is 6 k instructions, more than the instruction cache holds
+__global__ __launch_bounds__(DT, NA <= 2 ? GFX_MIX_WGS : 2) void dyn_oneshot_mix_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ log_threshold,
+                                                             const float* __restrict__ log_ratio,
+                                                             const float* __restrict__ log_knee,
+                                                             const float* __restrict__ tab, DynArgs a, unsigned ngroups,
+                                                             unsigned nblocks, float* __restrict__ u1, MixArgs m) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (b >= nblocks) return;
+    const unsigned g = b / ngroups;               // graph (batch index)
+    const unsigned grp = b - g * ngroups;
+    const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;
+    if (s >= a.L) return;
+    const int64_t n0 = s + DE * lane;
+    float acc0[NA][OS_SUB][DE], acc1[STEREO ? NA : 1][OS_SUB][DE];
+#pragma unroll
+    for (int c = 0; c < NA; ++c)
+#pragma unroll
+        for (int k = 0; k < OS_SUB; ++k)
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                acc0[c][k][i] = 0.0f;
+                if (STEREO) acc1[c][k][i] = 0.0f;
+            }
+    float* const obase = m.out + (int64_t)g * m.sb;
+    // the loads of the rows GFX_MIX_PF ahead are issued before this row's scan: a wave walks its rows serially, so what it
+    // keeps in flight itself is all the memory parallelism it has (8192 rows: 5.03 ms without, 4.03 one row ahead)
+    auto row_tab = [&](int jr) { return tab + (size_t)((g * (unsigned)m.inner + (unsigned)jr) % a.prows) * DP_TAB; };
+    auto row_x = [&](int jr, int c) { return x + drow_off(a.xmap, g * (unsigned)m.inner + (unsigned)jr, c); };
+    auto fetch = [&](int jr, OsIn& in) {          // uniform predicate: rows of the other kernel are read back from y instead
+        if (jr < m.inner && row_tab(jr)[DP_ONESHOT] != 0.0f)
+            os_load<true>(a, row_x(jr, 0), row_x(jr, STEREO ? 1 : 0), true, row_tab(jr), s, lane, in);
+    };
+    constexpr int PF = GFX_MIX_PF;                // rows ahead
+    constexpr int NR = PF + 1;                    // ring of row inputs; the loop is unrolled NR times so that ring slots are
+    OsIn ring[NR];                                // registers with static names (a rotating copy would wait for the loads)
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(d, ring[d]);
+    for (int j0 = 0; j0 < m.inner; j0 += NR) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int jr = j0 + u;
+            if (jr >= m.inner) break;             // uniform
+            const unsigned r = g * (unsigned)m.inner + (unsigned)jr;
+            const unsigned pr = r % a.prows;
+            const float* tb = tab + (size_t)pr * DP_TAB;
+            const uint64_t code = (uint64_t)m.sched[jr];
+            const unsigned add = (unsigned)code & 15u;
+            float* y0 = y + drow_off(a.ymap, r, 0);
+            float* y1 = y + drow_off(a.ymap, r, STEREO ? 1 : 0);
+            float ga[OS_SUB][DE], gb[OS_SUB][DE];
+            fetch(jr + PF, ring[(u + PF) % NR]);
+            if (tb[DP_ONESHOT] != 0.0f) {         // uniform
+                Knee q;
+                knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
+                os_finish<true>(a, ring[u], y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb);
+            } else if (add != 0u) {
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k) {
+                    ld4<true>(y0, n0 + 256 * k, a.L, true, ga[k]);
+                    if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, gb[k]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                if ((add >> c) & 1u) {            // uniform
+#pragma unroll
+                    for (int k = 0; k < OS_SUB; ++k)
+#pragma unroll
+                        for (int i = 0; i < DE; ++i) {
+                            acc0[c][k][i] += ga[k][i];
+                            if (STEREO) acc1[c][k][i] += gb[k][i];
+                        }
+                }
+                const unsigned fl = (unsigned)(code >> (8 + 8 * c)) & 255u;
+                if (fl != 0u) {                   // uniform: this destination is complete
+                    float* o0 = obase + (int64_t)(fl - 1u) * m.sv;
+                    float* o1 = o0 + m.sc;
+#pragma unroll
+                    for (int k = 0; k < OS_SUB; ++k) {
+                        st4<true>(o0, n0 + 256 * k, a.L, true, acc0[c][k]);
+                        if (STEREO) st4<true>(o1, n0 + 256 * k, a.L, true, acc1[c][k]);
+#pragma unroll
+                        for (int i = 0; i < DE; ++i) {
+                            acc0[c][k][i] = 0.0f;
+                            if (STEREO) acc1[c][k][i] = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -1574,10 +1747,10 @@ size_t gfx_dynamics_ws_bytes(int64_t param_rows) {
     return param_rows <= 0 ? 0 : (size_t)param_rows * DP_TAB * sizeof(float);
 }
 
-int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
-                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
-                              int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
-                              float* u1, void* ws, size_t ws_bytes, void* stream) {
+static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                                 const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                                 int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                                 float* u1, void* ws, size_t ws_bytes, void* stream, const MixArgs* mix, int mix_na = 0) {
     if (param_rows < 1 || param_rows > R) return GFX_EINVAL;
     if (u1 && smoother != 1) return GFX_EINVAL;
     if (!x || !y || !log_threshold || !log_ratio || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
@@ -1596,15 +1769,19 @@ int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     // history fits (decided per row on the device), then the row kernel for the others (same table, complementary test).
     const float* tab = nullptr;
     const int64_t ngroups = (L + OS_GTILE - 1) / OS_GTILE;
-    if (ws && smoother == 1 && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL) {
+    const bool oneshot = ws && smoother == 1 && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL;
+    if (mix && !oneshot) return GFX_EINVAL;
+    if (oneshot) {
         float* t = (float*)ws;
         hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, t, param_rows, iir_len);
-        const unsigned nblocks = (unsigned)(R * ngroups);
-        a.nchunks = 1;
-        a.chunk_tiles = 1;
-        hipLaunchKernelGGL(dyn_oneshot_kernel, dim3((nblocks + 7u) & ~7u), dim3(DT), 0, st, x, y, log_threshold, log_ratio,
-                           log_knee, (const float*)t, a, (unsigned)ngroups, nblocks, u1);
         tab = t;
+        if (!mix) {
+            const unsigned nblocks = (unsigned)(R * ngroups);
+            a.nchunks = 1;
+            a.chunk_tiles = 1;
+            hipLaunchKernelGGL(dyn_oneshot_kernel, dim3((nblocks + 7u) & ~7u), dim3(DT), 0, st, x, y, log_threshold,
+                               log_ratio, log_knee, (const float*)t, a, (unsigned)ngroups, nblocks, u1);
+        }
     }
     // Few rows: one workgroup per row walks the whole length serially (~2 us per tile) and the launch is bound by
     // that latency, not by bandwidth.  Split every row into time chunks then; a chunk re-scans N samples of history
@@ -1617,7 +1794,63 @@ int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
     if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, st, x, y,
                        log_threshold, log_ratio, log_knee, z_alpha, a, u1, tab);
+    if (mix) {   // after the row kernel: its rows are read back by the tiles that sum them
+        const unsigned nblocks = (unsigned)((R / mix->inner) * ngroups);
+        a.nchunks = 1;
+        a.chunk_tiles = 1;
+        const dim3 grid((nblocks + 7u) & ~7u), blk(DT);
+#define GFX_MIX3(NA_, ST, KN, GT)                                                                                            \
+    hipLaunchKernelGGL((dyn_oneshot_mix_kernel<NA_, ST, KN, GT>), grid, blk, 0, st, x, y, log_threshold, log_ratio, log_knee, \
+                       tab, a, (unsigned)ngroups, nblocks, u1, *mix)
+#define GFX_MIX2(NA_, ST, KN)           \
+    do {                                \
+        if (gate) GFX_MIX3(NA_, ST, KN, true); \
+        else GFX_MIX3(NA_, ST, KN, false);     \
+    } while (0)
+#define GFX_MIX(NA_, ST)                       \
+    do {                                       \
+        if (knee == 0) GFX_MIX2(NA_, ST, 0);   \
+        else if (knee == 1) GFX_MIX2(NA_, ST, 1); \
+        else GFX_MIX2(NA_, ST, 2);             \
+    } while (0)
+        if (C == 2) {
+            if (mix_na <= 2) GFX_MIX(2, true);
+            else GFX_MIX(4, true);
+        } else {
+            if (mix_na <= 2) GFX_MIX(2, false);
+            else GFX_MIX(4, false);
+        }
+#undef GFX_MIX2
+#undef GFX_MIX3
+#undef GFX_MIX
+    }
     return GFX_LAUNCH_OK();
+}
+
+int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                              const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                              int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                              float* u1, void* ws, size_t ws_bytes, void* stream) {
+    return dynamics_fused_launch(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L, smoother,
+                                 iir_len, knee, gate, u1, ws, ws_bytes, stream, nullptr);
+}
+
+int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                               const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                               int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                               float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
+                               float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, void* stream) {
+    if (!sched || !mix || inner < 1 || inner > 65535 || n_acc < 1 || n_acc > 4 || R % inner != 0 || !ws || smoother != 1)
+        return GFX_EINVAL;
+    // every access of the fused kernel is a whole aligned float4 (the element-wise paths would triple its code size)
+    const int64_t strides = xmap.stride_outer | xmap.stride_inner | xmap.stride_ch | ymap.stride_outer | ymap.stride_inner |
+                            ymap.stride_ch | mix_sb | mix_sv | mix_sc;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mix | (uintptr_t)u1) & 15) != 0 || (strides & 3) != 0 || (L & 3) != 0)
+        return GFX_EINVAL;
+    MixArgs m;
+    m.sched = sched; m.out = mix; m.sb = mix_sb; m.sv = mix_sv; m.sc = mix_sc; m.inner = (int)inner;
+    return dynamics_fused_launch(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L, smoother,
+                                 iir_len, knee, gate, u1, ws, ws_bytes, stream, &m, (int)n_acc);
 }
 
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream) {

@@ -460,16 +460,44 @@ def _rowvec(p, R):
 # Default schedule of dynamics_fused: "oneshot" hands the library a workspace, with which the smoothed configuration runs
 # as dependency-free 1024-sample tiles for every row whose smoother memory is short (decided per row on the device,
 # gfx_dynamics_fused_ws_f32) and as one workgroup per row for the others; "rows" forces one workgroup per row.
+MIX_FUSION = True          # dynamics stages take the routing sum that follows them (see dynamics_fused(mix=))
 DYN_SCHEDULE = "oneshot"
+
+
+def mix_schedule(dest_sources, n):
+    """The per-row schedule of gfx_dynamics_fused_mix_f32 for a routing sum over the n rows of a graph: ``dest_sources[d]``
+    = the rows (0 .. n-1, strictly increasing) added into destination d.  A destination occupies an accumulator from its
+    first to its last source; live ranges are coloured greedily.  -> (codes (list of n ints), accumulators used), or None
+    when a destination has no source, its rows are not increasing, or more than four destinations are live at once."""
+    if not dest_sources or len(dest_sources) > 254:
+        return None
+    for rows in dest_sources:
+        if not rows or any(b <= a for a, b in zip(rows, rows[1:])) or rows[0] < 0 or rows[-1] >= n:
+            return None
+    codes, free_at, slot = [0] * n, [0] * 4, {}
+    for d in sorted(range(len(dest_sources)), key=lambda d: dest_sources[d][0]):
+        first, last = dest_sources[d][0], dest_sources[d][-1]
+        a = next((k for k in range(4) if free_at[k] <= first), None)
+        if a is None:
+            return None
+        free_at[a], slot[d] = last + 1, a
+        for j in dest_sources[d]:
+            codes[j] |= 1 << a
+        codes[last] |= (d + 1) << (8 + 8 * a)
+    return codes, max(slot.values()) + 1
 
 
 @_on_device
 def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir_len, knee, gate, out=None,
-                   param_rows=None, schedule=None, u1_out=None):
+                   param_rows=None, schedule=None, u1_out=None, mix=None):
     """``param_rows``: number of parameter rows when shared across the batch (row r uses r % param_rows).
     ``schedule``: "oneshot" (default) or "rows", see above.
     ``u1_out``: optional (R, L) tensor that receives the smoother's un-truncated scan for :func:`dynamics_bwd` (the
-    training forward; smoother = 1 only)."""
+    training forward; smoother = 1 only).
+    ``mix``: a dict {"sched": int64 device tensor (n,), "n_acc": int, "out": (B, J, C, L) view} for a strided (B, n, C, L)
+    input (see :func:`mix_schedule`) -- the routing sum that follows is computed by the same kernel
+    (gfx_dynamics_fused_mix_f32) and ``mix["done"]`` is set; when the configuration cannot take it, nothing is summed and
+    ``mix["done"]`` stays unset (the caller runs the gather-sum stage)."""
     schedule = DYN_SCHEDULE if schedule is None else schedule
     if schedule not in ("oneshot", "rows"):
         raise ValueError(f"dynamics_fused: unknown schedule {schedule!r}")
@@ -491,6 +519,19 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
     args = (_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)), pin(_rowvec(log_ratio, P)),
             pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate),
             _ptr(u1_out), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
+    if mix is not None and ws is not None and MIX_FUSION and x.ndim == 4 and out.ndim == 4:
+        mo, sched = mix["out"], mix["sched"]
+        n, J = x.shape[1], mo.shape[1]
+        if (mo.shape == (x.shape[0], J, C, L) and mo.stride(-1) == 1 and sched.numel() == n and xmap.inner == n
+                and ymap.inner == n):
+            with _timed("dyn_fused_kernel", 8 * R * C * L + 4 * mo.numel() + (4 * R * L if u1_out is not None else 0)):
+                rc = lib().gfx_dynamics_fused_mix_f32(*args[:-1], _ptr(sched), n, mix["n_acc"], _ptr(mo), mo.stride(0),
+                                                      mo.stride(1), mo.stride(2) if C == 2 else 0, _stream())
+            if rc == 0:
+                mix["done"] = True
+                return out
+            if rc != -1:   # GFX_EINVAL: not a configuration of the fused kernel
+                check(rc, "gfx_dynamics_fused_mix_f32")
     with _timed("dyn_fused_kernel", 8 * R * C * L + (4 * R * L if u1_out is not None else 0)):
         check(lib().gfx_dynamics_fused_ws_f32(*args), "gfx_dynamics_fused_ws_f32")
     return out

@@ -40,12 +40,14 @@ class _Dynamics(BufferIO, nn.Module):
     accepts_shared_params = True  # render_into(..., _shared_rows=n): parameters hold n rows shared by the batch
     accepts_strided_rows = True   # forward() also takes a strided (B, n, C, L) view and then returns (B, n, C, L)
     accepts_aux = True            # _aux=(dict, key): the training render's per-stage store (see forward)
+    accepts_mix = True            # _mix={"mask", "out"}: the routing sum that follows, see ops.dynamics_fused(mix=)
 
-    def render_into(self, x4, out4, _shared_rows=None, _aux=None, **params):
-        return self.forward(x4, _out=out4, _shared_rows=_shared_rows, _aux=_aux, **params)
+    def render_into(self, x4, out4, _shared_rows=None, _aux=None, _mix=None, **params):
+        extra = {} if _mix is None else {"_mix": _mix}
+        return self.forward(x4, _out=out4, _shared_rows=_shared_rows, _aux=_aux, **extra, **params)
 
     def forward(self, input_signals, log_threshold, log_ratio, log_knee=None, z_alpha_pre=None, z_alpha_post=None,
-                _out=None, _shared_rows=None, _aux=None):
+                _out=None, _shared_rows=None, _aux=None, _mix=None):
         """``_aux = (store, key)`` (render_grafx's training path): the tape-free forward render leaves the smoother's scan
         in ``store[key]`` and the stage-wise backward, which re-traces this call on the same rows, hands it to the
         autograd node, so that the backward does not have to scan the input again."""
@@ -79,7 +81,8 @@ class _Dynamics(BufferIO, nn.Module):
                 u1 = _aux[0][_aux[1]] = torch.empty((rows, L), dtype=torch.float32, device=input_signals.device)
             return ops.dynamics_fused(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                       smoother=int(self.energy_smoother == "iir"), iir_len=self.iir_len,
-                                      knee=self.knee, gate=self._gate, out=_out, param_rows=_shared_rows, u1_out=u1)
+                                      knee=self.knee, gate=self._gate, out=_out, param_rows=_shared_rows, u1_out=u1,
+                                      mix=_mix)
         if _out is not None:  # unfused configurations: run on flattened rows, then copy into the buffer slice
             y = self.forward(input_signals.reshape(-1, *input_signals.shape[2:]), log_threshold, log_ratio, log_knee,
                              z_alpha_pre, z_alpha_post)
@@ -172,9 +175,9 @@ class ApproxCompressor(Compressor):
                          flashfftconv=flashfftconv, max_input_len=max_input_len)
 
     def forward(self, input_signals, z_alpha, log_threshold, log_ratio, log_knee=None, _out=None, _shared_rows=None,
-                _aux=None):
+                _aux=None, _mix=None):
         return super().forward(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre=z_alpha, _out=_out,
-                               _shared_rows=_shared_rows, _aux=_aux)
+                               _shared_rows=_shared_rows, _aux=_aux, _mix=_mix)
 
     def parameter_size(self):
         return {"z_alpha": 1, "log_threshold": 1, "log_ratio": 1, "log_knee": 1}

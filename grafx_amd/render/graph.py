@@ -110,6 +110,27 @@ def _transposed_plan(step, plan, device):
     return cache[key]
 
 
+def _mix_schedule(step, nxt, device):
+    """When `nxt` is a routing-sum stage fed by `step`'s rows alone: (schedule tensor, accumulators) with which a
+    processor that ``accepts_mix`` computes the sums itself (ops.mix_schedule: every destination adds its rows in
+    increasing order, as the gather-sum kernels do); else None."""
+    from .. import ops
+
+    cache = step.__dict__.setdefault("_mix_sched", {})
+    key = (device.type, device.index)
+    if key not in cache:
+        cache[key] = None
+        plan = _gather_plan(nxt, device)
+        d0, d1 = step.dest_write.idx
+        if plan:
+            src, seg = plan[0].tolist(), plan[1].tolist()
+            if all(d0 <= v < d1 for v in src):
+                sched = ops.mix_schedule([[v - d0 for v in src[seg[j]:seg[j + 1]]] for j in range(plan[2])], d1 - d0)
+                if sched is not None:
+                    cache[key] = (torch.tensor(sched[0], dtype=torch.long, device=device), sched[1])
+    return cache[key]
+
+
 def _plan_max_row(step, plan):
     """Highest buffer row a gather plan reads (cached: the plan lives on the device)."""
     cache = step.__dict__.setdefault("_plan_max", [])
@@ -303,9 +324,13 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         return ready
 
     prepared = None
+    mixed = -1  # order of a routing-sum stage the stage before it has already produced
     for i in range(1, render_data.max_order + 1):
         step = render_data.iter_list[i]
         d0, d1 = step.dest_write.idx
+        if i == mixed:
+            out_view = buf.narrow(1, d0, d1 - d0)
+            continue
         out_view = buf.narrow(1, d0, d1 - d0)
         plan = _gather_plan(step, x.device)
         node_type = step.node_type
@@ -340,7 +365,17 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             # only for the exact library types whose backward consumes it (see `trusted` in the backward); a gathered
             # input is a temporary: the backward re-gathers it, same values
             extra["_aux"] = (aux, i)
+        mix = None
+        if (i < render_data.max_order and getattr(proc, "accepts_mix", False) and type(proc) in _tape_safe_types()
+                and render_data.iter_list[i + 1].node_type not in processors):
+            nxt = render_data.iter_list[i + 1]
+            sched = _mix_schedule(step, nxt, x.device)
+            if sched is not None:
+                e0, e1 = nxt.dest_write.idx
+                mix = extra["_mix"] = {"sched": sched[0], "n_acc": sched[1], "out": buf.narrow(1, e0, e1 - e0)}
         proc.render_into(x_view, out_view, **extra, **params, **common_i)
+        if mix is not None and mix.get("done"):
+            mixed = i + 1
         if prepared is None:  # the first processor stage is on its way: now design the later ones underneath it
             prepared = prepare_later_stages(i)
     if side is not None and not copied:

@@ -1,0 +1,161 @@
+"""The routing sum fused into the dynamics kernel (gfx_dynamics_fused_mix_f32): a "mix" stage fed by a compressor / gate
+stage alone (render/core.py:36-112 after dynamics.py:361-489) is produced by the compressor's one-shot tiles -- every
+row's output AND the destination sums, bit for bit what the two separate kernels give."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(n, seed, slow_rows=()):
+    g = torch.Generator().manual_seed(seed)
+    p = {k: torch.randn(n, 1, generator=g) for k in ("log_threshold", "log_ratio", "log_knee")}
+    z = torch.randn(n, 1, generator=g)
+    for j in slow_rows:
+        z[j] = 9.0            # pole 0.9999: history beyond the one-shot budget, the row kernel's row
+    p["z_alpha"] = z
+    return {k: v.cuda() for k, v in p.items()}
+
+
+def _random_routing(n, J, seed):
+    """J destinations over n rows with at most four live at a time (what the kernel's accumulators hold)."""
+    import random
+
+    from grafx_amd import ops
+
+    rnd = random.Random(seed)
+    for _ in range(1000):
+        dests = []
+        for d in range(J):
+            lo = rnd.randrange(n)
+            hi = rnd.randrange(lo, n)
+            rows = sorted({lo, hi} | {j for j in range(lo, hi + 1) if rnd.random() < 0.5})
+            dests.append(rows)
+        sched = ops.mix_schedule(dests, n)
+        if sched is not None:
+            return dests, sched
+    raise AssertionError("no schedule found")
+
+
+@pytest.mark.parametrize("B,n,C,L,J,slow", [(3, 8, 2, 4096, 3, ()), (2, 32, 2, 20000, 5, (3, 17)), (4, 5, 1, 3001, 8, (0,)),
+                                            (1, 1, 2, 1024, 1, ()), (2, 6, 2, 8191, 2, (5,)), (2, 7, 1, 2048, 4, ()),
+                                            (2, 40, 2, 6000, 13, (1, 2, 39))])
+@pytest.mark.parametrize("knee", ["hard", "quadratic", "exponential"])
+def test_fused_mix_equals_the_two_kernels(B, n, C, L, J, slow, knee):
+    from grafx_amd import ops
+
+    torch.manual_seed(B * 100 + n + L)
+    buf = torch.randn(B, n + n + J + 2, C, L, device="cuda")       # [inputs | outputs | mix | spare]
+    x, y, mo = buf[:, :n], buf[:, n : 2 * n], buf[:, 2 * n : 2 * n + J]
+    spare = buf[:, 2 * n + J :].clone()
+    p = _params(n, L + J, slow)
+    dests, (codes, n_acc) = _random_routing(n, J, seed=J * 1000 + n)
+    kw = dict(smoother=1, iir_len=8193, knee=knee, gate=False, param_rows=n)
+    a = (p["log_threshold"], p["log_ratio"], p["log_knee"] if knee != "hard" else None, p["z_alpha"])
+    want_y = ops.dynamics_fused(x, *a, **kw)                       # (B * n, C, L)
+    want_y = want_y.view(B, n, C, L)
+    want_m = torch.zeros(B, J, C, L, device="cuda")
+    for d, rows in enumerate(dests):                               # sequential fp32 additions from 0.0, increasing row
+        for j in rows:
+            want_m[:, d] = want_m[:, d] + want_y[:, j]
+    mix = {"sched": torch.tensor(codes, device="cuda"), "n_acc": n_acc, "out": mo}
+    got_y = ops.dynamics_fused(x, *a, **kw, out=y, mix=mix)
+    assert torch.equal(got_y, want_y)
+    if L % 4:                                                      # the fused kernel takes whole aligned float4 only
+        assert "done" not in mix
+        return
+    assert mix.get("done") is True
+    assert torch.equal(mo, want_m)
+    assert torch.equal(buf[:, 2 * n + J :], spare)                 # nothing written past the destinations
+
+
+def test_fused_mix_declines_what_it_cannot_do():
+    from grafx_amd import ops
+
+    x = torch.randn(2, 4, 2, 2048, device="cuda")
+    p = _params(4, 1)
+    a = (p["log_threshold"], p["log_ratio"], None, p["z_alpha"])
+    codes, n_acc = ops.mix_schedule([[0, 1], [2, 3]], 4)
+    for kw in (dict(smoother=0, iir_len=1), dict(smoother=1, iir_len=4097, schedule="rows")):
+        mix = {"sched": torch.tensor(codes, device="cuda"), "n_acc": n_acc, "out": torch.empty(2, 2, 2, 2048, device="cuda")}
+        ops.dynamics_fused(x, *a, knee="hard", gate=False, param_rows=4, mix=mix, **kw)
+        assert "done" not in mix
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_console_render_with_and_without_the_fused_mix(train):
+    """render_grafx on the bench's console graph: identical buffers with the fusion on and off (forward), identical
+    gradients in training (the backward does not depend on how the forward summed)."""
+    import bench
+    from grafx_amd import ops
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    dev = torch.device("cuda")
+    G = bench.console_graph(n_ch=8, n_bus=2)
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
+    procs = {k: v.to(dev) for k, v in bench.hip_processors().items()}
+    torch.manual_seed(3)
+    B, L = 2, 32768
+    x = torch.randn(B, 8, 2, L, device=dev)
+    params = {t: {k: v.detach().to(dev) for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    outs, seen = {}, {}
+    real = ops.lib().gfx_dynamics_fused_mix_f32
+    for flag in (True, False):
+        ops.MIX_FUSION = flag
+        try:
+            if train:
+                leaves = [v.requires_grad_(True) for d in params.values() for v in d.values()]
+                for t in leaves:
+                    t.grad = None
+                out, _, buf = render_grafx(procs, x, params, rd)
+                out.square().mean().backward()
+                outs[flag] = (buf.detach().clone(), out.detach().clone(), [t.grad.clone() for t in leaves])
+            else:
+                with torch.no_grad():
+                    out, _, buf = render_grafx(procs, x, params, rd, parameters_grad=False)
+                outs[flag] = (buf.clone(), out.clone(), [])
+        finally:
+            ops.MIX_FUSION = True
+    # the reverb's impulse-response normalisation sums its energy with float atomics (1-ulp run-to-run differences in
+    # its gain): the reverb node and the output node are compared to 1e-6, every other node bit for bit
+    rev = [i for i in range(1, rd.max_order + 1) if rd.iter_list[i].node_type == "reverb"][0]
+    first_loose = rd.iter_list[rev].dest_write.idx[0]
+    assert torch.equal(outs[True][0][:, :first_loose], outs[False][0][:, :first_loose])
+    scale = outs[False][0][:, first_loose:].abs().max()
+    assert (outs[True][0][:, first_loose:] - outs[False][0][:, first_loose:]).abs().max() <= 1e-6 * scale
+    for a, b in zip(outs[True][2], outs[False][2]):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max().clamp_min(1e-12)
+
+
+def test_the_console_graph_takes_the_fused_path(monkeypatch):
+    """The schedule of the bench graph has compressor -> mix (channel strips -> the buses and the send): that routing sum
+    is produced by the dynamics kernel, no gather-sum launch is left for it."""
+    import bench
+    from grafx_amd import ops
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    dev = torch.device("cuda")
+    G = bench.console_graph(n_ch=8, n_bus=2)
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
+    procs = {k: v.to(dev) for k, v in bench.hip_processors().items()}
+    params = {t: {k: v.detach().to(dev) for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    x = torch.randn(2, 8, 2, 16384, device=dev)
+    calls = {"fanout": 0, "plain": 0}
+    f0, g0 = ops.gather_sum_fanout, ops.gather_sum
+    monkeypatch.setattr(ops, "gather_sum_fanout", lambda *a, **k: (calls.__setitem__("fanout", calls["fanout"] + 1), f0(*a, **k))[1])
+    monkeypatch.setattr(ops, "gather_sum", lambda *a, **k: (calls.__setitem__("plain", calls["plain"] + 1), g0(*a, **k))[1])
+    with torch.no_grad():
+        render_grafx(procs, x, params, rd, parameters_grad=False)
+    fused = dict(calls)
+    ops.MIX_FUSION = False
+    try:
+        with torch.no_grad():
+            render_grafx(procs, x, params, rd, parameters_grad=False)
+    finally:
+        ops.MIX_FUSION = True
+    separate = {k: calls[k] - fused[k] for k in calls}
+    assert sum(separate.values()) >= 2 and sum(fused.values()) <= sum(separate.values()) - 1, (fused, separate)

@@ -1,0 +1,18 @@
+"""Host side of the fused routing sum (gfx_dynamics_fused_mix_f32): the per-row schedule that assigns every mix
+destination one of four accumulators between its first and last source (grafx_amd.ops.mix_schedule)."""
+
+
+def test_mix_schedule_colours_live_ranges():
+    from grafx_amd import ops
+
+    # the console: four buses of eight strips take turns in one accumulator, the send bus holds the other
+    dests = [list(range(8 * k, 8 * k + 8)) for k in range(4)] + [list(range(32))]
+    codes, n_acc = ops.mix_schedule(dests, 32)
+    assert n_acc == 2
+    assert all(c & 3 == 3 for c in codes)
+    assert [(c >> 8) & 255 for c in codes if (c >> 8) & 255] + [(c >> 16) & 255 for c in codes if (c >> 16) & 255] in (
+        [1, 2, 3, 4, 5], [5, 1, 2, 3, 4])
+    assert ops.mix_schedule([[0, 1], []], 4) is None               # a destination without sources
+    assert ops.mix_schedule([[1, 0]], 4) is None                   # not increasing
+    assert ops.mix_schedule([[0, 3]] * 5, 4) is None               # five live at once
+    assert ops.mix_schedule([[0, 3]] * 4, 4)[1] == 4
