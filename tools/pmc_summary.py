@@ -71,7 +71,7 @@ def main():
     rec = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); sanity check: "
-                "dyn_fused_kernel streams exactly 4*R*C*L bytes each way",
+                "dyn_oneshot_mix_kernel reads 4*R*C*L bytes and writes 4*(R + 5*B)*C*L",
         "config": {"batch": cfg["batch_per_gpu"], "audio_len": cfg["audio_len"], "fsm_fir_len": cfg["fsm_fir_len"],
                    "iir_len": cfg["iir_len"], "ir_len": cfg["ir_len"]},
         "kernels": kernels,
@@ -100,8 +100,9 @@ def main():
     k = kernels.get("gfx::fftconv1_kernel")
     print("bench:", bench["ms_per_step"], "ms/step", bench["value"], bench["unit"])
     print("fftconv1 HBM bytes/launch:", k and k["hbm_bytes_per_launch"])
-    d = kernels.get("gfx::dyn_fused_kernel")
-    print("dyn_fused HBM bytes/launch:", d and (d["hbm_read_bytes_per_launch_corrected"], d["hbm_write_bytes_per_launch"]))
+    for name in ("gfx::dyn_oneshot_mix_kernel", "gfx::dyn_oneshot_kernel"):
+        d = kernels.get(name)
+        print(name, "HBM bytes/launch:", d and (d["hbm_read_bytes_per_launch_corrected"], d["hbm_write_bytes_per_launch"]))
 
 
 if __name__ == "__main__":
