@@ -332,14 +332,11 @@ __global__ __launch_bounds__(256) void istft_frames_half_kernel(const float* __r
     }
 }
 
-// overlap-add + envelope division + trim (centre) + optional ms->lr + energy.
+// overlap-add + envelope division + trim (centre) + optional ms->lr.
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
-                                                        float* __restrict__ ir, float* __restrict__ energy, IstftArgs a,
-                                                        int ms_to_lr) {
-    __shared__ float red[4];
+                                                        float* __restrict__ ir, IstftArgs a, int ms_to_lr) {
     const int64_t r = blockIdx.y;
     const int64_t tp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output index after trimming
-    float e = 0.0f;
     if (tp < a.ir_len) {
         const int64_t t = tp + a.n_fft / 2;
         int64_t m_hi = t / a.hop;
@@ -363,18 +360,25 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
         }
         ir[(r * 2 + 0) * a.ir_len + tp] = v0;
         ir[(r * 2 + 1) * a.ir_len + tp] = v1;
-        e = v0 * v0 + v1 * v1;
     }
+}
+
+// row_gain[r] = 1 / sqrt(mean_c sum_t ir[r,c,t]^2 + 1e-12)  (core/utils.py:16-17), one workgroup per row, summed in a fixed
+// order: thread t takes samples t, t + 256, ... of both channels, then a shuffle tree and four partials in index order.
+// (The overlap-add kernel used to add its blocks' partial energies with float atomics: 1-ulp run-to-run differences in
+// the gain, i.e. in every sample of the reverb's output.)
+__global__ __launch_bounds__(256) void ir_energy_gain_kernel(const float* __restrict__ ir, float* __restrict__ gain,
+                                                             int64_t ir_len) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const float* p = ir + r * 2 * ir_len;
+    float e = 0.0f;
+    for (int64_t t = threadIdx.x; t < 2 * ir_len; t += 256) e = fmaf(p[t], p[t], e);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) e += __shfl_down(e, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&energy[r], 0.5f * (red[0] + red[1] + red[2] + red[3]));  // mean over 2 channels
-}
-
-__global__ void energy_to_gain_kernel(float* __restrict__ e, int64_t R) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R) e[i] = 1.0f / sqrtf(e[i] + 1e-12f);  // core/utils.py:16-17
+    if (threadIdx.x == 0) gain[r] = 1.0f / sqrtf(0.5f * (((red[0] + red[1]) + red[2]) + red[3]) + 1e-12f);
 }
 
 // ---- FilteredNoiseShapingReverb impulse response (reverb.py:343-366) -----------------------------------
@@ -495,7 +499,6 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
     a.ir_len = ir_len;
     a.nstride = noise_rows == 1 ? 0 : 2 * (n_fft / 2 + 1) * num_frames * 2;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(row_gain, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
     if (n_fft <= 384) {
         dim3 g1((unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
 #ifdef GFX_ISTFT_FULL   // round 1's full-matrix form, kept for A/B timing
@@ -511,8 +514,8 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
                            delta_log_magnitude, gain_env_log_magnitude, basis, (float*)ws, a);
     }
     dim3 g2((unsigned)((ir_len + 255) / 256), (unsigned)R);
-    hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, (const float*)ws, window, ir, row_gain, a, ms_to_lr);
-    hipLaunchKernelGGL(energy_to_gain_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, row_gain, R);
+    hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, (const float*)ws, window, ir, a, ms_to_lr);
+    hipLaunchKernelGGL(ir_energy_gain_kernel, dim3((unsigned)R), dim3(256), 0, st, (const float*)ir, row_gain, ir_len);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

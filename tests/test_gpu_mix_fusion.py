@@ -118,14 +118,9 @@ def test_console_render_with_and_without_the_fused_mix(train):
                 outs[flag] = (buf.clone(), out.clone(), [])
         finally:
             ops.MIX_FUSION = True
-    # the reverb's impulse-response normalisation sums its energy with float atomics (1-ulp run-to-run differences in
-    # its gain): the reverb node and the output node are compared to 1e-6, every other node bit for bit
-    rev = [i for i in range(1, rd.max_order + 1) if rd.iter_list[i].node_type == "reverb"][0]
-    first_loose = rd.iter_list[rev].dest_write.idx[0]
-    assert torch.equal(outs[True][0][:, :first_loose], outs[False][0][:, :first_loose])
-    scale = outs[False][0][:, first_loose:].abs().max()
-    assert (outs[True][0][:, first_loose:] - outs[False][0][:, first_loose:]).abs().max() <= 1e-6 * scale
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     for a, b in zip(outs[True][2], outs[False][2]):
+        # (per-row sums of the compressor backward land by float atomics: the order of additions varies run to run)
         assert (a - b).abs().max() <= 1e-5 * b.abs().max().clamp_min(1e-12)
 
 
