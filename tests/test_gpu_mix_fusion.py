@@ -40,8 +40,9 @@ def _random_routing(n, J, seed):
 @pytest.mark.parametrize("B,n,C,L,J,slow", [(3, 8, 2, 4096, 3, ()), (2, 32, 2, 20000, 5, (3, 17)), (4, 5, 1, 3001, 8, (0,)),
                                             (1, 1, 2, 1024, 1, ()), (2, 6, 2, 8191, 2, (5,)), (2, 7, 1, 2048, 4, ()),
                                             (2, 40, 2, 6000, 13, (1, 2, 39))])
-@pytest.mark.parametrize("knee", ["hard", "quadratic", "exponential"])
-def test_fused_mix_equals_the_two_kernels(B, n, C, L, J, slow, knee):
+@pytest.mark.parametrize("knee,gate", [("hard", False), ("quadratic", False), ("exponential", False), ("quadratic", True),
+                                       ("hard", True)])
+def test_fused_mix_equals_the_two_kernels(B, n, C, L, J, slow, knee, gate):
     from grafx_amd import ops
 
     torch.manual_seed(B * 100 + n + L)
@@ -50,7 +51,7 @@ def test_fused_mix_equals_the_two_kernels(B, n, C, L, J, slow, knee):
     spare = buf[:, 2 * n + J :].clone()
     p = _params(n, L + J, slow)
     dests, (codes, n_acc) = _random_routing(n, J, seed=J * 1000 + n)
-    kw = dict(smoother=1, iir_len=8193, knee=knee, gate=False, param_rows=n)
+    kw = dict(smoother=1, iir_len=8193, knee=knee, gate=gate, param_rows=n)
     a = (p["log_threshold"], p["log_ratio"], p["log_knee"] if knee != "hard" else None, p["z_alpha"])
     want_y = ops.dynamics_fused(x, *a, **kw)                       # (B * n, C, L)
     want_y = want_y.view(B, n, C, L)
