@@ -463,11 +463,19 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     }
     if args.dry:
         out["dry"] = "CPU plumbing check with pass-through processors: launch/sharding/JSON only, the numbers mean nothing"
-    # whole-graph view of the same roofline: 285 row transfers per graph
+    # whole-graph view of the same roofline: 285 row transfers per graph (every node reads its inputs and
+    # writes its output once).  32 of them -- the mix stage's read of the channel strips -- are no longer moved: the
+    # compressor stage's kernel sums the buses while it writes the strips (gfx_dynamics_fused_mix_f32), so the rate that
+    # can be held against the HBM peak is the one over the bytes that still cross the bus.
     graph_bytes = 285 * B * 2 * L * 4
+    from grafx_amd import ops as _ops
+    elided = 0 if (args.dry or not _ops.MIX_FUSION) else 32 * B * 2 * L * 4
+    moved = graph_bytes - elided
     out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
-                             "achieved_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9,
-                             "frac_of_hbm_peak": graph_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "elided_bytes_per_step": elided,
+                             "achieved_GBps": moved / (ms_per_step * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_equivalent_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9}
     if train is not None:
         out["training"] = train
     if secondary is not None:
