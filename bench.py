@@ -469,7 +469,7 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     # can be held against the HBM peak is the one over the bytes that still cross the bus.
     graph_bytes = 285 * B * 2 * L * 4
     from grafx_amd import ops as _ops
-    elided = 0 if (args.dry or not _ops.MIX_FUSION) else 32 * B * 2 * L * 4
+    elided = 0 if (args.dry or not _ops.MIX_FUSION or args.reference_default_lengths) else 32 * B * 2 * L * 4
     moved = graph_bytes - elided
     out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
                              "elided_bytes_per_step": elided,
