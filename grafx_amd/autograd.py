@@ -174,13 +174,12 @@ class OddAliasFn(torch.autograd.Function):
 
 def odd_alias(z, lo=0, length=None, precise=False):
     """Differentiable odd-length aliasing (``precise``: double-precision transforms, see
-    processors.core.convolution.odd_length_alias); lengths beyond the kernels' range (P > 699,051) fall to the FFT
-    library in float64, which differentiates itself."""
+    processors.core.convolution.odd_length_alias)."""
     Q = z.shape[-1] - 1
     length = Q - lo if length is None else length
-    if ops.odd_alias_supported(z.shape[-1]):
-        return OddAliasFn.apply(z, lo, length, bool(precise))
-    return torch.fft.irfft(torch.fft.rfft(z.double())).to(z.dtype)[..., lo : lo + length]
+    if not ops.odd_alias_supported(z.shape[-1]):
+        raise NotImplementedError(f"odd-length aliasing: P = {z.shape[-1]} is beyond the kernels' range (P <= 11,184,811)")
+    return OddAliasFn.apply(z, lo, length, bool(precise))
 
 
 def convolve(x, h, mode="causal", exact=False, final=False, precise=False):

@@ -15,9 +15,10 @@
 //   rows     : per row k1 one tile: forward, multiply by the chirp's spectrum (thread layout, precomputed), inverse
 //   cols_inv : conjugate twiddle, C-point inverse DFT, then the chirp / weights of the next step
 // all in place on one NFFT-point complex buffer per signal row.  fp32 throughout; the chirps are evaluated once per P
-// in double with the phase reduced exactly (k^2 mod 2P in integers).  C <= 32 covers P <= 174,763; up to P <= 699,051
-// (10 s of audio at 48 kHz plus the filter) an OUTER radix-4 level splits the 2^20-point transform into four 2^18-point
-// ones (czt_outer_*: 4-point DFT over the quarters + twiddle W_N^(n' k3), in place).
+// in double with the phase reduced exactly (k^2 mod 2P in integers).  C <= 32 covers P <= 174,763; beyond, up to three
+// OUTER radix-4 levels split the transform into 4 / 16 / 64 sub-transforms of C x 8192 points (czt_outer_*: 4-point DFT
+// over the quarters + twiddle W_N^(n' k3), in place, applied recursively): NFFT <= 2^24, P <= 11,184,811 (233 s of audio at
+// 48 kHz plus the filter).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -51,8 +52,11 @@ template <> struct Prec<double> {
 
 struct CztGeom {
     int64_t P, Q, K, NFFT;   // NFFT = S * C * 8192
-    int C, S;                // C <= 32 columns per sub-transform; S = 1, or 4 sub-transforms under an outer radix-4 level
+    int C, S;                // C <= 32 columns per sub-transform; S = 4^levels sub-transforms under `levels` outer radix-4 levels
+    int levels;
 };
+
+constexpr int CZT_MAX_LEVELS = 3;   // NFFT <= 2^24: P <= 11,184,811 (233 s of audio at 48 kHz plus the filter)
 
 static inline bool czt_geom(int64_t P, CztGeom& g) {
     if (P < 3 || (P & 1) == 0) return false;
@@ -60,15 +64,16 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
     g.Q = P - 1;
     g.K = (P + 1) / 2;
     const int64_t need = P + g.K - 1;
-    int C = 1;
-    while ((int64_t)C * TILE_M < need) C *= 2;
-    g.S = 1;
-    if (C > CZT_MAXC) {
-        if (C > 4 * CZT_MAXC) return false;
-        g.S = 4;
-        C = CZT_MAXC;
+    int64_t C = 1;
+    while (C * TILE_M < need) C *= 2;
+    g.levels = 0;
+    while (C > CZT_MAXC) {
+        C /= 4;
+        ++g.levels;
     }
-    g.C = C;
+    if (g.levels > CZT_MAX_LEVELS || C < 1) return false;
+    g.S = 1 << (2 * g.levels);
+    g.C = (int)C;
     g.NFFT = (int64_t)g.S * C * TILE_M;
     return true;
 }
@@ -366,7 +371,9 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2
     for (int n3 = 0; n3 < 4; ++n3) {
         const int64_t i = n3 * NS + np;
         const cx e = v[brev(n3, 2)] * (T)0.25;
-        if (MODE == 0) {
+        if (MODE == 3) {                                   // plain inverse of an inner level
+            b[i] = Prec<T>::make(e.x, e.y);
+        } else if (MODE == 0) {
             cx o = {0, 0};
             if (i < g.K) {
                 const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
@@ -459,6 +466,34 @@ template <typename T> static const typename Prec<T>::T2* czt_twiddles(hipStream_
 template <> const float2* czt_twiddles<float>(hipStream_t st) { return tile_twiddle_table(st); }
 template <> const double2* czt_twiddles<double>(hipStream_t st) { return tile_twiddle_table_f64(st); }
 
+// The levels below the outermost one and the column pass: every 4^lvl-th part of the buffer is its own transform
+template <typename T>
+static void czt_inner_fwd(const CztGeom& g, typename Prec<T>::T2* buf, int64_t rows, hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    const ChirpSeq none{0, 0, 1, 1.0};
+    for (int lvl = 1; lvl < g.levels; ++lvl) {
+        CztGeom gl = g;
+        gl.NFFT = g.NFFT >> (2 * lvl);
+        const dim3 grid((unsigned)(gl.NFFT / 4 / 256), (unsigned)(rows << (2 * lvl)));
+        hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 1>), grid, dim3(256), 0, st, (const float*)nullptr, (const T2*)nullptr, buf,
+                           gl, (int64_t)0, (int64_t)0, (int64_t)0, none);
+    }
+    launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+}
+
+template <typename T>
+static void czt_inner_inv(const CztGeom& g, typename Prec<T>::T2* buf, const typename Prec<T>::T2* cP,
+                          const typename Prec<T>::T2* cQ, int64_t rows, hipStream_t st) {
+    launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    for (int lvl = g.levels - 1; lvl >= 1; --lvl) {
+        CztGeom gl = g;
+        gl.NFFT = g.NFFT >> (2 * lvl);
+        const dim3 grid((unsigned)(gl.NFFT / 4 / 256), (unsigned)(rows << (2 * lvl)));
+        hipLaunchKernelGGL((czt_outer_inv_kernel<T, 3>), grid, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0,
+                           (int64_t)0, (int64_t)0, gl);
+    }
+}
+
 template <typename T>
 static int czt_plan(void* plan, int64_t P, void* ws, size_t ws_bytes, hipStream_t st) {
     using T2 = typename Prec<T>::T2;
@@ -479,11 +514,11 @@ static int czt_plan(void* plan, int64_t P, void* ws, size_t ws_bytes, hipStream_
     const ChirpSeq seqs[4] = {{g.P - 1, g.K - 1, g.P, 1.0}, {g.K - 1, g.Q - 1, g.Q, -1.0},
                               {g.Q - 1, g.K - 1, g.Q, -1.0}, {g.K - 1, g.P - 1, g.P, 1.0}};
     for (int i = 0; i < 4; ++i) {
-        if (g.S == 1) launch_cols_fwd<T, 2>(g, nullptr, nullptr, buf, 1, st, 0, 0, 0, seqs[i]);
+        if (g.levels == 0) launch_cols_fwd<T, 2>(g, nullptr, nullptr, buf, 1, st, 0, 0, 0, seqs[i]);
         else {
             hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 2>), og, dim3(256), 0, st, (const float*)nullptr, (const T2*)nullptr,
                                buf, g, (int64_t)0, (int64_t)0, (int64_t)0, seqs[i]);
-            launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, 1, st);
+            czt_inner_fwd<T>(g, buf, 1, st);
         }
         hipLaunchKernelGGL((czt_rows_kernel<T, true>), dim3((unsigned)ctot), dim3(TILE_T), Prec<T>::lds_bytes, st, buf,
                            (const T2*)nullptr, spec + (int64_t)i * g.NFFT, ctot, tw);
@@ -506,7 +541,7 @@ static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, 
     const int ctot = g.S * g.C;
     const unsigned tiles = (unsigned)(rows * ctot);
     const ChirpSeq none{0, 0, 1, 1.0};
-    if (g.S == 1) {
+    if (g.levels == 0) {
         launch_cols_fwd<T, 0>(g, in, tab1, buf, rows, st, ldi, ilo, ilen);
         hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec1, (T2*)nullptr, ctot, tw);
         launch_cols_inv<T, 3>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
@@ -514,17 +549,17 @@ static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, 
         launch_cols_inv<T, 1>(g, buf, cP, tab2, out, ldo, olo, olen, rows, st);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
-    // outer radix-4 level around four 2^18-point transforms per row
+    // outer radix-4 levels around 4^levels sub-transforms of C x 8192 points per row
     const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)rows);
     hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 0>), og, dim3(256), 0, st, in, tab1, buf, g, ldi, ilo, ilen, none);
-    launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+    czt_inner_fwd<T>(g, buf, rows, st);
     hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec1, (T2*)nullptr, ctot, tw);
-    launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    czt_inner_inv<T>(g, buf, cP, cQ, rows, st);
     hipLaunchKernelGGL((czt_outer_inv_kernel<T, 2>), og, dim3(256), 0, st, buf, cP, cQ, (float*)nullptr, (int64_t)0,
                        (int64_t)0, (int64_t)0, g);
-    launch_cols_fwd<T, 1>(g, nullptr, nullptr, buf, rows, st);
+    czt_inner_fwd<T>(g, buf, rows, st);
     hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec2, (T2*)nullptr, ctot, tw);
-    launch_cols_inv<T, 2>(g, buf, cP, cQ, nullptr, 0, 0, 0, rows, st);
+    czt_inner_inv<T>(g, buf, cP, cQ, rows, st);
     hipLaunchKernelGGL((czt_outer_inv_kernel<T, 1>), og, dim3(256), 0, st, buf, cP, tab2, out, ldo, olo, olen, g);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
@@ -540,12 +575,20 @@ static int czt_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t 
     const T2* cP = (const T2*)plan;
     const T2* cQ = cP + g.P;
     const T2* spec = cQ + g.Q;
-    if (!adjoint)   // z (rows x P) -> y[:, lo : lo + len]
-        return czt_run<T>(g, z, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, y, ldy, lo, len, rows, cP, cQ, (T2*)ws,
-                          (hipStream_t)stream);
-    // `z` is the gradient gy (row stride ldy) of y[:, lo : lo + len], `y` the gradient gz (rows x P)
-    return czt_run<T>(g, z, ldy, lo, len, cQ, spec + 2 * g.NFFT, spec + 3 * g.NFFT, cP, y, g.P, 0, g.P, rows, cP, cQ, (T2*)ws,
-                      (hipStream_t)stream);
+    const int64_t step = 65535 / g.S;        // rows * S sub-transforms ride on a grid dimension
+    for (int64_t r0 = 0; r0 < rows; r0 += step) {
+        const int64_t n = rows - r0 < step ? rows - r0 : step;
+        T2* buf = (T2*)ws + r0 * g.NFFT;
+        int rc;
+        if (!adjoint)   // z (rows x P) -> y[:, lo : lo + len]
+            rc = czt_run<T>(g, z + r0 * g.P, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, y + r0 * ldy, ldy, lo, len, n, cP, cQ, buf,
+                            (hipStream_t)stream);
+        else   // `z` is the gradient gy (row stride ldy) of y[:, lo : lo + len], `y` the gradient gz (rows x P)
+            rc = czt_run<T>(g, z + r0 * ldy, ldy, lo, len, cQ, spec + 2 * g.NFFT, spec + 3 * g.NFFT, cP, y + r0 * g.P, g.P, 0,
+                            g.P, n, cP, cQ, buf, (hipStream_t)stream);
+        if (rc != GFX_OK) return rc;
+    }
+    return GFX_OK;
 }
 
 }  // namespace gfx

@@ -288,7 +288,7 @@ _ALIAS_PLANS_MAX = 8
 
 
 def odd_alias_supported(P):
-    """Whether gfx_odd_alias_f32 handles a linear convolution of odd length P (3 <= P <= 699,051)."""
+    """Whether gfx_odd_alias_f32 handles a linear convolution of odd length P (3 <= P <= 11,184,811)."""
     return lib().gfx_odd_alias_plan_bytes(P) > 0
 
 

@@ -11,8 +11,8 @@ for odd P it inverts a P-point spectrum on a (P-1)-point grid
 * odd P   -> the HIP kernels produce the full linear convolution z (length P) and
   the reference's aliasing ``irfft_{P-1}(rfft_P(z))`` is applied on top, natively as two
   chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, its transpose for the gradient,
-  double-precision transforms for the dynamics envelope; the float64 FFT-library route
-  remains only for P > 699,051 -- DESIGN.md §2).
+  double-precision transforms for the dynamics envelope; no FFT library; P <= 11,184,811,
+  longer signals raise -- DESIGN.md §2).
 
 ``set_exact_convolution(True)`` opts out of the quirk (true linear convolution
 for every length; deviates from the reference when P is odd).
@@ -66,7 +66,7 @@ def reference_aliases(lx, lh, exact=False):
     return (lx + lh - 1) % 2 == 1 and not (_EXACT.get() or exact)
 
 
-def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
+def odd_length_alias(z, lo=0, length=None, precise=False):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for a full linear convolution z of odd length P
     (convolution.py:123-126): two chirp-z transforms on the LDS FFT tile (gfx_odd_alias_f32, no FFT library).
 
@@ -74,22 +74,19 @@ def odd_length_alias(z, lo=0, length=None, rows_per_chunk=2048, precise=False):
     in double precision (gfx_odd_alias_precise_f32) -- for the energy-envelope smoother of the dynamics processors,
     whose output feeds log() and a gain curve: there the fp32 chirp-z noise (~1e-6 of the peak, about twice what the
     reference's own mixed-radix fp32 FFT leaves) is amplified on quiet passages beyond the parity bound
-    (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths).  Only P > 699,051 (a 2^20-point transform no
-    longer covers 1.5 P) still goes through the device FFT library, in float64."""
-    Q = z.shape[-1] - 1
-    length = Q - lo if length is None else length
+    (tests/test_gpu_edge_cases.py::test_compressor_ragged_lengths).  P <= 11,184,811 (a 2^24-point transform must cover
+    1.5 P: 233 s of audio at 48 kHz); longer signals raise."""
+    P = z.shape[-1]
+    length = P - 1 - lo if length is None else length
+    if not ops.odd_alias_supported(P):
+        raise NotImplementedError(f"convolve: the reference's odd-length aliasing (P = Lx + Lh - 1 = {P}) is implemented for "
+                                  "P <= 11,184,811; use a filter length that makes P even, or flashfftconv=True / "
+                                  "set_exact_convolution(True) for the plain linear convolution")
     if torch.is_grad_enabled() and z.requires_grad:
         from ... import autograd as diff
 
         return diff.odd_alias(z, lo, length, precise)
-    if ops.odd_alias_supported(z.shape[-1]):
-        return ops.odd_alias(z, lo, length, precise=precise)
-    flat = z.reshape(-1, z.shape[-1])
-    out = torch.empty((flat.shape[0], length), dtype=z.dtype, device=z.device)
-    for i in range(0, flat.shape[0], rows_per_chunk):
-        out[i : i + rows_per_chunk] = torch.fft.irfft(torch.fft.rfft(flat[i : i + rows_per_chunk].double())).to(z.dtype)[
-            :, lo : lo + length]
-    return out.view(*z.shape[:-1], length)
+    return ops.odd_alias(z, lo, length, precise=precise)
 
 
 def compute_pad_len(x, y, pad_mode="min"):

@@ -151,7 +151,7 @@ int gfx_fir_direct_f32(const float* x, gfx_rowmap_t xmap, const float* h, int64_
  * convolve() (core/convolution.py:119-134) inverts a P-point spectrum (P = Lx + Lh - 1) with irfft's default length
  * 2 (P // 2): for odd P the result is  y = irfft_{P-1}(rfft_P(z))  of the linear convolution z -- what every reference
  * default length produces.  gfx_odd_alias_f32 computes y[:, lo : lo + len] from z (rows x P, contiguous) with two
- * chirp-z transforms on the LDS FFT tile (no FFT library, fp32); 3 <= P <= 699,051 odd (NFFT up to 4 x 32 x 8192), rows
+ * chirp-z transforms on the LDS FFT tile (no FFT library, fp32); 3 <= P <= 11,184,811 odd (NFFT up to 64 x 32 x 8192), rows
  * <= 16383 per call, else the size queries return 0.  `plan` (per P: chirps and their spectra) comes from gfx_odd_alias_plan_f32, which needs a
  * workspace of gfx_odd_alias_workspace_bytes(1, P); the transform needs gfx_odd_alias_workspace_bytes(rows, P).
  * gfx_odd_alias_adjoint_f32 is the transposed map (the gradient the reference gets from differentiating its

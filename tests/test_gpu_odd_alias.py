@@ -1,6 +1,7 @@
 """The reference's odd-length aliasing y = irfft_{P-1}(rfft_P(z)) (core/convolution.py:123-126) on the native chirp-z
 kernels (gfx_odd_alias_f32) against torch.fft in float64, for lengths around every transform-size boundary
-(NFFT = C x 8192 >= (3P - 1) / 2 for C = 1 .. 32, then 4 x 32 with an outer radix-4 level), primes, and the headline length 131072 + 4000 - 1."""
+(NFFT = C x 8192 >= (3P - 1) / 2 for C = 1 .. 32, then one, two and three outer radix-4 levels up to 2^24 points), primes, and
+the headline length 131072 + 4000 - 1."""
 import pytest
 import torch
 
@@ -8,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("P", [3, 5, 101, 4001, 5461, 5463, 10921, 10923, 21845, 21847, 43691, 87381, 87383, 135071,
-                               147455, 174761, 174763, 174765, 300001, 483999, 699051])
+                               147455, 174761, 174763, 174765, 300001, 349525, 349527, 483999, 699051, 699053, 1000001,
+                               2796201, 2796203])
 def test_odd_alias_matches_float64_fft(P):
     from grafx_amd import ops
 
@@ -19,7 +21,7 @@ def test_odd_alias_matches_float64_fft(P):
     got = ops.odd_alias(z)
     assert got.shape == want.shape
     err = (got.double() - want).abs().max() / want.abs().max()
-    assert err <= 3e-6, f"P={P}: {err:.2e}"
+    assert err <= (3e-6 if P < 700000 else 5e-6), f"P={P}: {err:.2e}"
     lo, n = P // 3, max(1, P // 5)
     part = ops.odd_alias(z, lo, n)
     assert torch.equal(part, got[..., lo : lo + n])
@@ -28,7 +30,8 @@ def test_odd_alias_matches_float64_fft(P):
 def test_odd_alias_limits():
     from grafx_amd import ops
 
-    assert not ops.odd_alias_supported(699053) and not ops.odd_alias_supported(1) and not ops.odd_alias_supported(4000)
+    assert ops.odd_alias_supported(11184811) and not ops.odd_alias_supported(11184813)
+    assert not ops.odd_alias_supported(1) and not ops.odd_alias_supported(4000)
     # structured input: a unit impulse at m0 aliases to the Dirichlet-kernel row of the resampling matrix; rows sum to 1
     P = 1001
     z = torch.zeros(1, P, device="cuda")
@@ -40,7 +43,7 @@ def test_odd_alias_limits():
     assert (ones - P / (P - 1)).abs().max() <= 1e-5   # DC gain of irfft_{P-1} o rfft_P
 
 
-@pytest.mark.parametrize("P", [3, 5, 101, 4001, 10923, 43691, 135071, 147455, 174765, 300001, 699051])
+@pytest.mark.parametrize("P", [3, 5, 101, 4001, 10923, 43691, 135071, 147455, 174765, 300001, 699051, 1000001, 2796203])
 def test_odd_alias_adjoint_matches_float64_autograd(P):
     """gfx_odd_alias_adjoint_f32 against torch autograd of the float64 rfft / irfft pair (what the reference's backward
     computes, core/convolution.py:123-126), whole grid and a slice; and <A z, g> = <z, A^T g> on the native pair."""
@@ -57,7 +60,7 @@ def test_odd_alias_adjoint_matches_float64_autograd(P):
         got = ops.odd_alias_adjoint(g, P, lo)
         assert got.shape == z.shape
         err = (got.double() - zd.grad).abs().max() / zd.grad.abs().max()
-        assert err <= 3e-6, f"P={P} lo={lo}: {err:.2e}"
+        assert err <= (3e-6 if P < 700000 else 5e-6), f"P={P} lo={lo}: {err:.2e}"
         lhs = (ops.odd_alias(z, lo, n).double() * g.double()).sum()
         rhs = (z.double() * got.double()).sum()
         assert abs(lhs - rhs) <= 1e-5 * (z.double().norm() * g.double().norm()), f"P={P}: {lhs} vs {rhs}"
@@ -87,7 +90,7 @@ def test_convolve_gradient_with_aliasing_is_native():
             assert (a.double() - b).abs().max() <= 2e-5 * b.abs().max()
 
 
-@pytest.mark.parametrize("P", [3, 101, 4001, 10923, 87383, 147455, 174765, 300001])
+@pytest.mark.parametrize("P", [3, 101, 4001, 10923, 87383, 147455, 174765, 300001, 1000001, 2796203])
 def test_precise_odd_alias_is_float64_accurate(P):
     """gfx_odd_alias_precise_f32 (double-precision transforms, fp32 in / out): the result is the float64 FFT's rounded to
     fp32 -- also where the signal is 1e-6 of its peak, which is what the energy envelope needs -- and so is the adjoint."""
@@ -113,3 +116,29 @@ def test_precise_odd_alias_is_float64_accurate(P):
     torch.fft.irfft(torch.fft.rfft(zd))[..., lo : lo + n].backward(g.double())
     adj = ops.odd_alias_adjoint(g, P, lo, precise=True)
     assert (adj.double() - zd.grad).abs().max() <= 2e-7 * zd.grad.abs().max()
+
+
+def test_longer_than_the_kernels_reach_fails_loudly():
+    from grafx_amd.processors.core.convolution import odd_length_alias
+
+    with pytest.raises(NotImplementedError):
+        odd_length_alias(torch.zeros(1, 11184813, device="cuda"))
+
+
+def test_three_outer_levels():
+    """P = 3,000,001: a 2^24-point transform (64 sub-transforms of 32 x 8192 under three radix-4 levels), one row."""
+    from grafx_amd import ops
+
+    P = 3000001
+    torch.manual_seed(P)
+    z = torch.randn(1, P, device="cuda")
+    want = torch.fft.irfft(torch.fft.rfft(z.double()))
+    got = ops.odd_alias(z)
+    err = (got.double() - want).abs().max() / want.abs().max()
+    assert err <= 6e-6, f"{err:.2e}"
+    g = torch.randn(1, 1000, device="cuda")
+    zd = z.double().requires_grad_(True)
+    torch.fft.irfft(torch.fft.rfft(zd))[..., 5000:6000].backward(g.double())
+    adj = ops.odd_alias_adjoint(g, P, 5000)
+    assert (adj.double() - zd.grad).abs().max() <= 6e-6 * zd.grad.abs().max()
+    ops._ALIAS_PLANS.clear()   # half a gigabyte of plan
