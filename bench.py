@@ -464,15 +464,18 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     if args.dry:
         out["dry"] = "CPU plumbing check with pass-through processors: launch/sharding/JSON only, the numbers mean nothing"
     # whole-graph view of the same roofline: 285 row transfers per graph (every node reads its inputs and
-    # writes its output once).  32 of them -- the mix stage's read of the channel strips -- are no longer moved: the
-    # compressor stage's kernel sums the buses while it writes the strips (gfx_dynamics_fused_mix_f32), so the rate that
-    # can be held against the HBM peak is the one over the bytes that still cross the bus.
+    # writes its output once).  Not all of them cross HBM any more, and the rate held against the HBM peak is the one over
+    # those that do: the `in` stage's 32 reads are the first eq stage's own (it writes the sources through), and of the
+    # mix stage's 64 reads of the channel strips (each strip feeds its bus and the send) the fan-out kernel makes 32,
+    # the compressor stage's kernel none (gfx_dynamics_fused_mix_f32 sums the buses while it writes the strips).
     graph_bytes = 285 * B * 2 * L * 4
     from grafx_amd import ops as _ops
-    elided = 0 if (args.dry or not _ops.MIX_FUSION or args.reference_default_lengths) else 32 * B * 2 * L * 4
-    moved = graph_bytes - elided
+    fused_mix = _ops.MIX_FUSION and not args.reference_default_lengths
+    elided_rows = 0 if args.dry else 32 + (64 if fused_mix else 32)
+    moved = graph_bytes - elided_rows * B * 2 * L * 4
     out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,
-                             "elided_bytes_per_step": elided,
+                             "row_transfers": 285, "row_transfers_elided": elided_rows,
+                             "moved_bytes_per_step": moved,
                              "achieved_GBps": moved / (ms_per_step * 1e-3) / 1e9,
                              "frac_of_hbm_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_equivalent_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9}
