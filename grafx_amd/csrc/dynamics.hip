@@ -116,6 +116,9 @@ __device__ __forceinline__ void scan_tile(const OnePole& p, const float (&e)[DE]
 // ---- gain computer -----------------------------------------------------------------------------
 struct Knee {
     float T, R, invR, W, k, er;  // threshold (already -6), ratio, 1/ratio, half knee width, exp knee, exp(log_ratio)
+    float inv4W, invk;           // 1 / (4 W), 1 / k: the per-sample divisions of the gain curves are multiplications by
+                                 // these per-row reciprocals (an IEEE division is ~11 instructions, and the one-shot
+                                 // tiles are bound by their instruction count, not by memory: 2.1 M wave-steps of ~1100)
     int kind;                    // 0 hard, 1 quadratic, 2 exponential
     int gate;                    // 0 compressor, 1 noise gate
 };
@@ -128,31 +131,35 @@ __device__ __forceinline__ void knee_setup(Knee& q, float log_threshold, float l
     q.invR = 1.0f / q.R;
     q.k = expf(log_knee);
     q.W = q.k / 2.0f;
+    q.inv4W = 1.0f / (4.0f * q.W);
+    q.invk = 1.0f / q.k;
     q.kind = kind;
     q.gate = gate;
 }
 
-// log-gain g(G) for log-energy G
+// log-gain g(G) for log-energy G.  (The nested conditionals compile to an exec-masked region per sample; selects between
+// values computed for every sample were measured and are slower, 3.49 vs 3.32 ms for 8192 rows: a wave whose samples all
+// sit outside the knee skips the quadratic arm.)
 __device__ __forceinline__ float log_gain(const Knee& q, float G) {
     const float d = G - q.T;
     if (!q.gate) {
-        if (q.kind == 0) return fminf(G, q.T + d / q.R) - G;                                   // dynamics.py:444-453
+        if (q.kind == 0) return fminf(G, q.T + d * q.invR) - G;                                // dynamics.py:444-453
         if (q.kind == 1) {                                                                     // 456-475
             const bool below = G < (q.T - q.W), above = G > (q.T + q.W);
-            const float mid = G + (q.invR - 1.0f) * ((d + q.W) * (d + q.W)) / (4.0f * q.W);
-            const float out = below ? G : (above ? (q.T + d / q.R) : mid);
+            const float mid = G + (q.invR - 1.0f) * ((d + q.W) * (d + q.W)) * q.inv4W;
+            const float out = below ? G : (above ? (q.T + d * q.invR) : mid);
             return out - G;
         }
-        return (q.invR - 1.0f) * softplusf(q.k * d) / q.k;                                     // 478-489
+        return (q.invR - 1.0f) * softplusf(q.k * d) * q.invk;                                  // 478-489
     }
     if (q.kind == 0) return fminf(G, q.R * d + q.T) - G;                                       // 676-686
     if (q.kind == 1) {                                                                         // 688-707
         const bool below = G < (q.T - q.W), above = G > (q.T + q.W);
-        const float mid = G + (1.0f - q.R) * ((d - q.W) * (d - q.W)) / (4.0f * q.W);
+        const float mid = G + (1.0f - q.R) * ((d - q.W) * (d - q.W)) * q.inv4W;
         const float out = below ? (q.R * d + q.T) : (above ? G : mid);
         return out - G;
     }
-    return -q.er * softplusf(q.k * (-d)) / q.k;                                                // 709-721
+    return -q.er * softplusf(q.k * (-d)) * q.invk;                                             // 709-721
 }
 
 // Hardware log2 / exp2 forms (v_log_f32, v_exp_f32) for the forward kernels: the one-shot tiles run at copy speed once the
@@ -174,8 +181,8 @@ template <typename M>
 __device__ __forceinline__ float log_gain_m(const Knee& q, float G) {
     if (q.kind != 2) return log_gain(q, G);       // hard / quadratic knees: no transcendental
     const float d = G - q.T;
-    if (!q.gate) return (q.invR - 1.0f) * M::softplus(q.k * d) / q.k;      // dynamics.py:478-489
-    return -q.er * M::softplus(q.k * (-d)) / q.k;                            // 709-721
+    if (!q.gate) return (q.invR - 1.0f) * M::softplus(q.k * d) * q.invk;   // dynamics.py:478-489
+    return -q.er * M::softplus(q.k * (-d)) * q.invk;                         // 709-721
 }
 
 // ---- loads / stores of 4 consecutive samples with bounds -----------------------------------------
