@@ -254,6 +254,11 @@ class PipeGen(TileGen):
         out-of-range offset and read as zero.  `carried`: rows below a_lo come from the previous window's registers
         (`carry_overlap`), only the rows from a_lo on are loaded."""
         out = []
+        if carried and "wideload" in self.ablate:     # timing experiment (wrong results): the carried form as 16-byte loads
+            for p in range(self.a_lo // 2, 16):
+                out.append([Inst("s_mov_b32", S_OFF, (Lit(4096 * p),)),
+                            Inst("buffer_load_dwordx4", R("v", bank[2 * p].idx, 4), (V_OFF16, NX_X, S_OFF), {})])
+            return out
         if carried:
             for a in range(self.a_lo, 32):
                 out.append([Inst("s_mov_b32", S_OFF, (Lit(2048 * a),)),
@@ -280,7 +285,7 @@ class PipeGen(TileGen):
     def g_stores(self, regs_of_row, desc):
         """stores of the rows a >= a_lo (the tile's valid part): row a <- regs_of_row(a)"""
         out = []
-        if "widemem" in self.ablate:
+        if "widemem" in self.ablate or ("wideload" in self.ablate and desc is NX_T):
             for p in range(self.a_lo // 2, 16):
                 q = R("v", (BANK_A if regs_of_row(31).idx < BANK_B.land[0].idx else BANK_B).land[2 * p].idx, 4)
                 out.append([Inst("s_mov_b32", S_OFF, (Lit(4096 * p),)),
