@@ -606,6 +606,11 @@ struct MixArgs {
     float* out;                           // mix destinations: out + g * sb + j * sv + c * sc
     int64_t sb, sv, sc;
     int inner;
+    // sources of the routing sum that are NOT rows of this stage (finished rows of the same buffer, e.g. the reverb return
+    // next to the bus compressors in a master sum): pairs (row offset from the first destination row, code as in sched),
+    // n_pre of them added before the stage's rows and n_post after -- the sum stays in increasing row order
+    const int64_t* extras;
+    int n_pre, n_post;
 };
 
 #ifndef GFX_MIX_WGS
@@ -652,6 +657,49 @@ __global__ __launch_bounds__(DT, NA <= 2 ? GFX_MIX_WGS : 2) void dyn_oneshot_mix
     OsIn ring[NR];                                // registers with static names (a rotating copy would wait for the loads)
 #pragma unroll
     for (int d = 0; d < PF; ++d) fetch(d, ring[d]);
+    // add one row's tile to the accumulators `code` names, then store and clear the destinations it completes
+    auto settle = [&](uint64_t code, const float (&ga)[OS_SUB][DE], const float (&gb)[OS_SUB][DE]) {
+        const unsigned add = (unsigned)code & 15u;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            if ((add >> c) & 1u) {                // uniform
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k)
+#pragma unroll
+                    for (int i = 0; i < DE; ++i) {
+                        acc0[c][k][i] += ga[k][i];
+                        if (STEREO) acc1[c][k][i] += gb[k][i];
+                    }
+            }
+            const unsigned fl = (unsigned)(code >> (8 + 8 * c)) & 255u;
+            if (fl != 0u) {                       // uniform: this destination is complete
+                float* o0 = obase + (int64_t)(fl - 1u) * m.sv;
+                float* o1 = o0 + m.sc;
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k) {
+                    st4<true>(o0, n0 + 256 * k, a.L, true, acc0[c][k]);
+                    if (STEREO) st4<true>(o1, n0 + 256 * k, a.L, true, acc1[c][k]);
+#pragma unroll
+                    for (int i = 0; i < DE; ++i) {
+                        acc0[c][k][i] = 0.0f;
+                        if (STEREO) acc1[c][k][i] = 0.0f;
+                    }
+                }
+            }
+        }
+    };
+    auto extra = [&](int e) {                     // a finished row of the buffer that joins the sum
+        const float* p0 = obase + m.extras[2 * e] * m.sv;
+        const float* p1 = p0 + m.sc;
+        float ga[OS_SUB][DE], gb[OS_SUB][DE];
+#pragma unroll
+        for (int k = 0; k < OS_SUB; ++k) {
+            ld4<true>(p0, n0 + 256 * k, a.L, true, ga[k]);
+            if (STEREO) ld4<true>(p1, n0 + 256 * k, a.L, true, gb[k]);
+        }
+        settle((uint64_t)m.extras[2 * e + 1], ga, gb);
+    };
+    for (int e = 0; e < m.n_pre; ++e) extra(e);
     for (int j0 = 0; j0 < m.inner; j0 += NR) {
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
@@ -677,35 +725,10 @@ __global__ __launch_bounds__(DT, NA <= 2 ? GFX_MIX_WGS : 2) void dyn_oneshot_mix
                     if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, gb[k]);
                 }
             }
-#pragma unroll
-            for (int c = 0; c < NA; ++c) {
-                if ((add >> c) & 1u) {            // uniform
-#pragma unroll
-                    for (int k = 0; k < OS_SUB; ++k)
-#pragma unroll
-                        for (int i = 0; i < DE; ++i) {
-                            acc0[c][k][i] += ga[k][i];
-                            if (STEREO) acc1[c][k][i] += gb[k][i];
-                        }
-                }
-                const unsigned fl = (unsigned)(code >> (8 + 8 * c)) & 255u;
-                if (fl != 0u) {                   // uniform: this destination is complete
-                    float* o0 = obase + (int64_t)(fl - 1u) * m.sv;
-                    float* o1 = o0 + m.sc;
-#pragma unroll
-                    for (int k = 0; k < OS_SUB; ++k) {
-                        st4<true>(o0, n0 + 256 * k, a.L, true, acc0[c][k]);
-                        if (STEREO) st4<true>(o1, n0 + 256 * k, a.L, true, acc1[c][k]);
-#pragma unroll
-                        for (int i = 0; i < DE; ++i) {
-                            acc0[c][k][i] = 0.0f;
-                            if (STEREO) acc1[c][k][i] = 0.0f;
-                        }
-                    }
-                }
-            }
+            settle(code, ga, gb);
         }
     }
+    for (int e = m.n_pre; e < m.n_pre + m.n_post; ++e) extra(e);
 }
 
 // ---- standalone pieces (used when a configuration cannot take the fused kernel) --------------------
@@ -1856,9 +1879,11 @@ int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_
                                const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
                                int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
                                float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
-                               float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, void* stream) {
+                               float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
+                               int64_t n_pre, int64_t n_post, void* stream) {
     if (!sched || !mix || inner < 1 || inner > 65535 || n_acc < 1 || n_acc > 4 || R % inner != 0 || !ws || smoother != 1)
         return GFX_EINVAL;
+    if (n_pre < 0 || n_post < 0 || n_pre + n_post > 65535 || (n_pre + n_post > 0 && !extras)) return GFX_EINVAL;
     // every access of the fused kernel is a whole aligned float4 (the element-wise paths would triple its code size)
     const int64_t strides = xmap.stride_outer | xmap.stride_inner | xmap.stride_ch | ymap.stride_outer | ymap.stride_inner |
                             ymap.stride_ch | mix_sb | mix_sv | mix_sc;
@@ -1866,6 +1891,7 @@ int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_
         return GFX_EINVAL;
     MixArgs m;
     m.sched = sched; m.out = mix; m.sb = mix_sb; m.sv = mix_sv; m.sc = mix_sc; m.inner = (int)inner;
+    m.extras = extras; m.n_pre = (int)n_pre; m.n_post = (int)n_post;
     return dynamics_fused_launch(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L, smoother,
                                  iir_len, knee, gate, u1, ws, ws_bytes, stream, &m, (int)n_acc);
 }

@@ -465,26 +465,37 @@ DYN_SCHEDULE = "oneshot"
 
 
 def mix_schedule(dest_sources, n):
-    """The per-row schedule of gfx_dynamics_fused_mix_f32 for a routing sum over the n rows of a graph: ``dest_sources[d]``
-    = the rows (0 .. n-1, strictly increasing) added into destination d.  A destination occupies an accumulator from its
-    first to its last source; live ranges are coloured greedily.  -> (codes (list of n ints), accumulators used), or None
-    when a destination has no source, its rows are not increasing, or more than four destinations are live at once."""
+    """The schedule of gfx_dynamics_fused_mix_f32 for a routing sum over the n rows of a graph: ``dest_sources[d]`` = the
+    rows (strictly increasing) added into destination d, counted from the stage's first row -- 0 .. n-1 are the stage's
+    own rows, negative numbers and numbers >= n are finished rows of the buffer before / behind them ("extras").  A
+    destination occupies an accumulator from its first to its last source; live ranges are coloured greedily.
+    -> (codes (list of n ints), accumulators used, pre, post) with pre / post = [(row, code), ...] for the extras in
+    front of / behind the stage's rows; or None when a destination has no source, its rows are not increasing, no
+    destination takes any of the stage's rows, or more than four destinations are live at once."""
     if not dest_sources or len(dest_sources) > 254:
         return None
     for rows in dest_sources:
-        if not rows or any(b <= a for a, b in zip(rows, rows[1:])) or rows[0] < 0 or rows[-1] >= n:
+        if not rows or any(b <= a for a, b in zip(rows, rows[1:])):
             return None
-    codes, free_at, slot = [0] * n, [0] * 4, {}
-    for d in sorted(range(len(dest_sources)), key=lambda d: dest_sources[d][0]):
-        first, last = dest_sources[d][0], dest_sources[d][-1]
+    if not any(0 <= r < n for rows in dest_sources for r in rows):
+        return None
+    pre = sorted({r for rows in dest_sources for r in rows if r < 0})
+    post = sorted({r for rows in dest_sources for r in rows if r >= n})
+    pos = {r: k for k, r in enumerate(pre)}
+    pos.update({j: len(pre) + j for j in range(n)})
+    pos.update({r: len(pre) + n + k for k, r in enumerate(post)})
+    codes, free_at, slot = [0] * (len(pre) + n + len(post)), [0] * 4, {}
+    for d in sorted(range(len(dest_sources)), key=lambda d: pos[dest_sources[d][0]]):
+        first, last = pos[dest_sources[d][0]], pos[dest_sources[d][-1]]
         a = next((k for k in range(4) if free_at[k] <= first), None)
         if a is None:
             return None
         free_at[a], slot[d] = last + 1, a
-        for j in dest_sources[d]:
-            codes[j] |= 1 << a
+        for r in dest_sources[d]:
+            codes[pos[r]] |= 1 << a
         codes[last] |= (d + 1) << (8 + 8 * a)
-    return codes, max(slot.values()) + 1
+    return (codes[len(pre) : len(pre) + n], max(slot.values()) + 1, list(zip(pre, codes[: len(pre)])),
+            list(zip(post, codes[len(pre) + n :])))
 
 
 @_on_device
@@ -494,8 +505,9 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
     ``schedule``: "oneshot" (default) or "rows", see above.
     ``u1_out``: optional (R, L) tensor that receives the smoother's un-truncated scan for :func:`dynamics_bwd` (the
     training forward; smoother = 1 only).
-    ``mix``: a dict {"sched": int64 device tensor (n,), "n_acc": int, "out": (B, J, C, L) view} for a strided (B, n, C, L)
-    input (see :func:`mix_schedule`) -- the routing sum that follows is computed by the same kernel
+    ``mix``: a dict {"sched": int64 device tensor (n,), "n_acc": int, "out": (B, J, C, L) view, optionally "extras": int64
+    device tensor (n_pre + n_post, 2) of (row offset from ``out``'s first row, code) and "n_pre"} for a strided
+    (B, n, C, L) input (see :func:`mix_schedule`) -- the routing sum that follows is computed by the same kernel
     (gfx_dynamics_fused_mix_f32) and ``mix["done"]`` is set; when the configuration cannot take it, nothing is summed and
     ``mix["done"]`` stays unset (the caller runs the gather-sum stage)."""
     schedule = DYN_SCHEDULE if schedule is None else schedule
@@ -525,8 +537,12 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
         if (mo.shape == (x.shape[0], J, C, L) and mo.stride(-1) == 1 and sched.numel() == n and xmap.inner == n
                 and ymap.inner == n):
             with _timed("dyn_fused_kernel", 8 * R * C * L + 4 * mo.numel() + (4 * R * L if u1_out is not None else 0)):
+                ex = mix.get("extras")
+                n_ex = 0 if ex is None else ex.shape[0]
+                n_pre = mix.get("n_pre", 0)
                 rc = lib().gfx_dynamics_fused_mix_f32(*args[:-1], _ptr(sched), n, mix["n_acc"], _ptr(mo), mo.stride(0),
-                                                      mo.stride(1), mo.stride(2) if C == 2 else 0, _stream())
+                                                      mo.stride(1), mo.stride(2) if C == 2 else 0, _ptr(ex), n_pre,
+                                                      n_ex - n_pre, _stream())
             if rc == 0:
                 mix["done"] = True
                 return out

@@ -111,24 +111,37 @@ def _transposed_plan(step, plan, device):
 
 
 def _mix_schedule(step, nxt, device):
-    """When `nxt` is a routing-sum stage fed by `step`'s rows alone: (schedule tensor, accumulators) with which a
-    processor that ``accepts_mix`` computes the sums itself (ops.mix_schedule: every destination adds its rows in
-    increasing order, as the gather-sum kernels do); else None."""
+    """When `nxt` is a routing-sum stage that adds up rows of `step` (and possibly finished rows of other stages):
+    {"sched", "n_acc", "extras", "n_pre"} with which a processor that ``accepts_mix`` computes the sums itself
+    (ops.mix_schedule: every destination adds its rows in increasing order, as the gather-sum kernels do); else None."""
     from .. import ops
 
     cache = step.__dict__.setdefault("_mix_sched", {})
-    key = (device.type, device.index)
+    key = (device.type, device.index, id(nxt))
     if key not in cache:
         cache[key] = None
         plan = _gather_plan(nxt, device)
         d0, d1 = step.dest_write.idx
+        e0 = nxt.dest_write.idx[0]
         if plan:
             src, seg = plan[0].tolist(), plan[1].tolist()
-            if all(d0 <= v < d1 for v in src):
-                sched = ops.mix_schedule([[v - d0 for v in src[seg[j]:seg[j + 1]]] for j in range(plan[2])], d1 - d0)
-                if sched is not None:
-                    cache[key] = (torch.tensor(sched[0], dtype=torch.long, device=device), sched[1])
+            sched = ops.mix_schedule([[v - d0 for v in src[seg[j]:seg[j + 1]]] for j in range(plan[2])], d1 - d0)
+            if sched is not None:
+                codes, n_acc, pre, post = sched
+                extras = [(d0 + r - e0, c) for r, c in pre + post]
+                cache[key] = {"sched": torch.tensor(codes, dtype=torch.long, device=device), "n_acc": n_acc,
+                              "extras": torch.tensor(extras, dtype=torch.long, device=device) if extras else None,
+                              "n_pre": len(pre), "extra_rows": [d0 + r for r, _ in pre + post]}
     return cache[key]
+
+
+def _reads_rows(step, a, b):
+    """Does the stage read a buffer row in [a, b)?"""
+    read = step.source_reads[0]
+    if read.method == "slice":
+        return read.idx[0] < b and a < read.idx[1]
+    rows = read.idx.tolist() if isinstance(read.idx, torch.Tensor) else list(read.idx)
+    return any(a <= r < b for r in rows)
 
 
 def _plan_max_row(step, plan):
@@ -324,14 +337,14 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         return ready
 
     prepared = None
-    mixed = -1  # order of a routing-sum stage the stage before it has already produced
-    for i in range(1, render_data.max_order + 1):
+    done = set()  # stages already produced out of schedule order (see below)
+
+    def run_stage(i, mix_with=None):
+        """Stage i; `mix_with`: the routing-sum stage the processor is offered to produce too -> did it?"""
+        nonlocal copied, prepared
         step = render_data.iter_list[i]
         d0, d1 = step.dest_write.idx
-        if i == mixed:
-            out_view = buf.narrow(1, d0, d1 - d0)
-            continue
-        out_view = buf.narrow(1, d0, d1 - d0)
+        out_v = buf.narrow(1, d0, d1 - d0)
         plan = _gather_plan(step, x.device)
         node_type = step.node_type
         src_read = step.source_reads[0]
@@ -342,10 +355,10 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         if node_type not in processors:  # in / out / mix: the (summed) input is the output
             if plan is None:
                 a, b = step.source_reads[0].idx
-                out_view.copy_((x if from_inputs else buf).narrow(1, a, b - a))
+                out_v.copy_((x if from_inputs else buf).narrow(1, a, b - a))
             else:
-                _gather(ops, buf, plan, out_view)
-            continue
+                _gather(ops, buf, plan, out_v)
+            return False
         if plan is None:
             a, b = step.source_reads[0].idx
             x_view = (x if from_inputs else buf).narrow(1, a, b - a)
@@ -366,18 +379,62 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             # input is a temporary: the backward re-gathers it, same values
             extra["_aux"] = (aux, i)
         mix = None
-        if (i < render_data.max_order and getattr(proc, "accepts_mix", False) and type(proc) in _tape_safe_types()
-                and render_data.iter_list[i + 1].node_type not in processors):
-            nxt = render_data.iter_list[i + 1]
+        if mix_with is not None:
+            nxt = render_data.iter_list[mix_with]
             sched = _mix_schedule(step, nxt, x.device)
-            if sched is not None:
-                e0, e1 = nxt.dest_write.idx
-                mix = extra["_mix"] = {"sched": sched[0], "n_acc": sched[1], "out": buf.narrow(1, e0, e1 - e0)}
-        proc.render_into(x_view, out_view, **extra, **params, **common_i)
-        if mix is not None and mix.get("done"):
-            mixed = i + 1
+            e0, e1 = nxt.dest_write.idx
+            mix = extra["_mix"] = {"sched": sched["sched"], "n_acc": sched["n_acc"], "extras": sched["extras"],
+                                   "n_pre": sched["n_pre"], "out": buf.narrow(1, e0, e1 - e0)}
+        proc.render_into(x_view, out_v, **extra, **params, **common_i)
         if prepared is None:  # the first processor stage is on its way: now design the later ones underneath it
             prepared = prepare_later_stages(i)
+        return mix is not None and bool(mix.get("done"))
+
+    def mix_candidate(i):
+        """The routing-sum stage that stage i may produce itself, and the stages to run before stage i for that:
+        the stage right behind it -- or the one behind ONE processor stage that does not read stage i's rows (the
+        console: the bus compressors, then the reverb, then the master sum of both), which then runs first."""
+        step = render_data.iter_list[i]
+        proc = processors[step.node_type]
+        if not (getattr(proc, "accepts_mix", False) and type(proc) in _tape_safe_types()):
+            return None, []
+        first = []
+        j = i + 1
+        if j <= render_data.max_order and render_data.iter_list[j].node_type in processors and j not in done:
+            if _reads_rows(render_data.iter_list[j], *step.dest_write.idx):
+                return None, []
+            first, j = [j], j + 1
+        if j > render_data.max_order or render_data.iter_list[j].node_type in processors:
+            return None, []
+        sched = _mix_schedule(step, render_data.iter_list[j], x.device)
+        if sched is None:
+            return None, []
+        if first:
+            f0, f1 = render_data.iter_list[first[0]].dest_write.idx
+            if not any(f0 <= r < f1 for r in sched["extra_rows"]):
+                return None, []      # the sum does not need the stage in between: keep the schedule's order
+        rows_ready = lambda r: r < step.dest_write.idx[0] or any(  # noqa: E731
+            render_data.iter_list[f].dest_write.idx[0] <= r < render_data.iter_list[f].dest_write.idx[1] for f in first)
+        if not all(rows_ready(r) for r in sched["extra_rows"]):
+            return None, []
+        return j, first
+
+    for i in range(1, render_data.max_order + 1):
+        step = render_data.iter_list[i]
+        d0, d1 = step.dest_write.idx
+        out_view = buf.narrow(1, d0, d1 - d0)
+        if i in done:
+            continue
+        j, first = mix_candidate(i) if step.node_type in processors else (None, [])
+        if j is not None and first and not (ops.MIX_FUSION and L % 4 == 0):
+            j, first = None, []      # (the fused kernel would decline: do not reorder for nothing)
+        for f in first:
+            run_stage(f)
+            done.add(f)
+        if run_stage(i, mix_with=j):
+            done.add(j)
+        elif first:
+            pass                     # the stage in between ran early, the sum runs at its own place: still a valid order
     if side is not None and not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:

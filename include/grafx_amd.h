@@ -256,20 +256,23 @@ int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
                               int smoother, int64_t iir_len, int knee, int gate, float* u1,
                               void* ws, size_t ws_bytes, void* stream);
-/* The same with the routing sum that follows fused in (render/core.py:36-112, a "mix" stage whose sources are exactly
- * this call's rows): rows come in graphs of `inner` consecutive rows (r = g * inner + j, R % inner == 0); destination d
- * of graph g is written to mix + g * mix_sb + d * mix_sv + c * mix_sc, every row's output to y as before.  Per
- * destination the rows are added in increasing j, from 0.0f -- the order of the gather-sum kernels, so the sums are
- * identical to that separate pass.  A destination holds one of n_acc <= 4 accumulators between its first and its last
- * source; sched (device memory, `inner` entries) says per row j: bits 0..3 = accumulators the row is added to; byte
- * 1 + a = destination + 1 to store accumulator a to (and clear it) after this row, 0 = none (the caller colours the live
- * ranges: grafx_amd.ops.mix_schedule).  Needs the one-pole smoother and the workspace; GFX_EINVAL otherwise (callers run
- * the two stages separately then). */
+/* The same with the routing sum that follows fused in (render/core.py:36-112, a "mix" stage that sums this call's rows):
+ * rows come in graphs of `inner` consecutive rows (r = g * inner + j, R % inner == 0); destination d of graph g is
+ * written to mix + g * mix_sb + d * mix_sv + c * mix_sc, every row's output to y as before.  Per destination the rows
+ * are added in increasing j, from 0.0f -- the order of the gather-sum kernels, so the sums are identical to that separate
+ * pass.  A destination holds one of n_acc <= 4 accumulators between its first and its last source; sched (device memory,
+ * `inner` entries) says per row j: bits 0..3 = accumulators the row is added to; byte 1 + a = destination + 1 to store
+ * accumulator a to (and clear it) after this row, 0 = none (the caller colours the live ranges:
+ * grafx_amd.ops.mix_schedule).  `extras` (nullable; n_pre + n_post pairs of int64) names sources of the sum that are not
+ * rows of this call but finished rows of the same buffer: (row offset from `mix` in units of mix_sv, code as in sched);
+ * the first n_pre are added before the call's rows, the others after them.  Needs the one-pole smoother, the workspace and
+ * 16-byte aligned rows with L % 4 == 0; GFX_EINVAL otherwise (callers run the two stages separately then). */
 int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
                                const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
                                int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
                                float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
-                               float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, void* stream);
+                               float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
+                               int64_t n_pre, int64_t n_post, void* stream);
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);

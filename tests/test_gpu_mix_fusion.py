@@ -50,7 +50,7 @@ def test_fused_mix_equals_the_two_kernels(B, n, C, L, J, slow, knee, gate):
     x, y, mo = buf[:, :n], buf[:, n : 2 * n], buf[:, 2 * n : 2 * n + J]
     spare = buf[:, 2 * n + J :].clone()
     p = _params(n, L + J, slow)
-    dests, (codes, n_acc) = _random_routing(n, J, seed=J * 1000 + n)
+    dests, (codes, n_acc, _, _) = _random_routing(n, J, seed=J * 1000 + n)
     kw = dict(smoother=1, iir_len=8193, knee=knee, gate=gate, param_rows=n)
     a = (p["log_threshold"], p["log_ratio"], p["log_knee"] if knee != "hard" else None, p["z_alpha"])
     want_y = ops.dynamics_fused(x, *a, **kw)                       # (B * n, C, L)
@@ -70,13 +70,47 @@ def test_fused_mix_equals_the_two_kernels(B, n, C, L, J, slow, knee, gate):
     assert torch.equal(buf[:, 2 * n + J :], spare)                 # nothing written past the destinations
 
 
+@pytest.mark.parametrize("C", [1, 2])
+def test_fused_mix_with_rows_of_other_stages(C):
+    """Destinations that also sum finished rows of the buffer in front of and behind the stage's rows (the console's master
+    sum: four bus compressors and the reverb return): added in increasing row order, bit for bit the gather-sum."""
+    from grafx_amd import ops
+
+    torch.manual_seed(7 + C)
+    B, n, L = 3, 4, 6000
+    # buffer rows: [0,2) earlier stages | [2,6) inputs | [6,10) this stage's outputs | [10,12) a later-indexed finished stage
+    #              | [12,15) mix destinations
+    buf = torch.randn(B, 16, C, L, device="cuda")
+    x, y, mo = buf[:, 2:6], buf[:, 6:10], buf[:, 12:15]
+    p = _params(n, 3, slow_rows=(2,))
+    dests_global = [[0, 6, 7, 11], [8, 9, 10], [1, 7, 9]]          # buffer rows per destination, increasing
+    sched = ops.mix_schedule([[r - 6 for r in rows] for rows in dests_global], n)
+    assert sched is not None
+    codes, n_acc, pre, post = sched
+    extras = torch.tensor([(6 + r - 12, c) for r, c in pre + post], device="cuda")
+    kw = dict(smoother=1, iir_len=1023, knee="quadratic", gate=False, param_rows=n)
+    a = (p["log_threshold"], p["log_ratio"], p["log_knee"], p["z_alpha"])
+    want_y = ops.dynamics_fused(x, *a, **kw).view(B, n, C, L)
+    ref = buf.clone()
+    ref[:, 6:10] = want_y
+    want_m = torch.zeros(B, 3, C, L, device="cuda")
+    for d, rows in enumerate(dests_global):
+        for r in rows:
+            want_m[:, d] = want_m[:, d] + ref[:, r]
+    mix = {"sched": torch.tensor(codes, device="cuda"), "n_acc": n_acc, "out": mo, "extras": extras, "n_pre": len(pre)}
+    ops.dynamics_fused(x, *a, **kw, out=y, mix=mix)
+    assert mix.get("done") is True
+    assert torch.equal(buf[:, 6:10], want_y) and torch.equal(mo, want_m)
+    assert torch.equal(buf[:, :6], ref[:, :6]) and torch.equal(buf[:, 10:12], ref[:, 10:12]) and torch.equal(buf[:, 15:], ref[:, 15:])
+
+
 def test_fused_mix_declines_what_it_cannot_do():
     from grafx_amd import ops
 
     x = torch.randn(2, 4, 2, 2048, device="cuda")
     p = _params(4, 1)
     a = (p["log_threshold"], p["log_ratio"], None, p["z_alpha"])
-    codes, n_acc = ops.mix_schedule([[0, 1], [2, 3]], 4)
+    codes, n_acc, _, _ = ops.mix_schedule([[0, 1], [2, 3]], 4)
     for kw in (dict(smoother=0, iir_len=1), dict(smoother=1, iir_len=4097, schedule="rows")):
         mix = {"sched": torch.tensor(codes, device="cuda"), "n_acc": n_acc, "out": torch.empty(2, 2, 2, 2048, device="cuda")}
         ops.dynamics_fused(x, *a, knee="hard", gate=False, param_rows=4, mix=mix, **kw)
@@ -126,8 +160,9 @@ def test_console_render_with_and_without_the_fused_mix(train):
 
 
 def test_the_console_graph_takes_the_fused_path(monkeypatch):
-    """The schedule of the bench graph has compressor -> mix (channel strips -> the buses and the send): that routing sum
-    is produced by the dynamics kernel, no gather-sum launch is left for it."""
+    """The schedule of the bench graph has compressor -> mix (channel strips -> the buses and the send) and compressor ->
+    reverb -> out (the master sum of the bus compressors and the reverb return; the reverb does not depend on the bus
+    compressors and runs first): both routing sums are produced by the dynamics kernels, no gather-sum launch is left."""
     import bench
     from grafx_amd import ops
     from grafx_amd.data import convert_to_tensor
@@ -154,7 +189,8 @@ def test_the_console_graph_takes_the_fused_path(monkeypatch):
     finally:
         ops.MIX_FUSION = True
     separate = {k: calls[k] - fused[k] for k in calls}
-    assert sum(separate.values()) >= 2 and sum(fused.values()) <= sum(separate.values()) - 1, (fused, separate)
+    # both sums -- strips -> buses + send, and bus compressors + reverb return -> out -- ride on compressor kernels
+    assert sum(separate.values()) == 2 and sum(fused.values()) == 0, (fused, separate)
 
 
 _FUSED_SEEN = []

@@ -7,7 +7,8 @@ def test_mix_schedule_colours_live_ranges():
 
     # the console: four buses of eight strips take turns in one accumulator, the send bus holds the other
     dests = [list(range(8 * k, 8 * k + 8)) for k in range(4)] + [list(range(32))]
-    codes, n_acc = ops.mix_schedule(dests, 32)
+    codes, n_acc, pre, post = ops.mix_schedule(dests, 32)
+    assert pre == [] and post == []
     assert n_acc == 2
     assert all(c & 3 == 3 for c in codes)
     assert [(c >> 8) & 255 for c in codes if (c >> 8) & 255] + [(c >> 16) & 255 for c in codes if (c >> 16) & 255] in (
@@ -16,3 +17,10 @@ def test_mix_schedule_colours_live_ranges():
     assert ops.mix_schedule([[1, 0]], 4) is None                   # not increasing
     assert ops.mix_schedule([[0, 3]] * 5, 4) is None               # five live at once
     assert ops.mix_schedule([[0, 3]] * 4, 4)[1] == 4
+    # the master sum of the console: four bus compressors (the stage's rows 0..3) and the reverb return behind them
+    codes, n_acc, pre, post = ops.mix_schedule([[0, 1, 2, 3, 4]], 4)
+    assert n_acc == 1 and pre == [] and codes == [1, 1, 1, 1] and post == [(4, 1 | (1 << 8))]
+    # a finished row in front of the stage's rows, and a destination made of extras alone is not this stage's business
+    codes, n_acc, pre, post = ops.mix_schedule([[-3, 0, 1], [1, 5]], 2)
+    assert pre == [(-3, 1)] and codes == [1, 1 | (1 << 8) | 2] and post == [(5, 2 | (2 << 16))] and n_acc == 2
+    assert ops.mix_schedule([[-1, 7]], 4) is None
