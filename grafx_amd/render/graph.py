@@ -433,8 +433,7 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             done.add(f)
         if run_stage(i, mix_with=j):
             done.add(j)
-        elif first:
-            pass                     # the stage in between ran early, the sum runs at its own place: still a valid order
+        # (declined: the stage in between has run early and the sum runs at its own place -- still a valid order)
     if side is not None and not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
     if squeeze:
