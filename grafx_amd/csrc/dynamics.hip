@@ -594,13 +594,10 @@ __global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict
 // (its whole traffic but the output rows) disappears.  A destination occupies one of NA accumulators only between its
 // first and its last source (the host colours the live ranges: the console's four buses take turns in one accumulator,
 // the send bus holds the other), and is stored right after its last source -- 32 accumulator registers instead of 16 per
-// destination, which is what keeps five waves per SIMD resident.  sched[j], per row of a graph: bits 0..3 = accumulators
+// destination: 115 VGPRs, four waves per SIMD.  sched[j], per row of a graph: bits 0..3 = accumulators
 // the row is added to; byte 1 + a = (destination + 1) to store accumulator a to, and clear it, after this row (0: none).
 // Rows the pole table sends to dyn_fused_kernel have been written by it BEFORE this grid (the launcher orders it so) and
 // are read back here.
-#ifndef GFX_MIX_PF
-#define GFX_MIX_PF 0
-#endif
 struct MixArgs {
     const int64_t* sched;                 // [inner]
     float* out;                           // mix destinations: out + g * sb + j * sv + c * sc
@@ -613,12 +610,13 @@ struct MixArgs {
     int n_pre, n_post;
 };
 
-#ifndef GFX_MIX_WGS
-#define GFX_MIX_WGS 3   // workgroups per CU the register budget is held to (168 VGPRs; two rows ahead need 171 unconstrained)
-#endif
-template <int NA, bool STEREO, int KIND, bool GATE>   // knee kind and compressor / gate at compile time: a wave runs the
-// row body `inner` times, and with every gain curve inlined it is 6 k instructions, more than the instruction cache holds
-__global__ __launch_bounds__(DT, NA <= 2 ? GFX_MIX_WGS : 2) void dyn_oneshot_mix_kernel(const float* __restrict__ x, float* __restrict__ y,
+// Knee kind and compressor / gate are template parameters: a wave runs the row body `inner` times, and with every gain curve
+// (and the element-wise tail paths of load4 / store4) inlined it is 6 k instructions, more than the instruction cache holds
+// -- 5.0 ms for 8192 rows where this form takes 3.3-3.5.  Requesting rows ahead of the one being scanned was measured too
+// (register rings of 2-4 rows): slower at every depth, the registers cost more waves than the loads in flight gain
+// (EXPERIMENTS.md).
+template <int NA, bool STEREO, int KIND, bool GATE>
+__global__ __launch_bounds__(DT) void dyn_oneshot_mix_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ log_threshold,
                                                              const float* __restrict__ log_ratio,
                                                              const float* __restrict__ log_knee,
@@ -644,19 +642,6 @@ __global__ __launch_bounds__(DT, NA <= 2 ? GFX_MIX_WGS : 2) void dyn_oneshot_mix
                 if (STEREO) acc1[c][k][i] = 0.0f;
             }
     float* const obase = m.out + (int64_t)g * m.sb;
-    // the loads of the rows GFX_MIX_PF ahead are issued before this row's scan: a wave walks its rows serially, so what it
-    // keeps in flight itself is all the memory parallelism it has (8192 rows: 5.03 ms without, 4.03 one row ahead)
-    auto row_tab = [&](int jr) { return tab + (size_t)((g * (unsigned)m.inner + (unsigned)jr) % a.prows) * DP_TAB; };
-    auto row_x = [&](int jr, int c) { return x + drow_off(a.xmap, g * (unsigned)m.inner + (unsigned)jr, c); };
-    auto fetch = [&](int jr, OsIn& in) {          // uniform predicate: rows of the other kernel are read back from y instead
-        if (jr < m.inner && row_tab(jr)[DP_ONESHOT] != 0.0f)
-            os_load<true>(a, row_x(jr, 0), row_x(jr, STEREO ? 1 : 0), true, row_tab(jr), s, lane, in);
-    };
-    constexpr int PF = GFX_MIX_PF;                // rows ahead
-    constexpr int NR = PF + 1;                    // ring of row inputs; the loop is unrolled NR times so that ring slots are
-    OsIn ring[NR];                                // registers with static names (a rotating copy would wait for the loads)
-#pragma unroll
-    for (int d = 0; d < PF; ++d) fetch(d, ring[d]);
     // add one row's tile to the accumulators `code` names, then store and clear the destinations it completes
     auto settle = [&](uint64_t code, const float (&ga)[OS_SUB][DE], const float (&gb)[OS_SUB][DE]) {
         const unsigned add = (unsigned)code & 15u;
@@ -700,33 +685,28 @@ __global__ __launch_bounds__(DT, NA <= 2 ? GFX_MIX_WGS : 2) void dyn_oneshot_mix
         settle((uint64_t)m.extras[2 * e + 1], ga, gb);
     };
     for (int e = 0; e < m.n_pre; ++e) extra(e);
-    for (int j0 = 0; j0 < m.inner; j0 += NR) {
+    for (int jr = 0; jr < m.inner; ++jr) {
+        const unsigned r = g * (unsigned)m.inner + (unsigned)jr;
+        const unsigned pr = r % a.prows;
+        const float* tb = tab + (size_t)pr * DP_TAB;
+        const uint64_t code = (uint64_t)m.sched[jr];
+        float* y0 = y + drow_off(a.ymap, r, 0);
+        float* y1 = y + drow_off(a.ymap, r, STEREO ? 1 : 0);
+        float ga[OS_SUB][DE], gb[OS_SUB][DE];
+        if (tb[DP_ONESHOT] != 0.0f) {             // uniform
+            Knee q;
+            knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
+            OsIn in;
+            os_load<true>(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, STEREO ? 1 : 0), true, tb, s, lane, in);
+            os_finish<true>(a, in, y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb);
+        } else if (((unsigned)code & 15u) != 0u) {   // the row kernel's row: read back what it wrote
 #pragma unroll
-        for (int u = 0; u < NR; ++u) {
-            const int jr = j0 + u;
-            if (jr >= m.inner) break;             // uniform
-            const unsigned r = g * (unsigned)m.inner + (unsigned)jr;
-            const unsigned pr = r % a.prows;
-            const float* tb = tab + (size_t)pr * DP_TAB;
-            const uint64_t code = (uint64_t)m.sched[jr];
-            const unsigned add = (unsigned)code & 15u;
-            float* y0 = y + drow_off(a.ymap, r, 0);
-            float* y1 = y + drow_off(a.ymap, r, STEREO ? 1 : 0);
-            float ga[OS_SUB][DE], gb[OS_SUB][DE];
-            fetch(jr + PF, ring[(u + PF) % NR]);
-            if (tb[DP_ONESHOT] != 0.0f) {         // uniform
-                Knee q;
-                knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
-                os_finish<true>(a, ring[u], y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb);
-            } else if (add != 0u) {
-#pragma unroll
-                for (int k = 0; k < OS_SUB; ++k) {
-                    ld4<true>(y0, n0 + 256 * k, a.L, true, ga[k]);
-                    if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, gb[k]);
-                }
+            for (int k = 0; k < OS_SUB; ++k) {
+                ld4<true>(y0, n0 + 256 * k, a.L, true, ga[k]);
+                if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, gb[k]);
             }
-            settle(code, ga, gb);
         }
+        settle(code, ga, gb);
     }
     for (int e = m.n_pre; e < m.n_pre + m.n_post; ++e) extra(e);
 }

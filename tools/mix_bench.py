@@ -15,7 +15,7 @@ buf[:, :n].normal_()
 x, y, mo = buf[:, :n], buf[:, n : 2 * n], buf[:, 2 * n :]
 p = [torch.randn(n, 1, device=dev) * 0.1 for _ in range(4)]
 dests = [list(range(8 * k, 8 * k + 8)) for k in range(4)] + [list(range(n))]
-codes, n_acc = ops.mix_schedule(dests, n)
+codes, n_acc, _, _ = ops.mix_schedule(dests, n)
 sched = torch.tensor(codes, device=dev)
 uniq = torch.arange(n, device=dev)
 masks = torch.tensor([sum(1 << d for d, rows in enumerate(dests) if j in rows) for j in range(n)], device=dev)
