@@ -572,7 +572,7 @@ def call_roofline(R, C, L, ms_per_step):
     return {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
 
 
-def secondary_leg(torch, dev, sync, steps=10, warmup=3):
+def secondary_leg(torch, dev, sync, steps=20, warmup=5):
     """BASELINE configs[1] and configs[2] on this GPU, a few milliseconds each, appended to the headline line so that the
     driver's own run records them: ms per call, the call's algorithmic-bytes roofline and the dominant kernel's."""
     from grafx_amd import ops
