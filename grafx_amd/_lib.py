@@ -83,6 +83,8 @@ SIGNATURES = {
     "gfx_dyn_gain_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "gfx_apply_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, ctypes.c_int, vp]),
     "gfx_stereo_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, vp]),
+    "gfx_stereo_gain_mix_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, vp, i64, i64, f32p, i64, i64,
+                                               i64, vp, i64, i64, vp]),
     "gfx_biquad_cascade_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, i64, i64, i64, i64, i64, ctypes.c_int, vp]),
     "gfx_noise_shaping_ir_f32": (ctypes.c_int, [f32p, i64, f32p, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                 ctypes.c_float, ctypes.c_float, vp]),

@@ -108,6 +108,75 @@ __global__ __launch_bounds__(256) void gather_sum_fanout_kernel(const float* __r
     }
 }
 
+// StereoGain (stereo.py:25-48: y[r,c,n] = x[r,cx,n] exp(log_gain[r,c])) with the routing sum that follows fused in -- the
+// gain / pan stage in front of a bus, the elementwise twin of dyn_oneshot_mix_kernel (dynamics.hip: same schedule words,
+// same extras, same increasing summation order, bit-identical sums).  One thread per 16-byte column of a graph: it walks
+// the `inner` rows, scales, stores the row and adds it to the accumulators of the destinations the row feeds.
+struct GainMixArgs {
+    const float* x;
+    float* y;
+    gfx_rowmap_t xmap, ymap;
+    const float* log_gain;                // (R, 2)
+    const int64_t* sched;                 // [inner], see gfx_dynamics_fused_mix_f32
+    float* out;
+    int64_t sb, sv, sc;
+    const int64_t* extras;
+    int inner, n_pre, n_post, Cin;
+    int64_t L4;
+};
+
+__device__ __forceinline__ int64_t gm_row_off(const gfx_rowmap_t& m, unsigned r, int c) {
+    const unsigned inner = (unsigned)m.inner;
+    const unsigned q = r / inner, rem = r - q * inner;
+    return (int64_t)q * m.stride_outer + (int64_t)rem * m.stride_inner + (int64_t)c * m.stride_ch;
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void gain_mix_kernel(GainMixArgs a) {
+    const unsigned g = blockIdx.y;
+    float* const obase = a.out + (int64_t)g * a.sb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.L4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc0[NA], acc1[NA];
+#pragma unroll
+        for (int c = 0; c < NA; ++c) acc0[c] = acc1[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        auto settle = [&](uint64_t code, float4 v0, float4 v1) {
+            const unsigned add = (unsigned)code & 15u;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                if ((add >> c) & 1u) {
+                    acc0[c].x += v0.x; acc0[c].y += v0.y; acc0[c].z += v0.z; acc0[c].w += v0.w;
+                    acc1[c].x += v1.x; acc1[c].y += v1.y; acc1[c].z += v1.z; acc1[c].w += v1.w;
+                }
+                const unsigned fl = (unsigned)(code >> (8 + 8 * c)) & 255u;
+                if (fl != 0u) {
+                    float* o = obase + (int64_t)(fl - 1u) * a.sv;
+                    nt_store(reinterpret_cast<float4*>(o) + i, acc0[c]);
+                    nt_store(reinterpret_cast<float4*>(o + a.sc) + i, acc1[c]);
+                    acc0[c] = acc1[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+        };
+        auto extra = [&](int e) {
+            const float* p = obase + a.extras[2 * e] * a.sv;
+            settle((uint64_t)a.extras[2 * e + 1], reinterpret_cast<const float4*>(p)[i],
+                   reinterpret_cast<const float4*>(p + a.sc)[i]);
+        };
+        for (int e = 0; e < a.n_pre; ++e) extra(e);
+        for (int j = 0; j < a.inner; ++j) {
+            const unsigned r = g * (unsigned)a.inner + (unsigned)j;
+            const float g0 = expf(a.log_gain[2 * (int64_t)r]), g1 = expf(a.log_gain[2 * (int64_t)r + 1]);
+            const float4 x0 = reinterpret_cast<const float4*>(a.x + gm_row_off(a.xmap, r, 0))[i];
+            const float4 x1 = a.Cin == 2 ? reinterpret_cast<const float4*>(a.x + gm_row_off(a.xmap, r, 1))[i] : x0;
+            const float4 y0 = make_float4(x0.x * g0, x0.y * g0, x0.z * g0, x0.w * g0);
+            const float4 y1 = make_float4(x1.x * g1, x1.y * g1, x1.z * g1, x1.w * g1);
+            nt_store(reinterpret_cast<float4*>(a.y + gm_row_off(a.ymap, r, 0)) + i, y0);
+            nt_store(reinterpret_cast<float4*>(a.y + gm_row_off(a.ymap, r, 1)) + i, y1);
+            settle((uint64_t)a.sched[j], y0, y1);
+        }
+        for (int e = a.n_pre; e < a.n_pre + a.n_post; ++e) extra(e);
+    }
+}
+
 }  // namespace gfx
 
 extern "C" int gfx_gather_sum_fanout_f32(const float* buf, int64_t buf_sb, int64_t buf_sv, int64_t buf_sc,
@@ -148,5 +217,28 @@ extern "C" int gfx_gather_sum_f32(const float* buf, int64_t buf_sb, int64_t buf_
     hipLaunchKernelGGL(gfx::gather_sum_kernel, dim3((unsigned)bx, (unsigned)(J * C), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, buf, buf_sb, buf_sv, buf_sc, src_idx, seg_ptr, out, out_sb, out_sv, out_sc,
                        (int)C, L, aligned ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+extern "C" int gfx_stereo_gain_mix_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
+                                       int64_t R, int64_t C_in, int64_t L, const int64_t* sched, int64_t inner,
+                                       int64_t n_acc, float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc,
+                                       const int64_t* extras, int64_t n_pre, int64_t n_post, void* stream) {
+    if (!x || !log_gain || !y || !sched || !mix || R <= 0 || L <= 0 || (C_in != 1 && C_in != 2)) return GFX_EINVAL;
+    if (inner < 1 || R % inner != 0 || R / inner > 65535 || n_acc < 1 || n_acc > 4) return GFX_EINVAL;
+    if (n_pre < 0 || n_post < 0 || (n_pre + n_post > 0 && !extras)) return GFX_EINVAL;
+    if (xmap.inner != inner || ymap.inner != inner) return GFX_EINVAL;
+    const int64_t strides = xmap.stride_outer | xmap.stride_inner | xmap.stride_ch | ymap.stride_outer | ymap.stride_inner |
+                            ymap.stride_ch | mix_sb | mix_sv | mix_sc;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mix) & 15) != 0 || (strides & 3) != 0 || (L & 3) != 0) return GFX_EINVAL;
+    gfx::GainMixArgs a;
+    a.x = x; a.y = y; a.xmap = xmap; a.ymap = ymap; a.log_gain = log_gain; a.sched = sched; a.out = mix;
+    a.sb = mix_sb; a.sv = mix_sv; a.sc = mix_sc; a.extras = extras; a.inner = (int)inner; a.n_pre = (int)n_pre;
+    a.n_post = (int)n_post; a.Cin = (int)C_in; a.L4 = L / 4;
+    int64_t bx = (L / 4 + 255) / 256;
+    if (bx > 512) bx = 512;
+    const dim3 grid((unsigned)bx, (unsigned)(R / inner));
+    if (n_acc <= 2) hipLaunchKernelGGL(gfx::gain_mix_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gfx::gain_mix_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }

@@ -726,7 +726,9 @@ def apply_gain(x, g, exp_gain=False, out=None):
 
 
 @_on_device
-def stereo_gain(x, log_gain, out=None):
+def stereo_gain(x, log_gain, out=None, mix=None):
+    """``mix``: as in :func:`dynamics_fused` -- the routing sum behind a strided (B, n, C, L) stage, produced by the same
+    kernel (gfx_stereo_gain_mix_f32); sets ``mix["done"]`` when it was."""
     _require_gpu(x, log_gain, out)
     xmap, R, C, L = rowmap(x)
     _expect(log_gain, (R, 2), "stereo_gain: log_gain")
@@ -735,6 +737,21 @@ def stereo_gain(x, log_gain, out=None):
     elif rowmap(out)[1:] != (R, 2, L):
         raise ValueError(f"stereo_gain: output {tuple(out.shape)} does not match {(R, 2, L)}")
     pin = _Pin()
+    if mix is not None and MIX_FUSION and x.ndim == 4 and out.ndim == 4:
+        mo, sched = mix["out"], mix["sched"]
+        n = x.shape[1]
+        if mo.shape == (x.shape[0], mo.shape[1], 2, L) and mo.stride(-1) == 1 and sched.numel() == n:
+            ex = mix.get("extras")
+            n_ex = 0 if ex is None else ex.shape[0]
+            n_pre = mix.get("n_pre", 0)
+            rc = lib().gfx_stereo_gain_mix_f32(_ptr(x), xmap, pin(log_gain), _ptr(out), rowmap(out)[0], R, C, L, _ptr(sched), n,
+                                               mix["n_acc"], _ptr(mo), mo.stride(0), mo.stride(1), mo.stride(2), _ptr(ex),
+                                               n_pre, n_ex - n_pre, _stream())
+            if rc == 0:
+                mix["done"] = True
+                return out
+            if rc != -1:
+                check(rc, "gfx_stereo_gain_mix_f32")
     check(lib().gfx_stereo_gain_f32(_ptr(x), xmap, pin(log_gain), _ptr(out), rowmap(out)[0], R, C, L, _stream()), "gfx_stereo_gain_f32")
     return out
 

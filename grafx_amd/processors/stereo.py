@@ -14,10 +14,12 @@ class StereoGain(BufferIO, nn.Module):
             return input_signals * torch.exp(log_gain)[..., None]
         return ops.stereo_gain(input_signals, log_gain)
 
-    def render_into(self, x4, out4, log_gain):
+    accepts_mix = True   # _mix: the routing sum behind this stage, see ops.stereo_gain(mix=)
+
+    def render_into(self, x4, out4, log_gain, _mix=None):
         if needs_grad(x4, log_gain):
             return super().render_into(x4, out4, log_gain=log_gain)
-        return ops.stereo_gain(x4, log_gain, out=out4)
+        return ops.stereo_gain(x4, log_gain, out=out4, mix=_mix)
 
     def parameter_size(self):
         return {"log_gain": 2}

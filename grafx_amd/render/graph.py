@@ -396,7 +396,7 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         console: the bus compressors, then the reverb, then the master sum of both), which then runs first."""
         step = render_data.iter_list[i]
         proc = processors[step.node_type]
-        if not (getattr(proc, "accepts_mix", False) and type(proc) in _tape_safe_types()):
+        if not (getattr(proc, "accepts_mix", False) and type(proc) in _mix_safe_types()):
             return None, []
         first = []
         j = i + 1
@@ -447,6 +447,14 @@ def _tape_safe_types():
     from .. import processors as P
 
     return (P.ParametricEqualizer, P.Compressor, P.NoiseGate, P.STFTMaskedNoiseReverb, P.BiquadFilter)
+
+
+def _mix_safe_types():
+    """Exact processor classes whose render_into(..., _mix=) writes exactly the stage's output rows and their sums (a user
+    subclass may post-process them: it gets the two stages one after the other)."""
+    from .. import processors as P
+
+    return (P.Compressor, P.NoiseGate, P.StereoGain)
 
 
 def _flatten_tree(tree, leaves):

@@ -339,6 +339,14 @@ int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float*
                        int64_t R, int64_t C, int64_t L, int exp_gain, void* stream);
 int gfx_stereo_gain_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
                         int64_t R, int64_t C_in, int64_t L, void* stream);
+/* StereoGain with the routing sum behind it fused in (the gain / pan stage in front of a bus): y as above, and the mix
+ * destinations as gfx_dynamics_fused_mix_f32 produces them -- same sched / n_acc / extras words, same summation order,
+ * identical sums.  log_gain is (R, 2); rows in graphs of `inner` (the row maps' `inner`); needs 16-byte aligned rows and
+ * L % 4 == 0, GFX_EINVAL otherwise (callers run gfx_stereo_gain_f32 and the gather-sum then). */
+int gfx_stereo_gain_mix_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
+                            int64_t R, int64_t C_in, int64_t L, const int64_t* sched, int64_t inner, int64_t n_acc,
+                            float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
+                            int64_t n_pre, int64_t n_post, void* stream);
 
 /* ---- STFT-masked noise reverb: impulse response ------------------------------------------
  * replaces STFTMaskedNoiseReverb.compute_stft_mask + compute_ir (reverb.py:161-200: mask, torch.istft),

@@ -259,3 +259,77 @@ def test_random_graphs_render_identically_with_and_without_the_fused_mix(seed, m
     assert torch.equal(bufs[True][0], bufs[False][0]) and torch.equal(bufs[True][1], bufs[False][1])
     if seed == 9:
         assert len(set(_FUSED_SEEN)) >= 2, _FUSED_SEEN
+
+
+@pytest.mark.parametrize("Cin", [1, 2])
+def test_stereo_gain_with_the_fused_mix(Cin):
+    """gfx_stereo_gain_mix_f32 (stereo.py:25-48 + render/core.py:36-112): the scaled rows and the routing sums, incl. rows of
+    other stages, bit for bit what gfx_stereo_gain_f32 and the gather-sum give."""
+    from grafx_amd import ops
+
+    torch.manual_seed(21 + Cin)
+    B, n, L = 3, 6, 5000
+    xin = torch.randn(B, n, Cin, L, device="cuda")
+    buf = torch.randn(B, 16, 2, L, device="cuda")                  # rows [2,8): this stage | 0, 1, 9: finished | [12,15): mix
+    y, mo = buf[:, 2:8], buf[:, 12:15]
+    lg = torch.randn(B * n, 2, device="cuda")
+    dests_global = [[0, 2, 3, 7, 9], [4, 5, 6], [1, 3, 5]]
+    codes, n_acc, pre, post = ops.mix_schedule([[r - 2 for r in rows] for rows in dests_global], n)
+    extras = torch.tensor([(2 + r - 12, c) for r, c in pre + post], device="cuda")
+    want_y = ops.stereo_gain(xin, lg).view(B, n, 2, L)
+    ref = buf.clone()
+    ref[:, 2:8] = want_y
+    want_m = torch.zeros(B, 3, 2, L, device="cuda")
+    for d, rows in enumerate(dests_global):
+        for r in rows:
+            want_m[:, d] = want_m[:, d] + ref[:, r]
+    mix = {"sched": torch.tensor(codes, device="cuda"), "n_acc": n_acc, "out": mo, "extras": extras, "n_pre": len(pre)}
+    ops.stereo_gain(xin, lg, out=y, mix=mix)
+    assert mix.get("done") is True
+    assert torch.equal(buf[:, 2:8], want_y) and torch.equal(mo, want_m)
+    keep = [0, 1, 8, 9, 10, 11, 15]
+    assert torch.equal(buf[:, keep], ref[:, keep])
+
+
+def test_gain_stage_in_front_of_buses_renders_identically():
+    """in -> eq -> gain -> {bus mix, send mix} -> out: the gain stage produces the bus sums (identical buffer, fewer launches)."""
+    import grafx_amd.processors as P
+    from grafx_amd import ops
+    from grafx_amd.data import GRAFX, NodeConfigs, convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    torch.manual_seed(4)
+    G = GRAFX(config=NodeConfigs(["eq", "gain"]))
+    out = G.add("out")
+    buses = [G.add("mix") for _ in range(2)]
+    for ch in range(6):
+        _, last = G.add_serial_chain(["in", "eq", "gain"])
+        G.connect(last, buses[ch // 3])
+        G.connect(last, out)
+    for b in buses:
+        G.connect(b, out)
+    procs = {"eq": P.ParametricEqualizer(num_filters=4, flashfftconv=False, fsm_fir_len=257).cuda(), "gain": P.StereoGain().cuda()}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    params = {t: {k: v.cuda() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.3).items()}
+    x = torch.randn(2, 6, 2, 4096, device="cuda")
+    seen = []
+    real = ops.stereo_gain
+
+    def spy(*a, **k):
+        o = real(*a, **k)
+        seen.append(bool(k.get("mix") is not None and k["mix"].get("done")))
+        return o
+
+    bufs = {}
+    for flag in (True, False):
+        ops.MIX_FUSION = flag
+        ops.stereo_gain = spy
+        try:
+            with torch.no_grad():
+                yy, _, buf = render_grafx(procs, x, params, rd)
+            bufs[flag] = (buf.clone(), yy.clone())
+        finally:
+            ops.MIX_FUSION, ops.stereo_gain = True, real
+    assert torch.equal(bufs[True][0], bufs[False][0]) and torch.equal(bufs[True][1], bufs[False][1])
+    assert seen[0] is True and seen[-1] is False
