@@ -57,8 +57,9 @@ def parse_args(argv=None):
                     help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
                          "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
     ap.add_argument("--reference-default-args", action="store_true",
-                    help="build the processors with upstream's constructor defaults (flashfftconv=True, 4000/16384/60000 taps): "
-                         "the FlashFFTConv flavour, i.e. plain causal convolutions; not the headline configuration")
+                    help="build the processors exactly as written for upstream (constructor defaults: flashfftconv=True, "
+                         "4000/16384/60000 taps).  As on the reference's CPU path the flag falls back to the native convolve(), "
+                         "so this is --reference-default-lengths reached through the default arguments")
     ap.add_argument("--capture", action="store_true",
                     help="replay the render as one captured HIP graph (grafx_amd.render.CapturedRender): the serving "
                          "path for small batches, where the eager loop is host-bound")
@@ -140,7 +141,7 @@ LENS = dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001)
 def hip_processors(default_args=False):
     from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
 
-    if default_args:  # upstream's constructor defaults: flashfftconv=True, 4000 / 16384 / 60000 taps
+    if default_args:  # upstream's constructor defaults: flashfftconv=True (-> warning + native convolve), 4000 / 16384 / 60000 taps
         return {"eq": ParametricEqualizer(num_filters=6), "compressor": Compressor(energy_smoother="iir"),
                 "reverb": STFTMaskedNoiseReverb()}
     return {
@@ -451,7 +452,8 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
                    "fsm_fir_len": LENS["fsm_fir_len"], "iir_len": LENS["iir_len"], "ir_len": LENS["ir_len"],
                    "mode": ("forward render, reference-default even lengths (odd L+N-1: aliasing compatibility path)"
                             if args.reference_default_lengths else
-                            "forward render, upstream default constructor arguments (flashfftconv=True: plain causal convolutions)"
+                            "forward render, upstream default constructor arguments (flashfftconv=True falls back to the native convolve(), "
+                            "even lengths: aliasing compatibility path)"
                             if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"),
                    "parallelism": f"batch-shard x{world}",
                    "launch": "one captured HIP graph per step" if args.capture else "eager render loop"},
@@ -471,7 +473,7 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     # bus compressors' kernel likewise produces the master sum (4 of the `out` stage's 5 reads).
     graph_bytes = 285 * B * 2 * L * 4
     from grafx_amd import ops as _ops
-    fused_mix = _ops.MIX_FUSION and not args.reference_default_lengths
+    fused_mix = _ops.MIX_FUSION and not (args.reference_default_lengths or args.reference_default_args)
     elided_rows = 0 if args.dry else 32 + (64 + 4 if fused_mix else 32)
     moved = graph_bytes - elided_rows * B * 2 * L * 4
     out["graph_roofline"] = {"algorithmic_bytes_per_step": graph_bytes,

@@ -14,7 +14,11 @@ for odd P it inverts a P-point spectrum on a (P-1)-point grid
   double-precision transforms for the dynamics envelope; no FFT library; P <= 11,184,811,
   longer signals raise -- DESIGN.md §2).
 
-``set_exact_convolution(True)`` opts out of the quirk (true linear convolution
+``flashfftconv=True`` -- the constructor default of every upstream processor -- is resolved the way the reference's
+PyTorch-CPU path resolves it (convolution.py:47-51): FlashFFTConv is a CUDA library, so the flag falls back to the
+native convolve() above with upstream's warning, aliasing included (pinned by golden g17).
+
+``set_exact_convolution(True)`` is the explicit opt-out of the quirk (true linear convolution
 for every length; deviates from the reference when P is odd).
 """
 import contextlib
@@ -56,13 +60,23 @@ def exact_convolution_scope(flag):
         _EXACT.reset(token)
 
 
-def reference_aliases(lx, lh, exact=False):
-    """True when the reference's *native* convolve() is NOT a linear convolution for these lengths.
+FLASHFFTCONV_AVAILABLE = False   # a CUDA library (convolution.py:9-14): never importable next to a HIP device
 
-    ``exact`` is a call site's own request for the true linear convolution: the processors pass their
-    ``flashfftconv`` constructor flag here, because that is what the flag selects upstream — FlashFFTConv computes
-    the plain causal convolution (convolution.py:85-106), only the native torch.fft path has the odd-length
-    aliasing (convolution.py:119-134)."""
+
+def resolve_flashfftconv(flashfftconv, warn=True):
+    """What upstream's FIRConvolution.__init__ makes of the ``flashfftconv`` constructor argument when FlashFFTConv
+    cannot be imported -- always the case on the reference's PyTorch-CPU path, the parity target (convolution.py:47-53):
+    a warning and the native convolve().  Returns the resolved flag (False).  ``warn=False`` for a wrapper whose inner
+    module has already warned (upstream warns once per FIRConvolution it builds)."""
+    if flashfftconv and warn:
+        warnings.warn("FlashFFTConv is not available. Using native convolution instead.")
+    return False
+
+
+def reference_aliases(lx, lh, exact=False):
+    """True when the reference's convolve() is NOT a linear convolution for these lengths (odd lx + lh - 1,
+    convolution.py:119-134).  ``exact`` is a call site's own request for the true linear convolution (the processors
+    pass their resolved ``flashfftconv`` attribute, which is False: see resolve_flashfftconv)."""
     return (lx + lh - 1) % 2 == 1 and not (_EXACT.get() or exact)
 
 
@@ -80,7 +94,7 @@ def odd_length_alias(z, lo=0, length=None, precise=False):
     length = P - 1 - lo if length is None else length
     if not ops.odd_alias_supported(P):
         raise NotImplementedError(f"convolve: the reference's odd-length aliasing (P = Lx + Lh - 1 = {P}) is implemented for "
-                                  "P <= 11,184,811; use a filter length that makes P even, or flashfftconv=True / "
+                                  "P <= 11,184,811; use a filter length that makes P even, or "
                                   "set_exact_convolution(True) for the plain linear convolution")
     if torch.is_grad_enabled() and z.requires_grad:
         from ... import autograd as diff
@@ -143,21 +157,17 @@ def convolve(x, h, mode="zerophase", pad_mode="min", exact=False):
 class FIRConvolution(nn.Module):
     """Same constructor as the reference (convolution.py:38-65).
 
-    ``flashfftconv=True`` (the upstream default) selects, upstream, the FlashFFTConv CUDA library: a plain causal
-    convolution in bf16, capped at ``max_input_len``.  Its MI355X counterpart is the fp32 HIP overlap-save kernel
-    computing that same causal convolution (no length cap; ``max_input_len`` is accepted and unused).
-    ``flashfftconv=False`` selects upstream's native torch.fft path, whose odd-length aliasing is reproduced
-    (DESIGN.md section 2).  As upstream, the FlashFFTConv flavour has no zero-phase mode (convolution.py:86-89)."""
+    ``flashfftconv=True`` (the upstream default) asks for the FlashFFTConv CUDA library; where that cannot be imported
+    -- the reference's PyTorch-CPU path, and any machine with this package's HIP device -- upstream warns and uses its
+    native torch.fft ``convolve`` (convolution.py:47-53).  So does this class: the flag resolves to False, the module
+    computes ``convolve`` with its odd-length aliasing, and ``max_input_len`` is accepted and
+    unused.  Because the flag is resolved before upstream's zero-phase check (convolution.py:55-58), zero-phase mode
+    works under either value, as it does upstream on CPU."""
 
     def __init__(self, mode="causal", flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.mode = mode
-        self.flashfftconv = bool(flashfftconv)
-        if self.flashfftconv and mode == "zerophase":
-            warnings.warn("When using FlashFFTConv with zerophase mode, make sure that the sum of the input and kernel "
-                          "lengths is less than or equal to max_input_len.")
+        self.flashfftconv = resolve_flashfftconv(flashfftconv)
 
     def forward(self, input_signals, fir):
-        if self.flashfftconv:
-            assert self.mode != "zerophase", "We currently do not support zerophase mode with FlashFFTConv."
         return convolve(input_signals, fir, mode=self.mode, exact=self.flashfftconv)

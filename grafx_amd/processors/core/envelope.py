@@ -5,7 +5,7 @@ import torch.nn as nn
 from ... import autograd as diff
 from ... import ops
 from ...autograd import needs_grad
-from .convolution import odd_length_alias, reference_aliases
+from .convolution import odd_length_alias, reference_aliases, resolve_flashfftconv
 
 
 class TruncatedOnePoleIIRFilter(nn.Module):
@@ -18,7 +18,8 @@ class TruncatedOnePoleIIRFilter(nn.Module):
     def __init__(self, iir_len=16384, flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.iir_len = iir_len
-        self.flashfftconv = bool(flashfftconv)  # True: plain causal convolution, see FIRConvolution
+        # upstream: FIRConvolution(mode="causal", **backend_kwargs) (envelope.py:32) -> warning + native convolve()
+        self.flashfftconv = resolve_flashfftconv(flashfftconv)
 
     def forward(self, input_signals, z_alpha):
         if needs_grad(input_signals, z_alpha):

@@ -17,7 +17,7 @@ class IIRFilter(nn.Module):
         self.backend = backend
         self.fsm_fir_len = fsm_fir_len
         self.fsm_regularization = fsm_regularization
-        self.flashfftconv = bool(flashfftconv)  # True: plain causal convolution (FlashFFTConv's role), see FIRConvolution
+        self.flashfftconv = False  # resolved as upstream resolves it without FlashFFTConv (FIRConvolution below warns)
         if flashfftconv:  # same precondition as upstream (iir.py:110-112)
             assert fsm_fir_len % 2 == 0
             assert fsm_max_input_len % 2 == 0
@@ -28,6 +28,7 @@ class IIRFilter(nn.Module):
             if fsm_regularization:
                 assert False  # upstream: iir.py:122-123
             self.conv = FIRConvolution(mode="causal", flashfftconv=flashfftconv, max_input_len=fsm_max_input_len)
+            self.flashfftconv = self.conv.flashfftconv
             self._plans = {}
         elif backend in ("lfilter", "ssm"):
             # upstream: torchaudio.functional.lfilter per section / a state-space form on torchlpc (iir.py:154-261).

@@ -6,7 +6,7 @@ from .. import autograd as diff
 from .. import ops
 from ..autograd import needs_grad
 from .core._buffer_io import BufferIO, expand_shared, shared_reps
-from .core.convolution import reference_aliases
+from .core.convolution import reference_aliases, resolve_flashfftconv
 from .core.envelope import Ballistics, TruncatedOnePoleIIRFilter
 
 
@@ -17,7 +17,7 @@ class _Dynamics(BufferIO, nn.Module):
                  iir_len=16384, flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.iir_len = iir_len
-        self.flashfftconv = bool(flashfftconv)
+        self.flashfftconv = resolve_flashfftconv(flashfftconv, warn=False)   # the smoother modules below warn, as upstream's
         self.energy_smoother = energy_smoother
         if energy_smoother == "iir":
             self.energy_smoother_module = TruncatedOnePoleIIRFilter(iir_len=iir_len, flashfftconv=flashfftconv)

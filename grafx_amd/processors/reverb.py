@@ -10,7 +10,7 @@ from .. import ops
 from ..autograd import needs_grad
 from .core._buffer_io import BufferIO, Prepared, expand_shared, shared_reps
 from .core.utils import normalize_impulse
-from .core.convolution import convolve_taps
+from .core.convolution import convolve_taps, resolve_flashfftconv
 from .core.midside import lr_to_ms, ms_to_lr
 
 
@@ -19,7 +19,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
                  fixed_noise=True, gain_envelope=False, flashfftconv=True, max_input_len=2**17):
         super().__init__()
         self.ir_len, self.n_fft, self.hop_length = ir_len, n_fft, hop_length
-        self.flashfftconv = bool(flashfftconv)  # True: plain causal convolution (FlashFFTConv's role), see FIRConvolution
+        # upstream builds a FIRConvolution here (reverb.py:86-90), which without FlashFFTConv warns and goes native
+        self.flashfftconv = resolve_flashfftconv(flashfftconv)
         self.num_frames = 1 + (ir_len // hop_length)
         self.num_bins = 1 + n_fft // 2
         self.register_buffer("window", torch.hann_window(n_fft))

@@ -759,9 +759,58 @@ def g16(n_graphs=10):
     save("g16_render_gradients", **arrays)
 
 
+def g17():
+    """Upstream's DEFAULT constructor arguments on the reference's PyTorch-CPU path: `flashfftconv=True` warns
+    ("FlashFFTConv is not available. Using native convolution instead.", core/convolution.py:47-51) and takes
+    `_native_forward` (convolution.py:82-83), i.e. convolve() with its odd-length aliasing.  Outputs and parameter
+    gradients at an even audio length (L + N - 1 odd for every default tap count: aliased) and an odd one (plain)."""
+    import warnings
+
+    from grafx.processors.core.convolution import FIRConvolution
+
+    out = {}
+    for L in (4096, 4095):
+        torch.manual_seed(17)
+        x = torch.randn(2, 2, L)
+        out[f"x_L{L}"] = x
+        cases = {}
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            cases["peq"] = (ParametricEqualizer(num_filters=6),
+                            {k: (0.3 * torch.randn(2, 1, 6)).requires_grad_() for k in ("w0", "q_inv", "log_gain")})
+            cases["compressor"] = (Compressor(),
+                                   {"log_threshold": (torch.randn(2, 1) - 2).requires_grad_(),
+                                    "log_ratio": torch.randn(2, 1).requires_grad_(),
+                                    "log_knee": torch.randn(2, 1).requires_grad_(),
+                                    "z_alpha_pre": (torch.randn(2, 1) + 2).requires_grad_()})
+            cases["reverb"] = (STFTMaskedNoiseReverb(),
+                               {k: torch.randn(2, 2, 193).requires_grad_()
+                                for k in ("init_log_magnitude", "delta_log_magnitude")})
+            r, th = torch.rand(2, 2, 3) * 0.9, torch.rand(2, 2, 3) * 3.1
+            cases["iir"] = (IIRFilter(),
+                            {"Bs": (torch.randn(2, 2, 3, 3) * 0.3 + torch.tensor([1.0, 0, 0])).requires_grad_(),
+                             "As": torch.stack([torch.ones_like(r), -2 * r * torch.cos(th), r * r], -1).requires_grad_()})
+            cases["fir"] = (FIRConvolution(), {"fir": (torch.randn(2, 1, 512) / 16).requires_grad_()})
+        msgs = sorted({str(w.message) for w in rec})
+        assert msgs == ["FlashFFTConv is not available. Using native convolution instead."], msgs
+        out["warning"] = msgs[0]
+        for name, (m, p) in cases.items():
+            assert set(p) == set(m.parameter_size()) if hasattr(m, "parameter_size") else True
+            y = m(x, **p)
+            tag = f"{name}_L{L}"
+            w, gr = grads(y, p, 170)
+            out[f"y_{tag}"] = y
+            out[f"w_L{L}"] = w          # the same draw for every case (same shape, same seed)
+            for k, v in p.items():
+                out[f"{k}_{tag}"] = v
+            for k, v in gr.items():
+                out[f"{k}_{tag}"] = v
+    save("g17_default_arguments", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15, g16):
+    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15, g16, g17):
         if not only or fn.__name__ in only:
             fn()

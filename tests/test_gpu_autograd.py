@@ -118,8 +118,8 @@ def test_training_step_through_render_grafx():
 def test_training_backward_runs_under_the_callers_exact_convolution_setting():
     """set_exact_convolution() is context-local and the render's backward re-traces its stages on the autograd engine's
     worker thread: the node must carry the setting of its forward.  With even filter lengths (odd L + N - 1, where the
-    reference aliases) the gradients under set_exact_convolution(True) must equal those of the plain-convolution
-    processors (flashfftconv=True) and differ from the aliasing default."""
+    reference aliases) the gradients under set_exact_convolution(True) must equal those of processors whose backward ALSO
+    runs under the setting (the plain convolution) and differ from the aliasing default."""
     from grafx_amd.data import convert_to_tensor
     from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
     from grafx_amd.processors.core.convolution import exact_convolution, set_exact_convolution
@@ -127,33 +127,34 @@ def test_training_backward_runs_under_the_callers_exact_convolution_setting():
     from grafx_amd.utils import create_empty_parameters
     from test_routing_golden import build_console
 
-    def procs(flash):
-        return {"eq": ParametricEqualizer(num_filters=4, flashfftconv=flash, fsm_fir_len=128).cuda(),
-                "compressor": Compressor(iir_len=128, flashfftconv=flash).cuda(),
-                "reverb": STFTMaskedNoiseReverb(ir_len=1536, flashfftconv=flash).cuda()}
+    def procs():
+        return {"eq": ParametricEqualizer(num_filters=4, flashfftconv=False, fsm_fir_len=128).cuda(),
+                "compressor": Compressor(iir_len=128, flashfftconv=False).cuda(),
+                "reverb": STFTMaskedNoiseReverb(ir_len=1536, flashfftconv=False).cuda()}
 
     torch.manual_seed(1)
     G = build_console(4, 2)
     rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
-    params = create_empty_parameters(procs(False), G, std=0.2).cuda()
+    params = create_empty_parameters(procs(), G, std=0.2).cuda()
     x = torch.randn(2, 4, 2, 1024, device="cuda")
 
-    def grads(p, exact):
+    def grads(p, exact, reset_before_backward):
         assert exact_convolution() is False
         set_exact_convolution(exact)
         try:
             for q in params.parameters():
                 q.grad = None
             y = render_grafx(p, x, params, rd)[0]
-            set_exact_convolution(False)          # the backward must not depend on what the caller does afterwards
+            if reset_before_backward:
+                set_exact_convolution(False)      # the backward must not depend on what the caller does afterwards
             y.square().mean().backward()
         finally:
             set_exact_convolution(False)
         return y.detach(), [q.grad.clone() for q in params.parameters()]
 
-    y_alias, g_alias = grads(procs(False), False)
-    y_exact, g_exact = grads(procs(False), True)
-    y_plain, g_plain = grads(procs(True), False)
+    y_alias, g_alias = grads(procs(), False, True)
+    y_exact, g_exact = grads(procs(), True, True)
+    y_plain, g_plain = grads(procs(), True, False)      # setting held through the backward: the plain convolution
     assert_close(y_exact.cpu(), y_plain.cpu(), 1e-6, "forward under set_exact_convolution(True)")
     assert (y_alias - y_plain).abs().max() > 1e-4 * y_plain.abs().max()   # the aliasing is visible at these lengths
     differs = False
