@@ -182,6 +182,7 @@ def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
+GFX_EINVAL = -1                                  # include/grafx_amd.h
 SCHEDULES = {"auto": 0, "tile": 1, "pipe": 2}   # GFX_SCHED_* of include/grafx_amd.h
 # What `schedule="auto"` means to fftconv(): "auto" (the library decides: the persistent hand-scheduled kernel for large
 # launches it covers) or "pipe" (prefer that kernel at every size it covers -- tests and latency experiments).
@@ -225,8 +226,11 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
 
     with _timed(name, 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)):
         if schedule == "auto" and FFTCONV_SCHEDULE == "pipe":
-            if launch("pipe") == 0:       # GFX_EINVAL = not covered by the persistent kernel: the library's choice then
+            rc = launch("pipe")
+            if rc == 0:
                 return out
+            if rc != GFX_EINVAL:          # only "not covered by the persistent kernel" falls back to the library's choice;
+                check(rc, "gfx_fftconv_sched_f32 (pipe)")   # a failed launch / code-object load must not be masked
         check(launch(schedule), "gfx_fftconv_sched_f32")
     return out
 

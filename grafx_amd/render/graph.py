@@ -136,12 +136,16 @@ def _mix_schedule(step, nxt, device):
 
 
 def _reads_rows(step, a, b):
-    """Does the stage read a buffer row in [a, b)?"""
+    """Does the stage read a buffer row in [a, b)?  Cached on the stage like _touches_inputs: an index read lives on the
+    device, and asking it costs a host sync per render (illegal while the render is captured into a HIP graph)."""
     read = step.source_reads[0]
     if read.method == "slice":
         return read.idx[0] < b and a < read.idx[1]
-    rows = read.idx.tolist() if isinstance(read.idx, torch.Tensor) else list(read.idx)
-    return any(a <= r < b for r in rows)
+    cache = step.__dict__.setdefault("_reads_rows", {})
+    if (a, b) not in cache:
+        rows = read.idx.tolist() if isinstance(read.idx, torch.Tensor) else list(read.idx)
+        cache[(a, b)] = any(a <= r < b for r in rows)
+    return cache[(a, b)]
 
 
 def _plan_max_row(step, plan):
@@ -382,6 +386,11 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         if mix_with is not None:
             nxt = render_data.iter_list[mix_with]
             sched = _mix_schedule(step, nxt, x.device)
+            if side is not None and not copied and any(r < n_src for r in sched["extra_rows"]):
+                # the sum also takes SOURCE rows, which the kernel reads from `buf`: they are filled by the side stream's
+                # copy, and the skipped mix stage is the one that would have joined it (a stage reading `x` directly has not)
+                main.wait_stream(side)
+                copied = True
             e0, e1 = nxt.dest_write.idx
             mix = extra["_mix"] = {"sched": sched["sched"], "n_acc": sched["n_acc"], "extras": sched["extras"],
                                    "n_pre": sched["n_pre"], "out": buf.narrow(1, e0, e1 - e0)}

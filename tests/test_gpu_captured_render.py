@@ -1,6 +1,5 @@
 """The render captured into one HIP graph (serving path) replays what the eager loop computes: the same kernels in the
-same order -- bit-identical except behind the reverb, whose energy normalisation accumulates with float atomics (two
-eager renders differ from each other by the same last-bit amounts)."""
+same order -- bit-identical (no kernel on the forward path accumulates with float atomics)."""
 import pytest
 import torch
 
@@ -29,9 +28,7 @@ def test_captured_render_replays_the_eager_render(batch):
         with torch.no_grad():
             want_y, _, want_buf = render_grafx(procs, x, p, rd)
         got_y, _, got_buf = fast(x, p)
-        assert torch.equal(got_buf[:, :-2], want_buf[:, :-2])   # every node before the reverb and the output sum
-        assert (got_buf - want_buf).abs().max() <= 2e-6 * want_buf.abs().max()
-        assert (got_y - want_y).abs().max() <= 2e-6 * want_y.abs().max()
+        assert torch.equal(got_buf, want_buf) and torch.equal(got_y, want_y)
 
 
 def test_captured_render_with_the_persistent_convolution_kernel():

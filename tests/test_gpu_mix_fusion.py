@@ -333,3 +333,57 @@ def test_gain_stage_in_front_of_buses_renders_identically():
             ops.MIX_FUSION, ops.stereo_gain = True, real
     assert torch.equal(bufs[True][0], bufs[False][0]) and torch.equal(bufs[True][1], bufs[False][1])
     assert seen[0] is True and seen[-1] is False
+
+
+def test_fused_sum_of_a_source_row_waits_for_the_side_stream_copy():
+    """in -> compressor -> mix(in, compressor) -> out (parallel dry / wet routing): the first stage reads the sources
+    from the caller's tensor, so nothing before the fused kernel has joined the side stream that copies them into the
+    buffer -- the kernel's `extras` read of the source row must.  Large rows, so that the copy is still running when
+    the compressor kernel starts; many repetitions with a buffer whose previous contents are poison."""
+    import grafx_amd.processors as P
+    from grafx_amd import ops
+    from grafx_amd.data import GRAFX, NodeConfigs, convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    torch.manual_seed(11)
+    G = GRAFX(config=NodeConfigs(["compressor"]))
+    src = [G.add("in") for _ in range(3)]
+    out = G.add("out")
+    for s in src:
+        c, m = G.add("compressor"), G.add("mix")
+        G.connect(s, c)
+        G.connect(s, m)
+        G.connect(c, m)
+        G.connect(m, out)
+    procs = {"compressor": P.Compressor(energy_smoother="iir", iir_len=255, flashfftconv=False).cuda()}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    params = {t: {k: v.cuda() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.3).items()}
+    B, L = 48, 1 << 20                                       # 1.2 GB of sources: the copy takes ~0.4 ms
+    x = torch.randn(B, 3, 2, L, device="cuda")
+    seen = []
+    real = ops.dynamics_fused
+
+    def spy(*a, **k):
+        o = real(*a, **k)
+        seen.append(bool(k.get("mix") is not None and k["mix"].get("done")))
+        return o
+
+    ops.MIX_FUSION = False
+    try:
+        with torch.no_grad():
+            want = render_grafx(procs, x, params, rd)[0].clone()
+    finally:
+        ops.MIX_FUSION = True
+    ops.dynamics_fused = spy
+    try:
+        for rep in range(6):
+            # poison the block the allocator will hand out for the next signal buffer
+            poison = torch.full((B, rd.num_nodes, 2, L), float("nan"), device="cuda")
+            del poison
+            with torch.no_grad():
+                got = render_grafx(procs, x, params, rd)[0]
+            assert torch.equal(got, want), f"repetition {rep}: the fused sum read source rows before they were copied"
+    finally:
+        ops.dynamics_fused = real
+    assert any(seen), "the fused routing sum was not taken: the test does not exercise the race"

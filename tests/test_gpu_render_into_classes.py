@@ -68,7 +68,7 @@ def test_render_into_class_through_render_grafx(name, ndim, grad):
     fx = fx[0] if isinstance(fx, tuple) else fx
     want = fx.view(B, n, 2, L).sum(1, keepdim=True)
     got = y.view(B, 1, 2, L)
-    tol = 2e-6 if name == "reverb" else 1e-6   # (the reverb's energy normalisation accumulates with float atomics)
+    tol = 1e-6   # (the out node's sum runs in the gather kernel here and in torch there: same values, other order)
     assert (got - want).abs().max() <= tol * want.abs().max(), name
     if grad:
         got.square().mean().backward()
