@@ -50,9 +50,10 @@ def parse_args(argv=None):
                     help="CPU plumbing check: pass-through processors on CPU tensors (launch, sharding, barriers, JSON)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 6 s repetition of the headline step (`sustained`)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the cfg2 / cfg3 measurements (BASELINE configs[1] / configs[2]) that the default single-GPU "
-                         "run appends to the line as `secondary`")
+                         "run appends to the line as `secondary`, with their compat (upstream default tap counts) twins")
     ap.add_argument("--reference-default-lengths", action="store_true",
                     help="use the reference's default (even) filter lengths 4000/16384/60000: every convolve() then takes "
                          "the odd-P aliasing compatibility path (DESIGN.md section 2); not the headline configuration")
@@ -138,16 +139,26 @@ def console_graph(n_ch=32, n_bus=4):
 LENS = dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001)
 
 
-def hip_processors(default_args=False):
+# upstream's constructor defaults: even, so that L + N - 1 is odd at every BASELINE audio length and convolve() aliases
+# (SURVEY F3): the "compat" legs of the line
+REFERENCE_DEFAULT_LENS = dict(fsm_fir_len=4000, iir_len=16384, ir_len=60000)
+
+
+def hip_processors(default_args=False, lens=None):
     from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
 
     if default_args:  # upstream's constructor defaults: flashfftconv=True (-> warning + native convolve), 4000 / 16384 / 60000 taps
-        return {"eq": ParametricEqualizer(num_filters=6), "compressor": Compressor(energy_smoother="iir"),
-                "reverb": STFTMaskedNoiseReverb()}
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # "FlashFFTConv is not available. Using native convolution instead."
+            return {"eq": ParametricEqualizer(num_filters=6), "compressor": Compressor(energy_smoother="iir"),
+                    "reverb": STFTMaskedNoiseReverb()}
+    lens = lens or LENS
     return {
-        "eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=LENS["fsm_fir_len"]),
-        "compressor": Compressor(energy_smoother="iir", iir_len=LENS["iir_len"], flashfftconv=False),
-        "reverb": STFTMaskedNoiseReverb(ir_len=LENS["ir_len"], flashfftconv=False),
+        "eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=lens["fsm_fir_len"]),
+        "compressor": Compressor(energy_smoother="iir", iir_len=lens["iir_len"], flashfftconv=False),
+        "reverb": STFTMaskedNoiseReverb(ir_len=lens["ir_len"], flashfftconv=False),
     }
 
 
@@ -180,22 +191,47 @@ def oracle_processors():
     }
 
 
-def _timed_cpu(fn, budget_s, warm=2, reps=5):
-    """median of `reps` after `warm` warm-ups, cut short when the budget runs out"""
+def _timed_cpu(fn, budget_s, warm=2, reps=5, min_total_s=0.0):
+    """median of `reps` (more when they are short: at least `min_total_s` of timed work) after `warm` warm-ups
+    (SURVEY section 8d), cut short when the budget runs out"""
     t_all = time.perf_counter()
     times = []
-    for i in range(warm + reps):
+    i = 0
+    while True:
         t0 = time.perf_counter()
         fn()
         dt = time.perf_counter() - t0
         if i >= warm:
             times.append(dt)
-        if time.perf_counter() - t_all > budget_s and i >= warm:
+        i += 1
+        spent = time.perf_counter() - t_all
+        if i >= warm + 1 and spent > budget_s:
+            break
+        if len(times) >= reps and sum(times) >= min_total_s:
             break
     return times
 
 
-def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=20.0):
+def _cpu_thread_counts():
+    """SURVEY 8d asks for all host cores; torch's CPU FFT gets SLOWER when a large host is oversubscribed (256 threads on
+    the GPU box), so both are timed and the faster is reported, with the other one next to it."""
+    ncpu = os.cpu_count() or 1
+    return ncpu, sorted({ncpu, min(ncpu, 32)}, reverse=True)
+
+
+def _best_cpu(run, budget_s, min_total_s=0.0):
+    import torch
+
+    ncpu, counts = _cpu_thread_counts()
+    tried = {}
+    for th in counts:
+        torch.set_num_threads(th)
+        tried[th] = _timed_cpu(run, budget_s / len(counts), min_total_s=min_total_s / len(counts))
+    best = min(tried, key=lambda th: statistics.median(tried[th]))
+    return ncpu, best, tried
+
+
+def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=24.0):
     """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample."""
     import torch
 
@@ -204,26 +240,27 @@ def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=20.0):
     procs = oracle_processors()
     B = 4
     x = torch.randn(B, 32, 2, L)
-    ncpu = os.cpu_count() or 1
-    threads = min(ncpu, 32)  # torch's CPU FFT gets slower when a large host is oversubscribed
-    torch.set_num_threads(threads)
-    with torch.no_grad():
-        times = _timed_cpu(lambda: render_grafx(procs, x, params_cpu, render_data, parameters_grad=False), budget_s)
+
+    def run():
+        with torch.no_grad():
+            render_grafx(procs, x, params_cpu, render_data, parameters_grad=False)
+
+    ncpu, threads, tried = _best_cpu(run, budget_s)
+    times = tried[threads]
     med = statistics.median(times)
     return {"value": B * L / med, "unit": "audio samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
             "seconds": [round(t, 3) for t in times],
+            "other_thread_counts": {str(th): round(B * L / statistics.median(ts)) for th, ts in tried.items() if th != threads},
             "sample": f"same 111-node console graph and filter lengths, batch {B} (of 256), L={L}; median of "
-                      f"{len(times)} renders after 2 warm-ups, {threads} torch threads (torch CPU oracle, fp32)"}
+                      f"{len(times)} renders after 2 warm-ups, {threads} torch threads (the faster of "
+                      f"{sorted(tried)} threads; torch CPU oracle, fp32)"}
 
 
-def cpu_baseline_proc(kind, L, budget_s=15.0):
+def cpu_baseline_proc(kind, L, budget_s=24.0):
     import torch
 
     import oracle
 
-    ncpu = os.cpu_count() or 1
-    threads = min(ncpu, 32)
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     if kind == "cfg2":
         R = 8
@@ -232,22 +269,48 @@ def cpu_baseline_proc(kind, L, budget_s=15.0):
         p = {k: torch.randn(R, 1, 6) for k in ("w0", "q_inv", "log_gain")}
         C = 1
     else:
-        R = 8
+        R = 32
         proc = oracle.OracleSTFTMaskedNoiseReverb(ir_len=LENS["ir_len"])
         x = torch.randn(R, 2, L)
         p = {k: torch.randn(R, 2, 193) for k in ("init_log_magnitude", "delta_log_magnitude")}
         C = 2
-    with torch.no_grad():
-        times = _timed_cpu(lambda: proc(x, **p), budget_s)
+
+    def run():
+        with torch.no_grad():
+            proc(x, **p)
+
+    ncpu, threads, tried = _best_cpu(run, budget_s, min_total_s=10.0)
+    times = tried[threads]
     med = statistics.median(times)
     return {"value": R * C * L / med, "unit": "channel-samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
-            "seconds": [round(t, 3) for t in times],
+            "seconds": [round(t, 3) for t in times], "timed_seconds_total": round(sum(times), 2),
+            "other_thread_counts": {str(th): round(R * C * L / statistics.median(ts)) for th, ts in tried.items() if th != threads},
             "sample": f"{R} rows (of the full batch) x {C} x {L}, same processor and filter length; median of {len(times)} "
-                      f"calls after 2 warm-ups, {threads} torch threads (torch CPU oracle, fp32)"}
+                      f"calls after 2 warm-ups, {threads} torch threads (the faster of {sorted(tried)}; torch CPU oracle, fp32)"}
 
 
-def roofline_from_profile(prof, steps, elapsed, B, L):
-    """Dominant kernel (largest summed launch time inside the timed region, HIP events on its stream)."""
+def profile_traffic(kernel, B, L, lens):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rN/pmc_hbm_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied) -- a PROFILE figure,
+    not one measured in this run; None when no committed profile matches the workload."""
+    for rnd in ("r4", "r3", "r2", "r1"):
+        pmc = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
+        if not os.path.exists(pmc):
+            continue
+        with open(pmc) as f:
+            rec = json.load(f)
+        cfg = rec.get("config", {})
+        if cfg.get("batch") == B and cfg.get("audio_len") == L and all(cfg.get(k) == v for k, v in lens.items()):
+            for key in (kernel, "gfx::" + kernel, "gfx::" + kernel.split("<")[0]):
+                k = rec["kernels"].get(key)
+                if k:
+                    return k["hbm_bytes_per_launch"], f"profiles/{rnd}/pmc_hbm_traffic.json"
+    return None, None
+
+
+def roofline_from_profile(prof, steps, elapsed, B, L, lens=None):
+    """Dominant kernel (largest summed launch time inside the timed region, HIP events on its stream).  Records are keyed
+    by the kernels' own names -- what `rocprofv3 --kernel-trace` prints for the same launches."""
     stats = {}
     for name, recs in prof.items():
         ms = [a.elapsed_time(b) for a, b, _ in recs]
@@ -255,24 +318,69 @@ def roofline_from_profile(prof, steps, elapsed, B, L):
     name = max(stats, key=lambda k: stats[k][0])
     total_ms, avg_ms, avg_bytes, n = stats[name]
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
-    for rnd in ("r3", "r2", "r1"):
-        pmc = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
-        if not os.path.exists(pmc):  # PMC bytes come from a separate rocprofv3 --pmc pass of this same command
-            continue
-        with open(pmc) as f:
-            rec = json.load(f)
-        cfg = rec.get("config", {})
-        if cfg.get("batch") == B and cfg.get("audio_len") == L and all(cfg.get(k) == v for k, v in LENS.items()):
-            k = rec["kernels"].get("gfx::" + name) or rec["kernels"].get(name)
-            if k:
-                traffic, traffic_src = k["hbm_bytes_per_launch"], f"profiles/{rnd}/pmc_hbm_traffic.json"
-                break
+    traffic, traffic_src = profile_traffic(name, B, L, lens or LENS)
     return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_profile": traffic,
+            "traffic_source": None if traffic_src is None else
+            f"{traffic_src} (separate rocprofv3 --pmc passes of this command, not measured in this run)",
             "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": avg_bytes, "launches_per_step": n // steps,
             "share_of_step": total_ms / steps / (elapsed / steps * 1e3),
-            "per_kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(stats.items())}}
+            "per_kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(stats.items())},
+            "per_kernel_frac_of_hbm_peak": {k: round(v[2] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                            for k, v in sorted(stats.items())}}
+
+
+class GpuSampler:
+    """Shader clock and board power from the amdgpu hwmon files (readable without privileges), sampled by a thread every
+    50 ms while a loop runs.  A box may list several cards; the one that drew the most power is the one that worked."""
+
+    def __init__(self, period=0.05):
+        import glob
+        import threading
+
+        self.period = period
+        self.cards = {}
+        for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+            f, p = os.path.join(h, "freq1_input"), os.path.join(h, "power1_input")
+            if os.path.exists(f):
+                self.cards[h] = (f, p if os.path.exists(p) else None)
+        self.samples = {h: [] for h in self.cards}
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for h, (f, p) in self.cards.items():
+                self.samples[h].append((self._read(f), self._read(p) if p else None))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+
+    def summary(self):
+        best = None
+        for h, xs in self.samples.items():
+            fr = [a for a, _ in xs if a is not None]
+            pw = [b for _, b in xs if b is not None]
+            if not fr:
+                continue
+            rec = {"sclk_mhz_mean": sum(fr) / len(fr) / 1e6, "sclk_mhz_min": min(fr) / 1e6, "sclk_mhz_max": max(fr) / 1e6,
+                   "power_w_mean": sum(pw) / len(pw) / 1e6 if pw else None, "samples": len(fr), "source": h + "/freq1_input"}
+            if best is None or (rec["power_w_mean"] or 0) > (best["power_w_mean"] or 0):
+                best = rec
+        return best or {"sclk_mhz_mean": None, "samples": 0, "source": None}
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -413,6 +521,13 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     assert torch.isfinite(y).all(), "render produced non-finite samples"
     roof = roofline_from_profile(prof, args.steps, elapsed, B, L) if prof else None
 
+    sustained = None
+    if world == 1 and not (args.dry or args.no_sustained):
+        try:
+            sustained = sustained_leg(torch, step, sync, elapsed / args.steps * 1e3)
+        except Exception as e:
+            sustained = {"error": f"{type(e).__name__}: {e}"}
+
     train = None
     if not (args.no_train or args.capture):
         del y
@@ -482,6 +597,8 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
                              "achieved_GBps": moved / (ms_per_step * 1e-3) / 1e9,
                              "frac_of_hbm_peak": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_equivalent_GBps": graph_bytes / (ms_per_step * 1e-3) / 1e9}
+    if sustained is not None:
+        out["sustained"] = sustained
     if train is not None:
         out["training"] = train
     if secondary is not None:
@@ -541,10 +658,11 @@ def train_leg(args, torch, dist, dev, world, procs, params, x, rd_dev, L, sync, 
             "peak_mem_GiB": None if args.dry else torch.cuda.max_memory_allocated() / 2**30}
 
 
-def processor_case(cfg, torch, dev, rank, batch=None, length=None):
+def processor_case(cfg, torch, dev, rank, batch=None, length=None, lens=None):
     """BASELINE configs[1] / configs[2] as (step function, rows, channels, length, description)."""
     from grafx_amd.processors import ParametricEqualizer, STFTMaskedNoiseReverb
 
+    LENS = lens or globals()["LENS"]
     torch.manual_seed(1000 + rank)
     if cfg == "cfg2":
         R, C, L = batch or 1024, 1, length or 480000
@@ -574,33 +692,89 @@ def call_roofline(R, C, L, ms_per_step):
     return {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
 
 
+def console_case(torch, dev, B, L, lens, seed=1234):
+    """The headline console graph on a resident batch of B graphs as a step function (forward render)."""
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    G = console_graph()
+    procs = {k: v.to(dev) for k, v in hip_processors(lens=lens).items()}
+    torch.manual_seed(seed)
+    params = {t: {k: v.detach().to(dev) for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    x = torch.randn(B, 32, 2, L, device=dev)
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return render_grafx(procs, x, params, rd, parameters_grad=False)[0]
+
+    return step
+
+
 def secondary_leg(torch, dev, sync, steps=20, warmup=5):
-    """BASELINE configs[1] and configs[2] on this GPU, a few milliseconds each, appended to the headline line so that the
-    driver's own run records them: ms per call, the call's algorithmic-bytes roofline and the dominant kernel's."""
+    """The other single-GPU workloads, a few milliseconds to a few hundred each, appended to the headline line so that the
+    driver's own run records them: BASELINE configs[1] and configs[2] with the exact (odd) tap counts, and the "compat"
+    legs of SURVEY 8d -- the same two processors and the console graph with upstream's default even tap counts
+    (4000 / 16384 / 60000), where every convolve() takes the odd-length aliasing path.  Per leg:
+    ms per call, the call's algorithmic-bytes roofline and the dominant kernel's."""
     from grafx_amd import ops
 
     out = {}
-    for cfg in ("cfg2", "cfg3"):
+    legs = [("cfg2", "cfg2", None, steps, warmup), ("cfg3", "cfg3", None, steps, warmup),
+            ("cfg2_compat", "cfg2", REFERENCE_DEFAULT_LENS, 5, 2), ("cfg3_compat", "cfg3", REFERENCE_DEFAULT_LENS, 5, 2),
+            ("cfg4_compat", "cfg4", REFERENCE_DEFAULT_LENS, 5, 2)]
+    for key, cfg, lens, n, w in legs:
         torch.cuda.empty_cache()
-        step, R, C, L, what = processor_case(cfg, torch, dev, 0)
-        for _ in range(warmup):
-            y = step()
-        sync()
-        with ops.profiling() as prof:
-            t0 = time.perf_counter()
-            for _ in range(steps):
+        try:
+            if cfg == "cfg4":
+                R, C, L = 64, 2, 131072     # graphs (of 256): the aliasing workspaces are sized per row
+                step = console_case(torch, dev, R, L, lens)
+                what = (f"BASELINE configs[3] console graph at batch {R} (of 256), L={L}, upstream default tap counts "
+                        f"{lens['fsm_fir_len']} / {lens['iir_len']} / {lens['ir_len']}: every convolve() aliases (odd L + N - 1)")
+                unit, units = "audio samples/s", R * L
+                call_bytes = 285 * R * 2 * L * 4
+            else:
+                step, R, C, L, what = processor_case(cfg, torch, dev, 0, lens=lens)
+                unit, units = "channel-samples/s", R * C * L
+                call_bytes = 8 * R * C * L
+            for _ in range(w):
                 y = step()
             sync()
-            elapsed = time.perf_counter() - t0
-        assert torch.isfinite(y).all(), f"{cfg}: non-finite samples"
-        ms = elapsed / steps * 1e3
-        roof = roofline_from_profile(prof, steps, elapsed, R, L)
-        out[cfg] = {"workload": what, "steps": steps, "warmup": warmup, "ms_per_step": ms,
-                    "value": R * C * L * steps / elapsed, "unit": "channel-samples/s",
-                    "call_roofline": call_roofline(R, C, L, ms), "roofline": roof}
-        del step, y
+            with ops.profiling() as prof:
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    y = step()
+                sync()
+                elapsed = time.perf_counter() - t0
+            assert torch.isfinite(y).all(), f"{key}: non-finite samples"
+            ms = elapsed / n * 1e3
+            gbps = call_bytes / (ms * 1e-3) / 1e9
+            out[key] = {"workload": what, "steps": n, "warmup": w, "ms_per_step": ms,
+                        "value": units * n / elapsed, "unit": unit,
+                        "call_roofline": {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps,
+                                          "frac_of_hbm_peak": gbps / HBM_PEAK_GBS},
+                        "roofline": roofline_from_profile(prof, n, elapsed, R, L, lens)}
+            del step, y
+        except Exception as e:  # one leg must not take the others (or the headline) with it
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
     return out
+
+
+def sustained_leg(torch, step, sync, ms_per_step, seconds=6.0):
+    """The headline step repeated for >= `seconds` (the 20-step timed region is 0.2 s: too short for a power-limited
+    kernel to show the clock it holds), with the shader clock and the board power sampled meanwhile."""
+    n = max(50, int(seconds * 1e3 / ms_per_step) + 1)
+    sync()
+    with GpuSampler() as smp:
+        t0 = time.perf_counter()
+        for _ in range(n):
+            y = step()
+        sync()
+        dt = time.perf_counter() - t0
+    del y
+    return {"seconds": dt, "steps": n, "ms_per_step": dt / n * 1e3, **smp.summary()}
 
 
 def bench_processor(args, torch, dist, dev, world, rank, sync, fence):

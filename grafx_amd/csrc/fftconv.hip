@@ -675,6 +675,8 @@ static int auto_schedule() {
 }
 
 
+static thread_local const char* t_last_kernel = "";   // see gfx_fftconv_last_kernel
+
 template <typename K>
 static int allow_lds(K kernel) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -852,7 +854,11 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
         else return GFX_EINVAL;
     }
     if (schedule == GFX_SCHED_PIPE || (schedule == GFX_SCHED_AUTO && pv >= 0 && GFX_PIPE_AUTO && a.nblocks >= 16 * pm->cus))
-        return launch_pipe(pm, pv, x, Hs, y, xcopy, a, tw, st);
+    {
+        const int rc = launch_pipe(pm, pv, x, Hs, y, xcopy, a, tw, st);
+        if (rc == GFX_OK) t_last_kernel = kPipeVariants[pv].name;
+        return rc;
+    }
     if (g.nparts == 1) {
         if (allow_lds(fftconv1_kernel<false>) || allow_lds(fftconv1_kernel<true>)) return GFX_ELAUNCH;
         if (xcopy)
@@ -861,13 +867,17 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
         else
             hipLaunchKernelGGL(fftconv1_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
                                (const float4*)Hs, y, (float*)nullptr, a, tw);
-        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+        if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
+        t_last_kernel = xcopy ? "fftconv1_kernel<true>" : "fftconv1_kernel<false>";
+        return GFX_OK;
     }
     if (g.ntiles == 1) {
         if (allow_lds(winmac_kernel)) return GFX_ELAUNCH;
         hipLaunchKernelGGL(winmac_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, (const float4*)Hs, y,
                            a, tw);
-        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+        if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
+        t_last_kernel = "winmac_kernel";
+        return GFX_OK;
     }
     const int64_t nwin = g.ntiles + g.nparts - 1;
     const size_t need = (size_t)R * C_in * nwin * TILE_M * sizeof(float2);
@@ -880,7 +890,11 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                        nwin, tw);
     hipLaunchKernelGGL(macinv_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, (const float2*)ws,
                        (const float4*)Hs, y, a, nwin, tw);
-    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
+    t_last_kernel = "xspec_kernel+macinv_kernel";
+    return GFX_OK;
 }
+
+const char* gfx_fftconv_last_kernel(void) { return t_last_kernel; }
 
 }  // extern "C"

@@ -137,6 +137,12 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                           void* ws, size_t ws_bytes, int schedule, void* stream);
 
+/* Diagnostic: the name -- as rocprofv3's kernel trace prints it -- of the (dominant) kernel that the calling thread's last
+ * successful gfx_fftconv_* call launched: "gfx_fftconv_pipe_t1_o8", "fftconv1_kernel<true>", "winmac_kernel",
+ * "xspec_kernel+macinv_kernel"; "" before the first call.  The string is static.  (bench.py labels its live per-launch
+ * timings with it, so that the line's `roofline.kernel` is a name a profile of the same command contains.) */
+const char* gfx_fftconv_last_kernel(void);
+
 /* Short filters (N <= gfx_fir_direct_max_taps() = 512) as batched Toeplitz GEMMs on the fp32 matrix cores, taps given
  * directly (no spectra): the direct-form counterpart of gfx_fftconv_ex_f32 with the same meaning of every argument
  *   y[r, c, n] = sum_k h[r % h_rows, c_f, k] x[r, c_x, n + off - k],  n in [0, Lout),  x zero outside [0, L)

@@ -54,7 +54,8 @@ def test_captured_render_with_the_persistent_convolution_kernel():
         with ops.profiling() as prof:
             with torch.no_grad():
                 eager_y, _, _ = render_grafx(procs, x, params, rd)
-        assert "fftconv1_kernel" in prof
+        # the live timing hook keys its records by the launched kernel's own name (gfx_fftconv_last_kernel)
+        assert any(k.startswith("gfx_fftconv_pipe_t") for k in prof), list(prof)
         fast = CapturedRender(procs, x, params, rd)
         got_y, _, got_buf = fast(x, params)
     finally:

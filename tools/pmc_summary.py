@@ -3,8 +3,9 @@
 
 HBM bytes per launch = FETCH_SIZE (KB, x2 on gfx950: the counter tallies 128-byte requests as 64 bytes --
 MI355X_MICROARCH.md, HBM / rocprofv3 section) + WRITE_SIZE (KB), averaged over the launches of a kernel.
-Template instances of one kernel (fftconv1_kernel<true>/<false>) are pooled under the bare name, which is
-what bench.py's live timing hook keys on.
+Template instances of one kernel (fftconv1_kernel<true>/<false>) are pooled under the bare name; the hand-scheduled
+persistent kernels keep their own names (gfx_fftconv_pipe_t1_o8, ...), which is what bench.py's live timing hook
+keys on (gfx_fftconv_last_kernel).
 """
 import collections
 import csv
@@ -17,17 +18,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r3"))
+DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r4"))
 
 
 def bare(name):
     name = re.sub(r"^void\s+", "", name)
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"<.*$", "", name)
-    # the hand-scheduled persistent kernels (csrc/asm) are the large-launch form of fftconv1_kernel: bench.py times both
-    # under that one name, so their counters are pooled there too
-    if name.startswith("gfx_fftconv_pipe"):
-        return "gfx::fftconv1_kernel"
     return name
 
 
@@ -55,7 +52,7 @@ def main():
     fetch, write = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
-        if not k.startswith("gfx::"):
+        if not k.startswith(("gfx::", "gfx_")):
             continue
         f = sum(fetch[k]) / max(len(fetch[k]), 1)
         w = sum(write[k]) / max(len(write[k]), 1)
@@ -77,29 +74,31 @@ def main():
         "kernels": kernels,
     }
     json.dump(rec, open(os.path.join(DST, "pmc_hbm_traffic.json"), "w"), indent=1)
-    # the line's roofline, recomputed from the kernel trace of the same command: the convolution launches of the timed
-    # region are the last 2 * steps ones (nothing runs after it with --no-train --no-secondary --no-cpu-baseline)
+    # the line's roofline, recomputed from the kernel trace of the same command: the dominant kernel's launches of the
+    # timed region are its last launches_per_step * steps ones (nothing runs after it with --no-train --no-secondary
+    # --no-sustained --no-cpu-baseline)
     under = json.loads(open(os.path.join(RAW, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    roof = under["roofline"]
+    dom = roof["kernel"]
     rows = []
     for f in glob.glob(os.path.join(RAW, "trace", "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if bare(r["Kernel_Name"]) == "gfx::fftconv1_kernel":
+            if bare(r["Kernel_Name"]) in (dom, "gfx::" + dom.split("<")[0]):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    n = 2 * under["steps"]
+    n = roof["launches_per_step"] * under["steps"]
     last = rows[-n:]
     avg_ms = sum(d for _, d, _ in last) / len(last) / 1e6
-    roof = under["roofline"]
-    rec2 = {"what": "fftconv1 launches of the timed region of bench_under_rocprof.json, from the rocprofv3 kernel trace",
+    rec2 = {"what": f"launches of {dom} in the timed region of bench_under_rocprof.json, from the rocprofv3 kernel trace",
             "launches": len(last), "avg_launch_ms_trace": avg_ms, "avg_launch_ms_line": roof["avg_launch_ms"],
             "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
             "frac_trace": roof["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / roof["peak"], "frac_line": roof["frac"],
             "kernels": sorted({k for _, _, k in last})}
-    json.dump(rec2, open(os.path.join(DST, "fftconv1_roofline_from_trace.json"), "w"), indent=1)
+    json.dump(rec2, open(os.path.join(DST, "roofline_from_trace.json"), "w"), indent=1)
     print("roofline frac: line", round(roof["frac"], 4), "trace", round(rec2["frac_trace"], 4))
-    k = kernels.get("gfx::fftconv1_kernel")
+    k = kernels.get(dom) or kernels.get("gfx::" + dom.split("<")[0])
     print("bench:", bench["ms_per_step"], "ms/step", bench["value"], bench["unit"])
-    print("fftconv1 HBM bytes/launch:", k and k["hbm_bytes_per_launch"])
+    print(dom, "HBM bytes/launch:", k and k["hbm_bytes_per_launch"], "algorithmic", roof["algorithmic_bytes_per_launch"])
     for name in ("gfx::dyn_oneshot_mix_kernel", "gfx::dyn_oneshot_kernel"):
         d = kernels.get(name)
         print(name, "HBM bytes/launch:", d and (d["hbm_read_bytes_per_launch_corrected"], d["hbm_write_bytes_per_launch"]))
