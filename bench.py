@@ -212,26 +212,27 @@ def _timed_cpu(fn, budget_s, warm=2, reps=5, min_total_s=0.0):
     return times
 
 
-def _cpu_thread_counts():
-    """SURVEY 8d asks for all host cores; torch's CPU FFT gets SLOWER when a large host is oversubscribed (256 threads on
-    the GPU box), so both are timed and the faster is reported, with the other one next to it."""
-    ncpu = os.cpu_count() or 1
-    return ncpu, sorted({ncpu, min(ncpu, 32)}, reverse=True)
-
-
-def _best_cpu(run, budget_s, min_total_s=0.0):
+def _best_cpu(run, budget_s, min_total_s=0.0, probe=None):
+    """SURVEY 8d asks for all host cores; torch's CPU FFT gets much SLOWER when a large host is oversubscribed (256
+    threads on the GPU box: ~25x), so the sample is timed on min(cores, 32) threads and ONE un-warmed run of `probe`
+    (a smaller sample) on all cores is reported next to it.  -> (host cpus, threads used, times, all-core probe seconds)"""
     import torch
 
-    ncpu, counts = _cpu_thread_counts()
-    tried = {}
-    for th in counts:
-        torch.set_num_threads(th)
-        tried[th] = _timed_cpu(run, budget_s / len(counts), min_total_s=min_total_s / len(counts))
-    best = min(tried, key=lambda th: statistics.median(tried[th]))
-    return ncpu, best, tried
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    torch.set_num_threads(threads)
+    times = _timed_cpu(run, budget_s, min_total_s=min_total_s)
+    probe_s = None
+    if probe is not None and ncpu > threads:
+        torch.set_num_threads(ncpu)
+        t0 = time.perf_counter()
+        probe()
+        probe_s = time.perf_counter() - t0
+        torch.set_num_threads(threads)
+    return ncpu, threads, times, probe_s
 
 
-def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=24.0):
+def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=15.0):
     """The CPU oracle (a port of the reference's algorithm) on the host cores, bounded sample."""
     import torch
 
@@ -245,15 +246,19 @@ def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=24.0):
         with torch.no_grad():
             render_grafx(procs, x, params_cpu, render_data, parameters_grad=False)
 
-    ncpu, threads, tried = _best_cpu(run, budget_s)
-    times = tried[threads]
+    def probe():
+        with torch.no_grad():
+            render_grafx(procs, x[:1], params_cpu, render_data, parameters_grad=False)
+
+    ncpu, threads, times, probe_s = _best_cpu(run, budget_s, probe=probe)
     med = statistics.median(times)
     return {"value": B * L / med, "unit": "audio samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
             "seconds": [round(t, 3) for t in times],
-            "other_thread_counts": {str(th): round(B * L / statistics.median(ts)) for th, ts in tried.items() if th != threads},
+            "all_cores_probe": None if probe_s is None else {
+                "threads": ncpu, "value": L / probe_s, "seconds": round(probe_s, 2),
+                "sample": "one un-warmed render of batch 1 on all host threads (oversubscribed torch FFT: slower)"},
             "sample": f"same 111-node console graph and filter lengths, batch {B} (of 256), L={L}; median of "
-                      f"{len(times)} renders after 2 warm-ups, {threads} torch threads (the faster of "
-                      f"{sorted(tried)} threads; torch CPU oracle, fp32)"}
+                      f"{len(times)} renders after 2 warm-ups, {threads} torch threads (torch CPU oracle, fp32)"}
 
 
 def cpu_baseline_proc(kind, L, budget_s=24.0):
@@ -279,14 +284,12 @@ def cpu_baseline_proc(kind, L, budget_s=24.0):
         with torch.no_grad():
             proc(x, **p)
 
-    ncpu, threads, tried = _best_cpu(run, budget_s, min_total_s=10.0)
-    times = tried[threads]
+    ncpu, threads, times, _ = _best_cpu(run, budget_s, min_total_s=10.0)
     med = statistics.median(times)
     return {"value": R * C * L / med, "unit": "channel-samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
             "seconds": [round(t, 3) for t in times], "timed_seconds_total": round(sum(times), 2),
-            "other_thread_counts": {str(th): round(R * C * L / statistics.median(ts)) for th, ts in tried.items() if th != threads},
             "sample": f"{R} rows (of the full batch) x {C} x {L}, same processor and filter length; median of {len(times)} "
-                      f"calls after 2 warm-ups, {threads} torch threads (the faster of {sorted(tried)}; torch CPU oracle, fp32)"}
+                      f"calls after 2 warm-ups, {threads} torch threads (torch CPU oracle, fp32)"}
 
 
 def profile_traffic(kernel, B, L, lens):

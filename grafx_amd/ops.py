@@ -351,10 +351,13 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=256, precise=False):
     rows = flat.shape[0]
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
     chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise)
+    # one record per chunk: the column / tile / column passes of the two chirp-z transforms (czt.hip), read z + write y
+    name = "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel" + ("<double>" if precise else "<float>")
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
-        check(fwd(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
-                  _stream()), tag + "f32")
+        with _timed(name, 4 * n * (P + length)):
+            check(fwd(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
+                      _stream()), tag + "f32")
     return out.view(*z.shape[:-1], length)
 
 

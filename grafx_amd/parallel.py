@@ -20,10 +20,12 @@ def shard_batch(x, rank=None, world_size=None):
     return x[rank * per : min(B, (rank + 1) * per)]
 
 
-def all_reduce_gradients(parameters, average=True):
-    """Sum (or average) the gradients of shared parameters across ranks with ONE flat all-reduce."""
+def all_reduce_gradients(parameters, average=True, force=False):
+    """Sum (or average) the gradients of shared parameters across ranks with ONE flat all-reduce.  A single rank has
+    nothing to exchange and returns at once; ``force=True`` runs the collective anyway (a 1-rank RCCL all-reduce is an
+    identity, but it is the same flatten / all_reduce / scatter-back call sequence: tests/test_gpu_rccl.py)."""
     grads = [p.grad for p in parameters if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not grads or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
