@@ -1465,8 +1465,8 @@ __global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__
 // "walk" coordinates of dyn_bwd_c_stream the adjoint of the smoother is the same one-pole scan, so a wave takes 512 walk
 // positions, rebuilds the scan state entering them from the H positions before (= the H samples LATER in time: lanes
 // 4 l < H recompute denv there from their own predicated loads) and needs nothing from any other tile.  Rows are chosen
-// on the device from the same pole table; per-row sums (knee parameters, pole) are reduced per workgroup and added with
-// float atomics onto outputs the launcher zeroes.  gx, gparams and dalpha mean what they mean in dyn_bwd_c_kernel.
+// on the device from the same pole table; per-row sums (knee parameters, pole) are reduced per workgroup, written to
+// `partial` [row][group][4] and added up in group order by dyn_bwd_sums_kernel.  gx means what it means in dyn_bwd_c_kernel.
 // Knee kind and compressor / gate are template parameters (one gain-curve path per instantiation: the generic code is
 // 15 k instructions, more than the instruction cache holds), every access is a whole aligned float4 (the launcher only
 // takes this path for 16-byte aligned rows of a length divisible by four), and log / exp / the reciprocal are the hardware
@@ -1485,7 +1485,8 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
                                                              const float* __restrict__ log_ratio,
                                                              const float* __restrict__ log_knee,
                                                              const float* __restrict__ tab, const float* __restrict__ u1,
-                                                             float* __restrict__ dalpha, float* __restrict__ gparams,
+                                                             const float* __restrict__ dalpha /* only: wanted? */,
+                                                             float* __restrict__ partial,
                                                              float* __restrict__ gx, DynArgs a, unsigned ngroups,
                                                              unsigned nblocks) {
     __shared__ float red[4][4];
@@ -1616,8 +1617,34 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
         if (lane == 0) red[k][wave] = v;
     }
     __syncthreads();
-    if (t < 3) atomicAdd(gparams + 3 * (size_t)r + t, red[t][0] + red[t][1] + red[t][2] + red[t][3]);
-    if (t == 3 && dalpha) atomicAdd(dalpha + r, (red[3][0] + red[3][1] + red[3][2] + red[3][3]) / one_m_a);   // u1 = (1 - a) U
+    // this workgroup's share of the row's four sums; dyn_bwd_sums_kernel adds the shares in group order (no atomics: the
+    // parameter gradients are the same bits from run to run)
+    if (t < 4) partial[((size_t)r * ngroups + grp) * 4 + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
+}
+
+// gparams[r] (3 sums) and dalpha[r] of the rows dyn_bwd_oneshot_kernel took: its workgroups' partials in group order, one
+// wave per row (lane l adds groups l, l + 64, ... in order, then a shuffle tree).
+__global__ __launch_bounds__(64) void dyn_bwd_sums_kernel(const float* __restrict__ partial, const float* __restrict__ tab,
+                                                          float* __restrict__ gparams, float* __restrict__ dalpha,
+                                                          unsigned ngroups) {
+    const unsigned r = blockIdx.x;
+    const float* tb = tab + (size_t)r * DP_TAB;
+    if (tb[DP_ONESHOT] == 0.0f) return;                 // dyn_bwd_c_kernel wrote this row's sums itself
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (unsigned g = threadIdx.x; g < ngroups; g += 64) {
+        const float* p = partial + ((size_t)r * ngroups + g) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+    if (threadIdx.x == 0) {
+        gparams[3 * (size_t)r + 0] = v[0];
+        gparams[3 * (size_t)r + 1] = v[1];
+        gparams[3 * (size_t)r + 2] = v[2];
+        if (dalpha) dalpha[r] = v[3] / tb[78];   // u1 = (1 - a) U
+    }
 }
 
 // One pass over (x, gy, env): gain = exp(g(log(env + 1e-5))),  dgain = sum_c gy x,  dg = dgain * gain,
@@ -1765,6 +1792,11 @@ int gfx_dynamics_fused_u1_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
 
 size_t gfx_dynamics_ws_bytes(int64_t param_rows) {
     return param_rows <= 0 ? 0 : (size_t)param_rows * DP_TAB * sizeof(float);
+}
+
+size_t gfx_dynamics_bwd_ws_bytes(int64_t R, int64_t L) {   // the pole table + four partial sums per one-shot workgroup
+    if (R <= 0 || L <= 0) return 0;
+    return ((size_t)R * DP_TAB + (size_t)R * (size_t)((L + OS_GTILE - 1) / OS_GTILE) * 4) * sizeof(float);
 }
 
 static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
@@ -1977,7 +2009,7 @@ int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* g
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
         return GFX_EINVAL;
     if (R > 0x7fffffffLL || xmap.inner <= 0 || gmap.inner <= 0 || gxmap.inner <= 0) return GFX_EINVAL;
-    if (ws && ws_bytes < gfx_dynamics_ws_bytes(R)) return GFX_ENOSPC;
+    if (ws && ws_bytes < gfx_dynamics_bwd_ws_bytes(R, L)) return GFX_ENOSPC;
     DynArgs a;
     a.xmap = xmap; a.ymap = gxmap; a.R = R; a.L = L; a.N = iir_len; a.C = (int)C;
     a.smoother = 1; a.knee = knee; a.gate = gate; a.prows = (unsigned)R; a.nchunks = 1; a.chunk_tiles = 0;
@@ -1988,24 +2020,25 @@ int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* g
         return ((uintptr_t)p & 15) == 0 && m.stride_outer % 4 == 0 && m.stride_inner % 4 == 0 && m.stride_ch % 4 == 0;
     };
     const bool vec = L % 4 == 0 && aligned(x, xmap) && aligned(gy, gmap) && aligned(gx, gxmap) && ((uintptr_t)u1 & 15) == 0;
-    if (ws && vec && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL) {
+    if (ws && vec && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL && ws_bytes >= gfx_dynamics_bwd_ws_bytes(R, L)) {
         // rows with a short smoother memory (chosen on the device, as in gfx_dynamics_fused_ws_f32) run as one-shot tiles
-        // that add their per-row sums atomically: zero those outputs first; the row kernel writes the other rows
+        // whose workgroups leave partial sums behind the pole table; the row kernel writes the other rows
         float* t = (float*)ws;
-        if (hipMemsetAsync(gparams, 0, (size_t)R * 3 * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
-        if (dalpha && hipMemsetAsync(dalpha, 0, (size_t)R * sizeof(float), st) != hipSuccess) return GFX_ELAUNCH;
+        float* partial = t + (size_t)R * DP_TAB;
         hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)R), dim3(64), 0, st, z_alpha, t, R, iir_len);
         const unsigned nblocks = (unsigned)(R * ngroups);
         const dim3 grid((nblocks + 7u) & ~7u);
 #define GFX_BWD_OS(K, G)                                                                                                \
     hipLaunchKernelGGL((dyn_bwd_oneshot_kernel<K, G>), grid, dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,     \
-                       log_knee, (const float*)t, u1, dalpha, gparams, gx, a, (unsigned)ngroups, nblocks)
+                       log_knee, (const float*)t, u1, (const float*)dalpha, partial, gx, a, (unsigned)ngroups, nblocks)
         if (gate) {
             if (knee == 0) GFX_BWD_OS(0, true); else if (knee == 1) GFX_BWD_OS(1, true); else GFX_BWD_OS(2, true);
         } else {
             if (knee == 0) GFX_BWD_OS(0, false); else if (knee == 1) GFX_BWD_OS(1, false); else GFX_BWD_OS(2, false);
         }
 #undef GFX_BWD_OS
+        hipLaunchKernelGGL(dyn_bwd_sums_kernel, dim3((unsigned)R), dim3(64), 0, st, (const float*)partial, (const float*)t,
+                           gparams, dalpha, (unsigned)ngroups);
         tab = t;
     }
     hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold,

@@ -332,11 +332,16 @@ __global__ __launch_bounds__(256) void istft_frames_half_kernel(const float* __r
     }
 }
 
-// overlap-add + envelope division + trim (centre) + optional ms->lr.
+// overlap-add + envelope division + trim (centre) + optional ms->lr, and the block's share of the row's energy
+// sum_c sum_t ir[r,c,t]^2 (core/utils.py:16): partial[r][block], summed in a fixed order (a shuffle tree per wave, the four
+// waves in index order) -- the impulse response is not read again for its normalisation.
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
-                                                        float* __restrict__ ir, IstftArgs a, int ms_to_lr) {
+                                                        float* __restrict__ ir, float* __restrict__ partial, IstftArgs a,
+                                                        int ms_to_lr) {
+    __shared__ float red[4];
     const int64_t r = blockIdx.y;
     const int64_t tp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output index after trimming
+    float e = 0.0f;
     if (tp < a.ir_len) {
         const int64_t t = tp + a.n_fft / 2;
         int64_t m_hi = t / a.hop;
@@ -360,25 +365,26 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
         }
         ir[(r * 2 + 0) * a.ir_len + tp] = v0;
         ir[(r * 2 + 1) * a.ir_len + tp] = v1;
+        e = fmaf(v1, v1, v0 * v0);
     }
-}
-
-// row_gain[r] = 1 / sqrt(mean_c sum_t ir[r,c,t]^2 + 1e-12)  (core/utils.py:16-17), one workgroup per row, summed in a fixed
-// order: thread t takes samples t, t + 256, ... of both channels, then a shuffle tree and four partials in index order.
-// (The overlap-add kernel used to add its blocks' partial energies with float atomics: 1-ulp run-to-run differences in
-// the gain, i.e. in every sample of the reverb's output.)
-__global__ __launch_bounds__(256) void ir_energy_gain_kernel(const float* __restrict__ ir, float* __restrict__ gain,
-                                                             int64_t ir_len) {
-    __shared__ float red[4];
-    const int64_t r = blockIdx.x;
-    const float* p = ir + r * 2 * ir_len;
-    float e = 0.0f;
-    for (int64_t t = threadIdx.x; t < 2 * ir_len; t += 256) e = fmaf(p[t], p[t], e);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) e += __shfl_down(e, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0) gain[r] = 1.0f / sqrtf(0.5f * (((red[0] + red[1]) + red[2]) + red[3]) + 1e-12f);
+    if (threadIdx.x == 0) partial[r * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// row_gain[r] = 1 / sqrt(mean_c sum_t ir[r,c,t]^2 + 1e-12)  (core/utils.py:16-17) from the overlap-add kernel's block
+// partials: one wave per row, lane l takes partials l, l + 64, ... in order, then a shuffle tree -- a fixed order, so the
+// gain (a factor of every sample of the reverb's output) is the same bits from run to run.
+__global__ __launch_bounds__(64) void ir_energy_gain_kernel(const float* __restrict__ partial, float* __restrict__ gain,
+                                                            int nblk) {
+    const float* p = partial + (int64_t)blockIdx.x * nblk;
+    float e = 0.0f;
+    for (int b = threadIdx.x; b < nblk; b += 64) e += p[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) e += __shfl_down(e, d, 64);
+    if (threadIdx.x == 0) gain[blockIdx.x] = 1.0f / sqrtf(0.5f * e + 1e-12f);
 }
 
 // ---- FilteredNoiseShapingReverb impulse response (reverb.py:343-366) -----------------------------------
@@ -467,7 +473,8 @@ int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* 
 
 size_t gfx_stft_reverb_workspace_bytes(int64_t R, int64_t n_fft, int64_t num_frames) {
     if (R <= 0 || n_fft <= 0 || num_frames <= 0) return 0;
-    return (size_t)R * 2 * num_frames * n_fft * sizeof(float);
+    // the frames, then one energy partial per 256 impulse-response samples and row (ir_len < num_frames * hop <= num_frames * n_fft)
+    return ((size_t)R * 2 * num_frames * n_fft + (size_t)R * ((num_frames * n_fft + 255) / 256)) * sizeof(float);
 }
 
 int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnitude, const float* delta_log_magnitude,
@@ -513,9 +520,11 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
         hipLaunchKernelGGL(istft_frames_kernel, g1, dim3(256), 0, st, noise_stft, init_log_magnitude,
                            delta_log_magnitude, gain_env_log_magnitude, basis, (float*)ws, a);
     }
+    if (ir_len > num_frames * n_fft) return GFX_EINVAL;   // (the partials' share of the workspace is sized by this bound)
     dim3 g2((unsigned)((ir_len + 255) / 256), (unsigned)R);
-    hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, (const float*)ws, window, ir, a, ms_to_lr);
-    hipLaunchKernelGGL(ir_energy_gain_kernel, dim3((unsigned)R), dim3(256), 0, st, (const float*)ir, row_gain, ir_len);
+    float* partial = (float*)ws + (size_t)R * 2 * num_frames * n_fft;
+    hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, (const float*)ws, window, ir, partial, a, ms_to_lr);
+    hipLaunchKernelGGL(ir_energy_gain_kernel, dim3((unsigned)R), dim3(64), 0, st, (const float*)partial, row_gain, (int)g2.x);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

@@ -602,7 +602,7 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
         _expect(u1, (R, L), "dynamics_bwd: u1")
         ws = None
         if (DYN_SCHEDULE if schedule is None else schedule) == "oneshot":   # one-shot tiles for the short-memory rows
-            ws = torch.empty(lib().gfx_dynamics_ws_bytes(R), dtype=torch.uint8, device=x.device)
+            ws = torch.empty(lib().gfx_dynamics_bwd_ws_bytes(R, L), dtype=torch.uint8, device=x.device)
         check(lib().gfx_dynamics_bwd_u1_ws_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
                                                pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)),
                                                pin(_rowvec(z_alpha, R)), R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx),

@@ -25,6 +25,13 @@ from .core import (
 # re-scanning the input there (-4 % step time at the console graph, +4.8 GB at 256 graphs).  Set to False to trade the
 # memory back for the recompute pass.
 KEEP_SMOOTHER_SCAN = True
+# Where the parameter-only work of the later stages (filter design, the reverb's impulse response and spectra) runs:
+#   "under_first"   on a side stream underneath the first processor stage's signal kernel (the convolution of the first
+#                   equaliser stage in a console: compute-bound, the side kernels take CUs from it);
+#   "under_second"  underneath the second processor stage (the compressors in a console: memory-bound, idle ALUs);
+#   "inline"        no side stream: every stage designs its own filters on the main stream right before it runs.
+# Measured on the headline graph: profiles/r4/prepare_stream_ab.md.
+PREPARE_MODE = "under_first"
 
 
 def _gather_plan(step, device):
@@ -341,11 +348,12 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         return ready
 
     prepared = None
+    launched = 0  # processor stages launched so far
     done = set()  # stages already produced out of schedule order (see below)
 
     def run_stage(i, mix_with=None):
         """Stage i; `mix_with`: the routing-sum stage the processor is offered to produce too -> did it?"""
-        nonlocal copied, prepared
+        nonlocal copied, prepared, launched
         step = render_data.iter_list[i]
         d0, d1 = step.dest_write.idx
         out_v = buf.narrow(1, d0, d1 - d0)
@@ -395,8 +403,9 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
             mix = extra["_mix"] = {"sched": sched["sched"], "n_acc": sched["n_acc"], "extras": sched["extras"],
                                    "n_pre": sched["n_pre"], "out": buf.narrow(1, e0, e1 - e0)}
         proc.render_into(x_view, out_v, **extra, **params, **common_i)
-        if prepared is None:  # the first processor stage is on its way: now design the later ones underneath it
-            prepared = prepare_later_stages(i)
+        launched += 1
+        if prepared is None and PREPARE_MODE != "inline" and launched == (2 if PREPARE_MODE == "under_second" else 1):
+            prepared = prepare_later_stages(i)  # this stage is on its way: now design the later ones underneath it
         return mix is not None and bool(mix.get("done"))
 
     def mix_candidate(i):

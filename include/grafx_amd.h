@@ -329,9 +329,12 @@ int gfx_dynamics_bwd_u1_f32(const float* x, gfx_rowmap_t xmap, const float* gy, 
                             const float* log_threshold, const float* log_ratio, const float* log_knee,
                             const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                             float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* stream);
-/* The same with a workspace of gfx_dynamics_ws_bytes(R) bytes (scratch for this call; NULL = the call above): rows with a
- * short smoother memory -- chosen per row on the device, exactly as in gfx_dynamics_fused_ws_f32 -- run as dependency-free
- * one-shot tiles walking backward in time (their per-row sums land by float atomics), the others on the row kernel. */
+/* The same with a workspace of gfx_dynamics_bwd_ws_bytes(R, L) bytes (scratch for this call; NULL = the call above): rows
+ * with a short smoother memory -- chosen per row on the device, exactly as in gfx_dynamics_fused_ws_f32 -- run as
+ * dependency-free one-shot tiles walking backward in time, the others on the row kernel.  The tiles' shares of the
+ * per-row sums (gparams, dalpha) go through the workspace and are added in a fixed order: no float atomics, the gradients
+ * are the same bits from run to run. */
+size_t gfx_dynamics_bwd_ws_bytes(int64_t R, int64_t L);
 int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
                                const float* log_threshold, const float* log_ratio, const float* log_knee,
                                const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
