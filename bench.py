@@ -335,18 +335,34 @@ def roofline_from_profile(prof, steps, elapsed, B, L, lens=None):
 
 class GpuSampler:
     """Shader clock and board power from the amdgpu hwmon files (readable without privileges), sampled by a thread every
-    50 ms while a loop runs.  A box may list several cards; the one that drew the most power is the one that worked."""
+    50 ms while a loop runs.  The box lists every card of the node (other tenants' included): the card is the one whose
+    PCI address is the current torch device's (falling back to all cards, reported per card, when that cannot be told)."""
 
-    def __init__(self, period=0.05):
+    def __init__(self, period=0.05, device=None):
         import glob
         import threading
 
         self.period = period
         self.cards = {}
+        want = None
+        try:
+            import torch
+
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            want = None
+        self.matched = False
+        found = {}
         for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
             f, p = os.path.join(h, "freq1_input"), os.path.join(h, "power1_input")
             if os.path.exists(f):
-                self.cards[h] = (f, p if os.path.exists(p) else None)
+                addr = os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(h))))
+                found[h] = (f, p if os.path.exists(p) else None, addr)
+        mine = {h: v for h, v in found.items() if want is not None and v[2].lower() == want}
+        self.matched = bool(mine)
+        self.cards = {h: v[:2] for h, v in (mine or found).items()}
+        self.addr = {h: v[2] for h, v in found.items()}
         self.samples = {h: [] for h in self.cards}
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
@@ -380,7 +396,10 @@ class GpuSampler:
             if not fr:
                 continue
             rec = {"sclk_mhz_mean": sum(fr) / len(fr) / 1e6, "sclk_mhz_min": min(fr) / 1e6, "sclk_mhz_max": max(fr) / 1e6,
-                   "power_w_mean": sum(pw) / len(pw) / 1e6 if pw else None, "samples": len(fr), "source": h + "/freq1_input"}
+                   "power_w_mean": sum(pw) / len(pw) / 1e6 if pw else None, "samples": len(fr),
+                   "source": h + "/freq1_input", "pci": self.addr.get(h),
+                   "card": "matched to the torch device by PCI address" if self.matched else
+                           "NOT matched (no PCI address): the card that drew the most power -- may be another tenant's"}
             if best is None or (rec["power_w_mean"] or 0) > (best["power_w_mean"] or 0):
                 best = rec
         return best or {"sclk_mhz_mean": None, "samples": 0, "source": None}

@@ -41,6 +41,13 @@ def tape_only_active():
     return getattr(_STATE, "tape_only", False)
 
 
+def tape_placeholder(shape, device):
+    """What a node hands back as its output while `tape_only` is active: a tensor of the right shape whose values nobody
+    reads -- ONE element expanded with zero strides, so that it occupies no memory (the full-size outputs it stands in for
+    are 8 GiB per stage at the headline batch: two of them were a fifth of the training step's peak)."""
+    return torch.empty((1,), dtype=torch.float32, device=device).expand(shape)
+
+
 class tape_only:
     def __init__(self, enabled=True):
         self.enabled = enabled
@@ -117,7 +124,7 @@ class LinearConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, h)
         ctx.off = off
         if final and tape_only_active():  # see tape_only: nobody will read these values
-            y = torch.empty((rows, max(x.shape[-2], Cf), Lout), dtype=torch.float32, device=x.device)
+            y = tape_placeholder((rows, max(x.shape[-2], Cf), Lout), x.device)
         else:
             y = ops.fftconv(x, ops.fir_spectrum(h.reshape(Rh * Cf, N)), N, Cf, Lout=Lout, off=off, h_rows=Rh)
         return y.view(x.shape[0], x.shape[1], y.shape[1], Lout) if four else y
@@ -249,9 +256,38 @@ def fsm_fir(Bs, As, fir_len):
     resp = sections[..., 0, :]
     for i in range(1, sections.shape[-2]):  # not .prod(): its backward asks the host whether any factor is zero
         resp = resp * sections[..., i, :]
+    if resp.is_cuda and resp.dtype == torch.complex64 and fir_len <= ops.IRDFT_MAX_N:
+        return irfft_small(resp, fir_len)       # any length up to 8192: direct-sum kernels both ways, no FFT library
     if fir_len % 2 == 1 and resp.is_cuda:
         return _irfft_odd(resp, fir_len)
     return torch.fft.irfft(resp, dim=-1, n=fir_len)
+
+
+class IrdftFn(torch.autograd.Function):
+    """irfft(X, n) along the last axis on the direct-sum kernels (n <= 8192): forward gfx_irdft_f32, backward its
+    adjoint, (c_k / n) rfft(g) with c = (1, 2, 2, ..., [1 at n/2 for even n]) on gfx_rdft_f32 -- what torch.fft.irfft
+    computes and what autograd derives from it, without the FFT library."""
+
+    @staticmethod
+    def forward(ctx, X, n):
+        ctx.n = n
+        return ops.irdft(X.contiguous(), n)
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        G = ops.rdft(g.contiguous(), n) * (2.0 / n)
+        G[..., 0] = G[..., 0] * 0.5
+        if n % 2 == 0:
+            G[..., -1] = G[..., -1] * 0.5
+        return G, None
+
+
+def irfft_small(X, n):
+    """torch.fft.irfft(X, n=n, dim=-1) for complex64 X on the GPU and n <= 8192, off the FFT library (differentiable)."""
+    if X.is_cuda and X.dtype == torch.complex64 and n <= ops.IRDFT_MAX_N:
+        return IrdftFn.apply(X, n)
+    return torch.fft.irfft(X, n=n, dim=-1)
 
 
 class PeqCoeffsFn(torch.autograd.Function):
@@ -313,7 +349,7 @@ class FsmFirFn(torch.autograd.Function):
         resp = sections[..., 0, :]
         for i in range(1, sections.shape[-2]):
             resp = resp * sections[..., i, :]
-        G = torch.fft.rfft(gh, n=N, dim=-1) * (2.0 / N)
+        G = (ops.rdft(gh, N) if N <= ops.IRDFT_MAX_N else torch.fft.rfft(gh, n=N, dim=-1)) * (2.0 / N)
         G[..., 0] = G[..., 0] * 0.5
         if N % 2 == 0:
             G[..., -1] = G[..., -1] * 0.5
@@ -444,7 +480,7 @@ class DynamicsFn(torch.autograd.Function):
             x = x.contiguous()
         rows = x.shape[0] * x.shape[1] if four else x.shape[0]
         if tape_only_active():  # the output of this node is the processor's output: its values are not read (see tape_only)
-            y = torch.empty((rows, x.shape[-2], x.shape[-1]), dtype=torch.float32, device=x.device)
+            y = tape_placeholder((rows, x.shape[-2], x.shape[-1]), x.device)
         else:
             if smoother and u1 is None:
                 u1 = torch.empty((rows, x.shape[-1]), dtype=torch.float32, device=x.device)

@@ -246,7 +246,48 @@ __global__ __launch_bounds__(256) void irdft_kernel(const float* __restrict__ X,
     }
 }
 
+// X[k] = sum_m x[m] e^{-2 pi i k m / n}, k = 0 .. n/2: the forward twin (rfft) of irdft_kernel, same table, same exact
+// phase index, double accumulation.  The gradient of an inverse real DFT is this transform of the incoming gradient
+// (autograd.IrdftFn, autograd.FsmFirFn.backward): with it the parameter-side front-ends of the training path stay off the
+// FFT library for every length the inverse kernel covers.
+__global__ __launch_bounds__(256) void rdft_kernel(const float* __restrict__ x, float* __restrict__ X, int K, int n) {
+    extern __shared__ float2 tab[];                       // tab[j] = e^{2 pi i j / n}, then the row's samples
+    float* sig = reinterpret_cast<float*>(tab + n);
+    const int64_t row = blockIdx.x;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)n, &s, &c);
+        tab[j] = make_float2((float)c, (float)s);
+        sig[j] = x[row * n + j];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;                                       // k m mod n
+        for (int m = 0; m < n; ++m) {
+            const float2 w = tab[idx];
+            re += (double)sig[m] * (double)w.x;
+            im -= (double)sig[m] * (double)w.y;
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        X[(row * K + k) * 2] = (float)re;
+        X[(row * K + k) * 2 + 1] = (float)im;
+    }
+}
+
 }  // namespace gfx
+
+extern "C" int gfx_rdft_f32(const float* x, float* X, int64_t rows, int64_t K, int64_t n, void* stream) {
+    if (!x || !X || rows <= 0 || rows > 0x7fffffffLL || n < 1 || n > 8192 || K != n / 2 + 1) return GFX_EINVAL;
+    const size_t lds = (size_t)n * (sizeof(float2) + sizeof(float));
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gfx::rdft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return GFX_ELAUNCH;
+    hipLaunchKernelGGL(gfx::rdft_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, x, X, (int)K, (int)n);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
 
 extern "C" int gfx_irdft_f32(const float* X, int is_real, float* y, int64_t rows, int64_t K, int64_t n, int64_t roll,
                              const float* window, void* stream) {

@@ -6,6 +6,7 @@ and stream plumbing; all arithmetic happens in the HIP kernels.  CPU tensors are
 rejected: there is no fallback path.
 """
 import contextvars
+import os
 
 import torch
 
@@ -287,9 +288,36 @@ def irdft(X, n, roll=0, window=None):
     return y.view(*X.shape[:-1], n)
 
 
+@_on_device
+def rdft(x, n=None):
+    """rfft(x, n) along the last axis for short transforms (n <= 8192, any n) as a direct sum on the GPU (gfx_rdft_f32):
+    x (..., n) float32 -> (..., n//2 + 1) complex64."""
+    _require_gpu(x)
+    n = x.shape[-1] if n is None else n
+    if x.shape[-1] != n:
+        raise ValueError(f"rdft: {x.shape[-1]} samples per row, n = {n}")
+    K = n // 2 + 1
+    flat = x.reshape(-1, n).contiguous()
+    rows = flat.shape[0]
+    X = torch.empty((rows, K, 2), dtype=torch.float32, device=x.device)
+    if rows:
+        check(lib().gfx_rdft_f32(_ptr(flat), _ptr(X), rows, K, n, _stream()), "gfx_rdft_f32")
+    return torch.view_as_complex(X).view(*x.shape[:-1], K)
+
+
 # ----------------------------------------------------------------------------------------- odd-length aliasing
 _ALIAS_PLANS = {}          # (P, device) -> plan, most recently used last; at most _ALIAS_PLANS_MAX entries (up to 36 MB each, 72 MB precise)
-_ALIAS_PLANS_MAX = 8
+_ALIAS_PLANS_MAX = max(1, int(os.environ.get("GRAFX_ALIAS_PLANS", "8")))
+
+
+def set_alias_plan_cache(entries):
+    """How many chirp plans of the odd-length aliasing (one per distinct P = Lx + Lh - 1 and precision, up to 36 / 72 MB
+    each) stay cached per process; default 8, or GRAFX_ALIAS_PLANS.  A workload with many distinct lengths (ragged
+    batches through upstream's default even tap counts) rebuilds a plan -- one small kernel chain and a stream
+    synchronisation -- whenever a length falls out of the cache: size it to the number of distinct lengths in flight."""
+    global _ALIAS_PLANS_MAX
+    _ALIAS_PLANS_MAX = max(1, int(entries))
+
 
 
 def odd_alias_supported(P):

@@ -94,8 +94,11 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
         training step can be captured into a HIP graph."""
         n_fft, hop, T = self.n_fft, self.hop_length, spec.shape[-1]
         total = n_fft + hop * (T - 1)
-        frames = torch.fft.irfft(spec, n=n_fft, dim=-2) * self.window[:, None]
-        y = self._overlap_add(frames.transpose(-1, -2))
+        # the frames' inverse real DFT on the direct-sum kernels (autograd.IrdftFn; n_fft <= 8192), not the FFT library
+        from .. import autograd as diff
+
+        frames = diff.irfft_small(spec.transpose(-1, -2), n_fft) * self.window
+        y = self._overlap_add(frames)
         key = (spec.device.type, spec.device.index, T)
         if key not in self._envelope:
             self._envelope[key] = self._overlap_add((self.window * self.window).expand(1, T, n_fft))[0]

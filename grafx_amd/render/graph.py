@@ -651,9 +651,12 @@ class _BufferRenderFn(torch.autograd.Function):
                 for j, g in zip(live, grads[1:] if want_gx else grads):
                     if g is not None:
                         leaf_grads[j] = g if leaf_grads[j] is None else leaf_grads[j] + g
-                if not want_gx:
+                g_in = grads[0].reshape(B, -1, C, L) if want_gx else None
+                # this stage's tape (and whatever it kept alive) goes now, not when the next stage rebinds the names:
+                # otherwise two stages' temporaries overlap at the peak
+                del y, grads, wrt, grad_out, x_in, local, params
+                if g_in is None:
                     continue
-                g_in = grads[0].reshape(B, -1, C, L)
             else:  # in / out / mix: the (summed) input is the output
                 g_in = g_out
             # add the stage's input gradient onto the rows it read

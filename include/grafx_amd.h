@@ -190,6 +190,11 @@ int gfx_odd_alias_precise_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, 
  * surrogate delay (core/delay.py:73-76). */
 int gfx_irdft_f32(const float* X, int is_real, float* y, int64_t rows, int64_t K, int64_t n, int64_t roll,
                   const float* window, void* stream);
+/* The forward twin: X[row, k] = sum_m x[row, m] e^{-2 pi i k m / n}, k = 0 .. n/2 (torch.fft.rfft), X (rows, K, 2), any
+ * n <= 8192, direct sum.  It is the adjoint of gfx_irdft_f32 up to the bin weights, i.e. the gradient of every
+ * frequency-sampled front-end (core/iir.py:150 irfft(n=fsm_fir_len), reverb.py:176-184 istft frames): the training path's
+ * parameter-side transforms stay off the FFT library. */
+int gfx_rdft_f32(const float* x, float* X, int64_t rows, int64_t K, int64_t n, void* stream);
 
 /* ---- frequency-sampled IIR -------------------------------------------------------------
  * replaces IIRFilter._process_fsm / iir_fsm / delay: core/iir.py:147-150, 263-276

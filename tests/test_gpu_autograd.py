@@ -332,5 +332,32 @@ def test_compressor_backward_with_and_without_the_kept_scan_agree():
                 if sched == "rows":     # the row kernel keeps exactly the scan the backward would recompute
                     assert torch.equal(ta, tb), name
                 else:                   # one-shot tiles (forward and backward) rebuild the state from a history dot product and
-                                        # add the per-row sums with float atomics: same to rounding
+                                        # add the per-row sums tile by tile (ordered partials): same to rounding
                     assert (ta - tb).abs().max() <= 2e-5 * ta.abs().max().clamp_min(1e-12), (name, sched)
+
+
+@pytest.mark.gpu
+def test_training_gradients_are_the_same_bits_from_run_to_run():
+    """No kernel of the training path accumulates with float atomics (the one-shot compressor backward writes ordered
+    partial sums, gfx_dynamics_bwd_ws_bytes): two identical training steps give bit-identical parameter gradients."""
+    import bench
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    dev = torch.device("cuda")
+    G = bench.console_graph(n_ch=8, n_bus=2)
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
+    procs = {k: v.to(dev) for k, v in bench.hip_processors().items()}
+    torch.manual_seed(5)
+    x = torch.randn(6, 8, 2, 65536, device=dev)
+    params = create_empty_parameters(procs, G, std=0.1).to(dev)
+    runs = []
+    for _ in range(3):
+        for q in params.parameters():
+            q.grad = None
+        render_grafx(procs, x, params, rd)[0].square().mean().backward()
+        runs.append([q.grad.clone() for q in params.parameters()])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)

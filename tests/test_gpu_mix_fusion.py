@@ -155,8 +155,9 @@ def test_console_render_with_and_without_the_fused_mix(train):
             ops.MIX_FUSION = True
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     for a, b in zip(outs[True][2], outs[False][2]):
-        # (per-row sums of the compressor backward land by float atomics: the order of additions varies run to run)
-        assert (a - b).abs().max() <= 1e-5 * b.abs().max().clamp_min(1e-12)
+        # the same backward kernels on the same buffers, and no kernel of the training path adds with float atomics
+        # (the compressor backward's per-row sums go through ordered partials): the same bits
+        assert torch.equal(a, b)
 
 
 def test_the_console_graph_takes_the_fused_path(monkeypatch):

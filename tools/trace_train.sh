@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/trace_train_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --train-steps 3 --no-secondary > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --train-steps 3 --no-secondary --no-sustained > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)[0]
