@@ -10,7 +10,8 @@
 //   y[n] = Re( cQ[n] sum_k (w_k Z[k] cQ[k]) bQ[n - k] ) / Q,   cQ[k] = e^{+i pi k^2 / Q},  bQ[j] = e^{-i pi j^2 / Q},
 //          Q = P - 1,  w_0 = w_{K-1} = 1, else 2   (taking the real part drops Im Z[0], Im Z[K-1] like a c2r transform)
 //
-// two circular convolutions of NFFT = C x 8192 >= (3P - 1) / 2 points, each a "four-step" FFT around the tile:
+// two circular convolutions of NFFT = C x 8192 >= (3P - 1) / 2 points (C = the smallest count of tiles with prime factors
+// up to 7 that covers them: 25 for P = 135 071, where the next power of two is 32), each a "four-step" FFT around the tile:
 //   cols_fwd : per column n2 (of 8192) a C-point DFT over n1 (registers) and the twiddle W_NFFT^(n2 k1)
 //   rows     : per row k1 one tile: forward, multiply by the chirp's spectrum (thread layout, precomputed), inverse
 //   cols_inv : conjugate twiddle, C-point inverse DFT, then the chirp / weights of the next step
@@ -27,10 +28,14 @@
 #include "../../include/grafx_amd.h"
 #include "fft_tile.hpp"
 #include "fft_tile_f64.hpp"
+#include "small_dft.hpp"
 
 namespace gfx {
 
 constexpr int CZT_MAXC = 32;
+// tiles per (sub-)transform: every size up to 32 with prime factors up to 7 (czt_geom picks the smallest that covers P)
+#define GFX_CZT_SIZES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(14) X(15) X(16) X(18) X(20) X(21) X(24) \
+    X(25) X(27) X(28) X(30) X(32)
 
 // Working precision of the transforms (the data in and out is fp32 either way): float = the packed-FP32 tile, double =
 // the `precise` form for the energy envelope (fft_tile_f64.hpp).  Tables, spectra and the workspace are T2 per point.
@@ -64,13 +69,16 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
     g.Q = P - 1;
     g.K = (P + 1) / 2;
     const int64_t need = P + g.K - 1;
-    int64_t C = 1;
-    while (C * TILE_M < need) C *= 2;
+    const int64_t tiles = (need + TILE_M - 1) / TILE_M;
+    // C <= 32 tiles per (sub-)transform with prime factors up to 7 (small_dft.hpp); beyond 32, outer radix-4 levels
     g.levels = 0;
-    while (C > CZT_MAXC) {
-        C /= 4;
+    int64_t per = tiles;
+    while (per > CZT_MAXC) {
+        per = (per + 3) / 4;
         ++g.levels;
     }
+    int64_t C = per;
+    while (!sd_supported((int)C)) ++C;       // (32 is supported: the loop ends)
     if (g.levels > CZT_MAX_LEVELS || C < 1) return false;
     g.S = 1 << (2 * g.levels);
     g.C = (int)C;
@@ -103,11 +111,17 @@ __global__ void czt_chirp_table_kernel(typename Prec<T>::T2* __restrict__ tab, i
     if (i < n) tab[i] = chirp_d<T>(i, den, sign);
 }
 
-// W_NFFT^(n2 k1): the argument 2 n2 k1 / NFFT is exact in float (NFFT is a power of two, n2 k1 < 2^18)
-__device__ __forceinline__ cx col_twiddle(int n2, int k1, float inv_half_nfft, bool conj) {
+// e^{-+ 2 pi i r / N} for 0 <= r < N, N a multiple of 4 (N = C x 8192, not a power of two in general): the quarter turn is
+// taken off in integers and the rest, rem / (N / 2) <= 1/2 half-turns with rem < 2^24 exact, goes to sincospif -- the phase
+// is good to 1e-7 rad whatever N (for a power of two the quotient is exact, as before).
+__device__ __forceinline__ cx unit_root_f(int r, int N, bool conj) {
+    const int quarter = N >> 2;
+    const int q = r / quarter, rem = r - q * quarter;
     float s, c;
-    sincospif((float)(n2 * k1) * inv_half_nfft, &s, &c);
-    return cx{c, conj ? s : -s};
+    sincospif((float)rem / (float)(N >> 1), &s, &c);
+    const float cr = (q & 1) ? ((q & 2) ? s : -s) : ((q & 2) ? -c : c);     // cos of the full angle
+    const float sr = (q & 1) ? ((q & 2) ? -c : c) : ((q & 2) ? -s : s);     // sin of the full angle
+    return cx{cr, conj ? sr : -sr};
 }
 __device__ __forceinline__ cxd col_twiddle(int n2, int k1, double inv_half_nfft, bool conj) {
     double s, c;
@@ -115,22 +129,33 @@ __device__ __forceinline__ cxd col_twiddle(int n2, int k1, double inv_half_nfft,
     return cxd{c, conj ? s : -s};
 }
 
-// The column twiddles W_NFFT^(n2 k1), k1 = 0 .. C-1 in turn.  float: one sincospif each (exact argument); double: powers
-// of W^(n2) by repeated multiplication (31 steps lose ~1e-15, and a double sincospi per point would make the column
-// kernels compute-bound).
+// The column twiddles W_NS^(n2 k1), k1 = 1, 2, ... C-1 IN TURN.  float: n2 k1 mod NS carried incrementally, one sincospif
+// each; double: powers of W^(n2) by repeated multiplication (31 steps lose ~1e-15, and a double sincospi per point would
+// make the column kernels compute-bound).
 template <typename T> struct ColTw;
 template <> struct ColTw<float> {
-    int n2;
-    float ihn;
+    int n2, NS, r;
     bool conj;
-    __device__ __forceinline__ ColTw(int n2_, float ihn_, bool conj_) : n2(n2_), ihn(ihn_), conj(conj_) {}
-    __device__ __forceinline__ cx at(int k1) { return col_twiddle(n2, k1, ihn, conj); }   // k1 = 1, 2, ... in order
+    __device__ __forceinline__ ColTw(int n2_, int NS_, bool conj_) : n2(n2_), NS(NS_), r(0), conj(conj_) {}
+    __device__ __forceinline__ cx at(int) {
+        r += n2;
+        r -= r >= NS ? NS : 0;
+        return unit_root_f(r, NS, conj);
+    }
 };
 template <> struct ColTw<double> {
     cxd w1, w;
-    __device__ __forceinline__ ColTw(int n2, double ihn, bool conj) : w1(col_twiddle(n2, 1, ihn, conj)), w(cxd{1.0, 0.0}) {}
-    __device__ __forceinline__ cxd at(int) { w = cmul(w, w1); return w; }                  // k1 = 1, 2, ... in order
+    __device__ __forceinline__ ColTw(int n2, int NS, bool conj) : w1(col_twiddle(n2, 1, 2.0 / (double)NS, conj)), w(cxd{1.0, 0.0}) {}
+    __device__ __forceinline__ cxd at(int) { w = cmul(w, w1); return w; }
 };
+
+// C-point DFT of a column in registers: the power-of-two sizes on the tile's radix-2 codelet (bit-identical with the
+// rounds before), the others on small_dft.hpp; either way frequency k ends up at v[spos(C, k)].
+template <int C, bool INV, typename V>
+__device__ __forceinline__ void col_dft(V (&v)[C]) {
+    if constexpr ((C & (C - 1)) == 0) dif<C, INV>(v);
+    else sdft<C, INV>(v);
+}
 
 // MODE 0: real rows, z[row, i - lo] tab[i] for lo <= i < lo + len (row stride ldz), zero elsewhere;  MODE 1: the complex
 // buffer itself;  MODE 2: a chirp sequence (plan building)
@@ -159,13 +184,11 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
         }
         v[n1] = e;
     }
-    dif<C, false>(v);
-    const T ihn = (T)2 / (T)NS;
-    constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
-    ColTw<T> tw(n2, ihn, false);
+    col_dft<C, false>(v);
+    ColTw<T> tw(n2, (int)NS, false);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = v[brev(k1, LOGC)];
+        const cx e = v[spos(C, k1)];
         const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
         b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
     }
@@ -221,16 +244,14 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
     const int64_t row = blockIdx.y;
     const int64_t NS = g.NFFT / g.S;
     typename Prec<T>::T2* b = buf + row * NS;
-    const T ihn = (T)2 / (T)NS;
     cx v[C];
-    ColTw<T> twi(n2, ihn, true);
+    ColTw<T> twi(n2, (int)NS, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
-    dif<C, true>(v);
-    constexpr int LOGC = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : C == 16 ? 4 : 5;
+    col_dft<C, true>(v);
     const T sc = (T)1 / (T)NS;
     if (MODE == 3) {   // the step between the two convolutions (S = 1): MODE 0's values, then cols_fwd's MODE 1 on them
         cx u[C];
@@ -240,15 +261,15 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
             cx o = {0, 0};
             if (i < g.K) {
                 const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
-                o = cmul(cmul(v[brev(n1, LOGC)] * sc, to_cx(cP[i])), to_cx(cQ[i])) * wk;
+                o = cmul(cmul(v[spos(C, n1)] * sc, to_cx(cP[i])), to_cx(cQ[i])) * wk;
             }
             u[n1] = o;
         }
-        dif<C, false>(u);
-        ColTw<T> twf(n2, ihn, false);
+        col_dft<C, false>(u);
+        ColTw<T> twf(n2, (int)NS, false);
 #pragma unroll
         for (int k1 = 0; k1 < C; ++k1) {
-            const cx e = u[brev(k1, LOGC)];
+            const cx e = u[spos(C, k1)];
             const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
             b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
         }
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
         const int64_t i = (int64_t)n1 * TILE_M + n2;
-        const cx e = v[brev(n1, LOGC)] * sc;
+        const cx e = v[spos(C, n1)] * sc;
         if (MODE == 2) {                                   // plain inverse of a sub-transform (outer level follows)
             b[i] = Prec<T>::make(e.x, e.y);
         } else if (MODE == 0) {
@@ -282,11 +303,9 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
 // in place (a thread owns the four positions n' + n3 NS).  Input / output modes as in the column kernels.
 template <typename T>
 __device__ __forceinline__ typename Prec<T>::cxt outer_twiddle(int64_t np, int k3, int64_t NFFT, bool conj) {
-    // W_NFFT^(np k3): np k3 < 3 * 2^18 is exact in float, and so is the quotient by the power of two NFFT
+    // W_NFFT^(np k3), np k3 < NFFT <= 2^24
     if constexpr (sizeof(T) == 4) {
-        float s, c;
-        sincospif(2.0f * (float)(np * k3) / (float)NFFT, &s, &c);
-        return cx{c, conj ? s : -s};
+        return unit_root_f((int)(np * k3), (int)NFFT, conj);
     } else {
         double s, c;
         sincospi(2.0 * (double)(np * k3) / (double)NFFT, &s, &c);
@@ -394,15 +413,8 @@ static void launch_cols_fwd(const CztGeom& g, const float* z, const typename Pre
                             int64_t rows, hipStream_t st, int64_t ldz = 0, int64_t lo = 0, int64_t len = 0,
                             ChirpSeq cs = ChirpSeq{0, 0, 1, 1.0}) {
     const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);   // one "row" per sub-transform
-#define GFX_CF(CC) hipLaunchKernelGGL((czt_cols_fwd_kernel<T, CC, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs)
-    switch (g.C) {
-        case 1: GFX_CF(1); break;
-        case 2: GFX_CF(2); break;
-        case 4: GFX_CF(4); break;
-        case 8: GFX_CF(8); break;
-        case 16: GFX_CF(16); break;
-        default: GFX_CF(32); break;
-    }
+#define GFX_CF(CC) case CC: hipLaunchKernelGGL((czt_cols_fwd_kernel<T, CC, MODE>), grid, blk, 0, st, z, cP, buf, g, ldz, lo, len, cs); break;
+    switch (g.C) { GFX_CZT_SIZES(GFX_CF) default: break; }
 #undef GFX_CF
 }
 
@@ -411,15 +423,8 @@ static void launch_cols_inv(const CztGeom& g, typename Prec<T>::T2* buf, const t
                             const typename Prec<T>::T2* cQ, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows,
                             hipStream_t st) {
     const dim3 grid(TILE_M / 256, (unsigned)(rows * g.S)), blk(256);
-#define GFX_CI(CC) hipLaunchKernelGGL((czt_cols_inv_kernel<T, CC, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g)
-    switch (g.C) {
-        case 1: GFX_CI(1); break;
-        case 2: GFX_CI(2); break;
-        case 4: GFX_CI(4); break;
-        case 8: GFX_CI(8); break;
-        case 16: GFX_CI(16); break;
-        default: GFX_CI(32); break;
-    }
+#define GFX_CI(CC) case CC: hipLaunchKernelGGL((czt_cols_inv_kernel<T, CC, MODE>), grid, blk, 0, st, buf, cP, cQ, y, ldy, lo, len, g); break;
+    switch (g.C) { GFX_CZT_SIZES(GFX_CI) default: break; }
 #undef GFX_CI
 }
 

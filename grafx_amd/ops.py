@@ -356,18 +356,22 @@ def _alias_plan(P, device, precise=False):
     return plan
 
 
+ALIAS_WS_CAP = 4 << 30     # bytes of chirp-z workspace per launch chain (rows go through in chunks that fit it; 1 -> 4 GB:
+                           # -6 % on the console's 4608 equaliser rows, tools/czt_chunk_ab.py)
+
+
 def _alias_chunks(rows, P, rows_per_chunk, device, precise):
     ws_bytes = _alias_fns(precise)[1]
-    chunk = max(1, min(rows, rows_per_chunk, (1 << 30) // ws_bytes(1, P)))   # at most 1 GB of workspace
+    chunk = max(1, min(rows, rows_per_chunk, ALIAS_WS_CAP // ws_bytes(1, P)))
     ws = torch.empty(ws_bytes(chunk, P), dtype=torch.uint8, device=device)
     return chunk, ws
 
 
 @_on_device
-def odd_alias(z, lo=0, length=None, rows_per_chunk=256, precise=False):
+def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
-    full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (2 MB of
-    workspace per row at P ~ 135 k, 8 MB beyond 174,763).  ``precise``: transforms in double precision (twice the
+    full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (1.6 MB of
+    workspace per row at P ~ 135 k: 25 tiles of 8192 points).  ``precise``: transforms in double precision (twice the
     workspace), for results that feed a logarithm -- the energy envelope, core/envelope.py:34-49."""
     _require_gpu(z)
     P = z.shape[-1]
@@ -390,7 +394,7 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=256, precise=False):
 
 
 @_on_device
-def odd_alias_adjoint(gy, P, lo=0, rows_per_chunk=256, precise=False):
+def odd_alias_adjoint(gy, P, lo=0, rows_per_chunk=1024, precise=False):
     """Transpose of odd_alias: the gradient with respect to z (..., P) given gy (..., length), the gradient with respect
     to odd_alias(z, lo, length) -- what autograd derives from the reference's rfft / irfft pair."""
     _require_gpu(gy)

@@ -75,3 +75,22 @@ def test_plain_c_program_links_and_runs_against_the_library(tmp_path):
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True)
     assert "abi_smoke ok" in out.stdout
+
+
+def test_small_composite_dfts_on_the_host(tmp_path):
+    """csrc/small_dft.hpp (the in-register DFTs of 3, 5, 6, 7, 9, ... 30 points behind the chirp-z column passes) is
+    __host__ __device__: tests/c/small_dft_host.hip runs every supported size, forward and inverse, float and double,
+    against a direct sum in double -- on the CPU, no GPU needed."""
+    import os
+    import subprocess
+
+    from grafx_amd import build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "small_dft_host"
+    cmd = [build.HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O1", os.path.join(root, "tests", "c", "small_dft_host.hip"),
+           "-o", str(exe)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "SMALL_DFT_OK" in out.stdout, out.stdout + out.stderr

@@ -28,7 +28,7 @@ def test_small_irfft_is_differentiable_like_torch_fft_irfft(n):
     K = n // 2 + 1
     X = torch.randn(4, K, dtype=torch.complex64)
     w = torch.randn(4, n)
-    Xr = X.clone().double().requires_grad_()
+    Xr = X.clone().to(torch.complex128).requires_grad_()
     yr = torch.fft.irfft(Xr, n=n, dim=-1)
     (yr * w.double()).sum().backward()
     Xg = X.cuda().requires_grad_()
