@@ -300,8 +300,9 @@ def rdft(x, n=None):
     flat = x.reshape(-1, n).contiguous()
     rows = flat.shape[0]
     X = torch.empty((rows, K, 2), dtype=torch.float32, device=x.device)
-    if rows:
-        check(lib().gfx_rdft_f32(_ptr(flat), _ptr(X), rows, K, n, _stream()), "gfx_rdft_f32")
+    for i in range(0, rows, 65535):     # rows ride on a grid dimension
+        m = min(65535, rows - i)
+        check(lib().gfx_rdft_f32(_ptr(flat[i:]), _ptr(X[i:]), m, K, n, _stream()), "gfx_rdft_f32")
     return torch.view_as_complex(X).view(*x.shape[:-1], K)
 
 

@@ -83,22 +83,20 @@ class _Dynamics(BufferIO, nn.Module):
                                       smoother=int(self.energy_smoother == "iir"), iir_len=self.iir_len,
                                       knee=self.knee, gate=self._gate, out=_out, param_rows=_shared_rows, u1_out=u1,
                                       mix=_mix)
-        if _out is not None:  # unfused configurations: run on flattened rows, then copy into the buffer slice
-            y = self.forward(input_signals.reshape(-1, *input_signals.shape[2:]), log_threshold, log_ratio, log_knee,
-                             z_alpha_pre, z_alpha_post)
-            _out.copy_(y.view(_out.shape))
-            return _out
+        # unfused configurations (a gain smoother, ballistics, or an energy smoother whose convolve() aliases): the energy
+        # and the gain kernels read / write the (B, n, C, L) buffer views in place through their row maps, the smoothers
+        # work on the (rows, L) envelope in between -- no flattened copy of the input, no copy of the output
         energy = ops.energy(input_signals)
         if self.energy_smoother is not None:
             energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)
         if self.gain_smoother is None:
             gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
-            return ops.apply_gain(input_signals, gain)
+            return ops.apply_gain(input_signals, gain, out=_out)
         if self.gain_smooth_in_log:  # dynamics.py:411-414
             g = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=True)
-            return ops.apply_gain(input_signals, self.gain_smoother_module(g, z_alpha=z_alpha_post), exp_gain=True)
+            return ops.apply_gain(input_signals, self.gain_smoother_module(g, z_alpha=z_alpha_post), exp_gain=True, out=_out)
         gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
-        return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post))
+        return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post), out=_out)
 
     def _forward_differentiable(self, x, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post, u1=None):
         """dynamics.py:390-405: one native autograd node when there is no gain smoother and the energy smoother is

@@ -142,3 +142,30 @@ def test_three_outer_levels():
     adj = ops.odd_alias_adjoint(g, P, 5000)
     assert (adj.double() - zd.grad).abs().max() <= 6e-6 * zd.grad.abs().max()
     ops._ALIAS_PLANS.clear()   # half a gigabyte of plan
+
+
+_TILE_COUNTS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 15, 16, 18, 20, 21, 24, 25, 27, 28, 30, 32]
+
+
+@pytest.mark.parametrize("C", _TILE_COUNTS)
+def test_every_supported_tile_count(C):
+    """The transform runs on C x 8192 points with C the smallest tile count of prime factors up to 7 that covers
+    (3P - 1) / 2 (csrc/small_dft.hpp): one P per supported C -- the largest odd length that still fits C tiles -- forward in
+    both precisions and the adjoint, against torch.fft in float64."""
+    from grafx_amd import ops
+
+    P = (2 * C * 8192 + 1) // 3
+    P -= 1 - (P & 1)                                   # odd, and (3P - 1) / 2 <= C * 8192
+    assert ops.lib().gfx_odd_alias_workspace_bytes(1, P) == C * 8192 * 8, "the geometry did not pick this tile count"
+    torch.manual_seed(C)
+    z = torch.randn(2, P, device="cuda")
+    want = torch.fft.irfft(torch.fft.rfft(z.double()))
+    for precise, tol in ((False, 3e-6), (True, 2e-7)):
+        got = ops.odd_alias(z, precise=precise)
+        err = (got.double() - want).abs().max() / want.abs().max()
+        assert err <= tol, f"C={C} P={P} precise={precise}: {err:.2e}"
+    g = torch.randn(2, P - 1, device="cuda")
+    gz = ops.odd_alias_adjoint(g, P)
+    lhs = (ops.odd_alias(z).double() * g.double()).sum()
+    rhs = (z.double() * gz.double()).sum()
+    assert abs(lhs - rhs) <= 1e-5 * (z.double().norm() * g.double().norm()), f"C={C}: <Az, g> {lhs} vs <z, A'g> {rhs}"
