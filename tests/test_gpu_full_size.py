@@ -261,3 +261,46 @@ def test_oneshot_dynamics_matches_the_oracle_on_a_loud_to_silent_signal():
         got = m(x.cuda(), **{k: v.cuda() for k, v in p.items()}).cpu()
     for sl in (slice(0, 20000), slice(20000, Lc)):
         assert (got[..., sl] - want[..., sl]).abs().max() <= 1e-5 * want[..., sl].abs().max()
+
+
+def test_console_training_step_at_batch_32_matches_the_oracles_autograd():
+    """One training step of the headline console (111 nodes, 4001 / 16383 / 60001 taps, L = 131072) at batch 32 -- the
+    persistent convolution and correlation kernels, the one-shot compressor tiles forward and backward, the fused routing
+    sums and their adjoint, the partitioned convolution's gradient, the stage-wise backward of render_grafx -- against torch
+    autograd through the CPU oracle on the same inputs: output and every shared-parameter gradient.  (The oracle's tape
+    for 32 graphs is ~22 GB of host memory and half a minute of CPU time.)"""
+    import psutil
+
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+
+    if psutil.virtual_memory().available < 48 * 2**30:
+        pytest.skip("the oracle's autograd tape for 32 graphs needs ~22 GB of host memory")
+    B = 32
+    G = build_console(32, 4)
+    lens = dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001)
+    hip = {"eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=lens["fsm_fir_len"]).cuda(),
+           "compressor": Compressor(energy_smoother="iir", iir_len=lens["iir_len"], flashfftconv=False).cuda(),
+           "reverb": STFTMaskedNoiseReverb(ir_len=lens["ir_len"], flashfftconv=False).cuda()}
+    cpu = {"eq": oracle.OracleParametricEqualizer(num_filters=6, fsm_fir_len=lens["fsm_fir_len"]),
+           "compressor": oracle.OracleCompressor(energy_smoother="iir", iir_len=lens["iir_len"]),
+           "reverb": oracle.OracleSTFTMaskedNoiseReverb(ir_len=lens["ir_len"])}
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
+    torch.manual_seed(21)
+    params = create_empty_parameters(hip, G, std=0.1)
+    x = torch.randn(B, 32, 2, L)
+    y_ref = render_grafx(cpu, x, params, rd)[0]
+    y_ref.square().mean().backward()
+    ref = [(n, p.grad.clone()) for n, p in params.named_parameters()]
+    y_ref = y_ref.detach()
+    for p in params.parameters():
+        p.grad = None
+    dev = params.cuda()
+    y = render_grafx(hip, x.cuda(), dev, rd.to("cuda"))[0]
+    y.square().mean().backward()
+    assert_close(y.detach().cpu(), y_ref, 1e-5, "console output (training forward, batch 32)")
+    for (name, want), got in zip(ref, dev.parameters()):
+        assert got.grad is not None, name
+        assert_close(got.grad.cpu(), want, 1e-3, f"gradient of {name}")

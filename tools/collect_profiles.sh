@@ -18,3 +18,6 @@ for cfg in cfg2 cfg3; do
   python3 $R/bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$cfg -- python3 $R/bench.py --config $cfg --no-cpu-baseline > /dev/null 2> $OUT/trace_$cfg.err
 done
+# the compat console (upstream's default tap counts, batch 64) as a kernel trace of its own
+rm -rf $OUT/trace_compat
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_compat -- python3 $R/bench.py --reference-default-lengths --batch 64 --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-secondary --no-sustained > $OUT/bench_compat.json 2> $OUT/trace_compat.err
