@@ -808,9 +808,52 @@ def g17():
     save("g17_default_arguments", **out)
 
 
+def g18():
+    """g17 for the rest of the processor zoo: every class that takes `flashfftconv` -- left at upstream's default (True ->
+    warning + native convolve() on the reference's CPU path) together with the default tap counts -- at an even audio
+    length, where every one of them aliases.  Outputs only."""
+    import warnings
+
+    import grafx.processors as P
+    out, specs = {}, []
+    torch.manual_seed(18)
+    L = 4096
+    x = torch.randn(2, 2, L)
+    out["x"] = x
+    cases = [
+        ("NoiseGate", lambda: P.NoiseGate(), None), ("ApproxCompressor", lambda: P.ApproxCompressor(), None),
+        ("ApproxNoiseGate", lambda: P.ApproxNoiseGate(), None),
+        ("LowPassFilter", lambda: P.LowPassFilter(), None), ("HighPassFilter", lambda: P.HighPassFilter(), None),
+        ("BandPassFilter", lambda: P.BandPassFilter(), None), ("BandRejectFilter", lambda: P.BandRejectFilter(), None),
+        ("AllPassFilter", lambda: P.AllPassFilter(), None),
+        ("PeakingFilter", lambda: P.PeakingFilter(num_filters=2), 0.5), ("LowShelf", lambda: P.LowShelf(num_filters=2), 0.5),
+        ("HighShelf", lambda: P.HighShelf(num_filters=2), 0.5),
+        ("StateVariableFilter", lambda: P.StateVariableFilter(num_filters=2), 0.5),
+        ("BiquadFilter", lambda: P.BiquadFilter(num_filters=2), 0.3),
+        ("GraphicEqualizer", lambda: P.GraphicEqualizer(), 0.5),
+    ]   # (IIREnvelopeFollower.parameter_size() raises upstream: dynamics.py:762 asks its smoother for one)
+    for name, make, std in cases:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            m = make()
+        assert any("FlashFFTConv is not available" in str(w.message) for w in rec), name
+        ps = {}
+        for k, shp in m.parameter_size().items():
+            shp = (shp,) if isinstance(shp, int) else tuple(shp)
+            ps[k] = (std or 1.0) * torch.randn(2, *shp)
+        y = m(x, **ps)
+        y = y[0] if isinstance(y, tuple) else y
+        out[f"y_{name}"] = y
+        for k, v in ps.items():
+            out[f"{k}_{name}"] = v
+        specs.append({"cls": name, "params": list(ps)})
+    out["specs"] = json.dumps(specs)
+    save("g18_default_arguments_zoo", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15, g16, g17):
+    for fn in (g1, g2, g3, g4, g5, g6, g7_g9, g8, g10, g11, g12, g13, g14, g15, g16, g17, g18):
         if not only or fn.__name__ in only:
             fn()
