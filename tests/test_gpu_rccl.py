@@ -59,4 +59,9 @@ def test_flat_gradient_all_reduce_runs_on_rccl_with_one_rank():
     finally:
         dist.all_reduce = real
         dist.destroy_process_group()
+        # RCCL writes its version banner through C stdio; flushed only at process exit it would land BEHIND pytest's
+        # summary line -- flush it now, while this test's output is still being captured
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
     assert not dist.is_initialized()
