@@ -607,8 +607,15 @@ static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* 
     if (xcopy) strides(a.cmap, k.cs_outer_lo, k.cs_outer_hi, k.cs_inner, k.cs_ch);
     size_t size = sizeof(k);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(pm->fn[variant], grid, 1, 1, TILE_T, 1, 1, 0, st, nullptr, config) == hipSuccess ? GFX_OK
-                                                                                                              : GFX_ELAUNCH;
+    // GRAFX_PIPE_THREADS: block size for an experimental code object loaded through GRAFX_PIPE_HSACO (timing experiments
+    // with other tile shapes, tools/experiments/r4_tile16); the shipped kernels are 256-thread tiles
+    static const unsigned threads = [] {
+        const char* e = getenv("GRAFX_PIPE_THREADS");
+        const int n = e ? atoi(e) : 0;
+        return n == 512 ? 512u : (unsigned)TILE_T;
+    }();
+    return hipModuleLaunchKernel(pm->fn[variant], grid, 1, 1, threads, 1, 1, 0, st, nullptr, config) == hipSuccess ? GFX_OK
+                                                                                                               : GFX_ELAUNCH;
 }
 
 // The hand-scheduled form of corr1_kernel (csrc/asm/gen_corr_pipe.py) covers off = 0 with the same row grouping on x and
