@@ -40,6 +40,7 @@ SIGNATURES = {
     "gfx_odd_alias_workspace_bytes": (sz, [i64, i64]),
     "gfx_odd_alias_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),
     "gfx_odd_alias_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
+    "gfx_odd_alias_rows_f32": (ctypes.c_int, [f32p, f32p, RowMap, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_odd_alias_adjoint_f32": (ctypes.c_int, [f32p, i64, i64, i64, f32p, i64, i64, vp, vp, sz, vp]),
     "gfx_odd_alias_precise_plan_bytes": (sz, [i64]),
     "gfx_odd_alias_precise_workspace_bytes": (sz, [i64, i64]),

@@ -59,12 +59,29 @@ struct CztGeom {
     int64_t P, Q, K, NFFT;   // NFFT = S * C * 8192
     int C, S;                // C <= 32 columns per sub-transform; S = 4^levels sub-transforms under `levels` outer radix-4 levels
     int levels;
+    // where the real output rows go: row r of the call at y + r * ldy (yC == 0), or -- gfx_odd_alias_rows_f32 -- row
+    // (row0 + r) of a (rows / yC, yC, len) signal addressed through a row map (a strided view of the render's buffer)
+    int yC;
+    int64_t row0;
+    gfx_rowmap_t ymap;
 };
+
+__device__ __forceinline__ float* czt_out_row(const CztGeom& g, float* y, int64_t ldy, int64_t row) {
+    if (g.yC == 0) return y + row * ldy;
+    const int64_t q = g.row0 + row;
+    const unsigned r = (unsigned)(q / g.yC);
+    const int c = (int)(q - (int64_t)r * g.yC);
+    const unsigned inner = (unsigned)g.ymap.inner, o = r / inner, rem = r - o * inner;
+    return y + (int64_t)o * g.ymap.stride_outer + (int64_t)rem * g.ymap.stride_inner + (int64_t)c * g.ymap.stride_ch;
+}
 
 constexpr int CZT_MAX_LEVELS = 3;   // NFFT <= 2^24: P <= 11,184,811 (233 s of audio at 48 kHz plus the filter)
 
 static inline bool czt_geom(int64_t P, CztGeom& g) {
     if (P < 3 || (P & 1) == 0) return false;
+    g.yC = 0;
+    g.row0 = 0;
+    g.ymap = gfx_rowmap_t{1, 0, 0, 0};
     g.P = P;
     g.Q = P - 1;
     g.K = (P + 1) / 2;
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);
-                y[row * ldy + (i - lo)] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
+                czt_out_row(g, y, ldy, row)[i - lo] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
             }
         }
     }
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);
-                y[row * ldy + (i - lo)] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
+                czt_out_row(g, y, ldy, row)[i - lo] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
             }
         }
     }
@@ -571,10 +588,17 @@ static int czt_run(const CztGeom& g, const float* in, int64_t ldi, int64_t ilo, 
 
 template <typename T>
 static int czt_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
-                     const void* plan, void* ws, size_t ws_bytes, void* stream, bool adjoint) {
+                     const void* plan, void* ws, size_t ws_bytes, void* stream, bool adjoint,
+                     const gfx_rowmap_t* ymap = nullptr, int yC = 0, int64_t row0 = 0) {
     using T2 = typename Prec<T>::T2;
     CztGeom g;
     if (!z || !y || !plan || rows <= 0 || rows > 16383 || !czt_geom(P, g)) return GFX_EINVAL;
+    if (ymap) {
+        if (adjoint || yC < 1 || row0 < 0 || ymap->inner <= 0 || ymap->inner > 0x7fffffffLL || (row0 + rows) / yC > 0x7fffffffLL)
+            return GFX_EINVAL;
+        g.yC = yC;
+        g.ymap = *ymap;
+    }
     if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
     if (!ws || ws_bytes < (size_t)rows * g.NFFT * sizeof(T2)) return GFX_ENOSPC;
     const T2* cP = (const T2*)plan;
@@ -585,9 +609,10 @@ static int czt_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t 
         const int64_t n = rows - r0 < step ? rows - r0 : step;
         T2* buf = (T2*)ws + r0 * g.NFFT;
         int rc;
+        g.row0 = row0 + r0;
         if (!adjoint)   // z (rows x P) -> y[:, lo : lo + len]
-            rc = czt_run<T>(g, z + r0 * g.P, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, y + r0 * ldy, ldy, lo, len, n, cP, cQ, buf,
-                            (hipStream_t)stream);
+            rc = czt_run<T>(g, z + r0 * g.P, g.P, 0, g.P, cP, spec, spec + g.NFFT, cQ, ymap ? y : y + r0 * ldy, ldy, lo, len, n, cP,
+                            cQ, buf, (hipStream_t)stream);
         else   // `z` is the gradient gy (row stride ldy) of y[:, lo : lo + len], `y` the gradient gz (rows x P)
             rc = czt_run<T>(g, z + r0 * ldy, ldy, lo, len, cQ, spec + 2 * g.NFFT, spec + 3 * g.NFFT, cP, y + r0 * g.P, g.P, 0,
                             g.P, n, cP, cQ, buf, (hipStream_t)stream);
@@ -620,6 +645,12 @@ int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, voi
 int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                       const void* plan, void* ws, size_t ws_bytes, void* stream) {
     return czt_alias<float>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream, false);
+}
+
+int gfx_odd_alias_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo, int64_t len,
+                           int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    if (C < 1 || C > 0x7fffffffLL) return GFX_EINVAL;
+    return czt_alias<float>(z, y, len, lo, len, rows, P, plan, ws, ws_bytes, stream, false, &ymap, (int)C, row0);
 }
 
 // Transpose of gfx_odd_alias_f32 (the gradient of the aliasing step): with G'[k] = sum_n gy[n] e^{+2 pi i k n / Q},

@@ -564,7 +564,7 @@ static inline void pipe_magic(uint32_t d, uint32_t& m, uint32_t& sh) {
 // the same batch-major row grouping on every tensor, byte strides inside 32 bits, and an overlap the build has a variant
 // for.  Everything else runs on fftconv1_kernel.
 static int pipe_variant(const ConvArgs& a, const ConvGeom& g, bool tee, int64_t N) {
-    if (g.nparts != 1 || a.off != 0 || (a.Lout & 1) || (tee && (a.L & 1)) || N > TILE_M + 1) return -1;
+    if (g.nparts != 1 || a.off != 0 || (a.Lout & 1) || (tee && ((a.L & 1) || a.Lout != a.L)) || N > TILE_M + 1) return -1;
     if (a.L * 4 >= (int64_t(1) << 30) || a.Lout * 4 >= (int64_t(1) << 30)) return -1;
     if (a.xmap.inner != a.ymap.inner || (tee && a.cmap.inner != a.xmap.inner)) return -1;
     auto fits = [](const gfx_rowmap_t& mp) {
@@ -824,7 +824,7 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PIPE) return GFX_EINVAL;
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
-    if (xcopy && (off != 0 || Lout != L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
+    if (xcopy && (off != 0 || Lout < L || C_in < C_f || N > TILE_M + 1 || cmap.inner <= 0 || cmap.inner > 0x7fffffffLL))
         return GFX_EINVAL;
     if (C_in < 1 || C_f < 1 || (C_in != C_f && C_in != 1 && C_f != 1)) return GFX_EINVAL;
     if (xmap.inner <= 0 || ymap.inner <= 0 || xmap.inner > 0x7fffffffLL || ymap.inner > 0x7fffffffLL) return GFX_EINVAL;

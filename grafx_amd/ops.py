@@ -180,7 +180,7 @@ def fir_grad(x, g, N, off):
 
 def fftconv_can_tee(Cin, Cf, L, Lout, off, N):
     """Whether :func:`fftconv` can also write a copy of its input (gfx_fftconv_tee_f32's conditions)."""
-    return off == 0 and Lout == L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
+    return off == 0 and Lout >= L and Cin >= Cf and lib().gfx_fftconv_nparts(N) == 1
 
 
 GFX_EINVAL = -1                                  # include/grafx_amd.h
@@ -369,7 +369,7 @@ def _alias_chunks(rows, P, rows_per_chunk, device, precise):
 
 
 @_on_device
-def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False):
+def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False, out=None):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
     full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (1.6 MB of
     workspace per row at P ~ 135 k: 25 tiles of 8192 points).  ``precise``: transforms in double precision (twice the
@@ -382,8 +382,22 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False):
     fwd, tag = _alias_fns(precise)[3], _alias_fns(precise)[5]
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
-    out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
     chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise)
+    if out is not None:
+        # ``out``: a (R, C, length) tensor or a strided (B, n, C, length) view whose rows, channels flattened, are z's
+        # rows: the last column pass writes them in place (gfx_odd_alias_rows_f32; float transforms only)
+        _require_gpu(out)
+        omap, Ro, Co, Lo = rowmap(out)
+        if precise or Ro * Co != rows or Lo != length:
+            raise ValueError(f"odd_alias: out {tuple(out.shape)} does not take {rows} rows of {length} samples")
+        name = "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel<float>"
+        for i in range(0, rows, chunk):
+            n = min(chunk, rows - i)
+            with _timed(name, 4 * n * (P + length)):
+                check(lib().gfx_odd_alias_rows_f32(_ptr(flat[i : i + n]), _ptr(out), omap, Co, i, lo, length, n, P, _ptr(plan),
+                                                   _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_rows_f32")
+        return out
+    out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
     # one record per chunk: the column / tile / column passes of the two chirp-z transforms (czt.hip), read z + write y
     name = "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel" + ("<double>" if precise else "<float>")
     for i in range(0, rows, chunk):

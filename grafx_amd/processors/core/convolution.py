@@ -120,7 +120,11 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False, h_rows=No
     if tee is not None:
         if mode == "causal" and not reference_aliases(L, N, exact) and ops.fftconv_can_tee(x.shape[-2], Cf, L, L, 0, N):
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, tee=tee, h_rows=h_rows)
-        tee.copy_(x)
+        if reference_aliases(L, N, exact) and ops.fftconv_can_tee(x.shape[-2], Cf, L, L + N - 1, 0, N):
+            pass        # the full-length convolution below writes the input through
+        else:
+            tee.copy_(x)
+            tee = None
     if not reference_aliases(L, N, exact):
         if mode == "causal":
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=0, out=out, h_rows=h_rows)
@@ -128,7 +132,10 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False, h_rows=No
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2, out=out, h_rows=h_rows)
         return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, out=out, h_rows=h_rows)
     lo, length = {"causal": (0, L), "zerophase": (N // 2, L)}.get(mode, (0, L + N - 2))
-    y = odd_length_alias(ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows), lo, length)
+    z = ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows, tee=tee)
+    if out is not None and not (torch.is_grad_enabled() and z.requires_grad):
+        return ops.odd_alias(z, lo, length, out=out)   # the last chirp-z pass writes the rows of the buffer view in place
+    y = odd_length_alias(z, lo, length)
     if out is None:
         return y.contiguous()
     out.copy_(y.reshape(out.shape))

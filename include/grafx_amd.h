@@ -87,7 +87,8 @@ int gfx_fftconv_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y,
  * the registers that already hold them.  render_grafx keeps every node's signal in one buffer
  * (render/graph.py:104-106: `signal_buffer[:, :num_sources] = input_signals`); when the first stage is a
  * convolution this folds that copy into the stage's kernel.  Only for the causal single-partition case
- * (off == 0, Lout == L, C_in == max(C_in, C_f), N <= 8193); anything else returns GFX_EINVAL. */
+ * (off == 0, Lout >= L -- the full-length convolution the odd-length aliasing starts from included --, C_in == max(C_in, C_f),
+ * N <= 8193); anything else returns GFX_EINVAL. */
 int gfx_fftconv_tee_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, float* y, gfx_rowmap_t ymap,
                         float* xcopy, gfx_rowmap_t cmap,
                         int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
@@ -168,6 +169,11 @@ size_t gfx_odd_alias_workspace_bytes(int64_t rows, int64_t P);
 int gfx_odd_alias_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                       const void* plan, void* ws, size_t ws_bytes, void* stream);
+/* The same with the output rows written straight into a signal addressed through a row map: row q = row0 + r of the call is
+ * row q / C, channel q % C of `y` (a strided (B, n, C, len) view of render_grafx's signal buffer, render/core.py:80-98), so
+ * that a stage on the aliasing path needs no copy of its result into the buffer.  `z` holds `rows` rows of this call. */
+int gfx_odd_alias_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo, int64_t len,
+                           int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows, int64_t P,
                               const void* plan, void* ws, size_t ws_bytes, void* stream);
 /* The same maps with the transforms carried in double precision (fp32 data in and out, own plan and workspace, both

@@ -169,3 +169,25 @@ def test_every_supported_tile_count(C):
     lhs = (ops.odd_alias(z).double() * g.double()).sum()
     rhs = (z.double() * gz.double()).sum()
     assert abs(lhs - rhs) <= 1e-5 * (z.double().norm() * g.double().norm()), f"C={C}: <Az, g> {lhs} vs <z, A'g> {rhs}"
+
+
+@pytest.mark.parametrize("P,C", [(4607, 1), (135071, 2), (191071, 2)])
+def test_odd_alias_writes_strided_buffer_rows_in_place(P, C):
+    """gfx_odd_alias_rows_f32: the aliased rows land directly in a strided (B, n, C, length) view of a signal buffer (the
+    stage's output slice in render_grafx) -- same values as the contiguous result, nothing outside the view touched,
+    across the chunk boundary (more rows than one launch chain takes)."""
+    from grafx_amd import ops
+
+    torch.manual_seed(P)
+    B, n = 3, 2
+    lo, length = 5, P - 1 - 9
+    z = torch.randn(B * n * C, P, device="cuda")
+    want = ops.odd_alias(z, lo, length)
+    buf = torch.full((B, n + 3, C, length + 7), float("nan"), device="cuda")
+    view = buf[:, 2 : 2 + n, :, :length]
+    got = ops.odd_alias(z, lo, length, out=view, rows_per_chunk=5)
+    assert got is view
+    assert torch.equal(view.reshape(B * n * C, length), want)
+    mask = torch.ones_like(buf, dtype=torch.bool)
+    mask[:, 2 : 2 + n, :, :length] = False
+    assert torch.isnan(buf[mask]).all()
