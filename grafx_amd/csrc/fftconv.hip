@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/grafx_amd.h"
 #include "fft_tile.hpp"
@@ -379,6 +380,211 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
 }
 
+// ---- two consecutive output tiles per 512-thread workgroup ---------------------------------------------------------
+// Output tiles i and i + 1 of a row meet the windows i + 1, i, ..., i + 1 - nparts; window i + 1 - k multiplies partition k
+// for tile i + 1 and partition k - 1 for tile i.  One workgroup of two 256-thread groups walks those nparts + 1 windows:
+// per turn it fetches ONE window spectrum and ONE filter partition (the other partition is the one of the turn before, kept
+// in registers), i.e. (nparts + 1) + nparts tile-sized operands per tile PAIR where macinv_kernel fetches 2 nparts per tile
+// (60 001 taps: 17 against 32) -- the loop is bound by what the CUs' L1 can take in, not by arithmetic.
+// Registers decide the shape: two accumulator sets, a window and two partitions are 340 registers per thread for a
+// 256-thread tile (round 4's first attempt, tools/experiments/r4_macinv2: spills, serialised loads, 1.6x slower).  Here
+// the mirrored bin pairs of a thread are split between the two groups -- group G multiplies pairs 8G .. 8G + 7 of BOTH
+// tiles -- so everything halves: 2 x 36 accumulators, 36 for the window rows the group's pairs touch, 2 x 36 for the
+// partitions.  After the loop the groups swap halves through LDS (group 0 gets tile i complete, group 1 tile i + 1) and run
+// the two inverse transforms side by side.  Every tile adds the same products in the same order as in macinv_kernel (equal
+// to the last bit or two: the compiler contracts the twiddle arithmetic of the two kernels differently).
+//
+// Mirrored pairs of a group, the same straight-line code for every lane: slot i < 8 of group G is pair 8 G + i of threads
+// t != 0 -- bins (row 0, k3) and (row 1, 15 - k3), k3 = 8 G + i, rows = the two butterflies bf of tile_forward's layout --
+// and, for thread 0, whose bins pair up INSIDE a row, (row 0: k3 = i with 16 - i; i = 0 with itself) in group 0 and
+// (row 1: k3 = i with 15 - i) in group 1; group 0 has a ninth slot for thread 0's self-paired bin (row 0, k3 = 8).  The
+// difference is data, not control flow: a per-lane row in the load offsets (two selects per load), W^(t + 512 k3) from a
+// per-lane base (thread 0 of group 1: W_32^17, so that base x W_32^(16 + 2 i) = W_32^(1 + 2 i), its pairs' factor), and
+// selects where the finished halves are put into place.  A divergent branch for thread 0 would double the code and, worse,
+// blur the compiler's wait counts at its join (every turn would start by waiting for all outstanding loads).
+//
+// Flat 16-entry layout of a group's half tile: e < 8 "lower" = row G, k3 = e;  e >= 8 "upper" = k3 = e of row
+// (G == 0) == (t != 0).
+constexpr int HALF_SLOTS = 9;   // (the ninth: group 0 only)
+
+// byte offset of window-spectrum row q = 16 bf + brev4(k3) (8-byte entries, row q at q * 256 + t)
+constexpr uint32_t zrow(int bf, int k3) { return 2048u * (uint32_t)(16 * bf + brev(k3 & 15, 4)); }
+
+template <int G>
+__device__ __forceinline__ void macinv_pair_half(const cx* __restrict__ Z, const f4v* __restrict__ H, const ConvArgs& a,
+                                                 int64_t tile, bool two, int t, cx wj, cx* lds_other,
+                                                 cx (&own)[16]) {
+    constexpr int NS = G ? 8 : 9;
+    cx aye[NS], ayo[NS], bye[NS], byo[NS];   // tile i ("a") and tile i + 1 ("b")
+#pragma unroll
+    for (int s = 0; s < NS; ++s) aye[s] = ayo[s] = bye[s] = byo[s] = cx{0.0f, 0.0f};
+
+    const bool z = t == 0;
+    const uint32_t t8 = 8u * (uint32_t)t;
+    // lane offset of a slot's two window rows (first / second bin of the pair)
+    auto off_a = [&](int i) -> uint32_t {
+        if (G == 0) return t8 + zrow(0, i);
+        return t8 + (z ? zrow(1, i) : zrow(0, 8 + i));
+    };
+    auto off_b = [&](int i) -> uint32_t {
+        if (G == 0) return i == 8 ? t8 + zrow(0, 8) : t8 + (z ? zrow(0, 16 - i) : zrow(1, 15 - i));
+        return t8 + (z ? zrow(1, 15 - i) : zrow(1, 7 - i));
+    };
+    // partition slots (16-byte entries, slot * 256 + t): group 1 multiplies slots 8.. (thread 0: 9..)
+    const uint32_t hv = 16u * (uint32_t)(t + (G ? (z ? 9 : 8) * TILE_T : 0));
+    const cx w32_17 = {-0.98078528040323044913f, 0.19509032201612826785f};
+    const cx wbase = (G && z) ? w32_17 : wj;
+
+    // turns k_lo .. k_hi: the windows tile + 1 - k that overlap the signal (window starts fall with k) and that one of the
+    // two tiles uses (turn 0: tile i + 1 only, turn nparts: tile i only)
+    const int64_t s0 = a.off - a.O + (tile + 1) * a.hop;                  // start of the window of turn 0
+    int k_lo = two ? 0 : 1, k_hi = a.nparts;
+    if (s0 >= a.L) k_lo = max(k_lo, (int)((s0 - a.L) / a.hop) + 1);       // first k with s0 - k hop < L
+    if (s0 + TILE_F <= (int64_t)k_hi * a.hop) k_hi = (int)((s0 + TILE_F - 1) / a.hop);   // last k with s0 - k hop + TILE_F > 0
+
+    // Operands come through two range-checked descriptors: the nparts partitions of this row's filter (partition k at
+    // k * 68 KB: a request for partition nparts -- the last turn has none for tile i + 1 -- falls outside and reads as
+    // zeros), and one window spectrum at a time (an empty descriptor for the turn after the last).  So every turn is
+    // the same straight-line code, with no test around a load or a product.
+    // (Tried and dropped: the turns in a cyclic order that makes all pairs of a row read the same window in the same turn
+    // -- the L2 hit rate was not what held the loop back: 2.36 against 2.25 ms with xspec at cfg3, all nparts + 1 turns
+    // taken by every pair.)
+    const rsrc_t hr = make_rsrc(H, (int64_t)a.nparts * H_TILE_F4 * 16);
+    auto window = [&](int k) {
+        return make_rsrc(Z + (tile + 1 - k + a.nparts - 1) * TILE_M, k <= k_hi ? (int64_t)TILE_M * 8 : 0);
+    };
+    // One turn: the window of turn k (in wa, wb) times partition k - 1 (ha) for tile i and partition k (hb) for tile i + 1.
+    // The operands of turn k + 1 are requested underneath, IN PLACE, as the products release registers: a mirrored pair is
+    // the only user of its two window rows, so once it has been split the rows of the next window go into the same
+    // registers; the NEW partition of the next turn (k + 1, tile i + 1's) replaces ha slot by slot behind the tile-i
+    // products -- so the next turn runs with (ha, hb) exchanged.  No second buffer: every operand of a turn was requested
+    // one full turn (~1300 instructions) ahead of its use.
+    auto turn = [&](int k, cx (&wa)[NS], cx (&wb)[NS], f4v (&ha)[NS], f4v (&hb)[NS]) {
+        const rsrc_t zr = window(k + 1);
+        const uint32_t hoff = (uint32_t)(k + 1) * (uint32_t)(H_TILE_F4 * 16);
+        cx wjt = wbase;
+        asm volatile("" : "+v"(wjt));   // the slots' W^(t + 512 k3) recomputed every turn (2 instructions each), not kept: 16 registers
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            cx xe, xo;
+            pair_split(wa[i], wb[i], xe, xo);
+            wa[i] = buf_load_f2(zr, off_a(i), 0);
+            wb[i] = buf_load_f2(zr, off_b(i), 0);
+            const cx wk = mul_w16(wjt, 8 * G + i);
+            pair_product_acc(xe, xo, ha[i], wk, aye[i], ayo[i]);
+            ha[i] = buf_load_f4(hr, hv, hoff + 4096u * i);
+            pair_product_acc(xe, xo, hb[i], wk, bye[i], byo[i]);
+            // slot by slot as written (left to itself the compiler gathers the requests of several slots and waits for
+            // nearly all outstanding loads in front of them)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (k_lo <= k_hi) {
+        cx wa[NS], wb[NS];
+        f4v h0[NS], h1[NS];
+        const rsrc_t zr = window(k_lo);
+        // (requested in the order a turn requests them -- partition k_lo - 1 as if by the turn before, then slot by slot --
+        // so that the wait counts the compiler derives for the loop hold from its first turn on instead of "everything")
+#pragma unroll
+        for (int i = 0; i < NS; ++i)   // partition -1 for a walk from turn 0: an offset far outside the descriptor -- zeros
+            h0[i] = buf_load_f4(hr, hv, (k_lo ? (uint32_t)(k_lo - 1) * (uint32_t)(H_TILE_F4 * 16) : 0x40000000u) + 4096u * i);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            wa[i] = buf_load_f2(zr, off_a(i), 0);
+            wb[i] = buf_load_f2(zr, off_b(i), 0);
+            h1[i] = buf_load_f4(hr, hv, (uint32_t)k_lo * (uint32_t)(H_TILE_F4 * 16) + 4096u * i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int k = k_lo; k <= k_hi; k += 2) {
+            turn(k, wa, wb, h0, h1);
+            if (k + 1 <= k_hi) turn(k + 1, wa, wb, h1, h0);
+        }
+    }
+
+    // the finished half tiles in the flat layout: this group's half of ITS tile stays in registers (own), its half of the
+    // other group's tile goes through LDS
+    auto place = [&](const cx (&ye)[NS], const cx (&yo)[NS], cx (&flat)[16]) {
+        cx za[NS], zb[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) pair_merge(ye[i], yo[i], za[i], zb[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (G == 0) {
+                flat[j] = za[j];
+                flat[8 + j] = z ? (j == 0 ? za[NS - 1] : zb[8 - j]) : zb[7 - j];
+            } else {
+                flat[j] = z ? za[j] : zb[7 - j];
+                flat[8 + j] = z ? zb[7 - j] : za[j];
+            }
+        }
+    };
+    cx other[16];
+    if (G == 0) {
+        place(aye, ayo, own);
+        place(bye, byo, other);
+    } else {
+        place(bye, byo, own);
+        place(aye, ayo, other);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds_other[e * TILE_T + t] = other[e];
+}
+
+// own / got: the flat rows of this group's pairs and of the other group's (see above) -> the [2][16] layout tile_inverse takes
+template <int G>
+__device__ __forceinline__ void macinv_pair_gather(const cx (&own)[16], const cx* lds_mine, int t, cx (&pz)[2][16]) {
+    cx got[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) got[e] = lds_mine[e * TILE_T + t];
+    const bool z = t == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        pz[G][brev(i, 4)] = own[i];
+        pz[1 - G][brev(i, 4)] = got[i];
+        // upper halves: own is row (G == 0) == (t != 0), got the other one
+        const cx up_own = own[8 + i], up_got = got[8 + i];
+        const bool own_is_row1 = (G == 0) != z;
+        pz[1][brev(8 + i, 4)] = own_is_row1 ? up_own : up_got;
+        pz[0][brev(8 + i, 4)] = own_is_row1 ? up_got : up_own;
+    }
+}
+
+__global__ __launch_bounds__(2 * TILE_T, 1) void macinv_pair_kernel(const float2* __restrict__ Zs,
+                                                                    const float4* __restrict__ Hs,
+                                                                    float* __restrict__ y, ConvArgs a, int64_t nwin,
+                                                                    const float2* __restrict__ twtab) {
+    extern __shared__ __attribute__((aligned(16))) cx lds[];
+    const int t = threadIdx.x & (TILE_T - 1);
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const unsigned lb = xcd_logical_block();
+    if (lb >= (unsigned)a.nblocks) return;
+    const unsigned npairs = (unsigned)((a.ntiles + 1) >> 1);
+    const unsigned rco = lb / npairs;
+    const int64_t tile = 2 * (int64_t)(lb - rco * npairs);
+    const bool two = tile + 1 < a.ntiles;
+    const unsigned r = rco / (unsigned)a.Cout;
+    const int c = (int)(rco - r * (unsigned)a.Cout);
+    float* yrow = y + row_off(a.ymap, r, c);
+    const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
+    const cx* Z = reinterpret_cast<const cx*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
+    const cx wj = to_cx(twtab[TILE_T + t]);  // W_8192^t
+    cx* lds_mine = lds + grp * TILE_LDS_F2;
+    cx* lds_other = lds + (1 - grp) * TILE_LDS_F2;
+
+    cx own[16], pz[2][16], v[32];
+    if (grp == 0) macinv_pair_half<0>(Z, H, a, tile, two, t, wj, lds_other, own);
+    else macinv_pair_half<1>(Z, H, a, tile, two, t, wj, lds_other, own);
+    __syncthreads();
+    if (grp == 0) macinv_pair_gather<0>(own, lds_mine, t, pz);
+    else macinv_pair_gather<1>(own, lds_mine, t, pz);
+    __syncthreads();
+    TileTw tw;
+    tile_twiddles(tw, twtab, t);
+    tile_inverse(pz, v, tw, lds_mine, t);
+    if (grp == 0 || two) store_valid(v, yrow, (tile + grp) * a.V, a.O, a.Lout, t);
+}
+
 // One output tile per row (ntiles == 1, the filter-gradient shape: a long "filter", few outputs): every signal window
 // meets exactly one filter partition, so its spectrum is used once -- transform it here instead of writing it to
 // a workspace (xspec_kernel) and reading it back (macinv_kernel).
@@ -685,9 +891,9 @@ static int auto_schedule() {
 static thread_local const char* t_last_kernel = "";   // see gfx_fftconv_last_kernel
 
 template <typename K>
-static int allow_lds(K kernel) {
+static int allow_lds(K kernel, int bytes = TILE_LDS_BYTES) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               TILE_LDS_BYTES) == hipSuccess
+                               bytes) == hipSuccess
                ? 0
                : GFX_ELAUNCH;
 }
@@ -895,6 +1101,17 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     if (ax.nblocks > 0x7ffffff0LL) return GFX_EINVAL;
     hipLaunchKernelGGL(xspec_kernel, dim3(pad8(ax.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, (float2*)ws, ax,
                        nwin, tw);
+    if (schedule != GFX_SCHED_TILE) {
+        // two consecutive output tiles per 512-thread workgroup: each window spectrum and filter partition fetched once a pair
+        if (allow_lds(macinv_pair_kernel, 2 * TILE_LDS_BYTES)) return GFX_ELAUNCH;
+        ConvArgs ap = a;
+        ap.nblocks = R * a.Cout * ((g.ntiles + 1) / 2);
+        hipLaunchKernelGGL(macinv_pair_kernel, dim3(pad8(ap.nblocks)), dim3(2 * TILE_T), 2 * TILE_LDS_BYTES, st,
+                           (const float2*)ws, (const float4*)Hs, y, ap, nwin, tw);
+        if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
+        t_last_kernel = "xspec_kernel+macinv_pair_kernel";
+        return GFX_OK;
+    }
     hipLaunchKernelGGL(macinv_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, (const float2*)ws,
                        (const float4*)Hs, y, a, nwin, tw);
     if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;

@@ -16,8 +16,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 #include "../../include/grafx_amd.h"
+#include "small_dft.hpp"
 
 namespace gfx {
 
@@ -387,6 +390,180 @@ __global__ __launch_bounds__(64) void ir_energy_gain_kernel(const float* __restr
     if (threadIdx.x == 0) gain[blockIdx.x] = 1.0f / sqrtf(0.5f * e + 1e-12f);
 }
 
+// ---- n_fft = 384, hop = 192 (the reference's defaults): frames by FFT, overlap-add in LDS --------------------------------
+// The matrix-core form above spends 2 x 193 x 384 multiply-adds on a frame; a 384-point inverse real FFT needs ~4000.  At
+// cfg3 (512 rows x 2 x 313 frames) that is 95 GFLOP = 0.9 ms of fp32 MFMA against microseconds of vector arithmetic, and
+// the frames no longer leave the chip: one workgroup = one row, both channels, FR consecutive frames, finishing the FR - 1
+// blocks of `hop` samples that lie between them.
+//   x[n] = 1/N sum_k Xh[k] e^(+2 pi i k n / N)  (Xh: the Hermitian extension of the K = 193 bins; Im Xh[0], Im Xh[192] ignored,
+//   as torch.istft / irfft do) is computed as one 192-point complex transform of z[j] = x[2j] + i x[2j+1]:
+//   Z[k] = E[k] + i O[k],  E[k] = (X[k] + conj X[192-k]) / 2,  O[k] = (X[k] - conj X[192-k]) / 2 * e^(+2 pi i k / 384),
+//   z[j] = 1/192 sum_k Z[k] e^(+2 pi i j k / 192).
+// 192 = 8 x 24: eight lanes per frame; lane l transforms Z[l + 8 j], j < 24, in registers (small_dft.hpp), multiplies by
+// e^(2 pi i b l / 192) and hands the 24 x 8 intermediate values over through LDS; then three 8-point transforms per lane
+// give z[24 a + b], b = l, l + 8, l + 16.  The windowed samples are added into an LDS image of the workgroup's output blocks
+// (a block = second half of one frame + first half of the next: every LDS word has one owner per pass, no atomics), then
+// envelope division, mid/side -> left/right, store and energy partial as in istft_ola_kernel.
+using cxf = float __attribute__((ext_vector_type(2)));
+
+template <int FR>
+__global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __restrict__ noise_stft,
+                                                                const float* __restrict__ init_lm,
+                                                                const float* __restrict__ delta_lm,
+                                                                const float* __restrict__ gain_env,
+                                                                const float* __restrict__ window, float* __restrict__ ir,
+                                                                float* __restrict__ partial, IstftArgs a, int ms_to_lr) {
+    constexpr int M = 192, NT = FR * 8, PITCH = 193, NB = FR - 1, K = 193;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    cxf* Xs = reinterpret_cast<cxf*>(smem);                 // [FR][PITCH]: the masked spectra, then the stage-1 results
+    float* ola = smem + 2 * FR * PITCH;                     // [2][NB * 192]
+    cxf* tw384 = reinterpret_cast<cxf*>(ola + 2 * NB * M);  // e^(+2 pi i k / 384), k < 192
+    cxf* tw192 = tw384 + M;                                 // e^(+2 pi i p / 192), p < 192
+    float* slope_s = reinterpret_cast<float*>(tw192 + M);   // -softplus(delta) per bin (200 floats)
+    float* h0_s = slope_s + 200;                            // the initial log-magnitudes (200 floats)
+    float* win_s = h0_s + 200;                              // the window (384 floats)
+    float* red = win_s + 384;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.y;
+    const int mfirst = blockIdx.x * NB;                     // first frame; the blocks are mfirst + 1 .. mfirst + NB
+    for (int i = tid; i < M; i += NT) {
+        float sn, cs;
+        sincospif((float)i / 192.0f, &sn, &cs);
+        tw384[i] = cxf{cs, sn};
+        sincospif((float)i / 96.0f, &sn, &cs);
+        tw192[i] = cxf{cs, sn};
+    }
+    for (int i = tid; i < 2 * M; i += NT) win_s[i] = window[i];
+    const int fm = tid % FR, kg = tid / FR;                 // step 1: lane -> frame (consecutive lanes: consecutive frames), 8 bin groups
+    const int f = tid >> 3, l = tid & 7;                    // steps 2, 3: eight lanes per frame
+    for (int c = 0; c < 2; ++c) {
+        const int64_t rc = r * 2 + c;
+        for (int i = tid; i < K; i += NT) {
+            slope_s[i] = -softplus_t(delta_lm[rc * K + i]);
+            h0_s[i] = init_lm[rc * K + i];
+        }
+        __syncthreads();   // (also: the previous channel's last reads of Xs are done)
+        {
+            const int m = mfirst + fm;
+            const bool m_ok = m < a.T;
+            const float mf = (float)m;
+            const float genv = (gain_env && m_ok) ? gain_env[rc * a.T + m] : 0.0f;
+            const float* nz0 = noise_stft + r * a.nstride + ((int64_t)c * K * a.T + (m_ok ? m : 0)) * 2;
+            // all 25 noise loads of the lane in flight together (one at a time, each would cost a trip to L2: the
+            // workgroup has only four waves to hide it behind)
+            float2 nz[25];
+#pragma unroll
+            for (int q = 0; q < 25; ++q) {
+                const int k = kg + 8 * q;
+                nz[q] = (m_ok && k < K) ? *reinterpret_cast<const float2*>(nz0 + (int64_t)k * a.T * 2) : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int q = 0; q < 25; ++q) {
+                const int k = kg + 8 * q;
+                if (k < K) {
+                    float lm = __fadd_rn(h0_s[k], __fmul_rn(slope_s[k], mf));
+                    if (gain_env) lm = __fadd_rn(lm, genv);
+                    const float mask = m_ok ? expf(lm / 8.0f) : 0.0f;
+                    Xs[fm * PITCH + k] = cxf{nz[q].x * mask, (k == 0 || k == M) ? 0.0f : nz[q].y * mask};
+                }
+            }
+        }
+        __syncthreads();
+        cxf v[24];
+        {
+            const cxf* X = Xs + f * PITCH;
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+                const int k = l + 8 * j;
+                const cxf A = X[k], Bc = X[M - k];                          // B = conj(Bc)
+                const cxf e = cxf{A.x + Bc.x, A.y - Bc.y};                  // A + B
+                const cxf d = cxf{A.x - Bc.x, A.y + Bc.y};                  // A - B
+                const cxf w = tw384[k];
+                const cxf o = cxf{d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x};
+                v[j] = cxf{e.x - o.y, e.y + o.x} * (1.0f / 384.0f);         // (E + i O) / 192
+            }
+        }
+        sdft<24, true>(v);
+        __syncthreads();   // every lane has read its spectrum
+#pragma unroll
+        for (int b = 0; b < 24; ++b) {
+            const cxf y = v[spos(24, b)], w = tw192[b * l];
+            Xs[f * PITCH + b * 8 + l] = cxf{y.x * w.x - y.y * w.y, y.x * w.y + y.y * w.x};
+        }
+        __syncthreads();
+        cxf u[3][8];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const cxf* Y = Xs + f * PITCH + (l + 8 * q) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u[q][i] = Y[i];
+            sdft<8, true>(u[q]);
+        }
+        float* o = ola + c * NB * M;
+        // first halves (a < 4: n = 2 (24 a + b) < 192) of frames 1 .. FR - 1 open their block
+        if (f >= 1) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    const int n = 2 * (24 * aa + l + 8 * q);
+                    const cxf z = u[q][spos(8, aa)];
+                    *reinterpret_cast<float2*>(o + (f - 1) * M + n) = make_float2(win_s[n] * z.x, win_s[n + 1] * z.y);
+                }
+        }
+        __syncthreads();
+        // second halves of frames 0 .. FR - 2 complete the block the next frame opened
+        if (f <= FR - 2) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int aa = 4; aa < 8; ++aa) {
+                    const int n = 2 * (24 * aa + l + 8 * q);
+                    const cxf z = u[q][spos(8, aa)];
+                    float2* dst = reinterpret_cast<float2*>(o + f * M + (n - M));
+                    const float2 old = *dst;
+                    // (frame m - 1 first, then frame m: the order of istft_ola_kernel's sum)
+                    *dst = make_float2(win_s[n] * z.x + old.x, win_s[n + 1] * z.y + old.y);
+                }
+        }
+    }
+    __syncthreads();
+    float e = 0.0f;
+    for (int i = tid; i < NB * M; i += NT) {
+        const int j = i / M, s = i - j * M;
+        const int jb = mfirst + 1 + j;                      // block: frames jb - 1 (second half) and jb (first half)
+        const int64_t tp = (int64_t)(jb - 1) * M + s;       // output index after the centre trim of n_fft / 2
+        if (tp < a.ir_len && jb - 1 < a.T) {
+            const float w1 = win_s[s + M], w0 = win_s[s];
+            float env = fmaf(w1, w1, 0.0f);
+            if (jb < a.T) env = fmaf(w0, w0, env);
+            float v0 = ola[i] / env, v1 = ola[NB * M + i] / env;
+            if (ms_to_lr) {
+                const float lft = v0 + v1, rgt = v0 - v1;
+                v0 = lft;
+                v1 = rgt;
+            }
+            ir[(r * 2 + 0) * a.ir_len + tp] = v0;
+            ir[(r * 2 + 1) * a.ir_len + tp] = v1;
+            e += fmaf(v1, v1, v0 * v0);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) e += __shfl_down(e, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = e;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = red[0];
+        for (int w = 1; w < NT / 64; ++w) tot += red[w];
+        partial[r * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+template <int FR>
+constexpr size_t fft384_lds_bytes() {
+    return (size_t)(2 * FR * 193 + 2 * (FR - 1) * 192 + 4 * 192 + 400 + 384 + 8) * sizeof(float);
+}
+
 // ---- FilteredNoiseShapingReverb impulse response (reverb.py:343-366) -----------------------------------
 //   ir[r,c,t] = sum_k noise[c,k,t] * gain[r,c,k] * (exp(t*d) - fg * exp(t*f))
 //   d  = sigmoid(log_decay)*(max_decay - min_decay) + min_decay
@@ -489,6 +666,16 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
                               const float* delta_log_magnitude, const float* gain_env_log_magnitude, const float* window,
                               const float* basis, float* ir, float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft,
                               int64_t hop, int64_t num_frames, int ms_to_lr, void* ws, size_t ws_bytes, void* stream) {
+    return gfx_stft_reverb_ir_sched_f32(noise_stft, noise_rows, init_log_magnitude, delta_log_magnitude,
+                                        gain_env_log_magnitude, window, basis, ir, row_gain, R, ir_len, n_fft, hop,
+                                        num_frames, ms_to_lr, ws, ws_bytes, GFX_ISTFT_AUTO, stream);
+}
+
+int gfx_stft_reverb_ir_sched_f32(const float* noise_stft, int64_t noise_rows, const float* init_log_magnitude,
+                                 const float* delta_log_magnitude, const float* gain_env_log_magnitude,
+                                 const float* window, const float* basis, float* ir, float* row_gain, int64_t R,
+                                 int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames, int ms_to_lr, void* ws,
+                                 size_t ws_bytes, int schedule, void* stream) {
     if (noise_rows != 1 && noise_rows != R) return GFX_EINVAL;
     if (!noise_stft || !init_log_magnitude || !delta_log_magnitude || !window || !basis || !ir || !row_gain)
         return GFX_EINVAL;
@@ -506,6 +693,33 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
     a.ir_len = ir_len;
     a.nstride = noise_rows == 1 ? 0 : 2 * (n_fft / 2 + 1) * num_frames * 2;
     hipStream_t st = (hipStream_t)stream;
+    if (schedule != GFX_ISTFT_AUTO && schedule != GFX_ISTFT_GEMM && schedule != GFX_ISTFT_FFT) return GFX_EINVAL;
+    const bool fft_ok = n_fft == 384 && hop == 192;
+    if (schedule == GFX_ISTFT_FFT && !fft_ok) return GFX_EINVAL;
+    if (fft_ok && schedule != GFX_ISTFT_GEMM) {
+        // frames by FFT, overlap-add in LDS: one workgroup = one row, 31 blocks of 192 samples
+        if (ir_len > num_frames * n_fft || R > 65535) return GFX_EINVAL;
+        const int64_t nblocks = (ir_len + 191) / 192;
+        float* partial = (float*)ws;
+        auto launch = [&](auto FRc) -> int {
+            constexpr int FR = decltype(FRc)::value;
+            static_assert(fft384_lds_bytes<FR>() <= 160 * 1024, "LDS");
+            const unsigned nwg = (unsigned)((nblocks + FR - 2) / (FR - 1));
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_ir_fft384_kernel<FR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft384_lds_bytes<FR>()) != hipSuccess)
+                return GFX_ELAUNCH;
+            hipLaunchKernelGGL(stft_ir_fft384_kernel<FR>, dim3(nwg, (unsigned)R), dim3(FR * 8), fft384_lds_bytes<FR>(), st,
+                               noise_stft, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, window, ir,
+                               partial, a, ms_to_lr);
+            hipLaunchKernelGGL(ir_energy_gain_kernel, dim3((unsigned)R), dim3(64), 0, st, (const float*)partial, row_gain,
+                               (int)nwg);
+            return GFX_OK;
+        };
+        static const int fr_env = [] { const char* e = getenv("GRAFX_ISTFT_FR"); return e ? atoi(e) : 0; }();
+        const int rc = fr_env == 32 ? launch(std::integral_constant<int, 32>{}) : launch(std::integral_constant<int, 16>{});
+        if (rc != GFX_OK) return rc;
+        return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+    }
     if (n_fft <= 384) {
         dim3 g1((unsigned)((num_frames + 63) / 64), (unsigned)(R * 2));
 #ifdef GFX_ISTFT_FULL   // round 1's full-matrix form, kept for A/B timing

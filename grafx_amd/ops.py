@@ -894,9 +894,13 @@ def istft_basis(window):
     return basis
 
 
+ISTFT_SCHEDULES = {"auto": 0, "gemm": 1, "fft": 2}   # GFX_ISTFT_* (include/grafx_amd.h)
+
+
 @_on_device
-def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_len, hop, ms_to_lr):
-    """-> (ir (R,2,ir_len) un-normalised, row_gain (R) = 1/sqrt(mean_c sum_t ir^2 + 1e-12))."""
+def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_len, hop, ms_to_lr, schedule="auto"):
+    """-> (ir (R,2,ir_len) un-normalised, row_gain (R) = 1/sqrt(mean_c sum_t ir^2 + 1e-12)).  `schedule`: how the frames
+    are transformed -- "gemm" (matrix cores, any even n_fft), "fft" (n_fft 384 / hop 192 only), "auto"."""
     _require_gpu(init_lm, delta_lm, gain_env, window, basis)
     R = init_lm.shape[0]
     n_fft = window.numel()
@@ -911,9 +915,10 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
     ws = torch.empty(nbytes, dtype=torch.uint8, device=init_lm.device)
     pin = _Pin()
     check(
-        lib().gfx_stft_reverb_ir_ex_f32(_ptr(nz), noise_rows, pin(init_lm), pin(delta_lm), pin(gain_env), pin(window), pin(basis),
-                                     _ptr(ir), _ptr(row_gain), R, ir_len, n_fft, hop, T, int(ms_to_lr), _ptr(ws), nbytes, _stream()),
-        "gfx_stft_reverb_ir_ex_f32",
+        lib().gfx_stft_reverb_ir_sched_f32(_ptr(nz), noise_rows, pin(init_lm), pin(delta_lm), pin(gain_env), pin(window),
+                                           pin(basis), _ptr(ir), _ptr(row_gain), R, ir_len, n_fft, hop, T, int(ms_to_lr),
+                                           _ptr(ws), nbytes, ISTFT_SCHEDULES[schedule], _stream()),
+        "gfx_stft_reverb_ir_sched_f32",
     )
     return ir, row_gain
 

@@ -393,6 +393,22 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
                               const float* delta_log_magnitude, const float* gain_env_log_magnitude, const float* window,
                               const float* basis, float* ir, float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft,
                               int64_t hop, int64_t num_frames, int ms_to_lr, void* ws, size_t ws_bytes, void* stream);
+/* The same with an explicit choice of how the frames are transformed (same results to rounding):
+ *   GFX_ISTFT_GEMM  the inverse real DFT of a frame as a matrix product on the fp32 matrix cores (any even n_fft), the frames
+ *                   written to the workspace and overlap-added by a second kernel.
+ *   GFX_ISTFT_FFT   n_fft = 384 with hop = 192 (the reference's defaults, reverb.py:48-49) only, else GFX_EINVAL: a 192-point
+ *                   complex FFT per frame (eight lanes a frame, 8 x 24 points), windowed and overlap-added in LDS; one
+ *                   workgroup finishes 31 blocks of 192 samples of both channels of a row -- ~70x less arithmetic, and the
+ *                   frames never reach memory.
+ *   GFX_ISTFT_AUTO  what gfx_stft_reverb_ir_f32 / _ex_f32 use: FFT where it applies. */
+#define GFX_ISTFT_AUTO 0
+#define GFX_ISTFT_GEMM 1
+#define GFX_ISTFT_FFT 2
+int gfx_stft_reverb_ir_sched_f32(const float* noise_stft, int64_t noise_rows, const float* init_log_magnitude,
+                                 const float* delta_log_magnitude, const float* gain_env_log_magnitude,
+                                 const float* window, const float* basis, float* ir, float* row_gain, int64_t R,
+                                 int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames, int ms_to_lr, void* ws,
+                                 size_t ws_bytes, int schedule, void* stream);
 
 /* ---- routing ----------------------------------------------------------------------------
  * replaces read_single_tensor("index") + aggregate_tensor("sum"/"scatter") + inplace_write_tensor

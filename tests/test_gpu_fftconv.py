@@ -288,3 +288,30 @@ def test_pipe_schedule_headline_shape_against_the_tile_schedule():
     h2 = torch.randn(n, 1, 1100, device="cuda")
     with pytest.raises(RuntimeError):                         # no variant for a 1536-sample overlap
         ops.fftconv(x4, ops.fir_spectrum(h2.reshape(-1, 1100)), 1100, 1, h_rows=n, schedule="pipe")
+
+
+@pytest.mark.parametrize("L,N,off", [(30000, 8200, 0), (50000, 20001, 0), (9000, 60001, 0), (70000, 16385, 0),
+                                     (240000, 60001, 0), (41000, 20001, 10000), (65536, 30000, 29999), (8192, 9000, 0),
+                                     (131072, 60000, 0), (24577, 8194, 3)])
+def test_two_output_tiles_per_workgroup_equal_the_one_tile_schedule(L, N, off):
+    """macinv_pair_kernel (GFX_SCHED_AUTO for partitioned filters: two consecutive output tiles per 512-thread workgroup,
+    each group of 256 threads multiplying half the mirrored bin pairs of both tiles) against macinv_kernel (GFX_SCHED_TILE):
+    the same partitions added in the same order -- equal to a few units in the last place of the largest output (the
+    twiddle arithmetic of the two kernels is contracted differently), including odd tile counts (a last group of one
+    tile), windows before the row start / past its end, output offsets, shared filter rows and strided views."""
+    from grafx_amd import ops
+
+    torch.manual_seed(L + N)
+    B, n = 2, 3
+    buf = torch.randn(B, n + 1, 2, L, device="cuda")
+    x4 = buf.narrow(1, 1, n)
+    h = torch.randn(n, 2, N, device="cuda") / N**0.5
+    Hs = ops.fir_spectrum(h.reshape(-1, N))
+    Lout = min(L, L + N - 1 - off)
+    a = ops.fftconv(x4, Hs, N, 2, Lout=Lout, off=off, h_rows=n, schedule="auto")
+    b = ops.fftconv(x4, Hs, N, 2, Lout=Lout, off=off, h_rows=n, schedule="tile")
+    assert (a - b).abs().max().item() <= 4e-7 * b.abs().max().item()
+    assert torch.equal(a, ops.fftconv(x4, Hs, N, 2, Lout=Lout, off=off, h_rows=n, schedule="auto"))
+    ref = lti.linear_convolve(x4.reshape(B * n, 2, L).cpu(), h.repeat(B, 1, 1).cpu(), "full")[..., off : off + Lout]
+    assert_close(a.cpu(), ref, 1e-5, "partitioned, two tiles per workgroup")
+    assert_close(b.cpu(), ref, 1e-5, "partitioned, one tile per workgroup")
