@@ -406,18 +406,46 @@ __global__ __launch_bounds__(64) void ir_energy_gain_kernel(const float* __restr
 // envelope division, mid/side -> left/right, store and energy partial as in istft_ola_kernel.
 using cxf = float __attribute__((ext_vector_type(2)));
 
-template <int FR>
-__global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __restrict__ noise_stft,
-                                                                const float* __restrict__ init_lm,
-                                                                const float* __restrict__ delta_lm,
-                                                                const float* __restrict__ gain_env,
-                                                                const float* __restrict__ window, float* __restrict__ ir,
-                                                                float* __restrict__ partial, IstftArgs a, int ms_to_lr) {
-    constexpr int M = 192, NT = FR * 8, PITCH = 193, NB = FR - 1, K = 193;
+// Behind the two bases (same buffer): e^(+2 pi i k / n_fft), k < n_fft / 2, then e^(+2 pi i p / (n_fft / 2)), p < n_fft / 2 -- the
+// factors of the even/odd split and of the two-stage transform, read through the (vector) L1 by every workgroup.
+__global__ void istft_fft_tables_kernel(float* __restrict__ tab, int n_fft) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, M = n_fft / 2;
+    if (i >= n_fft) return;
+    float sn, cs;
+    if (i < M) sincospif(2.0f * (float)i / (float)n_fft, &sn, &cs);
+    else sincospif(2.0f * (float)(i - M) / (float)M, &sn, &cs);
+    tab[2 * i] = cs;
+    tab[2 * i + 1] = sn;
+}
+
+// LN lanes work on a frame (LN = 8: 192 = 8 x 24, LN = 16: 192 = 16 x 12) and a wave on 64 / LN frames, each lane touching
+// 8-byte (spectrum) or 2 x 4-byte (overlap-add image) entries at l, l + LN, ...: a frame pitch of 2 LN banks (mod 64) puts
+// the dwords of neighbouring frames' lanes side by side, so that a wave's access takes the four cycles its 512 bytes need
+// anyway.  With the natural pitches (193 entries / 192 floats) lanes of neighbouring frames met in the same banks, up to
+// eight deep.
+template <int LN> constexpr int f3_pitch() { return LN == 8 ? 200 : 208; }       // 8-byte entries per frame: 2 LN dwords mod 64
+template <int LN> constexpr int f3_ola_pitch() { return LN == 8 ? 208 : 224; }   // floats per block of 192 samples: 2 LN mod 64
+
+template <int FR, int LN>
+constexpr size_t fft384_lds_bytes() {
+    return (size_t)(2 * FR * f3_pitch<LN>() + 2 * (FR - 1) * f3_ola_pitch<LN>() + 4 * 192 + 400 + 384 + 8) * sizeof(float);
+}
+
+template <int FR, int LN>
+__global__ __launch_bounds__(FR * LN) void stft_ir_fft384_kernel(const float* __restrict__ noise_stft,
+                                                                 const float* __restrict__ init_lm,
+                                                                 const float* __restrict__ delta_lm,
+                                                                 const float* __restrict__ gain_env,
+                                                                 const float* __restrict__ window,
+                                                                 const float* __restrict__ tables, float* __restrict__ ir,
+                                                                 float* __restrict__ partial, IstftArgs a, int ms_to_lr) {
+    constexpr int M = 192, C1 = M / LN, NT = FR * LN, PITCH = f3_pitch<LN>(), OP = f3_ola_pitch<LN>(), NB = FR - 1, K = 193;
+    constexpr int QG = (K + LN - 1) / LN;    // bins a lane generates
+    constexpr int QN = (C1 + LN - 1) / LN;   // second-stage transforms a lane may own (b = l + LN q < C1)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cxf* Xs = reinterpret_cast<cxf*>(smem);                 // [FR][PITCH]: the masked spectra, then the stage-1 results
-    float* ola = smem + 2 * FR * PITCH;                     // [2][NB * 192]
-    cxf* tw384 = reinterpret_cast<cxf*>(ola + 2 * NB * M);  // e^(+2 pi i k / 384), k < 192
+    float* ola = smem + 2 * FR * PITCH;                     // [2][NB][OP]
+    cxf* tw384 = reinterpret_cast<cxf*>(ola + 2 * NB * OP); // e^(+2 pi i k / 384), k < 192
     cxf* tw192 = tw384 + M;                                 // e^(+2 pi i p / 192), p < 192
     float* slope_s = reinterpret_cast<float*>(tw192 + M);   // -softplus(delta) per bin (200 floats)
     float* h0_s = slope_s + 200;                            // the initial log-magnitudes (200 floats)
@@ -426,16 +454,16 @@ __global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __r
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.y;
     const int mfirst = blockIdx.x * NB;                     // first frame; the blocks are mfirst + 1 .. mfirst + NB
-    for (int i = tid; i < M; i += NT) {
-        float sn, cs;
-        sincospif((float)i / 192.0f, &sn, &cs);
-        tw384[i] = cxf{cs, sn};
-        sincospif((float)i / 96.0f, &sn, &cs);
-        tw192[i] = cxf{cs, sn};
+    // (the tables could be read from the copy behind the bases directly -- 4.6 KB less LDS -- but per-lane 8-byte loads
+    // through L1 cost more than the occupancy gives: cfg3 3.00 against 2.92 ms)
+    for (int i = tid; i < 2 * M; i += NT) {
+        if (i < M) {
+            tw384[i] = reinterpret_cast<const cxf*>(tables)[i];
+            tw192[i] = reinterpret_cast<const cxf*>(tables)[M + i];
+        }
+        win_s[i] = window[i];
     }
-    for (int i = tid; i < 2 * M; i += NT) win_s[i] = window[i];
-    const int fm = tid % FR, kg = tid / FR;                 // step 1: lane -> frame (consecutive lanes: consecutive frames), 8 bin groups
-    const int f = tid >> 3, l = tid & 7;                    // steps 2, 3: eight lanes per frame
+    const int f = tid / LN, l = tid % LN;                   // LN lanes per frame
     for (int c = 0; c < 2; ++c) {
         const int64_t rc = r * 2 + c;
         for (int i = tid; i < K; i += NT) {
@@ -444,37 +472,37 @@ __global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __r
         }
         __syncthreads();   // (also: the previous channel's last reads of Xs are done)
         {
-            const int m = mfirst + fm;
+            const int m = mfirst + f;
             const bool m_ok = m < a.T;
             const float mf = (float)m;
             const float genv = (gain_env && m_ok) ? gain_env[rc * a.T + m] : 0.0f;
             const float* nz0 = noise_stft + r * a.nstride + ((int64_t)c * K * a.T + (m_ok ? m : 0)) * 2;
-            // all 25 noise loads of the lane in flight together (one at a time, each would cost a trip to L2: the
-            // workgroup has only four waves to hide it behind)
-            float2 nz[25];
+            // all noise loads of the lane in flight together (one at a time, each would cost a trip to L2: the workgroup
+            // has only a few waves to hide it behind); lane l takes bins l, l + LN, ...
+            float2 nz[QG];
 #pragma unroll
-            for (int q = 0; q < 25; ++q) {
-                const int k = kg + 8 * q;
+            for (int q = 0; q < QG; ++q) {
+                const int k = l + LN * q;
                 nz[q] = (m_ok && k < K) ? *reinterpret_cast<const float2*>(nz0 + (int64_t)k * a.T * 2) : make_float2(0.0f, 0.0f);
             }
 #pragma unroll
-            for (int q = 0; q < 25; ++q) {
-                const int k = kg + 8 * q;
+            for (int q = 0; q < QG; ++q) {
+                const int k = l + LN * q;
                 if (k < K) {
                     float lm = __fadd_rn(h0_s[k], __fmul_rn(slope_s[k], mf));
                     if (gain_env) lm = __fadd_rn(lm, genv);
                     const float mask = m_ok ? expf(lm / 8.0f) : 0.0f;
-                    Xs[fm * PITCH + k] = cxf{nz[q].x * mask, (k == 0 || k == M) ? 0.0f : nz[q].y * mask};
+                    Xs[f * PITCH + k] = cxf{nz[q].x * mask, (k == 0 || k == M) ? 0.0f : nz[q].y * mask};
                 }
             }
         }
         __syncthreads();
-        cxf v[24];
+        cxf v[C1];
         {
             const cxf* X = Xs + f * PITCH;
 #pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                const int k = l + 8 * j;
+            for (int j = 0; j < C1; ++j) {
+                const int k = l + LN * j;
                 const cxf A = X[k], Bc = X[M - k];                          // B = conj(Bc)
                 const cxf e = cxf{A.x + Bc.x, A.y - Bc.y};                  // A + B
                 const cxf d = cxf{A.x - Bc.x, A.y + Bc.y};                  // A - B
@@ -483,47 +511,54 @@ __global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __r
                 v[j] = cxf{e.x - o.y, e.y + o.x} * (1.0f / 384.0f);         // (E + i O) / 192
             }
         }
-        sdft<24, true>(v);
+        sdft<C1, true>(v);
         __syncthreads();   // every lane has read its spectrum
 #pragma unroll
-        for (int b = 0; b < 24; ++b) {
-            const cxf y = v[spos(24, b)], w = tw192[b * l];
-            Xs[f * PITCH + b * 8 + l] = cxf{y.x * w.x - y.y * w.y, y.x * w.y + y.y * w.x};
+        for (int b = 0; b < C1; ++b) {
+            const cxf y = v[spos(C1, b)], w = tw192[b * l];
+            Xs[f * PITCH + b * LN + l] = cxf{y.x * w.x - y.y * w.y, y.x * w.y + y.y * w.x};
         }
         __syncthreads();
-        cxf u[3][8];
+        cxf u[QN][LN];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const cxf* Y = Xs + f * PITCH + (l + 8 * q) * 8;
+        for (int q = 0; q < QN; ++q) {
+            const int b = l + LN * q;
+            if (b < C1) {
+                const cxf* Y = Xs + f * PITCH + b * LN;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) u[q][i] = Y[i];
-            sdft<8, true>(u[q]);
+                for (int i = 0; i < LN; ++i) u[q][i] = Y[i];
+                sdft<LN, true>(u[q]);
+            }
         }
-        float* o = ola + c * NB * M;
-        // first halves (a < 4: n = 2 (24 a + b) < 192) of frames 1 .. FR - 1 open their block
+        float* o = ola + c * NB * OP;
+        // first halves (a < LN / 2: n = 2 (C1 a + b) < 192) of frames 1 .. FR - 1 open their block
         if (f >= 1) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < QN; ++q)
+                if (l + LN * q < C1) {
 #pragma unroll
-                for (int aa = 0; aa < 4; ++aa) {
-                    const int n = 2 * (24 * aa + l + 8 * q);
-                    const cxf z = u[q][spos(8, aa)];
-                    *reinterpret_cast<float2*>(o + (f - 1) * M + n) = make_float2(win_s[n] * z.x, win_s[n + 1] * z.y);
+                    for (int aa = 0; aa < LN / 2; ++aa) {
+                        const int n = 2 * (C1 * aa + l + LN * q);
+                        const cxf z = u[q][spos(LN, aa)];
+                        *reinterpret_cast<float2*>(o + (f - 1) * OP + n) = make_float2(win_s[n] * z.x, win_s[n + 1] * z.y);
+                    }
                 }
         }
         __syncthreads();
         // second halves of frames 0 .. FR - 2 complete the block the next frame opened
         if (f <= FR - 2) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < QN; ++q)
+                if (l + LN * q < C1) {
 #pragma unroll
-                for (int aa = 4; aa < 8; ++aa) {
-                    const int n = 2 * (24 * aa + l + 8 * q);
-                    const cxf z = u[q][spos(8, aa)];
-                    float2* dst = reinterpret_cast<float2*>(o + f * M + (n - M));
-                    const float2 old = *dst;
-                    // (frame m - 1 first, then frame m: the order of istft_ola_kernel's sum)
-                    *dst = make_float2(win_s[n] * z.x + old.x, win_s[n + 1] * z.y + old.y);
+                    for (int aa = LN / 2; aa < LN; ++aa) {
+                        const int n = 2 * (C1 * aa + l + LN * q);
+                        const cxf z = u[q][spos(LN, aa)];
+                        float2* dst = reinterpret_cast<float2*>(o + f * OP + (n - M));
+                        const float2 old = *dst;
+                        // (frame m - 1 first, then frame m: the order of istft_ola_kernel's sum)
+                        *dst = make_float2(win_s[n] * z.x + old.x, win_s[n + 1] * z.y + old.y);
+                    }
                 }
         }
     }
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __r
             const float w1 = win_s[s + M], w0 = win_s[s];
             float env = fmaf(w1, w1, 0.0f);
             if (jb < a.T) env = fmaf(w0, w0, env);
-            float v0 = ola[i] / env, v1 = ola[NB * M + i] / env;
+            float v0 = ola[j * OP + s] / env, v1 = ola[NB * OP + j * OP + s] / env;
             if (ms_to_lr) {
                 const float lft = v0 + v1, rgt = v0 - v1;
                 v0 = lft;
@@ -557,11 +592,6 @@ __global__ __launch_bounds__(FR * 8) void stft_ir_fft384_kernel(const float* __r
         for (int w = 1; w < NT / 64; ++w) tot += red[w];
         partial[r * gridDim.x + blockIdx.x] = tot;
     }
-}
-
-template <int FR>
-constexpr size_t fft384_lds_bytes() {
-    return (size_t)(2 * FR * 193 + 2 * (FR - 1) * 192 + 4 * 192 + 400 + 384 + 8) * sizeof(float);
 }
 
 // ---- FilteredNoiseShapingReverb impulse response (reverb.py:343-366) -----------------------------------
@@ -634,7 +664,7 @@ int gfx_noise_shaping_ir_f32(const float* noise, int64_t noise_stride, const flo
 
 size_t gfx_istft_basis_bytes(int64_t n_fft) {
     if (n_fft < 2 || (n_fft & 1)) return 0;
-    return ((size_t)kpad_of(n_fft) * n_fft + (size_t)(n_fft / 2 + 1) * 2 * half_cols(n_fft)) * sizeof(float);
+    return ((size_t)kpad_of(n_fft) * n_fft + (size_t)(n_fft / 2 + 1) * 2 * half_cols(n_fft) + 2 * (size_t)n_fft) * sizeof(float);
 }
 
 int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* stream) {
@@ -645,6 +675,8 @@ int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* 
     const int64_t htotal = (n_fft / 2 + 1) * 2 * half_cols(n_fft);
     hipLaunchKernelGGL(istft_half_basis_kernel, dim3((unsigned)((htotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        basis + total, (int)n_fft, (int)half_cols(n_fft));
+    hipLaunchKernelGGL(istft_fft_tables_kernel, dim3((unsigned)((n_fft + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       basis + total + htotal, (int)n_fft);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
@@ -701,22 +733,28 @@ int gfx_stft_reverb_ir_sched_f32(const float* noise_stft, int64_t noise_rows, co
         if (ir_len > num_frames * n_fft || R > 65535) return GFX_EINVAL;
         const int64_t nblocks = (ir_len + 191) / 192;
         float* partial = (float*)ws;
-        auto launch = [&](auto FRc) -> int {
-            constexpr int FR = decltype(FRc)::value;
-            static_assert(fft384_lds_bytes<FR>() <= 160 * 1024, "LDS");
+        auto launch = [&](auto FRc, auto LNc) -> int {
+            constexpr int FR = decltype(FRc)::value, LN = decltype(LNc)::value;
+            constexpr size_t lds = fft384_lds_bytes<FR, LN>();
+            static_assert(lds <= 160 * 1024, "LDS");
             const unsigned nwg = (unsigned)((nblocks + FR - 2) / (FR - 1));
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_ir_fft384_kernel<FR>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft384_lds_bytes<FR>()) != hipSuccess)
+            auto kern = stft_ir_fft384_kernel<FR, LN>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
                 return GFX_ELAUNCH;
-            hipLaunchKernelGGL(stft_ir_fft384_kernel<FR>, dim3(nwg, (unsigned)R), dim3(FR * 8), fft384_lds_bytes<FR>(), st,
-                               noise_stft, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, window, ir,
-                               partial, a, ms_to_lr);
+            hipLaunchKernelGGL(kern, dim3(nwg, (unsigned)R), dim3(FR * LN), lds, st, noise_stft, init_log_magnitude,
+                               delta_log_magnitude, gain_env_log_magnitude, window,
+                               basis + kpad_of(n_fft) * n_fft + (n_fft / 2 + 1) * 2 * half_cols(n_fft), ir, partial, a,
+                               ms_to_lr);
             hipLaunchKernelGGL(ir_energy_gain_kernel, dim3((unsigned)R), dim3(64), 0, st, (const float*)partial, row_gain,
                                (int)nwg);
             return GFX_OK;
         };
         static const int fr_env = [] { const char* e = getenv("GRAFX_ISTFT_FR"); return e ? atoi(e) : 0; }();
-        const int rc = fr_env == 32 ? launch(std::integral_constant<int, 32>{}) : launch(std::integral_constant<int, 16>{});
+        using I8 = std::integral_constant<int, 8>;
+        using I16 = std::integral_constant<int, 16>;
+        using I32 = std::integral_constant<int, 32>;
+        const int rc = fr_env == 32 ? launch(I32{}, I8{}) : fr_env == 16 ? launch(I16{}, I8{}) : launch(I16{}, I16{});
         if (rc != GFX_OK) return rc;
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
