@@ -1101,7 +1101,8 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     if (ax.nblocks > 0x7ffffff0LL) return GFX_EINVAL;
     hipLaunchKernelGGL(xspec_kernel, dim3(pad8(ax.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, (float2*)ws, ax,
                        nwin, tw);
-    if (schedule != GFX_SCHED_TILE) {
+    // (the pair kernel reaches a filter's partitions through one 32-bit-ranged descriptor: 30 000 partitions = 250 M taps)
+    if (schedule != GFX_SCHED_TILE && (int64_t)g.nparts * H_TILE_F4 * 16 < 0x7fffffffLL) {
         // two consecutive output tiles per 512-thread workgroup: each window spectrum and filter partition fetched once a pair
         if (allow_lds(macinv_pair_kernel, 2 * TILE_LDS_BYTES)) return GFX_ELAUNCH;
         ConvArgs ap = a;

@@ -129,6 +129,10 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
  *                   allocation: the next tile's window, the filter spectrum and the output stores are interleaved
  *                   with the arithmetic of the running tile).  GFX_EINVAL where it does not apply.
  *   GFX_SCHED_AUTO  what gfx_fftconv_f32 / _tee_f32 / _ex_f32 use: the faster of the two for the shape at hand.
+ * For longer filters (partitioned convolution: xspec_kernel + a product kernel) GFX_SCHED_TILE selects one output tile per
+ * 256-thread workgroup (macinv_kernel) and GFX_SCHED_AUTO two consecutive ones per 512-thread workgroup (macinv_pair_kernel:
+ * each window spectrum and filter partition fetched once per pair; equal to a few units in the last place of the largest
+ * output); GFX_SCHED_PIPE: GFX_EINVAL.
  * (Round-2 experiments -- ping-pong, half-size exchanges, 512-thread tile -- live in tools/experiments/r2_schedules.) */
 #define GFX_SCHED_AUTO 0
 #define GFX_SCHED_TILE 1
@@ -140,7 +144,7 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
 
 /* Diagnostic: the name -- as rocprofv3's kernel trace prints it -- of the (dominant) kernel that the calling thread's last
  * successful gfx_fftconv_* call launched: "gfx_fftconv_pipe_t1_o8", "fftconv1_kernel<true>", "winmac_kernel",
- * "xspec_kernel+macinv_kernel"; "" before the first call.  The string is static.  (bench.py labels its live per-launch
+ * "xspec_kernel+macinv_pair_kernel"; "" before the first call.  The string is static.  (bench.py labels its live per-launch
  * timings with it, so that the line's `roofline.kernel` is a name a profile of the same command contains.) */
 const char* gfx_fftconv_last_kernel(void);
 
