@@ -326,9 +326,16 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
     load_window(v, xrow, s, a.L, t, 1.0f);
     tile_twiddles(tw, twtab, t);
     tile_forward(v, w, tw, lds, t);
-    cx* out = reinterpret_cast<cx*>(Zs) + (int64_t)lb * TILE_M;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) out[q * TILE_T + t] = w[q >> 4][q & 15];
+    // stored the way the filter spectra are: per mirrored bin pair one 16-byte entry (Xe, Xo) at [slot][t] (the seventeenth
+    // slot: thread 0 only), already split -- the product kernels fetch a pair with ONE instruction where two 8-byte rows
+    // cost the CU's address unit twice as much (a vector-memory instruction occupies it ~22 cycles whatever its width, and
+    // that is what bounds their loop), and thread 0's different pairing is settled here, once, instead of in every turn.
+    f4v* out = reinterpret_cast<f4v*>(Zs) + (int64_t)lb * H_TILE_F4;
+    for_each_pair(t, tw.base(), [&](int slot, int ia, int ib, cx, bool) {
+        cx xe, xo;
+        pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
+        out[slot * TILE_T + t] = __builtin_shufflevector(xe, xo, 0, 1, 2, 3);
+    });
 }
 
 __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restrict__ Zs, const float4* __restrict__ Hs,
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     const int c = (int)(rco - r * (unsigned)a.Cout);
     float* yrow = y + row_off(a.ymap, r, c);
     const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
-    const cx* Z = reinterpret_cast<const cx*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
+    const f4v* Z = reinterpret_cast<const f4v*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * H_TILE_F4;
 
     cx ye[H_SLOTS], yo[H_SLOTS];
 #pragma unroll
@@ -355,15 +362,19 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     for (int p = 0; p < a.nparts; ++p) {
         const int64_t j = tile - p;
         if (!window_live(a.off - a.O + j * a.hop, a.L)) continue;
-        const cx* Zj = Z + (j + a.nparts - 1) * TILE_M;
-        const f4v* Hp = H + (int64_t)p * H_TILE_F4;
-        cx w[2][16];
+        // every operand of the turn requested up front (left to itself the compiler fetches each pair right before its
+        // product and waits for it: 34 serialised trips to L2 per turn, 3.8 instead of 1.9 ms at cfg3)
+        const rsrc_t zr = make_rsrc(Z + (j + a.nparts - 1) * H_TILE_F4, (int64_t)H_TILE_F4 * 16);
+        const rsrc_t hr = make_rsrc(H + (int64_t)p * H_TILE_F4, (int64_t)H_TILE_F4 * 16);
+        f4v xreg[H_SLOTS], hreg[H_SLOTS];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = Zj[q * TILE_T + t];
-        for_each_pair(t, wj, [&](int slot, int ia, int ib, cx wk, bool) {
-            cx xe, xo;
-            pair_split(NAT(w, ia), NAT(w, ib), xe, xo);
-            pair_product_acc(xe, xo, Hp[slot * TILE_T + t], wk, ye[slot], yo[slot]);
+        for (int q = 0; q < H_SLOTS; ++q) {
+            xreg[q] = buf_load_f4(zr, 16u * (uint32_t)t, 4096u * q);
+            hreg[q] = buf_load_f4(hr, 16u * (uint32_t)t, 4096u * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for_each_pair(t, wj, [&](int slot, int, int, cx wk, bool) {
+            pair_product_acc(xreg[slot].lo, xreg[slot].hi, hreg[slot], wk, ye[slot], yo[slot]);
         });
     }
 
@@ -397,21 +408,20 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
 // Mirrored pairs of a group, the same straight-line code for every lane: slot i < 8 of group G is pair 8 G + i of threads
 // t != 0 -- bins (row 0, k3) and (row 1, 15 - k3), k3 = 8 G + i, rows = the two butterflies bf of tile_forward's layout --
 // and, for thread 0, whose bins pair up INSIDE a row, (row 0: k3 = i with 16 - i; i = 0 with itself) in group 0 and
-// (row 1: k3 = i with 15 - i) in group 1; group 0 has a ninth slot for thread 0's self-paired bin (row 0, k3 = 8).  The
-// difference is data, not control flow: a per-lane row in the load offsets (two selects per load), W^(t + 512 k3) from a
-// per-lane base (thread 0 of group 1: W_32^17, so that base x W_32^(16 + 2 i) = W_32^(1 + 2 i), its pairs' factor), and
-// selects where the finished halves are put into place.  A divergent branch for thread 0 would double the code and, worse,
-// blur the compiler's wait counts at its join (every turn would start by waiting for all outstanding loads).
+// (row 1: k3 = i with 15 - i) in group 1; group 0 has a ninth slot for thread 0's self-paired bin (row 0, k3 = 8).  These
+// are for_each_pair's slots, in which both the filter partitions (hspec_kernel) and the window spectra (xspec_kernel) are
+// stored, so the difference is data, not control flow: a per-lane slot base in the load offset (thread 0 of group 1:
+// slots 9.. instead of 8..), W^(t + 512 k3) from a per-lane base (thread 0 of group 1: W_32^17, so that base x
+// W_32^(16 + 2 i) = W_32^(1 + 2 i), its pairs' factor), and selects where the finished halves are put into place.  A
+// divergent branch for thread 0 would double the code and, worse, blur the compiler's wait counts at its join (every turn
+// would start by waiting for all outstanding loads).
 //
 // Flat 16-entry layout of a group's half tile: e < 8 "lower" = row G, k3 = e;  e >= 8 "upper" = k3 = e of row
 // (G == 0) == (t != 0).
 constexpr int HALF_SLOTS = 9;   // (the ninth: group 0 only)
 
-// byte offset of window-spectrum row q = 16 bf + brev4(k3) (8-byte entries, row q at q * 256 + t)
-constexpr uint32_t zrow(int bf, int k3) { return 2048u * (uint32_t)(16 * bf + brev(k3 & 15, 4)); }
-
 template <int G>
-__device__ __forceinline__ void macinv_pair_half(const cx* __restrict__ Z, const f4v* __restrict__ H, const ConvArgs& a,
+__device__ __forceinline__ void macinv_pair_half(const f4v* __restrict__ Z, const f4v* __restrict__ H, const ConvArgs& a,
                                                  int64_t tile, bool two, int t, cx wj, cx* lds_other,
                                                  cx (&own)[16]) {
     constexpr int NS = G ? 8 : 9;
@@ -420,17 +430,7 @@ __device__ __forceinline__ void macinv_pair_half(const cx* __restrict__ Z, const
     for (int s = 0; s < NS; ++s) aye[s] = ayo[s] = bye[s] = byo[s] = cx{0.0f, 0.0f};
 
     const bool z = t == 0;
-    const uint32_t t8 = 8u * (uint32_t)t;
-    // lane offset of a slot's two window rows (first / second bin of the pair)
-    auto off_a = [&](int i) -> uint32_t {
-        if (G == 0) return t8 + zrow(0, i);
-        return t8 + (z ? zrow(1, i) : zrow(0, 8 + i));
-    };
-    auto off_b = [&](int i) -> uint32_t {
-        if (G == 0) return i == 8 ? t8 + zrow(0, 8) : t8 + (z ? zrow(0, 16 - i) : zrow(1, 15 - i));
-        return t8 + (z ? zrow(1, 15 - i) : zrow(1, 7 - i));
-    };
-    // partition slots (16-byte entries, slot * 256 + t): group 1 multiplies slots 8.. (thread 0: 9..)
+    // window and partition slots alike (16-byte entries, slot * 256 + t): group 1 multiplies slots 8.. (thread 0: 9..)
     const uint32_t hv = 16u * (uint32_t)(t + (G ? (z ? 9 : 8) * TILE_T : 0));
     const cx w32_17 = {-0.98078528040323044913f, 0.19509032201612826785f};
     const cx wbase = (G && z) ? w32_17 : wj;
@@ -451,25 +451,23 @@ __device__ __forceinline__ void macinv_pair_half(const cx* __restrict__ Z, const
     // taken by every pair.)
     const rsrc_t hr = make_rsrc(H, (int64_t)a.nparts * H_TILE_F4 * 16);
     auto window = [&](int k) {
-        return make_rsrc(Z + (tile + 1 - k + a.nparts - 1) * TILE_M, k <= k_hi ? (int64_t)TILE_M * 8 : 0);
+        return make_rsrc(Z + (tile + 1 - k + a.nparts - 1) * H_TILE_F4, k <= k_hi ? (int64_t)H_TILE_F4 * 16 : 0);
     };
-    // One turn: the window of turn k (in wa, wb) times partition k - 1 (ha) for tile i and partition k (hb) for tile i + 1.
-    // The operands of turn k + 1 are requested underneath, IN PLACE, as the products release registers: a mirrored pair is
-    // the only user of its two window rows, so once it has been split the rows of the next window go into the same
-    // registers; the NEW partition of the next turn (k + 1, tile i + 1's) replaces ha slot by slot behind the tile-i
-    // products -- so the next turn runs with (ha, hb) exchanged.  No second buffer: every operand of a turn was requested
-    // one full turn (~1300 instructions) ahead of its use.
-    auto turn = [&](int k, cx (&wa)[NS], cx (&wb)[NS], f4v (&ha)[NS], f4v (&hb)[NS]) {
+    // One turn: the window of turn k (in wx) times partition k - 1 (ha) for tile i and partition k (hb) for tile i + 1.
+    // The operands of turn k + 1 are requested underneath, IN PLACE, as the products release registers: a slot's (Xe, Xo)
+    // are copied out (4 registers) and the next window's entry goes into the same registers; the NEW partition of the
+    // next turn (k + 1, tile i + 1's) replaces ha slot by slot behind the tile-i products -- so the next turn runs with
+    // (ha, hb) exchanged.  No second buffer: every operand of a turn was requested one full turn (~1100 instructions)
+    // ahead of its use.  Two 16-byte requests per slot and turn.
+    auto turn = [&](int k, f4v (&wx)[NS], f4v (&ha)[NS], f4v (&hb)[NS]) {
         const rsrc_t zr = window(k + 1);
         const uint32_t hoff = (uint32_t)(k + 1) * (uint32_t)(H_TILE_F4 * 16);
         cx wjt = wbase;
         asm volatile("" : "+v"(wjt));   // the slots' W^(t + 512 k3) recomputed every turn (2 instructions each), not kept: 16 registers
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            cx xe, xo;
-            pair_split(wa[i], wb[i], xe, xo);
-            wa[i] = buf_load_f2(zr, off_a(i), 0);
-            wb[i] = buf_load_f2(zr, off_b(i), 0);
+            const cx xe = wx[i].lo, xo = wx[i].hi;
+            wx[i] = buf_load_f4(zr, hv, 4096u * i);
             const cx wk = mul_w16(wjt, 8 * G + i);
             pair_product_acc(xe, xo, ha[i], wk, aye[i], ayo[i]);
             ha[i] = buf_load_f4(hr, hv, hoff + 4096u * i);
@@ -481,8 +479,7 @@ __device__ __forceinline__ void macinv_pair_half(const cx* __restrict__ Z, const
     };
 
     if (k_lo <= k_hi) {
-        cx wa[NS], wb[NS];
-        f4v h0[NS], h1[NS];
+        f4v wx[NS], h0[NS], h1[NS];
         const rsrc_t zr = window(k_lo);
         // (requested in the order a turn requests them -- partition k_lo - 1 as if by the turn before, then slot by slot --
         // so that the wait counts the compiler derives for the loop hold from its first turn on instead of "everything")
@@ -491,14 +488,13 @@ __device__ __forceinline__ void macinv_pair_half(const cx* __restrict__ Z, const
             h0[i] = buf_load_f4(hr, hv, (k_lo ? (uint32_t)(k_lo - 1) * (uint32_t)(H_TILE_F4 * 16) : 0x40000000u) + 4096u * i);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            wa[i] = buf_load_f2(zr, off_a(i), 0);
-            wb[i] = buf_load_f2(zr, off_b(i), 0);
+            wx[i] = buf_load_f4(zr, hv, 4096u * i);
             h1[i] = buf_load_f4(hr, hv, (uint32_t)k_lo * (uint32_t)(H_TILE_F4 * 16) + 4096u * i);
             __builtin_amdgcn_sched_barrier(0);
         }
         for (int k = k_lo; k <= k_hi; k += 2) {
-            turn(k, wa, wb, h0, h1);
-            if (k + 1 <= k_hi) turn(k + 1, wa, wb, h1, h0);
+            turn(k, wx, h0, h1);
+            if (k + 1 <= k_hi) turn(k + 1, wx, h1, h0);
         }
     }
 
@@ -567,7 +563,7 @@ __global__ __launch_bounds__(2 * TILE_T, 1) void macinv_pair_kernel(const float2
     const int c = (int)(rco - r * (unsigned)a.Cout);
     float* yrow = y + row_off(a.ymap, r, c);
     const f4v* H = reinterpret_cast<const f4v*>(Hs) + ((int64_t)(r % a.hrows) * a.Cf + (a.Cf == 1 ? 0 : c)) * a.nparts * H_TILE_F4;
-    const cx* Z = reinterpret_cast<const cx*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * TILE_M;
+    const f4v* Z = reinterpret_cast<const f4v*>(Zs) + ((int64_t)r * a.Cin + (a.Cin == 1 ? 0 : c)) * nwin * H_TILE_F4;
     const cx wj = to_cx(twtab[TILE_T + t]);  // W_8192^t
     cx* lds_mine = lds + grp * TILE_LDS_F2;
     cx* lds_other = lds + (1 - grp) * TILE_LDS_F2;
@@ -931,7 +927,7 @@ size_t gfx_fftconv_workspace_bytes_ex(int64_t R, int64_t C_in, int64_t L, int64_
     if (R <= 0 || N <= 0 || Lout <= 0) return 0;
     const ConvGeom g = conv_geom(N, Lout, part_len);
     if (!g.ok || g.nparts == 1 || g.ntiles == 1) return 0;  // one output tile: windows are transformed in place
-    return (size_t)R * C_in * (g.ntiles + g.nparts - 1) * TILE_M * sizeof(float2);
+    return (size_t)R * C_in * (g.ntiles + g.nparts - 1) * H_TILE_F4 * sizeof(float4);
 }
 
 int gfx_fir_spectrum_f32(const float* h, const float* gain, int64_t gain_div, void* Hs, int64_t RCf, int64_t N,
@@ -1093,7 +1089,7 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
         return GFX_OK;
     }
     const int64_t nwin = g.ntiles + g.nparts - 1;
-    const size_t need = (size_t)R * C_in * nwin * TILE_M * sizeof(float2);
+    const size_t need = (size_t)R * C_in * nwin * H_TILE_F4 * sizeof(float4);
     if (!ws || ws_bytes < need) return GFX_ENOSPC;
     if (allow_lds(xspec_kernel) || allow_lds(macinv_kernel)) return GFX_ELAUNCH;
     ConvArgs ax = a;

@@ -8,7 +8,10 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum" "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_WAIT_ANY" \
-           "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+           "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+           "TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCC_BUSY_sum TCC_TAG_STALL_sum" \
+           "TCP_GATE_EN1_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" "TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_COALESCED_READ_CYCLES_sum"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline ${CFG3_EXTRA} > $OUT/p$i.log 2>&1
 done
@@ -23,7 +26,7 @@ for f in glob.glob("$OUT/p1/**/*kernel_trace.csv", recursive=True):
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(.*$", "", re.sub(r"^void\s+", "", r["Kernel_Name"]))
-        if re.search("xspec|macinv|istft|ir_energy|hspec", k):
+        if re.search("xspec|macinv|istft|stft_ir|ir_energy|hspec", k):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     d = dur.get(k, [])
