@@ -439,6 +439,9 @@ __device__ __forceinline__ void macinv_pair_half(const f4v* __restrict__ Z, cons
     // two tiles uses (turn 0: tile i + 1 only, turn nparts: tile i only)
     const int64_t s0 = a.off - a.O + (tile + 1) * a.hop;                  // start of the window of turn 0
     int k_lo = two ? 0 : 1, k_hi = a.nparts;
+#ifdef GFX_PAIR_NOLOOP
+    k_hi = -1;   // timing experiment: the walk skipped, the rest of the kernel as it is
+#endif
     if (s0 >= a.L) k_lo = max(k_lo, (int)((s0 - a.L) / a.hop) + 1);       // first k with s0 - k hop < L
     if (s0 + TILE_F <= (int64_t)k_hi * a.hop) k_hi = (int)((s0 + TILE_F - 1) / a.hop);   // last k with s0 - k hop + TILE_F > 0
 
@@ -453,48 +456,47 @@ __device__ __forceinline__ void macinv_pair_half(const f4v* __restrict__ Z, cons
     auto window = [&](int k) {
         return make_rsrc(Z + (tile + 1 - k + a.nparts - 1) * H_TILE_F4, k <= k_hi ? (int64_t)H_TILE_F4 * 16 : 0);
     };
-    // One turn: the window of turn k (in wx) times partition k - 1 (ha) for tile i and partition k (hb) for tile i + 1.
-    // The operands of turn k + 1 are requested underneath, IN PLACE, as the products release registers: a slot's (Xe, Xo)
-    // are copied out (4 registers) and the next window's entry goes into the same registers; the NEW partition of the
-    // next turn (k + 1, tile i + 1's) replaces ha slot by slot behind the tile-i products -- so the next turn runs with
-    // (ha, hb) exchanged.  No second buffer: every operand of a turn was requested one full turn (~1100 instructions)
-    // ahead of its use.  Two 16-byte requests per slot and turn.
-    auto turn = [&](int k, f4v (&wx)[NS], f4v (&ha)[NS], f4v (&hb)[NS]) {
-        const rsrc_t zr = window(k + 1);
-        const uint32_t hoff = (uint32_t)(k + 1) * (uint32_t)(H_TILE_F4 * 16);
-        cx wjt = wbase;
-        asm volatile("" : "+v"(wjt));   // the slots' W^(t + 512 k3) recomputed every turn (2 instructions each), not kept: 16 registers
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const cx xe = wx[i].lo, xo = wx[i].hi;
-            wx[i] = buf_load_f4(zr, hv, 4096u * i);
-            const cx wk = mul_w16(wjt, 8 * G + i);
-            pair_product_acc(xe, xo, ha[i], wk, aye[i], ayo[i]);
-            ha[i] = buf_load_f4(hr, hv, hoff + 4096u * i);
-            pair_product_acc(xe, xo, hb[i], wk, bye[i], byo[i]);
-            // slot by slot as written (left to itself the compiler gathers the requests of several slots and waits for
-            // nearly all outstanding loads in front of them)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
+    // One turn: the window of turn k (w) times partition k - 1 (ha) for tile i, then times partition k (hb) for tile i + 1.
+    // The operands of turn k + 1 are requested a full turn ahead, in two bursts: its window into the second window
+    // register set at the start of the turn, its NEW partition (k + 1, tile i + 1's) into the registers of ha once all of
+    // tile i's products are done -- so the next turn runs with (ha, hb) and the two window sets exchanged.  (Requests
+    // slot by slot IN PLACE -- a slot's next operands into its own registers right after its products, no second window
+    // set -- measured the same to 1.5 %: the loop is bound by what the address unit moves, not by when it is asked.)
     if (k_lo <= k_hi) {
-        f4v wx[NS], h0[NS], h1[NS];
-        const rsrc_t zr = window(k_lo);
-        // (requested in the order a turn requests them -- partition k_lo - 1 as if by the turn before, then slot by slot --
-        // so that the wait counts the compiler derives for the loop hold from its first turn on instead of "everything")
+        f4v w0[NS], w1[NS], h0[NS], h1[NS];
+        auto req_w = [&](f4v (&w)[NS], int k) {
+            const rsrc_t zr = window(k);
 #pragma unroll
-        for (int i = 0; i < NS; ++i)   // partition -1 for a walk from turn 0: an offset far outside the descriptor -- zeros
-            h0[i] = buf_load_f4(hr, hv, (k_lo ? (uint32_t)(k_lo - 1) * (uint32_t)(H_TILE_F4 * 16) : 0x40000000u) + 4096u * i);
+            for (int i = 0; i < NS; ++i) w[i] = buf_load_f4(zr, hv, 4096u * i);
+        };
+        auto req_h = [&](f4v (&h)[NS], int k) {   // k = -1 / nparts: outside the descriptor, zeros
+            const uint32_t hoff = k < 0 ? 0x40000000u : (uint32_t)k * (uint32_t)(H_TILE_F4 * 16);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            wx[i] = buf_load_f4(zr, hv, 4096u * i);
-            h1[i] = buf_load_f4(hr, hv, (uint32_t)k_lo * (uint32_t)(H_TILE_F4 * 16) + 4096u * i);
+            for (int i = 0; i < NS; ++i) h[i] = buf_load_f4(hr, hv, hoff + 4096u * i);
+        };
+        auto bturn = [&](int k, f4v (&w)[NS], f4v (&wn)[NS], f4v (&ha)[NS], f4v (&hb)[NS]) {
+            req_w(wn, k + 1);
             __builtin_amdgcn_sched_barrier(0);
-        }
+            cx wjt = wbase;
+            asm volatile("" : "+v"(wjt));   // the slots' W^(t + 512 k3) recomputed every turn (2 instructions each), not kept: 16 registers
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                pair_product_acc(w[i].lo, w[i].hi, ha[i], mul_w16(wjt, 8 * G + i), aye[i], ayo[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            req_h(ha, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                pair_product_acc(w[i].lo, w[i].hi, hb[i], mul_w16(wjt, 8 * G + i), bye[i], byo[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        req_h(h0, k_lo - 1);
+        req_w(w0, k_lo);
+        req_h(h1, k_lo);
+        __builtin_amdgcn_sched_barrier(0);
         for (int k = k_lo; k <= k_hi; k += 2) {
-            turn(k, wx, h0, h1);
-            if (k + 1 <= k_hi) turn(k + 1, wx, h1, h0);
+            bturn(k, w0, w1, h0, h1);
+            if (k + 1 <= k_hi) bturn(k + 1, w1, w0, h1, h0);
         }
     }
 
