@@ -380,7 +380,8 @@ int gfx_stereo_gain_mix_f32(const float* x, gfx_rowmap_t xmap, const float* log_
  * Outputs ir (R, 2, ir_len), un-normalised, and row_gain (R) = 1/sqrt(mean_c sum_t ir^2 + 1e-12),
  * to be passed as `gain` (gain_div = 2) to gfx_fir_spectrum_f32.
  * `basis` is a per-(n_fft, window) constant from gfx_istft_basis_f32 (gfx_istft_basis_bytes: the windowed (kpad, n_fft)
- * matrix followed by the un-windowed half basis (n_fft/2+1, 2, roundup(n_fft/2+1, 16)) that the n_fft <= 384 kernel uses).
+ * matrix, the un-windowed half basis (n_fft/2+1, 2, roundup(n_fft/2+1, 16)) that the n_fft <= 384 matrix kernel uses, and
+ * the n_fft complex factors e^(2 pi i k / n_fft), e^(2 pi i p / (n_fft/2)) of the FFT form, GFX_ISTFT_FFT below).
  */
 size_t gfx_istft_basis_bytes(int64_t n_fft);
 int gfx_istft_basis_f32(const float* window, float* basis, int64_t n_fft, void* stream);

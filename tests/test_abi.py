@@ -39,9 +39,9 @@ def test_size_queries_need_no_gpu():
     assert lib.gfx_fftconv_nparts(8194) == 2 and lib.gfx_fftconv_nparts(60001) == 8
     assert lib.gfx_fir_spectrum_bytes(3, 4001) == 3 * 17 * 256 * 16
     assert lib.gfx_fftconv_workspace_bytes(2, 2, 131072, 131072, 0, 4001) == 0
-    assert lib.gfx_fftconv_workspace_bytes(2, 2, 131072, 131072, 0, 60001) == 2 * 2 * (16 + 7) * 8192 * 8
+    assert lib.gfx_fftconv_workspace_bytes(2, 2, 131072, 131072, 0, 60001) == 2 * 2 * (16 + 7) * 17 * 256 * 16
     assert lib.gfx_iir_fsm_plan_bytes(4001) == (8192 + 4096 + 2 * 2052) * 8 and lib.gfx_iir_fsm_plan_bytes(5000) == 0
-    assert lib.gfx_istft_basis_bytes(384) == (388 * 384 + 193 * 2 * 208) * 4   # full basis + the half basis behind it
+    assert lib.gfx_istft_basis_bytes(384) == (388 * 384 + 193 * 2 * 208 + 2 * 384) * 4   # full basis, half basis, FFT factors
 
 
 def test_processors_refuse_cpu_tensors_and_missing_library(monkeypatch):
