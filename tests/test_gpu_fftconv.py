@@ -38,6 +38,19 @@ def test_multi_partition_causal(L, N):
     assert_close(y, _full(x, h)[..., :L].float(), 1e-5, "partitioned causal")
 
 
+@pytest.mark.parametrize("C,Cf", [(1, 2), (2, 1), (1, 1)])
+@pytest.mark.parametrize("L,N,mode", [(40000, 20001, "causal"), (33000, 8200, "zerophase"), (26000, 17000, "full"),
+                                      (8192 * 3, 8192 * 2 + 1, "causal")])
+def test_multi_partition_channel_broadcast_and_modes(C, Cf, L, N, mode):
+    """The partitioned convolution (two output tiles per workgroup) with a mono signal through stereo filters and vice
+    versa, in all three output modes, odd and even tile counts, against the float64 oracle."""
+    torch.manual_seed(L + N + C + 2 * Cf)
+    x, h = torch.randn(3, C, L), torch.randn(3, Cf, N) / N**0.5
+    full = _full(x, h).float()
+    off, Lout = {"causal": (0, L), "zerophase": (N // 2, L), "full": (0, L + N - 1)}[mode]
+    assert_close(_run(x, h, off, Lout), full[..., off : off + Lout], 1e-5, f"partitioned {mode} C={C} Cf={Cf}")
+
+
 @pytest.mark.parametrize("L,N", [(5000, 2047), (5001, 300), (20000, 9001)])
 def test_zerophase_and_full(L, N):
     torch.manual_seed(7)
