@@ -418,8 +418,6 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
 //
 // Flat 16-entry layout of a group's half tile: e < 8 "lower" = row G, k3 = e;  e >= 8 "upper" = k3 = e of row
 // (G == 0) == (t != 0).
-constexpr int HALF_SLOTS = 9;   // (the ninth: group 0 only)
-
 template <int G>
 __device__ __forceinline__ void macinv_pair_half(const f4v* __restrict__ Z, const f4v* __restrict__ H, const ConvArgs& a,
                                                  int64_t tile, bool two, int t, cx wj, cx* lds_other,
