@@ -21,7 +21,7 @@ def _oracle_ir(m, p0, p1, genv, ms_lr):
     return ir
 
 
-@pytest.mark.parametrize("ir_len", [60000, 3001, 5952, 5953, 400, 12000])
+@pytest.mark.parametrize("ir_len", [60000, 3001, 5952, 5953, 400, 12000, 193, 2880, 2881])
 @pytest.mark.parametrize("genv,ms_lr", [(False, True), (True, False)])
 def test_fft_frames_equal_matrix_core_frames_and_the_oracle(ir_len, genv, ms_lr):
     from grafx_amd import ops
