@@ -7,8 +7,10 @@
 // Kernels
 //   hspec_kernel    taps -> per-partition tile spectra (He, Ho pairs in thread layout)
 //   fftconv1_kernel N <= 8193: load x tile -> FFT -> x H -> IFFT -> store valid samples (fused)
-//   xspec_kernel    N  > 8193: x window -> FFT -> spectra to HBM/L2
-//   macinv_kernel   N  > 8193: sum_p X[i-p] * H[p] in registers -> IFFT -> store
+//   xspec_kernel    N  > 8193: x window -> FFT -> split spectra (Xe, Xo pairs in thread layout) to HBM/L2
+//   macinv_pair_kernel  N > 8193: two output tiles per 512-thread workgroup, sum_p X[i-p] * H[p] in registers -> 2 x IFFT -> store
+//   macinv_kernel   the same with one output tile per 256-thread workgroup (GFX_SCHED_TILE)
+//   winmac_kernel / corr1_kernel / gfx_fftconv_pipe_*, gfx_corr_pipe (generated assembly): see below
 //
 // Algorithmic bytes: 4*(C_in + C_out) per output frame per row (read x once, write y once);
 // the tile overlap (N-1 of 16384 samples) is re-read through L2.
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
 // Registers decide the shape: two accumulator sets, a window and two partitions are 340 registers per thread for a
 // 256-thread tile (round 4's first attempt, tools/experiments/r4_macinv2: spills, serialised loads, 1.6x slower).  Here
 // the mirrored bin pairs of a thread are split between the two groups -- group G multiplies pairs 8G .. 8G + 7 of BOTH
-// tiles -- so everything halves: 2 x 36 accumulators, 36 for the window rows the group's pairs touch, 2 x 36 for the
-// partitions.  After the loop the groups swap halves through LDS (group 0 gets tile i complete, group 1 tile i + 1) and run
+// tiles -- so everything halves: 2 x 36 accumulators, 2 x 36 for two window sets (the running one and the next), 2 x 36
+// for the partitions.  After the loop the groups swap halves through LDS (group 0 gets tile i complete, group 1 tile i + 1) and run
 // the two inverse transforms side by side.  Every tile adds the same products in the same order as in macinv_kernel (equal
 // to the last bit or two: the compiler contracts the twiddle arithmetic of the two kernels differently).
 //
