@@ -7,14 +7,22 @@
 // with zero initial state.  No FFT, no truncation of the impulse response (the FSM backend aliases it to
 // fsm_fir_len taps), 8 B of HBM traffic per channel-sample.
 //
-// Parallelisation: one WAVE walks a row-channel in 512-sample tiles (64 lanes x 8 samples), four row-channels
-// per workgroup, no barriers in the time loop.  The recursion is the linear system s[n] = M s[n-1] + (x[n], 0),
+// Parallelisation: SIXTEEN LANES walk TWO row-channels (packed fp32: the two channels of a stereo row, or two neighbouring
+// mono rows) in 128-sample tiles (16 lanes x 8 samples); a wave (= a workgroup) carries four such pairs; no barriers
+// and no cross-lane LDS traffic in the time loop.  The recursion is the linear system s[n] = M s[n-1] + (x[n], 0),
 // M = [[-a1, -a2], [1, 0]], s = (w[n], w[n-1]):
 //   1. each lane runs its 8 samples from a zero state                 -> end state e_t
-//   2. Hillis-Steele scan over the 64 lanes with M^(8*2^d)            -> state at the end of every chunk
-//   3. every lane adds M^(8*lane) * (carry entering the tile), reruns its 8 samples from the true state and
-//      applies the numerator; the tile's end state (lane 63, plus M^512 * carry) is the next carry.
-// Matrix powers are formed in double per (row-channel, section) when the wave starts and live in LDS.
+//   2. Hillis-Steele scan over the 16 lanes with M^(8*2^d), d < 4     -> state at the end of every chunk.  The shifted
+//      operands come from DPP row shifts (row_shr:1/2/4/8, zero fill: the lanes a step does not reach add zero), i.e. from
+//      the vector ALU's own lane crossbar.  The state entering the tile (the carry) is injected at lane 0 (its end state
+//      += M^8 * carry), so the scan delivers every lane's TRUE entering state and lane 15's total (row_ror:1 -> lane 0)
+//      is the next tile's carry
+//   3. every lane reruns its 8 samples from that state and applies the numerator.
+// The matrix powers M^(8*2^d) are formed in double per (row-channel, section) when the workgroup starts and live in LDS
+// (192 B per pair and section).  Rounds 2-3 scanned over all 64 lanes of a wave with __shfl_up = ds_bpermute_b32: 16
+// (32 with two row-channels per wave) trips through the LDS crossbar per section and tile, ~9 cycles each of the CU's
+// ONE LDS unit -- that, not arithmetic or HBM, was the kernel's time (K = 6 at 8192 x 2 x 131072: 7.3 ms = 2.3 TB/s;
+// two row-channels per wave in packed fp32 alone changed nothing).
 //
 // ssm_quirk: upstream's "ssm" backend drives the recursive part of every section with the ORIGINAL input
 // instead of the previous section's output (core/iir.py:226-246 index `input_signal`, not `x`); for K = 1
@@ -27,34 +35,60 @@
 
 namespace gfx {
 
-constexpr int BQ_T = 256;            // threads per workgroup = 4 independent waves
-constexpr int BQ_W = BQ_T / 64;      // row-channels per workgroup
+constexpr int BQ_T = 64;             // threads per workgroup: one wave
 constexpr int BQ_E = 8;              // samples per lane
-constexpr int BQ_TILE = 64 * BQ_E;   // samples per wave tile
-constexpr int BQ_MAX_K = 32;  // 4 waves x K x (160 B constants + 1 KB lane powers) of LDS: 148 KB at K = 32
+constexpr int BQ_MAX_K = 32;
+// Lanes per pair of row-channels, RL: 16 (one DPP row; four pairs per wave) where there are rows enough to fill the chip
+// with such waves -- the scan then costs no LDS traffic -- and 64 (the whole wave, scan by __shfl_up) where there are not:
+// a pair's tiles are a sequential chain, and with few pairs the time is that chain's latency, which 64 lanes per pair
+// cut into a quarter as many links (2048 stereo rows, K = 6: 1.9 ms against 3.6).
 
-struct M2 {  // 2x2 matrix, row-major
-    float a, b, c, d;
-};
+using f2 = float __attribute__((ext_vector_type(2)));   // (row-channel 2p, row-channel 2p + 1)
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct M2d {
     double a, b, c, d;
 };
 __device__ __forceinline__ M2d mul(const M2d& x, const M2d& y) {
     return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
 }
-__device__ __forceinline__ M2 narrow(const M2d& m) { return {(float)m.a, (float)m.b, (float)m.c, (float)m.d}; }
-__device__ __forceinline__ float2 apply(const M2& m, float2 s) {
-    return make_float2(fmaf(m.a, s.x, m.b * s.y), fmaf(m.c, s.x, m.d * s.y));
+
+struct SecConst {       // per (pair, section), in LDS; [4] = the matrix entries a, b, c, d
+    f2 step[6][4];      // M^(E * 2^d)  (RL = 16 uses d < 4)
+    f2 b0, b1, b2, a1, a2;
+    f2 carry1, carry2;  // state (w[n-1], w[n-2]) entering the current tile
+    f2 pad;
+};
+static_assert(sizeof(SecConst) == 256, "SecConst layout");
+// LDS: SecConst sec[64 / RL][K]
+
+// (s1', s2') = M (s1, s2), the product rounded once before the fused multiply-add (as the scalar form did)
+__device__ __forceinline__ void apply2(const f2 (&m)[4], f2 s1, f2 s2, f2& o1, f2& o2) {
+    o1 = fma2(m[0], s1, m[1] * s2);
+    o2 = fma2(m[2], s1, m[3] * s2);
+}
+__device__ __forceinline__ f2 shfl_up2(f2 v, int d) { return f2{__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64)}; }
+__device__ __forceinline__ f2 shfl2(f2 v, int l) { return f2{__shfl(v.x, l, 64), __shfl(v.y, l, 64)}; }
+// the value of the lane CTRL selects within the 16-lane row (0x110 + n: n lanes below, zero where there is none;
+// 0x121: rotate right by one, i.e. lane 0 reads lane 15)
+template <int CTRL>
+__device__ __forceinline__ f2 dpp2(f2 v) {
+    // (one 64-bit move, which the back end splits into two v_mov_b32_dpp: given two 32-bit builtins on .x and .y, hipcc
+    // 7.2 folds the second into a copy of the first)
+    const long long w = __builtin_amdgcn_update_dpp(0LL, __builtin_bit_cast(long long, v), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(f2, w);
 }
 
-struct SecConst {       // per (wave, section), in LDS
-    M2 step[6];         // M^(E * 2^d)
-    M2 wave;            // M^(E * 64)
-    float b0, b1, b2, a1, a2, pad0, pad1, pad2;
-    float2 carry;       // state entering the current tile
-    float2 pad3;
-};
-// LDS: SecConst sec[4][K]; M2 lanepow[4][K][64]
+// the inclusive value 2^D lanes below in the pair's RL lanes, zero where there is none
+template <int RL, int D>
+__device__ __forceinline__ f2 below(f2 v, int rl) {
+    if constexpr (RL == 16) {
+        return dpp2<0x110 + (1 << D)>(v);
+    } else {
+        const f2 u = shfl_up2(v, 1 << D);
+        return rl >= (1 << D) ? u : f2{0.0f, 0.0f};
+    }
+}
 
 __device__ __forceinline__ int64_t brow_off(const gfx_rowmap_t& m, int64_t r, int c) {
     const unsigned inner = (unsigned)m.inner, rr = (unsigned)r;
@@ -68,139 +102,195 @@ struct BqArgs {
     int Cin, Cf, Cout, K, quirk, vec;
 };
 
+template <int RL, bool AHEAD>
 __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               const float* __restrict__ Bs,
                                                               const float* __restrict__ As, BqArgs a) {
+    constexpr int BQ_PW = BQ_T / RL, BQ_TILE = RL * BQ_E, STEPS = RL == 16 ? 4 : 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    SecConst* sec = reinterpret_cast<SecConst*>(smem) + wave * a.K;
-    M2* lanepow = reinterpret_cast<M2*>(reinterpret_cast<SecConst*>(smem) + BQ_W * a.K) + (size_t)wave * a.K * 64;
+    const int t = threadIdx.x, rl = t & (RL - 1), pw = t / RL;
+    SecConst* sec = reinterpret_cast<SecConst*>(smem) + pw * a.K;
 
-    const int64_t rc = (int64_t)blockIdx.x * BQ_W + wave;
-    const bool live = rc < a.total;
-    const int64_t r = live ? rc / a.Cout : 0;
-    const int c = live ? (int)(rc - r * a.Cout) : 0;
-    const float* xr = x + brow_off(a.xmap, r, a.Cin == 1 ? 0 : c);
-    float* yr = y + brow_off(a.ymap, r, c);
-    const float* B = Bs + ((r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.K) * 3;
-    const float* A = As + ((r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.K) * 3;
-
-    for (int k = 0; k < a.K; ++k) {
-        const float a0 = A[3 * k];
-        const float a1 = A[3 * k + 1] / a0, a2 = A[3 * k + 2] / a0;
-        M2d m = {-(double)a1, -(double)a2, 1.0, 0.0};
-        m = mul(m, m);
-        m = mul(m, m);
-        M2d s = mul(m, m);  // M^8
-        M2d p = {1.0, 0.0, 0.0, 1.0};
+    const int64_t rc0 = 2 * ((int64_t)blockIdx.x * BQ_PW + pw);
+    const bool live[2] = {rc0 < a.total, rc0 + 1 < a.total};
+    const float* xr[2];
+    float* yr[2];
+    const float *B[2], *A[2];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            if (lane == 0) sec[k].step[d] = narrow(s);
-            if ((lane >> d) & 1) p = mul(p, s);
+    for (int ch = 0; ch < 2; ++ch) {
+        const int64_t rc = live[ch] ? rc0 + ch : (live[0] ? rc0 : 0);   // a missing partner re-reads its neighbour, stores nothing
+        const int64_t r = rc / a.Cout;
+        const int c = (int)(rc - r * a.Cout);
+        xr[ch] = x + brow_off(a.xmap, r, a.Cin == 1 ? 0 : c);
+        yr[ch] = y + brow_off(a.ymap, r, c);
+        B[ch] = Bs + ((r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.K) * 3;
+        A[ch] = As + ((r * a.Cf + (a.Cf == 1 ? 0 : c)) * a.K) * 3;
+    }
+
+    // constants: lane (k, ch) of the pair's lanes takes section k + (RL / 2) j of row-channel ch
+    for (int k = rl >> 1; k < a.K; k += RL / 2) {
+        const int ch = rl & 1;
+        const float a0 = A[ch][3 * k];
+        const float a1 = A[ch][3 * k + 1] / a0, a2 = A[ch][3 * k + 2] / a0;
+        M2d s = {-(double)a1, -(double)a2, 1.0, 0.0};
+#pragma unroll
+        for (int e = 1; e < BQ_E; e *= 2) s = mul(s, s);  // M^E
+#pragma unroll
+        for (int d = 0; d < STEPS; ++d) {
+            reinterpret_cast<float*>(&sec[k].step[d][0])[ch] = (float)s.a;
+            reinterpret_cast<float*>(&sec[k].step[d][1])[ch] = (float)s.b;
+            reinterpret_cast<float*>(&sec[k].step[d][2])[ch] = (float)s.c;
+            reinterpret_cast<float*>(&sec[k].step[d][3])[ch] = (float)s.d;
             s = mul(s, s);
         }
-        lanepow[k * 64 + lane] = narrow(p);  // M^(8*lane)
-        if (lane == 0) {
-            sec[k].wave = narrow(s);  // M^512
-            sec[k].b0 = B[3 * k] / a0;
-            sec[k].b1 = B[3 * k + 1] / a0;
-            sec[k].b2 = B[3 * k + 2] / a0;
-            sec[k].a1 = a1;
-            sec[k].a2 = a2;
-            sec[k].carry = make_float2(0.0f, 0.0f);
-        }
+        reinterpret_cast<float*>(&sec[k].b0)[ch] = B[ch][3 * k] / a0;
+        reinterpret_cast<float*>(&sec[k].b1)[ch] = B[ch][3 * k + 1] / a0;
+        reinterpret_cast<float*>(&sec[k].b2)[ch] = B[ch][3 * k + 2] / a0;
+        reinterpret_cast<float*>(&sec[k].a1)[ch] = a1;
+        reinterpret_cast<float*>(&sec[k].a2)[ch] = a2;
+        reinterpret_cast<float*>(&sec[k].carry1)[ch] = 0.0f;
+        reinterpret_cast<float*>(&sec[k].carry2)[ch] = 0.0f;
     }
-    __syncthreads();  // the only barrier: tables written, every wave now works alone
-    if (!live) return;
+    __syncthreads();  // the only barrier: tables written, every pair's lanes now work alone
 
     using f4 = float __attribute__((ext_vector_type(4)));
-    for (int64_t n0 = 0; n0 < a.L; n0 += BQ_TILE) {
-        const int64_t n = n0 + BQ_E * lane;
-        float v[BQ_E], x0[BQ_E];
-        if (a.vec && n + BQ_E <= a.L) {
+    const int64_t len = live[0] ? a.L : 0;   // (a pair past the end walks nothing: the DPP rows of a wave are independent)
+    // the next tile's samples are requested before the running tile's sections are worked through: a pair's tiles are a
+    // sequential chain (1024 of them at L = 131072), and with few rows there are no other waves to hide a load behind
+    auto load = [&](int64_t n0, f2 (&w)[BQ_E]) {
+        const int64_t n = n0 + BQ_E * rl;
+        const bool whole = a.vec && n + BQ_E <= a.L;
 #pragma unroll
-            for (int j = 0; j < BQ_E / 4; ++j) {
-                const f4 q = *reinterpret_cast<const f4*>(xr + n + 4 * j);
-                v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        for (int ch = 0; ch < 2; ++ch) {
+            float e[BQ_E];
+            if (whole) {
+#pragma unroll
+                for (int j = 0; j < BQ_E / 4; ++j) {
+                    const f4 q = *reinterpret_cast<const f4*>(xr[ch] + n + 4 * j);
+                    e[4 * j] = q.x; e[4 * j + 1] = q.y; e[4 * j + 2] = q.z; e[4 * j + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BQ_E; ++i) e[i] = n + i < a.L ? xr[ch][n + i] : 0.0f;
             }
-        } else {
 #pragma unroll
-            for (int i = 0; i < BQ_E; ++i) v[i] = n + i < a.L ? xr[n + i] : 0.0f;
+            for (int i = 0; i < BQ_E; ++i) reinterpret_cast<float*>(&w[i])[ch] = e[i];
+        }
+    };
+    // AHEAD (few rows): the next tile's samples are requested before the running tile's sections are worked through --
+    // there are no other waves to hide a load behind.  (With rows enough to fill the chip the other waves do that, and the
+    // extra registers cost more than the request ahead brings: K = 1 at 8192 stereo rows 4.2 against 5.1 ms.)
+    f2 nxt[BQ_E];
+    if (AHEAD && len > 0) load(0, nxt);
+    for (int64_t n0 = 0; n0 < len; n0 += BQ_TILE) {
+        const int64_t n = n0 + BQ_E * rl;
+        const bool whole = a.vec && n + BQ_E <= a.L;
+        f2 v[BQ_E], x0[BQ_E];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int i = 0; i < BQ_E; ++i) v[i] = nxt[i];
+            if (n0 + BQ_TILE < len) load(n0 + BQ_TILE, nxt);
+        } else {
+            load(n0, v);
         }
 #pragma unroll
         for (int i = 0; i < BQ_E; ++i) x0[i] = v[i];
 
         for (int k = 0; k < a.K; ++k) {
             SecConst& q = sec[k];
-            const float a1 = q.a1, a2 = q.a2;
-            float in[BQ_E];
+            const f2 a1 = q.a1, a2 = q.a2;
+            f2 in[BQ_E];
 #pragma unroll
             for (int i = 0; i < BQ_E; ++i) in[i] = a.quirk ? x0[i] : v[i];
             // 1. zero-state run of this lane's chunk
-            float s1 = 0.0f, s2 = 0.0f;
+            f2 s1 = {0.0f, 0.0f}, s2 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < BQ_E; ++i) {
-                const float w = in[i] - a1 * s1 - a2 * s2;
+                const f2 w = fma2(-a2, s2, fma2(-a1, s1, in[i]));
                 s2 = s1;
                 s1 = w;
             }
-            // 2. inclusive scan of the chunk end states across the wave
-            float2 inc = make_float2(s1, s2);
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                const float ux = __shfl_up(inc.x, 1 << d, 64), uy = __shfl_up(inc.y, 1 << d, 64);
-                if (lane >= (1 << d)) {
-                    const float2 m = apply(q.step[d], make_float2(ux, uy));
-                    inc.x += m.x;
-                    inc.y += m.y;
-                }
+            // 2. inclusive scan of the chunk end states over the sixteen lanes, the tile's entering state riding along
+            const f2 c1 = q.carry1, c2 = q.carry2;
+            f2 i1 = s1, i2 = s2, m1, m2;
+            if (rl == 0) {
+                apply2(q.step[0], c1, c2, m1, m2);
+                i1 += m1;
+                i2 += m2;
             }
-            float2 excl = make_float2(__shfl_up(inc.x, 1, 64), __shfl_up(inc.y, 1, 64));
-            if (lane == 0) excl = make_float2(0.0f, 0.0f);
-            // 3. carry: state entering the tile; its successor is lane 63's total plus M^512 * carry
-            const float2 carry = q.carry;
-            const float2 h = apply(lanepow[k * 64 + lane], carry);
-            const float2 adv = apply(q.wave, carry);
-            const float2 next = make_float2(__shfl(inc.x, 63, 64) + adv.x, __shfl(inc.y, 63, 64) + adv.y);
-            if (lane == 0) q.carry = next;  // same-wave LDS accesses are ordered: read above, write here
-            // 4. true state before this lane's first sample, rerun, numerator
-            s1 = h.x + excl.x;
-            s2 = h.y + excl.y;
+            apply2(q.step[0], below<RL, 0>(i1, rl), below<RL, 0>(i2, rl), m1, m2);
+            i1 += m1;
+            i2 += m2;
+            apply2(q.step[1], below<RL, 1>(i1, rl), below<RL, 1>(i2, rl), m1, m2);
+            i1 += m1;
+            i2 += m2;
+            apply2(q.step[2], below<RL, 2>(i1, rl), below<RL, 2>(i2, rl), m1, m2);
+            i1 += m1;
+            i2 += m2;
+            apply2(q.step[3], below<RL, 3>(i1, rl), below<RL, 3>(i2, rl), m1, m2);
+            i1 += m1;
+            i2 += m2;
+            if constexpr (RL == 64) {
+                apply2(q.step[4], below<RL, 4>(i1, rl), below<RL, 4>(i2, rl), m1, m2);
+                i1 += m1;
+                i2 += m2;
+                apply2(q.step[5], below<RL, 5>(i1, rl), below<RL, 5>(i2, rl), m1, m2);
+                i1 += m1;
+                i2 += m2;
+            }
+            // this lane's entering state: the inclusive total of the lane below (lane 0: the carry itself); the last
+            // lane's total is the next tile's carry
+            s1 = below<RL, 0>(i1, rl);
+            s2 = below<RL, 0>(i2, rl);
+            const f2 nx1 = RL == 16 ? dpp2<0x121>(i1) : shfl2(i1, 63), nx2 = RL == 16 ? dpp2<0x121>(i2) : shfl2(i2, 63);
+            if (rl == 0) {
+                s1 = c1;
+                s2 = c2;
+                q.carry1 = nx1;   // same-wave LDS accesses are ordered: read above, write here
+                q.carry2 = nx2;
+            }
+            // 3. rerun from the true state, numerator
             if (!a.quirk) {
+                const f2 b0 = q.b0, b1 = q.b1, b2 = q.b2;
 #pragma unroll
                 for (int i = 0; i < BQ_E; ++i) {
-                    const float w = in[i] - a1 * s1 - a2 * s2;
-                    v[i] = q.b0 * w + q.b1 * s1 + q.b2 * s2;
+                    const f2 w = fma2(-a2, s2, fma2(-a1, s1, in[i]));
+                    v[i] = fma2(b0, w, fma2(b1, s1, b2 * s2));
                     s2 = s1;
                     s1 = w;
                 }
             } else {
-                const float c1 = q.b1 - q.b0 * a1, c2 = q.b2 - q.b0 * a2;  // strictly proper part
+                const f2 b0 = q.b0, cc1 = q.b1 - q.b0 * a1, cc2 = q.b2 - q.b0 * a2;  // strictly proper part
 #pragma unroll
                 for (int i = 0; i < BQ_E; ++i) {
-                    const float w = in[i] - a1 * s1 - a2 * s2;
-                    v[i] = q.b0 * v[i] + c1 * s1 + c2 * s2;
+                    const f2 w = fma2(-a2, s2, fma2(-a1, s1, in[i]));
+                    v[i] = fma2(b0, v[i], fma2(cc1, s1, cc2 * s2));
                     s2 = s1;
                     s1 = w;
                 }
             }
         }
-        if (a.vec && n + BQ_E <= a.L) {
 #pragma unroll
-            for (int j = 0; j < BQ_E / 4; ++j)
-                __builtin_nontemporal_store(f4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]},
-                                            reinterpret_cast<f4*>(yr + n + 4 * j));
-        } else {
+        for (int ch = 0; ch < 2; ++ch) {
+            if (!live[ch]) continue;
+            float e[BQ_E];
 #pragma unroll
-            for (int i = 0; i < BQ_E; ++i)
-                if (n + i < a.L) yr[n + i] = v[i];
+            for (int i = 0; i < BQ_E; ++i) e[i] = ch ? v[i].y : v[i].x;
+            if (whole) {
+#pragma unroll
+                for (int j = 0; j < BQ_E / 4; ++j)
+                    __builtin_nontemporal_store(f4{e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]},
+                                                reinterpret_cast<f4*>(yr[ch] + n + 4 * j));
+            } else {
+#pragma unroll
+                for (int i = 0; i < BQ_E; ++i)
+                    if (n + i < a.L) yr[ch][n + i] = e[i];
+            }
         }
     }
 }
 
-static inline size_t bq_lds_bytes(int64_t K) {
-    return (size_t)BQ_W * K * sizeof(SecConst) + (size_t)BQ_W * K * 64 * sizeof(M2);
-}
+static inline size_t bq_lds_bytes(int64_t K, int RL) { return (size_t)(BQ_T / RL) * K * sizeof(SecConst); }
 static inline bool bq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool bq_map_vec(const gfx_rowmap_t& m) {
     return m.stride_outer % 4 == 0 && m.stride_inner % 4 == 0 && m.stride_ch % 4 == 0;
@@ -224,13 +314,18 @@ int gfx_biquad_cascade_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowm
     a.K = (int)K; a.quirk = ssm_quirk ? 1 : 0;
     a.vec = bq_aligned16(x) && bq_aligned16(y) && bq_map_vec(xmap) && bq_map_vec(ymap);
     a.total = R * a.Cout;
-    const int64_t blocks = (a.total + BQ_W - 1) / BQ_W;
+    const int64_t pairs = (a.total + 1) / 2;
+    // sixteen lanes per pair where such waves fill the chip, else the whole wave
+    const bool narrow = pairs >= 8192;
+    const int RL = narrow ? 16 : 64;
+    const int64_t blocks = (pairs + BQ_T / RL - 1) / (BQ_T / RL);
     if (blocks > 0x7fffffffLL) return GFX_EINVAL;
-    const size_t lds = bq_lds_bytes(K);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(biquad_cascade_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const size_t lds = bq_lds_bytes(K, RL);
+    auto kern = narrow ? biquad_cascade_kernel<16, false> : biquad_cascade_kernel<64, true>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
         return GFX_ELAUNCH;
-    hipLaunchKernelGGL(biquad_cascade_kernel, dim3((unsigned)blocks), dim3(BQ_T), lds, (hipStream_t)stream, x, y, Bs, As, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BQ_T), lds, (hipStream_t)stream, x, y, Bs, As, a);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
