@@ -102,6 +102,7 @@ SIGNATURES = {
     "gfx_stft_reverb_workspace_bytes": (sz, [i64, i64, i64]),
     "gfx_stft_reverb_ir_ex_f32": (ctypes.c_int, [f32p, i64, f32p, f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, i64, i64, i64,
                                                  ctypes.c_int, vp, sz, vp]),
+    "gfx_stft_reverb_workspace_bytes_sched": (sz, [i64, i64, i64, i64, i64, ctypes.c_int]),
     "gfx_stft_reverb_ir_sched_f32": (ctypes.c_int, [f32p, i64, f32p, f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                     i64, ctypes.c_int, vp, sz, ctypes.c_int, vp]),
     "gfx_stft_reverb_ir_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, i64, i64, i64,

@@ -686,6 +686,14 @@ size_t gfx_stft_reverb_workspace_bytes(int64_t R, int64_t n_fft, int64_t num_fra
     return ((size_t)R * 2 * num_frames * n_fft + (size_t)R * ((num_frames * n_fft + 255) / 256)) * sizeof(float);
 }
 
+size_t gfx_stft_reverb_workspace_bytes_sched(int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
+                                             int schedule) {
+    if (R <= 0 || ir_len <= 0 || n_fft <= 0 || num_frames <= 0) return 0;
+    if (n_fft == 384 && hop == 192 && schedule != GFX_ISTFT_GEMM)   // the FFT form: one energy partial per workgroup
+        return (size_t)R * (size_t)(((ir_len + 191) / 192 + 14) / 15) * sizeof(float);
+    return gfx_stft_reverb_workspace_bytes(R, n_fft, num_frames);
+}
+
 int gfx_stft_reverb_ir_f32(const float* noise_stft, const float* init_log_magnitude, const float* delta_log_magnitude,
                            const float* gain_env_log_magnitude, const float* window, const float* basis, float* ir,
                            float* row_gain, int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
@@ -713,7 +721,7 @@ int gfx_stft_reverb_ir_sched_f32(const float* noise_stft, int64_t noise_rows, co
         return GFX_EINVAL;
     if (R <= 0 || ir_len <= 0 || n_fft < 2 || (n_fft & 1) || hop < 1 || hop > n_fft || num_frames < 1) return GFX_EINVAL;
     if (R * 2 > 65535) return GFX_EINVAL;
-    const size_t need = gfx_stft_reverb_workspace_bytes(R, n_fft, num_frames);
+    const size_t need = gfx_stft_reverb_workspace_bytes_sched(R, ir_len, n_fft, hop, num_frames, schedule);
     if (!ws || ws_bytes < need) return GFX_ENOSPC;
     IstftArgs a;
     a.R = R;

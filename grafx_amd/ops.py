@@ -911,15 +911,23 @@ def stft_reverb_ir(noise_stft, init_lm, delta_lm, gain_env, window, basis, ir_le
     nz = torch.view_as_real(noise_stft.contiguous())  # (…,2,K,T,2) float32 view of the complex64 buffer
     ir = torch.empty((R, 2, ir_len), dtype=torch.float32, device=init_lm.device)
     row_gain = torch.empty((R,), dtype=torch.float32, device=init_lm.device)
-    nbytes = lib().gfx_stft_reverb_workspace_bytes(R, n_fft, T)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=init_lm.device)
-    pin = _Pin()
-    check(
-        lib().gfx_stft_reverb_ir_sched_f32(_ptr(nz), noise_rows, pin(init_lm), pin(delta_lm), pin(gain_env), pin(window),
-                                           pin(basis), _ptr(ir), _ptr(row_gain), R, ir_len, n_fft, hop, T, int(ms_to_lr),
-                                           _ptr(ws), nbytes, ISTFT_SCHEDULES[schedule], _stream()),
-        "gfx_stft_reverb_ir_sched_f32",
-    )
+    sched = ISTFT_SCHEDULES[schedule]
+    init_lm, delta_lm = init_lm.contiguous(), delta_lm.contiguous()
+    gain_env = None if gain_env is None else gain_env.contiguous()
+    ROWS = 32767                                        # rows per launch (the kernels' grids index rows in 16 bits)
+    for r0 in range(0, R, ROWS):
+        n = min(ROWS, R - r0)
+        nbytes = lib().gfx_stft_reverb_workspace_bytes_sched(n, ir_len, n_fft, hop, T, sched)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=init_lm.device)
+        pin = _Pin()
+        check(
+            lib().gfx_stft_reverb_ir_sched_f32(_ptr(nz[r0:r0 + n] if noise_rows != 1 else nz), noise_rows if noise_rows == 1 else n,
+                                               pin(init_lm[r0:r0 + n]), pin(delta_lm[r0:r0 + n]),
+                                               pin(None if gain_env is None else gain_env[r0:r0 + n]), pin(window), pin(basis),
+                                               _ptr(ir[r0:r0 + n]), _ptr(row_gain[r0:r0 + n]), n, ir_len, n_fft, hop, T,
+                                               int(ms_to_lr), _ptr(ws), nbytes, sched, _stream()),
+            "gfx_stft_reverb_ir_sched_f32",
+        )
     return ir, row_gain
 
 

@@ -409,6 +409,8 @@ int gfx_stft_reverb_ir_ex_f32(const float* noise_stft, int64_t noise_rows, const
 #define GFX_ISTFT_AUTO 0
 #define GFX_ISTFT_GEMM 1
 #define GFX_ISTFT_FFT 2
+size_t gfx_stft_reverb_workspace_bytes_sched(int64_t R, int64_t ir_len, int64_t n_fft, int64_t hop, int64_t num_frames,
+                                             int schedule);   /* what _sched_f32 needs: the FFT form keeps no frames */
 int gfx_stft_reverb_ir_sched_f32(const float* noise_stft, int64_t noise_rows, const float* init_log_magnitude,
                                  const float* delta_log_magnitude, const float* gain_env_log_magnitude,
                                  const float* window, const float* basis, float* ir, float* row_gain, int64_t R,
