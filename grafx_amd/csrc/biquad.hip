@@ -7,22 +7,26 @@
 // with zero initial state.  No FFT, no truncation of the impulse response (the FSM backend aliases it to
 // fsm_fir_len taps), 8 B of HBM traffic per channel-sample.
 //
-// Parallelisation: SIXTEEN LANES walk TWO row-channels (packed fp32: the two channels of a stereo row, or two neighbouring
-// mono rows) in 128-sample tiles (16 lanes x 8 samples); a wave (= a workgroup) carries four such pairs; no barriers
-// and no cross-lane LDS traffic in the time loop.  The recursion is the linear system s[n] = M s[n-1] + (x[n], 0),
-// M = [[-a1, -a2], [1, 0]], s = (w[n], w[n-1]):
+// Parallelisation: RL lanes walk TWO row-channels (packed fp32: the two channels of a stereo row, or two neighbouring mono
+// rows) in tiles of RL x 8 samples, no barriers and no cross-lane LDS traffic in the time loop.  RL = 64 (one wave per pair,
+// 512-sample tiles, the next tile requested ahead) unless there are pairs enough (>= 8192) to fill the chip with RL = 16
+// (four pairs per wave, 128-sample tiles): a pair's tiles are a sequential chain, and with few pairs the time is that
+// chain's latency.  The recursion is the linear system s[n] = M s[n-1] + (x[n], 0), M = [[-a1, -a2], [1, 0]],
+// s = (w[n], w[n-1]):
 //   1. each lane runs its 8 samples from a zero state                 -> end state e_t
-//   2. Hillis-Steele scan over the 16 lanes with M^(8*2^d), d < 4     -> state at the end of every chunk.  The shifted
-//      operands come from DPP row shifts (row_shr:1/2/4/8, zero fill: the lanes a step does not reach add zero), i.e. from
-//      the vector ALU's own lane crossbar.  The state entering the tile (the carry) is injected at lane 0 (its end state
-//      += M^8 * carry), so the scan delivers every lane's TRUE entering state and lane 15's total (row_ror:1 -> lane 0)
-//      is the next tile's carry
+//   2. Hillis-Steele scan over the 16 lanes of a DPP row with M^(8*2^d), d < 4 -> state at the end of every chunk.  The
+//      shifted operands come from DPP row shifts (row_shr:1/2/4/8, zero fill: the lanes a step does not reach add zero),
+//      i.e. from the vector ALU's own lane crossbar.  RL = 64: two more steps carry the rows' totals across (row_bcast:15
+//      into rows 1 and 3, row_bcast:31 into rows 2 and 3), weighted per lane with M^(8 (l % 16 + 1)) from a 16-entry table.
+//      The state entering the tile (the carry) is injected at lane 0 (its end state += M^8 * carry), so the scan delivers
+//      every lane's TRUE entering state (one lane below: row_shr:1 / wave_shr:1) and the last lane's total is the next
+//      tile's carry (row_ror:1 / v_readlane)
 //   3. every lane reruns its 8 samples from that state and applies the numerator.
-// The matrix powers M^(8*2^d) are formed in double per (row-channel, section) when the workgroup starts and live in LDS
-// (192 B per pair and section).  Rounds 2-3 scanned over all 64 lanes of a wave with __shfl_up = ds_bpermute_b32: 16
-// (32 with two row-channels per wave) trips through the LDS crossbar per section and tile, ~9 cycles each of the CU's
-// ONE LDS unit -- that, not arithmetic or HBM, was the kernel's time (K = 6 at 8192 x 2 x 131072: 7.3 ms = 2.3 TB/s;
-// two row-channels per wave in packed fp32 alone changed nothing).
+// The matrix powers are formed in double per (row-channel, section) when the workgroup starts and live in LDS (256 B per
+// pair and section, + 512 B for RL = 64).  Rounds 2-3 scanned over the 64 lanes with __shfl_up = ds_bpermute_b32: 16 trips
+// through the LDS crossbar per section and tile of a row-channel, ~9 cycles each of the CU's ONE LDS unit -- that, not
+// arithmetic or HBM, was the kernel's time (K = 6 at 8192 x 2 x 131072: 7.3 ms = 2.3 TB/s; two row-channels per wave in
+// packed fp32 alone changed nothing).
 //
 // ssm_quirk: upstream's "ssm" backend drives the recursive part of every section with the ORIGINAL input
 // instead of the previous section's output (core/iir.py:226-246 index `input_signal`, not `x`); for K = 1
@@ -38,10 +42,8 @@ namespace gfx {
 constexpr int BQ_T = 64;             // threads per workgroup: one wave
 constexpr int BQ_E = 8;              // samples per lane
 constexpr int BQ_MAX_K = 32;
-// Lanes per pair of row-channels, RL: 16 (one DPP row; four pairs per wave) where there are rows enough to fill the chip
-// with such waves -- the scan then costs no LDS traffic -- and 64 (the whole wave, scan by __shfl_up) where there are not:
-// a pair's tiles are a sequential chain, and with few pairs the time is that chain's latency, which 64 lanes per pair
-// cut into a quarter as many links (2048 stereo rows, K = 6: 1.9 ms against 3.6).
+// Lanes per pair of row-channels, RL: 64 (the whole wave) or 16 (one DPP row; four pairs per wave) -- see the head of the file;
+// 2048 stereo rows, K = 6: 1.5 ms with RL = 64 against 3.6 with RL = 16; 8192 rows, K = 2: 3.7 with RL = 16 against 4.5.
 
 using f2 = float __attribute__((ext_vector_type(2)));   // (row-channel 2p, row-channel 2p + 1)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -60,34 +62,30 @@ struct SecConst {       // per (pair, section), in LDS; [4] = the matrix entries
     f2 pad;
 };
 static_assert(sizeof(SecConst) == 256, "SecConst layout");
-// LDS: SecConst sec[64 / RL][K]
+// LDS: SecConst sec[64 / RL][K]; for RL = 64 also f2 rowpow[K][16][4] = M^(E (j + 1)), j < 16
 
 // (s1', s2') = M (s1, s2), the product rounded once before the fused multiply-add (as the scalar form did)
 __device__ __forceinline__ void apply2(const f2 (&m)[4], f2 s1, f2 s2, f2& o1, f2& o2) {
     o1 = fma2(m[0], s1, m[1] * s2);
     o2 = fma2(m[2], s1, m[3] * s2);
 }
-__device__ __forceinline__ f2 shfl_up2(f2 v, int d) { return f2{__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64)}; }
-__device__ __forceinline__ f2 shfl2(f2 v, int l) { return f2{__shfl(v.x, l, 64), __shfl(v.y, l, 64)}; }
-// the value of the lane CTRL selects within the 16-lane row (0x110 + n: n lanes below, zero where there is none;
-// 0x121: rotate right by one, i.e. lane 0 reads lane 15)
-template <int CTRL>
+// the value of the lane CTRL selects: 0x110 + n: n lanes below within the 16-lane row, 0x121: the row rotated right by one
+// (lane 0 reads lane 15), 0x138: one lane below in the whole wave, 0x142 / 0x143: lane 15 of a row to the next row / lane 31
+// to rows 2 and 3; zero where there is no such lane and in the rows ROWS (a mask of the wave's four) leaves out
+template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ f2 dpp2(f2 v) {
     // (one 64-bit move, which the back end splits into two v_mov_b32_dpp: given two 32-bit builtins on .x and .y, hipcc
     // 7.2 folds the second into a copy of the first)
-    const long long w = __builtin_amdgcn_update_dpp(0LL, __builtin_bit_cast(long long, v), CTRL, 0xf, 0xf, true);
+    const long long w = __builtin_amdgcn_update_dpp(0LL, __builtin_bit_cast(long long, v), CTRL, ROWS, 0xf, ROWS == 0xf);
     return __builtin_bit_cast(f2, w);
 }
 
-// the inclusive value 2^D lanes below in the pair's RL lanes, zero where there is none
-template <int RL, int D>
-__device__ __forceinline__ f2 below(f2 v, int rl) {
-    if constexpr (RL == 16) {
-        return dpp2<0x110 + (1 << D)>(v);
-    } else {
-        const f2 u = shfl_up2(v, 1 << D);
-        return rl >= (1 << D) ? u : f2{0.0f, 0.0f};
-    }
+// lane 63's value, wave-uniform.  (The halves go through named floats: __builtin_bit_cast(int, v.y) of a vector element
+// reads v.x with hipcc 7.2 -- the same front-end slip that made two 32-bit DPP builtins on .x / .y one.)
+__device__ __forceinline__ f2 last_lane(f2 v) {
+    const float x = v.x, y = v.y;
+    return f2{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)),
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63))};
 }
 
 __device__ __forceinline__ int64_t brow_off(const gfx_rowmap_t& m, int64_t r, int c) {
@@ -106,10 +104,11 @@ template <int RL, bool AHEAD>
 __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               const float* __restrict__ Bs,
                                                               const float* __restrict__ As, BqArgs a) {
-    constexpr int BQ_PW = BQ_T / RL, BQ_TILE = RL * BQ_E, STEPS = RL == 16 ? 4 : 6;
+    constexpr int BQ_PW = BQ_T / RL, BQ_TILE = RL * BQ_E, STEPS = RL == 16 ? 4 : 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, rl = t & (RL - 1), pw = t / RL;
     SecConst* sec = reinterpret_cast<SecConst*>(smem) + pw * a.K;
+    f2* rowpow = reinterpret_cast<f2*>(reinterpret_cast<SecConst*>(smem) + BQ_PW * a.K);   // (RL = 64)
 
     const int64_t rc0 = 2 * ((int64_t)blockIdx.x * BQ_PW + pw);
     const bool live[2] = {rc0 < a.total, rc0 + 1 < a.total};
@@ -135,6 +134,17 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
         M2d s = {-(double)a1, -(double)a2, 1.0, 0.0};
 #pragma unroll
         for (int e = 1; e < BQ_E; e *= 2) s = mul(s, s);  // M^E
+        if constexpr (RL == 64) {
+            M2d pw_j = s;
+            for (int j = 0; j < 16; ++j) {   // M^(E (j + 1))
+                float* dst = reinterpret_cast<float*>(rowpow + (size_t)(k * 16 + j) * 4);
+                dst[0 + ch] = (float)pw_j.a;
+                dst[2 + ch] = (float)pw_j.b;
+                dst[4 + ch] = (float)pw_j.c;
+                dst[6 + ch] = (float)pw_j.d;
+                pw_j = mul(pw_j, s);
+            }
+        }
 #pragma unroll
         for (int d = 0; d < STEPS; ++d) {
             reinterpret_cast<float*>(&sec[k].step[d][0])[ch] = (float)s.a;
@@ -218,31 +228,48 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
                 i1 += m1;
                 i2 += m2;
             }
-            apply2(q.step[0], below<RL, 0>(i1, rl), below<RL, 0>(i2, rl), m1, m2);
+            apply2(q.step[0], dpp2<0x111>(i1), dpp2<0x111>(i2), m1, m2);   // within the 16-lane rows: the lanes a step does
+            i1 += m1;                                                       // not reach read zeros
+            i2 += m2;
+            apply2(q.step[1], dpp2<0x112>(i1), dpp2<0x112>(i2), m1, m2);
             i1 += m1;
             i2 += m2;
-            apply2(q.step[1], below<RL, 1>(i1, rl), below<RL, 1>(i2, rl), m1, m2);
+            apply2(q.step[2], dpp2<0x114>(i1), dpp2<0x114>(i2), m1, m2);
             i1 += m1;
             i2 += m2;
-            apply2(q.step[2], below<RL, 2>(i1, rl), below<RL, 2>(i2, rl), m1, m2);
+            apply2(q.step[3], dpp2<0x118>(i1), dpp2<0x118>(i2), m1, m2);
             i1 += m1;
             i2 += m2;
-            apply2(q.step[3], below<RL, 3>(i1, rl), below<RL, 3>(i2, rl), m1, m2);
-            i1 += m1;
-            i2 += m2;
+            f2 nx1, nx2;
             if constexpr (RL == 64) {
-                apply2(q.step[4], below<RL, 4>(i1, rl), below<RL, 4>(i2, rl), m1, m2);
+                // across the four rows: lane l of a row still lacks M^(8 (l % 16 + 1)) x (the state at the end of the row
+                // before).  Rows 1 and 3 take their neighbour's total (lane 15 -> next row); then lane 31 holds the true
+                // state at the end of row 1, which rows 2 and 3 take (row 3 through the 128 samples of row 2).
+                const f2* rp = rowpow + (size_t)(k * 16 + (rl & 15)) * 4;
+                const f2 w[4] = {rp[0], rp[1], rp[2], rp[3]};
+                apply2(w, dpp2<0x142, 0xa>(i1), dpp2<0x142, 0xa>(i2), m1, m2);
                 i1 += m1;
                 i2 += m2;
-                apply2(q.step[5], below<RL, 5>(i1, rl), below<RL, 5>(i2, rl), m1, m2);
+                f2 u1 = dpp2<0x143, 0xc>(i1), u2 = dpp2<0x143, 0xc>(i2);
+                apply2(q.step[4], u1, u2, m1, m2);   // M^128
+                if (rl >= 48) {
+                    u1 = m1;
+                    u2 = m2;
+                }
+                apply2(w, u1, u2, m1, m2);
                 i1 += m1;
                 i2 += m2;
+                // this lane's entering state: the inclusive total of the lane below (lane 0: the carry itself)
+                s1 = dpp2<0x138>(i1);
+                s2 = dpp2<0x138>(i2);
+                nx1 = last_lane(i1);   // the next tile's carry
+                nx2 = last_lane(i2);
+            } else {
+                s1 = dpp2<0x111>(i1);
+                s2 = dpp2<0x111>(i2);
+                nx1 = dpp2<0x121>(i1);   // lane 0 <- lane 15: the next tile's carry
+                nx2 = dpp2<0x121>(i2);
             }
-            // this lane's entering state: the inclusive total of the lane below (lane 0: the carry itself); the last
-            // lane's total is the next tile's carry
-            s1 = below<RL, 0>(i1, rl);
-            s2 = below<RL, 0>(i2, rl);
-            const f2 nx1 = RL == 16 ? dpp2<0x121>(i1) : shfl2(i1, 63), nx2 = RL == 16 ? dpp2<0x121>(i2) : shfl2(i2, 63);
             if (rl == 0) {
                 s1 = c1;
                 s2 = c2;
@@ -290,7 +317,9 @@ __global__ __launch_bounds__(BQ_T) void biquad_cascade_kernel(const float* __res
     }
 }
 
-static inline size_t bq_lds_bytes(int64_t K, int RL) { return (size_t)(BQ_T / RL) * K * sizeof(SecConst); }
+static inline size_t bq_lds_bytes(int64_t K, int RL) {
+    return (size_t)(BQ_T / RL) * K * sizeof(SecConst) + (RL == 64 ? (size_t)K * 16 * 4 * sizeof(f2) : 0);
+}
 static inline bool bq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool bq_map_vec(const gfx_rowmap_t& m) {
     return m.stride_outer % 4 == 0 && m.stride_inner % 4 == 0 && m.stride_ch % 4 == 0;
