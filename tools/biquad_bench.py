@@ -2,10 +2,13 @@
    python tools/biquad_bench.py [--rows 4096] [--length 131072] [--sections 6] [--iters 10]
 -> ms per call and GB/s over the algorithmic 8 bytes per channel-sample."""
 import argparse
+import os
+import sys
 
-import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
 
-from grafx_amd import ops
+from grafx_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=4096)
