@@ -62,6 +62,47 @@ def test_recursive_cascade_matches_float64_direct_form_across_tile_boundaries():
     assert torch.equal(buf[0, :2], torch.zeros_like(buf[0, :2]))
 
 
+@pytest.mark.parametrize("C,Cf,odd", [(2, 2, False), (2, 1, True), (1, 2, False), (1, 1, True)])
+def test_recursive_cascade_with_sixteen_lanes_per_pair_equals_the_whole_wave_form(C, Cf, odd):
+    """From 8192 pairs of row-channels on the cascade runs with sixteen lanes per pair (four pairs a wave, DPP row scans);
+    below, with the whole wave per pair (rows' totals carried across by row_bcast).  The same rows through both forms --
+    all at once, and in slices small enough for the other kernel -- against a float64 direct-form recursion of every row:
+    both are within rounding of it (random numerators make a few rows ill-conditioned in ANY fp32 evaluation: those are
+    compared form against form), row by row the sixteen-lane form is as close as the whole-wave form; odd row counts
+    leave a lane group / a pair's second half without work, L = 300 a ragged last tile in both tile sizes."""
+    from grafx_amd import ops
+
+    torch.manual_seed(C + 2 * Cf)
+    Cout = max(C, Cf)
+    R = (16384 // Cout) + (3 if odd else 0)        # >= 8192 pairs
+    K, L = 3, 300 if odd else 868
+    x = torch.randn(R, C, L, device="cuda")
+    rad = 0.5 + 0.45 * torch.rand(R, Cf, K, device="cuda")
+    th = 3.0 * torch.rand(R, Cf, K, device="cuda")
+    As = torch.stack([torch.ones_like(rad), -2 * rad * torch.cos(th), rad * rad], -1)
+    Bs = torch.randn(R, Cf, K, 3, device="cuda")
+    y = ops.biquad_cascade(x, Bs, As)
+    step = 2048 // Cout
+    parts = torch.cat([ops.biquad_cascade(x[i : i + step], Bs[i : i + step], As[i : i + step]) for i in range(0, R, step)])
+    ref = x.double().expand(R, Cout, L)
+    for k in range(K):
+        b, a = Bs[:, :, k].double().expand(R, Cout, 3), As[:, :, k].double().expand(R, Cout, 3)
+        out = torch.zeros_like(ref)
+        w1 = torch.zeros(R, Cout, dtype=torch.float64, device="cuda")
+        w2 = torch.zeros_like(w1)
+        for n in range(L):
+            w = ref[..., n] - a[..., 1] * w1 - a[..., 2] * w2
+            out[..., n] = b[..., 0] * w + b[..., 1] * w1 + b[..., 2] * w2
+            w2, w1 = w1, w
+        ref = out
+    scale = ref.abs().amax(dim=(1, 2), keepdim=True)
+    e16 = ((y.double() - ref).abs() / scale).amax(dim=(1, 2))
+    e64 = ((parts.double() - ref).abs() / scale).amax(dim=(1, 2))
+    assert e16.median().item() < 2e-6 and e64.median().item() < 2e-6
+    assert (e16 <= 3 * e64 + 2e-6).all(), f"worst row: {e16.max().item():.2e} against {e64[e16.argmax()].item():.2e}"
+    assert (e16 < 1e-5).float().mean().item() > 0.99
+
+
 def test_recursive_cascade_at_headline_length_is_linear_and_matches_the_fsm_limit():
     """L = 131072: superposition holds to rounding, and for a well-damped equaliser the FSM backend (whose only
     error is time aliasing of the truncated impulse response) agrees with the exact recursion."""
