@@ -81,3 +81,28 @@ def test_fft_schedule_is_refused_where_it_does_not_apply():
         ops.stft_reverb_ir(m.noise_stft, p0, p0, None, m.window, basis, 4000, 128, True, schedule="fft")
     ir, _ = ops.stft_reverb_ir(m.noise_stft, p0, p0, None, m.window, basis, 4000, 128, True, schedule="auto")
     assert torch.isfinite(ir).all()
+
+
+def test_more_rows_than_one_launch_takes():
+    """The kernels index rows with 16-bit grid coordinates: ops.stft_reverb_ir splits 32 780 rows into launches of 32 767
+    and the rows on either side of the seam come out as they do alone (shared and per-row noise, with a gain envelope)."""
+    from grafx_amd import ops
+    from grafx_amd.processors import STFTMaskedNoiseReverb
+
+    torch.manual_seed(11)
+    R, ir_len = 32780, 400
+    m = STFTMaskedNoiseReverb(ir_len=ir_len, gain_envelope=True, flashfftconv=False).cuda()
+    p0 = torch.randn(R, 2, m.num_bins, device="cuda")
+    p1 = torch.randn(R, 2, m.num_bins, device="cuda") - 3.0
+    g = torch.randn(R, 2, m.num_frames, device="cuda") * 0.5
+    basis = m._istft_basis(p0.device)
+    ir, gain = ops.stft_reverb_ir(m.noise_stft, p0, p1, g, m.window, basis, ir_len, m.hop_length, True)
+    for lo in (0, 32760, R - 10):
+        a, b = ops.stft_reverb_ir(m.noise_stft, p0[lo : lo + 10], p1[lo : lo + 10], g[lo : lo + 10], m.window, basis, ir_len,
+                                  m.hop_length, True)
+        assert torch.equal(ir[lo : lo + 10], a) and torch.equal(gain[lo : lo + 10], b)
+    noise = m.sample_noise(16, torch.device("cuda")).repeat(R // 16 + 1, 1, 1, 1)[:R].contiguous()
+    ir2, gain2 = ops.stft_reverb_ir(noise, p0, p1, g, m.window, basis, ir_len, m.hop_length, False)
+    sl = slice(32762, 32774)
+    a, b = ops.stft_reverb_ir(noise[sl].contiguous(), p0[sl], p1[sl], g[sl], m.window, basis, ir_len, m.hop_length, False)
+    assert torch.equal(ir2[sl], a) and torch.equal(gain2[sl], b)
