@@ -212,24 +212,36 @@ def _timed_cpu(fn, budget_s, warm=2, reps=5, min_total_s=0.0):
     return times
 
 
-def _best_cpu(run, budget_s, min_total_s=0.0, probe=None):
+def _best_cpu(run, budget_s, min_total_s=0.0, probe=None, sweep=(64, 128)):
     """SURVEY 8d asks for all host cores; torch's CPU FFT gets much SLOWER when a large host is oversubscribed (256
-    threads on the GPU box: ~25x), so the sample is timed on min(cores, 32) threads and ONE un-warmed run of `probe`
-    (a smaller sample) on all cores is reported next to it.  -> (host cpus, threads used, times, all-core probe seconds)"""
+    threads on the GPU box: ~25x), so the sample is timed on min(cores, 32) threads, then -- one warm-up and two timed runs
+    each -- on the thread counts of `sweep` the host has, and ONE un-warmed run of `probe` (a smaller sample) on all cores
+    is reported next to them.  The fastest thread count is the baseline.
+    -> (host cpus, threads of the best point, its times, all-core probe seconds, {threads: median seconds})"""
     import torch
 
     ncpu = os.cpu_count() or 1
     threads = min(ncpu, 32)
     torch.set_num_threads(threads)
     times = _timed_cpu(run, budget_s, min_total_s=min_total_s)
+    points = {threads: statistics.median(times)}
+    best = (threads, times)
+    for t in sweep:
+        if t > ncpu or t in points:
+            continue
+        torch.set_num_threads(t)
+        ts = _timed_cpu(run, budget_s / 3, warm=1, reps=2)
+        points[t] = statistics.median(ts)
+        if points[t] < statistics.median(best[1]):
+            best = (t, ts)
     probe_s = None
-    if probe is not None and ncpu > threads:
+    if probe is not None and ncpu > max(points):
         torch.set_num_threads(ncpu)
         t0 = time.perf_counter()
         probe()
         probe_s = time.perf_counter() - t0
-        torch.set_num_threads(threads)
-    return ncpu, threads, times, probe_s
+    torch.set_num_threads(best[0])
+    return ncpu, best[0], best[1], probe_s, points
 
 
 def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=15.0):
@@ -250,10 +262,11 @@ def cpu_baseline_console(G, render_data, params_cpu, L, budget_s=15.0):
         with torch.no_grad():
             render_grafx(procs, x[:1], params_cpu, render_data, parameters_grad=False)
 
-    ncpu, threads, times, probe_s = _best_cpu(run, budget_s, probe=probe)
+    ncpu, threads, times, probe_s, points = _best_cpu(run, budget_s, probe=probe)
     med = statistics.median(times)
     return {"value": B * L / med, "unit": "audio samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
             "seconds": [round(t, 3) for t in times],
+            "thread_sweep": {str(t): round(B * L / s_, 1) for t, s_ in sorted(points.items())},
             "all_cores_probe": None if probe_s is None else {
                 "threads": ncpu, "value": L / probe_s, "seconds": round(probe_s, 2),
                 "sample": "one un-warmed render of batch 1 on all host threads (oversubscribed torch FFT: slower)"},
@@ -284,7 +297,7 @@ def cpu_baseline_proc(kind, L, budget_s=24.0):
         with torch.no_grad():
             proc(x, **p)
 
-    ncpu, threads, times, _ = _best_cpu(run, budget_s, min_total_s=10.0)
+    ncpu, threads, times, _, _ = _best_cpu(run, budget_s, min_total_s=10.0, sweep=())
     med = statistics.median(times)
     return {"value": R * C * L / med, "unit": "channel-samples/s", "cores": threads, "host_cpus": ncpu, "kind": "port",
             "seconds": [round(t, 3) for t in times], "timed_seconds_total": round(sum(times), 2),
@@ -515,6 +528,13 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     torch.manual_seed(1000 + rank)  # each rank renders its own shard of the batch
     x = torch.randn(B, 32, 2, L, device=dev)
     rd_dev = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
+    # which shard each rank holds: a fingerprint of its first samples, gathered (N distinct values = N distinct shards)
+    shard_fp = None
+    if dist is not None:
+        fp = x.reshape(-1)[:256].double().sum().reshape(1)
+        every = [torch.zeros_like(fp) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, fp)
+        shard_fp = [float(e.item()) for e in every]
 
     captured = []
 
@@ -599,6 +619,7 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
         "world_size": world if dist is None else dist.get_world_size(),
         "backend": None if dist is None else dist.get_backend(),
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+        "shard_fingerprints": shard_fp,
         "roofline": roof,
     }
     if args.dry:

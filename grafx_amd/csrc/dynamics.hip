@@ -1799,6 +1799,8 @@ size_t gfx_dynamics_bwd_ws_bytes(int64_t R, int64_t L) {   // the pole table + f
     return ((size_t)R * DP_TAB + (size_t)R * (size_t)((L + OS_GTILE - 1) / OS_GTILE) * 4) * sizeof(float);
 }
 
+static thread_local const char* t_dyn_last_kernel = "";   // see gfx_dynamics_last_kernel
+
 static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
                                  const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
                                  int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
@@ -1876,8 +1878,12 @@ static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gf
 #undef GFX_MIX3
 #undef GFX_MIX
     }
-    return GFX_LAUNCH_OK();
+    const int rc = GFX_LAUNCH_OK();
+    if (rc == GFX_OK) t_dyn_last_kernel = mix ? "dyn_oneshot_mix_kernel" : (oneshot ? "dyn_oneshot_kernel" : "dyn_fused_kernel");
+    return rc;
 }
+
+const char* gfx_dynamics_last_kernel(void) { return t_dyn_last_kernel; }
 
 int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
                               const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,

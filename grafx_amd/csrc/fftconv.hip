@@ -815,9 +815,11 @@ static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* 
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     // GRAFX_PIPE_THREADS: block size for an experimental code object loaded through GRAFX_PIPE_HSACO (timing experiments
     // with other tile shapes, tools/experiments/r4_tile16); the shipped kernels are 256-thread tiles
+    // -- honoured ONLY together with GRAFX_PIPE_HSACO: the embedded code object never runs with another block size
     static const unsigned threads = [] {
+        const char* alt = getenv("GRAFX_PIPE_HSACO");
         const char* e = getenv("GRAFX_PIPE_THREADS");
-        const int n = e ? atoi(e) : 0;
+        const int n = (alt && *alt && e) ? atoi(e) : 0;
         return n == 512 ? 512u : (unsigned)TILE_T;
     }();
     return hipModuleLaunchKernel(pm->fn[variant], grid, 1, 1, threads, 1, 1, 0, st, nullptr, config) == hipSuccess ? GFX_OK
@@ -1101,8 +1103,9 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     if (ax.nblocks > 0x7ffffff0LL) return GFX_EINVAL;
     hipLaunchKernelGGL(xspec_kernel, dim3(pad8(ax.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x, (float2*)ws, ax,
                        nwin, tw);
-    // (the pair kernel reaches a filter's partitions through one 32-bit-ranged descriptor: 30 000 partitions = 250 M taps)
-    if (schedule != GFX_SCHED_TILE && (int64_t)g.nparts * H_TILE_F4 * 16 < 0x7fffffffLL) {
+    // (the pair kernel asks for "partition -1" at byte offset 0x40000000 and counts on the descriptor's range check to
+    // return zeros: the filter's partitions must end below that offset -- ~126 M taps; longer filters take macinv_kernel)
+    if (schedule != GFX_SCHED_TILE && (int64_t)(g.nparts + 1) * H_TILE_F4 * 16 < 0x40000000LL) {
         // two consecutive output tiles per 512-thread workgroup: each window spectrum and filter partition fetched once a pair
         if (allow_lds(macinv_pair_kernel, 2 * TILE_LDS_BYTES)) return GFX_ELAUNCH;
         ConvArgs ap = a;

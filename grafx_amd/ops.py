@@ -358,14 +358,32 @@ def _alias_plan(P, device, precise=False):
 
 
 ALIAS_WS_CAP = 4 << 30     # bytes of chirp-z workspace per launch chain (rows go through in chunks that fit it; 1 -> 4 GB:
-                           # -6 % on the console's 4608 equaliser rows, tools/czt_chunk_ab.py)
+                           # -6 % on the console's 4608 equaliser rows, tools/czt_chunk_ab.py).  Never more than a quarter
+                           # of the memory that is free when the call is made, and halved (down to one row) when the
+                           # allocation fails: a workload that fitted with the 1 GB chains of round 3 still fits.
+
+
+def set_alias_workspace_cap(nbytes):
+    """Upper bound, in bytes, of the transient chirp-z workspace one odd_alias / odd_alias_adjoint launch chain may hold
+    (default 4 GiB; the effective bound is also a quarter of the free device memory).  Returns the previous value."""
+    global ALIAS_WS_CAP
+    old, ALIAS_WS_CAP = ALIAS_WS_CAP, max(int(nbytes), 1)
+    return old
 
 
 def _alias_chunks(rows, P, rows_per_chunk, device, precise):
     ws_bytes = _alias_fns(precise)[1]
-    chunk = max(1, min(rows, rows_per_chunk, ALIAS_WS_CAP // ws_bytes(1, P)))
-    ws = torch.empty(ws_bytes(chunk, P), dtype=torch.uint8, device=device)
-    return chunk, ws
+    cap = ALIAS_WS_CAP
+    if not torch.cuda.is_current_stream_capturing():
+        cap = min(cap, max(torch.cuda.mem_get_info(device)[0] // 4, 1))
+    chunk = max(1, min(rows, rows_per_chunk, cap // ws_bytes(1, P)))
+    while True:
+        try:
+            return chunk, torch.empty(ws_bytes(chunk, P), dtype=torch.uint8, device=device)
+        except torch.OutOfMemoryError:
+            if chunk == 1:
+                raise
+            chunk = max(1, chunk // 2)
 
 
 @_on_device
@@ -591,20 +609,24 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
         n, J = x.shape[1], mo.shape[1]
         if (mo.shape == (x.shape[0], J, C, L) and mo.stride(-1) == 1 and sched.numel() == n and xmap.inner == n
                 and ymap.inner == n):
-            with _timed("dyn_fused_kernel", 8 * R * C * L + 4 * mo.numel() + (4 * R * L if u1_out is not None else 0)):
+            with _timed("dyn_fused_kernel", 8 * R * C * L + 4 * mo.numel() + (4 * R * L if u1_out is not None else 0)) as t:
                 ex = mix.get("extras")
                 n_ex = 0 if ex is None else ex.shape[0]
                 n_pre = mix.get("n_pre", 0)
                 rc = lib().gfx_dynamics_fused_mix_f32(*args[:-1], _ptr(sched), n, mix["n_acc"], _ptr(mo), mo.stride(0),
                                                       mo.stride(1), mo.stride(2) if C == 2 else 0, _ptr(ex), n_pre,
                                                       n_ex - n_pre, _stream())
+                if rc == 0 and t.rec is not None:    # keyed by the kernel's own name, as a profile prints it
+                    t.name = lib().gfx_dynamics_last_kernel().decode()
             if rc == 0:
                 mix["done"] = True
                 return out
             if rc != -1:   # GFX_EINVAL: not a configuration of the fused kernel
                 check(rc, "gfx_dynamics_fused_mix_f32")
-    with _timed("dyn_fused_kernel", 8 * R * C * L + (4 * R * L if u1_out is not None else 0)):
+    with _timed("dyn_fused_kernel", 8 * R * C * L + (4 * R * L if u1_out is not None else 0)) as t:
         check(lib().gfx_dynamics_fused_ws_f32(*args), "gfx_dynamics_fused_ws_f32")
+        if t.rec is not None:
+            t.name = lib().gfx_dynamics_last_kernel().decode()
     return out
 
 

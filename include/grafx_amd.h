@@ -277,6 +277,11 @@ int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
                               int smoother, int64_t iir_len, int knee, int gate, float* u1,
                               void* ws, size_t ws_bytes, void* stream);
+/* Diagnostic, the twin of gfx_fftconv_last_kernel: the name -- as rocprofv3's kernel trace prints it -- of the kernel that
+ * carries the rows of the calling thread's last successful gfx_dynamics_fused_* call: "dyn_oneshot_mix_kernel" (tiles with
+ * the routing sums), "dyn_oneshot_kernel" (tiles; rows the pole table rejects ride on dyn_fused_kernel in the same call)
+ * or "dyn_fused_kernel" (one workgroup per row: no workspace, or no smoother); "" before the first call. */
+const char* gfx_dynamics_last_kernel(void);
 /* The same with the routing sum that follows fused in (render/core.py:36-112, a "mix" stage that sums this call's rows):
  * rows come in graphs of `inner` consecutive rows (r = g * inner + j, R % inner == 0); destination d of graph g is
  * written to mix + g * mix_sb + d * mix_sv + c * mix_sc, every row's output to y as before.  Per destination the rows

@@ -41,6 +41,26 @@ def test_bench_gpus_2_launches_two_ranks():
     assert res.stderr.count("torch.distributed backend=gloo world_size=2") == 2, res.stderr[-2000:]
 
 
+def test_bench_gpus_8_dry_run_is_eight_ranks_eight_shards_one_gradient():
+    """The node the driver's SCALE run wants (8 ranks) has never been available: everything but RCCL itself is exercised
+    here -- eight processes, eight different shards of the batch, identical gradients after the flat all-reduce."""
+    res = _run("--gpus", "8", "--dry", "--backend", "gloo", "--batch", "1", "--length", "2048", "--steps", "1",
+               "--warmup", "0", timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["backend"] == "gloo"
+    assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "batch-shard x8"
+    assert len(out["per_rank_ms_per_step"]) == 8
+    assert len(set(out["shard_fingerprints"])) == 8, out["shard_fingerprints"]
+    tr = out["training"]
+    assert "error" not in tr, tr
+    assert tr["grad_sync"]["ranks"] == 8 and tr["grad_sync"]["grad_abs_sum"] > 0
+    assert tr["grad_sync"]["max_abs_diff_across_ranks"] == 0.0
+    assert res.stderr.count("torch.distributed backend=gloo world_size=8") == 8, res.stderr[-2000:]
+
+
 def test_bench_single_rank_dry():
     res = _run("--dry", "--backend", "gloo", "--batch", "1", "--length", "2048", "--steps", "1", "--warmup", "0")
     assert res.returncode == 0, res.stderr[-2000:]

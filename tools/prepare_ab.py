@@ -13,7 +13,7 @@ from grafx_amd.render import graph as rg
 
 dev = torch.device("cuda")
 step = bench.console_case(torch, dev, 256, 131072, bench.LENS)
-print("| mode | ms/step (40 steps) | " + " | ".join(["pipe_t1_o8", "pipe_t0_o8", "dyn_fused", "xspec+macinv"]) + " |")
+print("| mode | ms/step (40 steps) | " + " | ".join(["pipe_t1_o8", "pipe_t0_o8", "dyn kernels", "xspec + macinv"]) + " |")
 print("|---|---|---|---|---|---|")
 for rep in range(2):
     for mode in ("under_first", "under_second", "inline"):
@@ -28,6 +28,7 @@ for rep in range(2):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 40 * 1e3
         ms = {k: sum(a.elapsed_time(b) for a, b, _ in v) / 40 for k, v in prof.items()}
-        cols = [ms.get("gfx_fftconv_pipe_t1_o8", 0), ms.get("gfx_fftconv_pipe_t0_o8", 0), ms.get("dyn_fused_kernel", 0),
-                ms.get("xspec_kernel+macinv_kernel", 0)]
+        # records are keyed by the kernels' own names (gfx_fftconv_last_kernel / gfx_dynamics_last_kernel): sum by prefix
+        tot = lambda pre: sum(v for k, v in ms.items() if k.startswith(pre))  # noqa: E731
+        cols = [ms.get("gfx_fftconv_pipe_t1_o8", 0), ms.get("gfx_fftconv_pipe_t0_o8", 0), tot("dyn_"), tot("xspec_kernel+")]
         print(f"| {mode} | {dt:.3f} | " + " | ".join(f"{c:.3f}" for c in cols) + " |", flush=True)
