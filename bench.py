@@ -144,7 +144,7 @@ LENS = dict(fsm_fir_len=4001, iir_len=16383, ir_len=60001)
 REFERENCE_DEFAULT_LENS = dict(fsm_fir_len=4000, iir_len=16384, ir_len=60000)
 
 
-def hip_processors(default_args=False, lens=None):
+def hip_processors(default_args=False, lens=None, energy_smoother="iir"):
     from grafx_amd.processors import Compressor, ParametricEqualizer, STFTMaskedNoiseReverb
 
     if default_args:  # upstream's constructor defaults: flashfftconv=True (-> warning + native convolve), 4000 / 16384 / 60000 taps
@@ -157,7 +157,7 @@ def hip_processors(default_args=False, lens=None):
     lens = lens or LENS
     return {
         "eq": ParametricEqualizer(num_filters=6, flashfftconv=False, fsm_fir_len=lens["fsm_fir_len"]),
-        "compressor": Compressor(energy_smoother="iir", iir_len=lens["iir_len"], flashfftconv=False),
+        "compressor": Compressor(energy_smoother=energy_smoother, iir_len=lens["iir_len"], flashfftconv=False),
         "reverb": STFTMaskedNoiseReverb(ir_len=lens["ir_len"], flashfftconv=False),
     }
 
@@ -736,16 +736,21 @@ def call_roofline(R, C, L, ms_per_step):
     return {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
 
 
-def console_case(torch, dev, B, L, lens, seed=1234):
-    """The headline console graph on a resident batch of B graphs as a step function (forward render)."""
+def console_case(torch, dev, B, L, lens, seed=1234, energy_smoother="iir", z_alpha_pre=None):
+    """The headline console graph on a resident batch of B graphs as a step function (forward render).
+    ``energy_smoother``: the compressors' envelope follower ("iir" as in the headline, or "ballistics");
+    ``z_alpha_pre``: set every compressor's smoother logit to this value instead of randn * 0.1 (6 -> a pole at 0.9975,
+    a 400-sample time constant: the one-pole smoother's memory is then thousands of samples, not tens)."""
     from grafx_amd.data import convert_to_tensor
     from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
     from grafx_amd.utils import create_empty_parameters
 
     G = console_graph()
-    procs = {k: v.to(dev) for k, v in hip_processors(lens=lens).items()}
+    procs = {k: v.to(dev) for k, v in hip_processors(lens=lens, energy_smoother=energy_smoother).items()}
     torch.manual_seed(seed)
     params = {t: {k: v.detach().to(dev) for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    if z_alpha_pre is not None:
+        params["compressor"]["z_alpha_pre"] = torch.full_like(params["compressor"]["z_alpha_pre"], float(z_alpha_pre))
     x = torch.randn(B, 32, 2, L, device=dev)
     rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(dev)
 
@@ -766,12 +771,25 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
 
     out = {}
     legs = [("cfg2", "cfg2", None, steps, warmup), ("cfg3", "cfg3", None, steps, warmup),
+            ("cfg4_longpole", "cfg4v", dict(z_alpha_pre=6.0), 10, 3), ("cfg4_ballistics", "cfg4v", dict(energy_smoother="ballistics"), 10, 3),
             ("cfg2_compat", "cfg2", REFERENCE_DEFAULT_LENS, 5, 2), ("cfg3_compat", "cfg3", REFERENCE_DEFAULT_LENS, 5, 2),
             ("cfg4_compat", "cfg4", REFERENCE_DEFAULT_LENS, 5, 2)]
     for key, cfg, lens, n, w in legs:
         torch.cuda.empty_cache()
         try:
-            if cfg == "cfg4":
+            if cfg == "cfg4v":
+                # the headline console at the headline size with another compressor setting (SURVEY 8d "a ballistics
+                # variant"; the long-pole leg is the compressor's data-dependent path: bench.py's randn * 0.1 logits put
+                # every smoother pole near 0.5)
+                R, C, L = 256, 2, 131072
+                variant, lens = lens, None
+                step = console_case(torch, dev, R, L, LENS, **variant)
+                what = (f"BASELINE configs[3] console graph at batch {R}, L={L}, the headline's tap counts, "
+                        + ("every compressor's smoother logit z_alpha_pre = 6 (pole 0.9975)" if "z_alpha_pre" in variant
+                           else "Compressor(energy_smoother='ballistics') (attack / release recursion, z_alpha_pre ~ randn * 0.1)"))
+                unit, units = "audio samples/s", R * L
+                call_bytes = 285 * R * 2 * L * 4
+            elif cfg == "cfg4":
                 R, C, L = 64, 2, 131072     # graphs (of 256): the aliasing workspaces are sized per row
                 step = console_case(torch, dev, R, L, lens)
                 what = (f"BASELINE configs[3] console graph at batch {R} (of 256), L={L}, upstream default tap counts "

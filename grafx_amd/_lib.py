@@ -67,6 +67,7 @@ SIGNATURES = {
     "gfx_dynamics_bwd_u1_ws_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                   ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp, sz, vp]),
     "gfx_dynamics_ws_bytes": (sz, [i64]),
+    "gfx_dynamics_ws_bytes_ex": (sz, [i64, i64, i64]),
     "gfx_dynamics_last_kernel": (ctypes.c_char_p, []),
     "gfx_dynamics_bwd_ws_bytes": (sz, [i64, i64]),
     "gfx_dynamics_fused_ws_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
@@ -85,6 +86,11 @@ SIGNATURES = {
     "gfx_onepole_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, i64, i64, ctypes.c_int, vp]),
     "gfx_onepole_fir_f32": (ctypes.c_int, [f32p, f32p, i64, i64, vp]),
     "gfx_ballistics_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, vp]),
+    "gfx_dyn_gain_apply_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, f32p, f32p, f32p, i64, i64, i64, i64,
+                                              ctypes.c_int, ctypes.c_int, vp]),
+    "gfx_ballistics_ws_bytes": (sz, [i64]),
+    "gfx_ballistics_ws_f32": (ctypes.c_int, [f32p, f32p, ctypes.c_int, f32p, i64, i64, vp, sz, vp]),
+    "gfx_ballistics_energy_f32": (ctypes.c_int, [f32p, RowMap, i64, f32p, ctypes.c_int, f32p, i64, i64, vp, sz, vp]),
     "gfx_dyn_gain_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "gfx_apply_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, ctypes.c_int, vp]),
     "gfx_stereo_gain_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, i64, i64, i64, vp]),

@@ -33,9 +33,9 @@ constexpr int DT = 256;            // threads per workgroup
 constexpr int DE = 4;              // samples per thread per tile
 constexpr int DTILE = DT * DE;     // 1024 samples per tile
 // per-parameter-row pole table (dyn_pole_table_kernel), floats per row:
-//   a^(4 l) l < 64 | a_step[6] | a_wave | a_N | ap[0..4] | a | 1 - a | trunc | one-shot | H | pad
-constexpr int DP_TAB = 84;
-constexpr int DP_ONESHOT = 80, DP_HIST = 81;
+//   a^(4 l) l < 64 | a_step[6] | a_wave | a_N | ap[0..4] | a | 1 - a | trunc | one-shot | H | look-back | M | a^(512 i) i < 64
+constexpr int DP_TAB = 148;
+constexpr int DP_ONESHOT = 80, DP_HIST = 81, DP_LOOKBACK = 82, DP_LB_TILES = 83, DP_LB_W = 84;
 
 __device__ __forceinline__ int64_t drow_off(const gfx_rowmap_t& m, int64_t r, int c) {
     const unsigned inner = (unsigned)m.inner, rr = (unsigned)r;  // both fit 32 bits (launchers check)
@@ -368,7 +368,8 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
     p.trunc = false;
     const unsigned pr = (unsigned)r % a.prows;
     // rows the one-shot grid takes (dyn_oneshot_kernel, same pole table, complementary test) are not produced here
-    if (oneshot_tab && oneshot_tab[(size_t)pr * DP_TAB + DP_ONESHOT] != 0.0f) return;
+    if (oneshot_tab && (oneshot_tab[(size_t)pr * DP_TAB + DP_ONESHOT] != 0.0f ||
+                        oneshot_tab[(size_t)pr * DP_TAB + DP_LOOKBACK] != 0.0f)) return;
     if (a.smoother == 1) onepole_setup(p, z_alpha[pr], a.N, t & 63);
     Knee q;
     knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
@@ -405,7 +406,10 @@ __global__ __launch_bounds__(DT, GFX_DYN_WAVES) void dyn_fused_kernel(const floa
 #define GFX_DYN_OS_HMAX 256   // taps of history a one-shot tile may re-read (tile: 1024 samples)
 #endif
 
-__global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* __restrict__ tab, int64_t rows, int64_t N) {
+// `any_lb` (nullable): set to 1 when some row takes the look-back tiles -- only then do the tile grids draw tickets
+// (see LbArgs); without it no row is given to the look-back (the backward pass, callers without the larger workspace).
+__global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* __restrict__ tab, int64_t rows, int64_t N,
+                                      unsigned* __restrict__ any_lb) {
     const int64_t r = blockIdx.x;
     const int lane = threadIdx.x;   // 64 threads
     if (r >= rows) return;
@@ -413,6 +417,8 @@ __global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* 
     onepole_setup(p, z_alpha[r], N, lane);
     float* t = tab + r * DP_TAB;
     t[lane] = p.a_lane;
+    const double la = log((double)p.a);
+    t[DP_LB_W + lane] = powk(la, 512.0 * lane);   // weight of the tile `lane + 1` tiles back in the state entering a tile
     if (lane == 0) {
 #pragma unroll
         for (int d = 0; d < 6; ++d) t[64 + d] = p.a_step[d];
@@ -424,13 +430,18 @@ __global__ void dyn_pole_table_kernel(const float* __restrict__ z_alpha, float* 
         t[78] = p.one_m_a;
         t[79] = p.trunc ? 1.0f : 0.0f;
         // taps above 1e-12: H = ceil(log 1e-12 / log a); the row is one-shot material when the N-tap truncation is
-        // beyond that (so H <= N and the truncation term is dead) and the history fits the re-read budget
-        const double la = log((double)p.a);
+        // beyond that (so H <= N and the truncation term is dead) and the history fits the re-read budget; with a longer
+        // history (up to 64 tiles of 512 samples) the tiles get their entry state from their predecessors' aggregates
         const double h = ceil(-27.631021115928547 / la);
-        const bool os = h <= (double)GFX_DYN_OS_HMAX && h <= (double)N;
+        const bool dead = h <= (double)N;
+        const bool os = dead && h <= (double)GFX_DYN_OS_HMAX;
+        const double m = ceil(h / 512.0);
+        const bool lb = any_lb != nullptr && dead && !os && m <= 64.0;
         t[DP_ONESHOT] = os ? 1.0f : 0.0f;
         t[DP_HIST] = os ? (float)h : 0.0f;
-        t[82] = t[83] = 0.0f;
+        t[DP_LOOKBACK] = lb ? 1.0f : 0.0f;
+        t[DP_LB_TILES] = lb ? (float)m : 0.0f;
+        if (lb) *any_lb = 1u;
     }
 }
 
@@ -447,6 +458,38 @@ constexpr int OS_GTILE = OS_WTILE * (DT / 64);   // 2048 samples per workgroup
 struct OsIn {
     float xa[OS_SUB][DE], xb[OS_SUB][DE], ha[DE], hb[DE];
 };
+
+// LOOK-BACK tiles (round 5): a smoother memory longer than the history a tile may re-read (H > GFX_DYN_OS_HMAX samples,
+// up to 64 tiles) does not send the row to the row kernel any more.  The scan is linear, so the state entering tile j is
+//     u[s - 1] = sum_{i >= 1} a^(512 (i - 1)) A[j - i],      A[t] = the state tile t leaves from a ZERO entry state,
+// and A[t] depends on tile t's own samples only: every tile publishes its aggregate as soon as its local scans are done
+// -- before it needs anything from anybody -- and then reads the M = ceil(H / 512) aggregates before it (lane i polls tile
+// j - 1 - i; a 64-lane weighted sum).  One hop of latency, no chain along the row, 8 bytes of traffic per tile and row.
+//   * hand-off: one naturally aligned 8-byte {aggregate, 1} granule per (row, tile), written by ONE agent-scope relaxed
+//     store and polled with agent-scope relaxed loads (both bypass the CU's L1; an 8-byte granule needs no fence);
+//     the granules are zeroed by a memset node in front of the launch.
+//   * progress: a tile only ever waits for tiles of the same row with smaller indices, which live in workgroups with
+//     smaller logical indices.  Logical indices are handed out by TICKETS (one counter per blockIdx & 7, so that a
+//     workgroup's tiles stay on the XCD the block index maps to): whoever holds ticket t knows tickets < t were drawn by
+//     workgroups that are running or done -- no assumption about the order in which the hardware starts workgroups.
+//     Tickets are drawn only when the pole table found a look-back row (ctrl[8]).
+struct LbArgs {
+    unsigned long long* gran;   // [row][tile]; nullptr: no look-back in this launch
+    unsigned* ctrl;             // [0..7] tickets, [8] "some row looks back"
+    unsigned ntiles;            // 512-sample tiles per row
+    int split;                  // the routing-sum kernel is launched in both forms (plain / deferred walk), see there
+};
+
+__device__ __forceinline__ unsigned lb_block_index(const LbArgs& lb, unsigned per_xcd) {
+    __shared__ unsigned ticket;
+    unsigned bi = blockIdx.x >> 3;
+    if (lb.gran && lb.ctrl[8] != 0u) {     // uniform over the grid
+        if (threadIdx.x == 0) ticket = atomicAdd(&lb.ctrl[blockIdx.x & 7u], 1u);
+        __syncthreads();
+        bi = ticket;
+    }
+    return (blockIdx.x & 7u) * per_xcd + bi;
+}
 
 template <bool AL>
 __device__ __forceinline__ void os_load(const DynArgs& a, const float* __restrict__ x0, const float* __restrict__ x1,
@@ -470,28 +513,30 @@ __device__ __forceinline__ void os_load(const DynArgs& a, const float* __restric
     }
 }
 
+// A tile in three steps, so that a caller walking several rows can put other rows' work between them:
+//   os_scan    energies, the sub-tiles' local and in-wave scans; the state entering the tile from the re-read history
+//              (one-shot rows) -- or, for a look-back row, the tile's aggregate PUBLISHED (see LbArgs)
+//   os_lookback  the entry state of a look-back row from the aggregates of the tiles before it (polls them)
+//   os_emit    envelope -> gain -> outputs, stores
+struct OsMid {
+    float loc[OS_SUB][DE], excl[OS_SUB], total[OS_SUB], carry;
+};
+
 template <bool AL>
-__device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, float* __restrict__ y0, float* __restrict__ y1,
-                                          bool vx, float* __restrict__ u1row, const float* __restrict__ tb, const Knee& q,
-                                          int64_t s, int lane, float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE]) {
+__device__ __forceinline__ void os_scan(const DynArgs& a, const OsIn& in, const float* __restrict__ tb, int64_t s, int lane,
+                                        OsMid& mid, unsigned long long* __restrict__ grow) {
     const bool stereo = a.C == 2;
-    const int64_t n0 = s + DE * lane;
     const float (&xa)[OS_SUB][DE] = in.xa;
     const float (&xb)[OS_SUB][DE] = in.xb;
-    const float (&ha)[DE] = in.ha;
-    const float (&hb)[DE] = in.hb;
     const int H = (int)tb[DP_HIST];
     const bool hist = s != 0 && DE * lane < H;
-    const float a1 = tb[77], one_m_a = tb[78], a_sub = tb[70];          // a, 1 - a, a^256
-    const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};              // a^1 .. a^4
+    const float a1 = tb[77], a_sub = tb[70];                             // a, a^256
     const float a_lane = tb[lane];                                       // a^(4 lane)
     float a_step[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) a_step[d] = tb[64 + d];
     const float invC = 1.0f / (float)a.C;
-
     // the sub-tiles' local and in-wave scans do not depend on each other
-    float loc[OS_SUB][DE], excl[OS_SUB], total[OS_SUB];
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
         float acc = 0.0f;
@@ -499,7 +544,7 @@ __device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, floa
         for (int i = 0; i < DE; ++i) {
             const float e = (stereo ? (xa[k][i] * xa[k][i] + xb[k][i] * xb[k][i]) : xa[k][i] * xa[k][i]) * invC;
             acc = fmaf(a1, acc, e);
-            loc[k][i] = acc;
+            mid.loc[k][i] = acc;
         }
         float inc = acc;
 #pragma unroll
@@ -508,18 +553,25 @@ __device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, floa
             if (lane >= (1 << d)) inc = fmaf(a_step[d], up, inc);
         }
         const float ex = __shfl_up(inc, 1, 64);
-        excl[k] = lane == 0 ? 0.0f : ex;
-        total[k] = __shfl(inc, 63, 64);          // the sub-tile's aggregate, uniform
+        mid.excl[k] = lane == 0 ? 0.0f : ex;
+        mid.total[k] = __shfl(inc, 63, 64);      // the sub-tile's aggregate, uniform
     }
     // state entering the tile: sum over the live taps of a^k e[s-1-k], k = 4 lane + (3 - i)
     float carry = 0.0f;
-    if (s != 0 && H > 0) {                        // uniform
+    if (grow) {                                   // look-back row (uniform): publish the tile's aggregate
+        float agg = mid.total[0];
+#pragma unroll
+        for (int k = 1; k < OS_SUB; ++k) agg = fmaf(a_sub, agg, mid.total[k]);
+        if (lane == 0)
+            __hip_atomic_store(grow + (int)(s / OS_WTILE), (1ull << 32) | (unsigned long long)__float_as_uint(agg),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (s != 0 && H > 0) {                 // uniform
         float hs = 0.0f;
         if (hist) {
             float w = 0.0f;                       // Horner, oldest first: ((e0 a + e1) a + e2) a + e3
 #pragma unroll
             for (int i = 0; i < DE; ++i) {
-                const float eh = (stereo ? (ha[i] * ha[i] + hb[i] * hb[i]) : ha[i] * ha[i]) * invC;
+                const float eh = (stereo ? (in.ha[i] * in.ha[i] + in.hb[i] * in.hb[i]) : in.ha[i] * in.ha[i]) * invC;
                 w = fmaf(a1, w, eh);
             }
             hs = w * a_lane;
@@ -528,15 +580,47 @@ __device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, floa
         for (int d = 32; d >= 1; d >>= 1) hs += __shfl_xor(hs, d, 64);
         carry = hs;
     }
+    mid.carry = carry;
+}
+
+__device__ __forceinline__ float os_lookback(const float* __restrict__ tb, int64_t s, int lane,
+                                              const unsigned long long* __restrict__ grow) {
+    const int j = (int)(s / OS_WTILE);
+    const int M = (int)tb[DP_LB_TILES];
+    float hs = 0.0f;
+    if (lane < M && lane < j) {
+        const unsigned long long* g = grow + (j - 1 - lane);
+        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((v >> 32) == 0ull) {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        hs = __uint_as_float((unsigned)v) * tb[DP_LB_W + lane];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hs += __shfl_xor(hs, d, 64);
+    return hs;
+}
+
+template <bool AL>
+__device__ __forceinline__ void os_emit(const DynArgs& a, const float (&xa)[OS_SUB][DE], const float (&xb)[OS_SUB][DE],
+                                        const OsMid& mid, float carry, float* __restrict__ y0, float* __restrict__ y1,
+                                        bool vx, float* __restrict__ u1row, const float* __restrict__ tb, const Knee& q,
+                                        int64_t s, int lane, float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE]) {
+    const bool stereo = a.C == 2;
+    const int64_t n0 = s + DE * lane;
+    const float one_m_a = tb[78], a_sub = tb[70];
+    const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};              // a^1 .. a^4
+    const float a_lane = tb[lane];
     const bool vu = (a.L % 4) == 0;
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
-        const float pre = fmaf(a_lane, carry, excl[k]);   // u just before this lane's first sample of sub-tile k
-        carry = fmaf(a_sub, carry, total[k]);
+        const float pre = fmaf(a_lane, carry, mid.excl[k]);   // u just before this lane's first sample of sub-tile k
+        carry = fmaf(a_sub, carry, mid.total[k]);
         float raw[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
-            const float u = fmaf(apk[i], pre, loc[k][i]);
+            const float u = fmaf(apk[i], pre, mid.loc[k][i]);
             raw[i] = one_m_a * u;
             const float env = fmaxf(raw[i], 0.0f);                       // relu, envelope.py:48
             const float G = FastMath::log(env + 1e-5f);                  // dynamics.py:394
@@ -551,14 +635,65 @@ __device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, floa
     }
 }
 
+// os_emit for a row whose local scans were NOT kept (the deferred walk of the routing-sum kernel keeps the samples, the
+// exclusive in-wave scans and the sub-tile totals of its pending row, 18 registers + 2 scalars, and rebuilds the
+// four-sample local scans here -- the same fused multiply-adds in the same order, so the same bits)
+template <bool AL>
+__device__ __forceinline__ void os_emit_lean(const DynArgs& a, const float (&xa)[OS_SUB][DE], const float (&xb)[OS_SUB][DE],
+                                             const float (&excl)[OS_SUB], const float (&total)[OS_SUB], float carry,
+                                             float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ u1row,
+                                             const float* __restrict__ tb, const Knee& q, int64_t s, int lane,
+                                             float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE]) {
+    const bool stereo = a.C == 2;
+    const int64_t n0 = s + DE * lane;
+    const float a1 = tb[77], one_m_a = tb[78], a_sub = tb[70];
+    const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};              // a^1 .. a^4
+    const float a_lane = tb[lane];
+    const float invC = 1.0f / (float)a.C;
+#pragma unroll
+    for (int k = 0; k < OS_SUB; ++k) {
+        const float pre = fmaf(a_lane, carry, excl[k]);
+        carry = fmaf(a_sub, carry, total[k]);
+        float raw[DE], acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DE; ++i) {
+            const float e = (stereo ? (xa[k][i] * xa[k][i] + xb[k][i] * xb[k][i]) : xa[k][i] * xa[k][i]) * invC;
+            acc = fmaf(a1, acc, e);
+            const float u = fmaf(apk[i], pre, acc);
+            raw[i] = one_m_a * u;
+            const float env = fmaxf(raw[i], 0.0f);
+            const float G = FastMath::log(env + 1e-5f);
+            const float g = FastMath::exp(log_gain_m<FastMath>(q, G));
+            ga[k][i] = g * xa[k][i];
+            gb[k][i] = g * xb[k][i];
+        }
+        const int64_t n = n0 + 256 * k;
+        if (u1row) st4<AL>(u1row, n, a.L, true, raw);
+        st4<AL>(y0, n, a.L, true, ga[k]);
+        if (stereo) st4<AL>(y1, n, a.L, true, gb[k]);
+    }
+}
+
+template <bool AL>
+__device__ __forceinline__ void os_finish(const DynArgs& a, const OsIn& in, float* __restrict__ y0, float* __restrict__ y1,
+                                          bool vx, float* __restrict__ u1row, const float* __restrict__ tb, const Knee& q,
+                                          int64_t s, int lane, float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE],
+                                          unsigned long long* __restrict__ grow = nullptr) {
+    OsMid mid;
+    os_scan<AL>(a, in, tb, s, lane, mid, grow);
+    const float carry = grow ? os_lookback(tb, s, lane, grow) : mid.carry;
+    os_emit<AL>(a, in.xa, in.xb, mid, carry, y0, y1, vx, u1row, tb, q, s, lane, ga, gb);
+}
+
 __device__ __forceinline__ void os_tile(const DynArgs& a, const float* __restrict__ x0, const float* __restrict__ x1,
                                         float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ u1row,
                                         const float* __restrict__ tb, const Knee& q, int64_t s, int lane,
-                                        float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE]) {
+                                        float (&ga)[OS_SUB][DE], float (&gb)[OS_SUB][DE],
+                                        unsigned long long* __restrict__ grow) {
     const bool vx = vec_ok(x0) && vec_ok(x1) && vec_ok(y0) && vec_ok(y1);
     OsIn in;
     os_load<false>(a, x0, x1, vx, tb, s, lane, in);
-    os_finish<false>(a, in, y0, y1, vx, u1row, tb, q, s, lane, ga, gb);
+    os_finish<false>(a, in, y0, y1, vx, u1row, tb, q, s, lane, ga, gb, grow);
 }
 
 __global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -566,24 +701,27 @@ __global__ __launch_bounds__(DT) void dyn_oneshot_kernel(const float* __restrict
                                                          const float* __restrict__ log_ratio,
                                                          const float* __restrict__ log_knee,
                                                          const float* __restrict__ tab, DynArgs a, unsigned ngroups,
-                                                         unsigned nblocks, float* __restrict__ u1) {
+                                                         unsigned nblocks, float* __restrict__ u1, LbArgs lb) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (a tile's history is its neighbour's data)
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (a tile's history is its neighbour's data);
+    // the runs are whole rows (the launcher pads the grid), so a row's tiles never straddle two runs
     const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const unsigned b = lb_block_index(lb, per_xcd);
     if (b >= nblocks) return;
     const unsigned r = b / ngroups;
     const unsigned grp = b - r * ngroups;
     const unsigned pr = r % a.prows;
     const float* tb = tab + (size_t)pr * DP_TAB;
-    if (tb[DP_ONESHOT] == 0.0f) return;          // produced by dyn_fused_kernel (uniform)
+    const bool looks_back = lb.gran && tb[DP_LOOKBACK] != 0.0f;   // (the launchers hand look-back rows to the row-group walk)
+    if (tb[DP_ONESHOT] == 0.0f && !looks_back) return;          // produced by dyn_fused_kernel / the row-group walk (uniform)
     const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;     // first sample of this wave's tile
     if (s >= a.L) return;
     Knee q;
     knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, a.knee, a.gate);
     float ga[OS_SUB][DE], gb[OS_SUB][DE];
     os_tile(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0), y + drow_off(a.ymap, r, 0),
-            y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0), u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb);
+            y + drow_off(a.ymap, r, a.C == 2 ? 1 : 0), u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb,
+            looks_back ? lb.gran + (size_t)r * lb.ntiles : nullptr);
 }
 
 // The one-shot tiles with the ROUTING SUM that follows fused in (render/core.py:36-112: the "mix" stage whose sources are
@@ -615,23 +753,32 @@ struct MixArgs {
 // -- 5.0 ms for 8192 rows where this form takes 3.3-3.5.  Requesting rows ahead of the one being scanned was measured too
 // (register rings of 2-4 rows): slower at every depth, the registers cost more waves than the loads in flight gain
 // (EXPERIMENTS.md).
-template <int NA, bool STEREO, int KIND, bool GATE>
-__global__ __launch_bounds__(DT) void dyn_oneshot_mix_kernel(const float* __restrict__ x, float* __restrict__ y,
+#ifndef GFX_DEFER_WAVES
+#define GFX_DEFER_WAVES 1     // waves per SIMD the deferred walk is compiled for: left to the compiler (155 VGPRs, three waves,
+                              // 4.19 ms for the 8192-row stage at a = 0.9975); 4 forces 128 VGPRs and 84 bytes of scratch: 4.31 ms
+#endif
+template <int NA, bool STEREO, int KIND, bool GATE, bool DEFER>
+__global__ __launch_bounds__(DT, (DEFER && NA <= 2) ? GFX_DEFER_WAVES : 1) void dyn_oneshot_mix_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ log_threshold,
                                                              const float* __restrict__ log_ratio,
                                                              const float* __restrict__ log_knee,
                                                              const float* __restrict__ tab, DynArgs a, unsigned ngroups,
-                                                             unsigned nblocks, float* __restrict__ u1, MixArgs m) {
+                                                             unsigned nblocks, float* __restrict__ u1, MixArgs m, LbArgs lb) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // the launcher starts both forms of this kernel: the deferred walk takes the call when some row looks back, the plain
+    // walk when none does (uniform over the grid; the other grid leaves at once)
+    if (lb.split && (lb.gran && lb.ctrl[8] != 0u) != DEFER) return;
     const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const unsigned b = lb_block_index(lb, per_xcd);
     if (b >= nblocks) return;
     const unsigned g = b / ngroups;               // graph (batch index)
     const unsigned grp = b - g * ngroups;
     const int64_t s = (int64_t)grp * OS_GTILE + (int64_t)wave * OS_WTILE;
     if (s >= a.L) return;
     const int64_t n0 = s + DE * lane;
-    float acc0[NA][OS_SUB][DE], acc1[STEREO ? NA : 1][OS_SUB][DE];
+    // NA == 0: no routing sum at all -- the walk over groups of `inner` rows that produces the LOOK-BACK rows of a call
+    // without a fused sum (every other row belongs to dyn_oneshot_kernel / dyn_fused_kernel and is skipped here)
+    float acc0[NA ? NA : 1][OS_SUB][DE], acc1[STEREO && NA ? NA : 1][OS_SUB][DE];
 #pragma unroll
     for (int c = 0; c < NA; ++c)
 #pragma unroll
@@ -641,7 +788,7 @@ __global__ __launch_bounds__(DT) void dyn_oneshot_mix_kernel(const float* __rest
                 acc0[c][k][i] = 0.0f;
                 if (STEREO) acc1[c][k][i] = 0.0f;
             }
-    float* const obase = m.out + (int64_t)g * m.sb;
+    float* const obase = NA ? m.out + (int64_t)g * m.sb : nullptr;
     // add one row's tile to the accumulators `code` names, then store and clear the destinations it completes
     auto settle = [&](uint64_t code, const float (&ga)[OS_SUB][DE], const float (&gb)[OS_SUB][DE]) {
         const unsigned add = (unsigned)code & 15u;
@@ -685,28 +832,109 @@ __global__ __launch_bounds__(DT) void dyn_oneshot_mix_kernel(const float* __rest
         settle((uint64_t)m.extras[2 * e + 1], ga, gb);
     };
     for (int e = 0; e < m.n_pre; ++e) extra(e);
-    for (int jr = 0; jr < m.inner; ++jr) {
-        const unsigned r = g * (unsigned)m.inner + (unsigned)jr;
-        const unsigned pr = r % a.prows;
-        const float* tb = tab + (size_t)pr * DP_TAB;
-        const uint64_t code = (uint64_t)m.sched[jr];
-        float* y0 = y + drow_off(a.ymap, r, 0);
-        float* y1 = y + drow_off(a.ymap, r, STEREO ? 1 : 0);
-        float ga[OS_SUB][DE], gb[OS_SUB][DE];
-        if (tb[DP_ONESHOT] != 0.0f) {             // uniform
-            Knee q;
-            knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
+    if (!DEFER) {
+        for (int jr = 0; jr < m.inner; ++jr) {
+            const unsigned r = g * (unsigned)m.inner + (unsigned)jr;
+            const unsigned pr = r % a.prows;
+            const float* tb = tab + (size_t)pr * DP_TAB;
+            const uint64_t code = (uint64_t)m.sched[jr];
+            float* y0 = y + drow_off(a.ymap, r, 0);
+            float* y1 = y + drow_off(a.ymap, r, STEREO ? 1 : 0);
+            float ga[OS_SUB][DE], gb[OS_SUB][DE];
+            const bool looks_back = tb[DP_LOOKBACK] != 0.0f;
+            if (tb[DP_ONESHOT] != 0.0f || looks_back) {   // uniform
+                Knee q;
+                knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
+                OsIn in;
+                os_load<true>(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, STEREO ? 1 : 0), true, tb, s, lane, in);
+                os_finish<true>(a, in, y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb,
+                                looks_back ? lb.gran + (size_t)r * lb.ntiles : nullptr);
+            } else if (((unsigned)code & 15u) != 0u) {   // the row kernel's row: read back what it wrote
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k) {
+                    ld4<true>(y0, n0 + 256 * k, a.L, true, ga[k]);
+                    if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, gb[k]);
+                }
+            }
+            settle(code, ga, gb);
+        }
+    } else {
+        // The same walk, one row DEFERRED: row jr is loaded, scanned and -- if it looks back -- its aggregate published
+        // before row jr - 1 is finished.  A look-back row then asks for its predecessors' aggregates a whole row time
+        // after they were published (the waves of a graph walk the rows side by side), instead of right behind its own
+        // publication, when the tiles before it are at the same point of the same row: without the deferral every row of
+        // every wave waits out a hand-off (1-3 us of a ~6 us row).  The rows are still finished, and added to the
+        // routing sums, in increasing order.
+        float pxa[OS_SUB][DE], pxb[OS_SUB][DE], pexcl[OS_SUB];
+        float ptotal[OS_SUB], pcarry = 0.0f;      // uniform
+        int pkind = 0;                            // 0 nothing pending, 1 computed row, 2 look-back row, 3 read-back row
+        unsigned prow = 0;
+        uint64_t pcode = 0;
+        auto finish = [&]() {
+            if (pkind == 1 || pkind == 2) {       // uniform
+                const unsigned pr = prow % a.prows;
+                const float* tb = tab + (size_t)pr * DP_TAB;
+                Knee q;
+                knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
+                const float carry = pkind == 2 ? os_lookback(tb, s, lane, lb.gran + (size_t)prow * lb.ntiles) : pcarry;
+                float ga[OS_SUB][DE], gb[OS_SUB][DE];
+                os_emit_lean<true>(a, pxa, pxb, pexcl, ptotal, carry, y + drow_off(a.ymap, prow, 0),
+                                   y + drow_off(a.ymap, prow, STEREO ? 1 : 0), u1 ? u1 + (int64_t)prow * a.L : nullptr, tb, q, s,
+                                   lane, ga, gb);
+                settle(pcode, ga, gb);
+            } else {
+                settle(pcode, pxa, pxb);          // a row the row kernel wrote (read back below), or one nobody sums
+            }
+        };
+        int walked = 0;
+        for (int jr = 0; jr < m.inner; ++jr) {
+            const unsigned r = g * (unsigned)m.inner + (unsigned)jr;
+            if (NA == 0 && (int64_t)r >= a.R) break;      // (the last group of a call without a sum may be short)
+            const unsigned pr = r % a.prows;
+            const float* tb = tab + (size_t)pr * DP_TAB;
+            const uint64_t code = NA ? (uint64_t)m.sched[jr] : 0ull;
+            const bool looks_back = tb[DP_LOOKBACK] != 0.0f;
             OsIn in;
-            os_load<true>(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, STEREO ? 1 : 0), true, tb, s, lane, in);
-            os_finish<true>(a, in, y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb);
-        } else if (((unsigned)code & 15u) != 0u) {   // the row kernel's row: read back what it wrote
+            float cexcl[OS_SUB], ctotal[OS_SUB], ccarry = 0.0f;
+            int ckind = 3;
+            if ((NA != 0 && tb[DP_ONESHOT] != 0.0f) || looks_back) {   // uniform
+                os_load<true>(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, STEREO ? 1 : 0), true, tb, s, lane, in);
+                OsMid cmid;
+                os_scan<true>(a, in, tb, s, lane, cmid, looks_back ? lb.gran + (size_t)r * lb.ntiles : nullptr);
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k) {
+                    cexcl[k] = cmid.excl[k];
+                    ctotal[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cmid.total[k])));
+                }
+                ccarry = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cmid.carry)));
+                ckind = looks_back ? 2 : 1;
+            } else if (NA != 0 && ((unsigned)code & 15u) != 0u) {   // the row kernel's row: read back what it wrote
+                const float* y0 = y + drow_off(a.ymap, r, 0);
+                const float* y1 = y + drow_off(a.ymap, r, STEREO ? 1 : 0);
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k) {
+                    ld4<true>(y0, n0 + 256 * k, a.L, true, in.xa[k]);
+                    if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, in.xb[k]);
+                }
+            }
+            if (walked > 0) finish();
+            ++walked;
 #pragma unroll
             for (int k = 0; k < OS_SUB; ++k) {
-                ld4<true>(y0, n0 + 256 * k, a.L, true, ga[k]);
-                if (STEREO) ld4<true>(y1, n0 + 256 * k, a.L, true, gb[k]);
+#pragma unroll
+                for (int i = 0; i < DE; ++i) {
+                    pxa[k][i] = in.xa[k][i];
+                    pxb[k][i] = in.xb[k][i];
+                }
+                pexcl[k] = cexcl[k];
+                ptotal[k] = ctotal[k];
             }
+            pcarry = ccarry;
+            pkind = ckind;
+            prow = r;
+            pcode = code;
         }
-        settle(code, ga, gb);
+        if (walked > 0) finish();
     }
     for (int e = m.n_pre; e < m.n_pre + m.n_post; ++e) extra(e);
 }
@@ -782,62 +1010,8 @@ __global__ void onepole_fir_kernel(const float* __restrict__ z_alpha, float* __r
     }
 }
 
-// ballistics (torchcomp.compressor_core as recalled — PARITY UNPINNED, see oracle/__init__.py):
-//   y[-1] = 1;  c = (x[n] < y[n-1]) ? at : rt;  y[n] = (1-c) y[n-1] + c x[n]
-// One wave per 64 rows; 64x64 tiles staged through LDS so HBM access stays coalesced while each
-// lane walks its own row sequentially.
+// (the ballistics recursion itself lives in ballistics.hip; its adjoint below keeps the 64 x 64 LDS tiling)
 constexpr int BROWS = 64, BCOLS = 64, BPAD = BCOLS + 4;
-__global__ __launch_bounds__(64) void ballistics_kernel(const float* __restrict__ u, const float* __restrict__ z_alpha,
-                                                        float* __restrict__ y, int64_t R, int64_t L) {
-    __shared__ __attribute__((aligned(16))) float tile[BROWS * BPAD];
-    const int lane = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * BROWS;
-    const int64_t my = r0 + lane;
-    float at = 0.0f, rt = 0.0f;
-    if (my < R) {
-        at = sigmoidf(z_alpha[2 * my]);       // envelope.py:97-99
-        rt = sigmoidf(z_alpha[2 * my + 1]);
-    }
-    float state = 1.0f;                       // zi = ones
-    const int cr = lane >> 4, cc = (lane & 15) * 4;  // cooperative copy: 4 rows x 16 float4 per pass
-    const bool vec = (L % 4 == 0) && vec_ok(u) && vec_ok(y);
-    for (int64_t n0 = 0; n0 < L; n0 += BCOLS) {
-#pragma unroll 4
-        for (int pass = 0; pass < BROWS / 4; ++pass) {
-            const int row = pass * 4 + cr;
-            const int64_t rr = r0 + row;
-            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (rr < R) load4(u + rr * L, n0 + cc, L, vec, v);
-            *reinterpret_cast<float4*>(&tile[row * BPAD + cc]) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        __syncthreads();
-        float* mine = &tile[lane * BPAD];
-#pragma unroll 4
-        for (int j = 0; j < BCOLS; j += 4) {
-            float4 q = *reinterpret_cast<float4*>(mine + j);
-            float* qs = reinterpret_cast<float*>(&q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float c = qs[i] < state ? at : rt;
-                state = (1.0f - c) * state + c * qs[i];
-                qs[i] = state;
-            }
-            *reinterpret_cast<float4*>(mine + j) = q;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int pass = 0; pass < BROWS / 4; ++pass) {
-            const int row = pass * 4 + cr;
-            const int64_t rr = r0 + row;
-            if (rr < R) {
-                const float4 q = *reinterpret_cast<const float4*>(&tile[row * BPAD + cc]);
-                const float v[4] = {q.x, q.y, q.z, q.w};
-                store4(y + rr * L, n0 + cc, L, vec, v);
-            }
-        }
-        __syncthreads();
-    }
-}
 
 // Adjoint of the ballistics recursion (the branch choice c[n] is piecewise constant in the inputs):
 //   lambda[n] = g[n] + (1 - c[n+1]) lambda[n+1];   gx[n] = c[n] lambda[n];
@@ -936,6 +1110,41 @@ __global__ void apply_gain_kernel(const float* __restrict__ x, gfx_rowmap_t xmap
         for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < L; n += (int64_t)gridDim.x * blockDim.x) {
             const float gv = g[r * L + n];
             yr[n] = (exp_gain ? expf(gv) : gv) * xr[n];
+        }
+    }
+}
+
+// y[r,c,n] = exp(log_gain(log(env[r,n] + 1e-5))) * x[r,c,n]: gain computer and gain stage in one pass over an envelope
+// that a smoother kernel left in memory (the ballistics configurations: dynamics.py:394-405 behind core/envelope.py:84-101).
+// Four samples per thread, 16-byte accesses when the rows allow it.
+__global__ __launch_bounds__(256) void dyn_gain_apply_kernel(const float* __restrict__ x, gfx_rowmap_t xmap,
+                                                             const float* __restrict__ env, float* __restrict__ y,
+                                                             gfx_rowmap_t ymap, const float* __restrict__ log_threshold,
+                                                             const float* __restrict__ log_ratio,
+                                                             const float* __restrict__ log_knee, int64_t R, int64_t L, int C,
+                                                             int knee, int gate, unsigned prows, int vec) {
+    for (int64_t r = blockIdx.y; r < R; r += gridDim.y) {
+        const unsigned pr = (unsigned)r % prows;
+        Knee q;
+        knee_setup(q, log_threshold[pr], log_ratio[pr], log_knee ? log_knee[pr] : 0.0f, knee, gate);
+        const float* x0 = x + drow_off(xmap, r, 0);
+        const float* x1 = x + drow_off(xmap, r, C == 2 ? 1 : 0);
+        float* y0 = y + drow_off(ymap, r, 0);
+        float* y1 = y + drow_off(ymap, r, C == 2 ? 1 : 0);
+        const float* er = env + r * L;
+        for (int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * DE; n < L; n += (int64_t)gridDim.x * blockDim.x * DE) {
+            float e[DE], a[DE], b[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+            load4(er, n, L, vec, e);
+            load4(x0, n, L, vec, a);
+            if (C == 2) load4(x1, n, L, vec, b);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) {
+                const float g = expf(log_gain(q, logf(e[i] + 1e-5f)));
+                a[i] *= g;
+                b[i] *= g;
+            }
+            store4(y0, n, L, vec, a);
+            if (C == 2) store4(y1, n, L, vec, b);
         }
     }
 }
@@ -1794,6 +2003,13 @@ size_t gfx_dynamics_ws_bytes(int64_t param_rows) {
     return param_rows <= 0 ? 0 : (size_t)param_rows * DP_TAB * sizeof(float);
 }
 
+// pole table | 16 control words (tickets, "some row looks back") | one 8-byte granule per row and 512-sample tile
+static size_t dyn_lb_offset(int64_t param_rows) { return ((size_t)param_rows * DP_TAB * sizeof(float) + 255) & ~(size_t)255; }
+size_t gfx_dynamics_ws_bytes_ex(int64_t param_rows, int64_t R, int64_t L) {
+    if (param_rows <= 0 || R <= 0 || L <= 0) return 0;
+    return dyn_lb_offset(param_rows) + 64 + (size_t)R * (size_t)((L + OS_WTILE - 1) / OS_WTILE) * 8;
+}
+
 size_t gfx_dynamics_bwd_ws_bytes(int64_t R, int64_t L) {   // the pole table + four partial sums per one-shot workgroup
     if (R <= 0 || L <= 0) return 0;
     return ((size_t)R * DP_TAB + (size_t)R * (size_t)((L + OS_GTILE - 1) / OS_GTILE) * 4) * sizeof(float);
@@ -1823,18 +2039,35 @@ static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gf
     // history fits (decided per row on the device), then the row kernel for the others (same table, complementary test).
     const float* tab = nullptr;
     const int64_t ngroups = (L + OS_GTILE - 1) / OS_GTILE;
-    const bool oneshot = ws && smoother == 1 && L > OS_WTILE && R * ngroups <= 0x7ffffff0LL;
+    // (tile grids: 8 runs of whole rows / graphs, one per XCD -- see lb_block_index)
+    const bool oneshot = ws && smoother == 1 && L > OS_WTILE && (R + 8) * ngroups <= 0x7ffffff0LL;
     if (mix && !oneshot) return GFX_EINVAL;
+    LbArgs lb = {nullptr, nullptr, 0, 0};
+    auto tile_grid = [&](int64_t units) { return dim3((unsigned)(((units + 7) / 8) * ngroups * 8)); };
     if (oneshot) {
         float* t = (float*)ws;
-        hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, t, param_rows, iir_len);
+        // the look-back walks move whole aligned float4 (as the fused routing sum does: its entry point checked already)
+        auto al16 = [](const void* p, const gfx_rowmap_t& mp) {
+            return ((uintptr_t)p & 15) == 0 && ((mp.stride_outer | mp.stride_inner | mp.stride_ch) & 3) == 0;
+        };
+        const bool lb_ok = mix || (al16(x, xmap) && al16(y, ymap) && ((uintptr_t)u1 & 15) == 0 && (L & 3) == 0);
+        if (lb_ok && ws_bytes >= gfx_dynamics_ws_bytes_ex(param_rows, R, L)) {   // room for the look-back granules: rows with
+            char* base = (char*)ws + dyn_lb_offset(param_rows);                  // a long smoother memory stay on the tile grid
+            lb.ctrl = (unsigned*)base;
+            lb.gran = (unsigned long long*)(base + 64);
+            lb.ntiles = (unsigned)((L + OS_WTILE - 1) / OS_WTILE);
+            if (hipMemsetAsync(base, 0, 64 + (size_t)R * lb.ntiles * 8, st) != hipSuccess) return GFX_ELAUNCH;
+        }
+        hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)param_rows), dim3(64), 0, st, z_alpha, t, param_rows, iir_len,
+                           lb.gran ? lb.ctrl + 8 : (unsigned*)nullptr);
         tab = t;
         if (!mix) {
             const unsigned nblocks = (unsigned)(R * ngroups);
             a.nchunks = 1;
             a.chunk_tiles = 1;
-            hipLaunchKernelGGL(dyn_oneshot_kernel, dim3((nblocks + 7u) & ~7u), dim3(DT), 0, st, x, y, log_threshold,
-                               log_ratio, log_knee, (const float*)t, a, (unsigned)ngroups, nblocks, u1);
+            const LbArgs none = {nullptr, nullptr, 0, 0};   // (look-back rows are produced by the row-group walk below)
+            hipLaunchKernelGGL(dyn_oneshot_kernel, tile_grid(R), dim3(DT), 0, st, x, y, log_threshold,
+                               log_ratio, log_knee, (const float*)t, a, (unsigned)ngroups, nblocks, u1, none);
         }
     }
     // Few rows: one workgroup per row walks the whole length serially (~2 us per tile) and the launch is bound by
@@ -1848,14 +2081,59 @@ static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gf
     if (R * nchunks > 0x7fffffffLL) return GFX_EINVAL;
     hipLaunchKernelGGL(dyn_fused_kernel, dim3((unsigned)(R * nchunks)), dim3(DT), 0, st, x, y,
                        log_threshold, log_ratio, log_knee, z_alpha, a, u1, tab);
+    if (!mix && lb.gran) {
+        // look-back rows of a call without a routing sum: waves walk groups of 16 rows tile by tile, one row deferred (the
+        // schedule of the fused sum without accumulators); leaves at once when the pole table found no such row
+        constexpr int LB_GROUP = 16;
+        const int64_t units = (R + LB_GROUP - 1) / LB_GROUP;
+        const unsigned nblocks = (unsigned)(units * ngroups);
+        MixArgs none;
+        none.sched = nullptr; none.out = nullptr; none.sb = none.sv = none.sc = 0; none.inner = LB_GROUP;
+        none.extras = nullptr; none.n_pre = none.n_post = 0;
+        a.nchunks = 1;
+        a.chunk_tiles = 1;
+        lb.split = 1;
+        const dim3 grid = tile_grid(units), blk(DT);
+#define GFX_LBW3(ST, KN, GT)                                                                                               \
+    hipLaunchKernelGGL((dyn_oneshot_mix_kernel<0, ST, KN, GT, true>), grid, blk, 0, st, x, y, log_threshold, log_ratio,   \
+                       log_knee, tab, a, (unsigned)ngroups, nblocks, u1, none, lb)
+#define GFX_LBW2(ST, KN)                    \
+    do {                                    \
+        if (gate) GFX_LBW3(ST, KN, true);   \
+        else GFX_LBW3(ST, KN, false);       \
+    } while (0)
+#define GFX_LBW(ST)                            \
+    do {                                       \
+        if (knee == 0) GFX_LBW2(ST, 0);        \
+        else if (knee == 1) GFX_LBW2(ST, 1);   \
+        else GFX_LBW2(ST, 2);                  \
+    } while (0)
+        if (C == 2) GFX_LBW(true);
+        else GFX_LBW(false);
+#undef GFX_LBW
+#undef GFX_LBW2
+#undef GFX_LBW3
+    }
     if (mix) {   // after the row kernel: its rows are read back by the tiles that sum them
         const unsigned nblocks = (unsigned)((R / mix->inner) * ngroups);
         a.nchunks = 1;
         a.chunk_tiles = 1;
-        const dim3 grid((nblocks + 7u) & ~7u), blk(DT);
+        const dim3 grid = tile_grid(R / mix->inner), blk(DT);
+        // GRAFX_DYN_DEFER (experiments): 0 = the plain walk only, 1 = the deferred walk only; default: both, chosen on the device
+        static const int defer_mode = [] {
+            const char* e = getenv("GRAFX_DYN_DEFER");
+            return e && *e ? atoi(e) : -1;
+        }();
+        lb.split = (defer_mode < 0 && lb.gran) ? 1 : 0;
 #define GFX_MIX3(NA_, ST, KN, GT)                                                                                            \
-    hipLaunchKernelGGL((dyn_oneshot_mix_kernel<NA_, ST, KN, GT>), grid, blk, 0, st, x, y, log_threshold, log_ratio, log_knee, \
-                       tab, a, (unsigned)ngroups, nblocks, u1, *mix)
+    do {                                                                                                                     \
+        if (defer_mode != 1)                                                                                                 \
+            hipLaunchKernelGGL((dyn_oneshot_mix_kernel<NA_, ST, KN, GT, false>), grid, blk, 0, st, x, y, log_threshold,     \
+                               log_ratio, log_knee, tab, a, (unsigned)ngroups, nblocks, u1, *mix, lb);                       \
+        if (defer_mode == 1 || lb.split)                                                                                     \
+            hipLaunchKernelGGL((dyn_oneshot_mix_kernel<NA_, ST, KN, GT, true>), grid, blk, 0, st, x, y, log_threshold,      \
+                               log_ratio, log_knee, tab, a, (unsigned)ngroups, nblocks, u1, *mix, lb);                       \
+    } while (0)
 #define GFX_MIX2(NA_, ST, KN)           \
     do {                                \
         if (gate) GFX_MIX3(NA_, ST, KN, true); \
@@ -1931,13 +2209,6 @@ int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R,
 int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_len, void* stream) {
     if (!z_alpha || !h || R <= 0 || iir_len < 1) return GFX_EINVAL;
     hipLaunchKernelGGL(onepole_fir_kernel, row_grid(R, iir_len), dim3(256), 0, (hipStream_t)stream, z_alpha, h, R, iir_len);
-    return GFX_LAUNCH_OK();
-}
-
-int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R, int64_t L, void* stream) {
-    if (!u || !z_alpha || !y || R <= 0 || L <= 0) return GFX_EINVAL;
-    hipLaunchKernelGGL(ballistics_kernel, dim3((unsigned)((R + BROWS - 1) / BROWS)), dim3(64), 0, (hipStream_t)stream,
-                       u, z_alpha, y, R, L);
     return GFX_LAUNCH_OK();
 }
 
@@ -2031,7 +2302,7 @@ int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* g
         // whose workgroups leave partial sums behind the pole table; the row kernel writes the other rows
         float* t = (float*)ws;
         float* partial = t + (size_t)R * DP_TAB;
-        hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)R), dim3(64), 0, st, z_alpha, t, R, iir_len);
+        hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)R), dim3(64), 0, st, z_alpha, t, R, iir_len, (unsigned*)nullptr);
         const unsigned nblocks = (unsigned)(R * ngroups);
         const dim3 grid((nblocks + 7u) & ~7u);
 #define GFX_BWD_OS(K, G)                                                                                                \
@@ -2072,6 +2343,23 @@ int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float*
     if (!x || !g || !y || R <= 0 || L <= 0 || C < 1) return GFX_EINVAL;
     hipLaunchKernelGGL(apply_gain_kernel, row_grid(R, L), dim3(256), 0, (hipStream_t)stream, x, xmap, g, y, ymap, R, L,
                        (int)C, exp_gain);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_dyn_gain_apply_f32(const float* x, gfx_rowmap_t xmap, const float* env, float* y, gfx_rowmap_t ymap,
+                           const float* log_threshold, const float* log_ratio, const float* log_knee, int64_t param_rows,
+                           int64_t R, int64_t C, int64_t L, int knee, int gate, void* stream) {
+    if (!x || !env || !y || !log_threshold || !log_ratio || R <= 0 || L <= 0 || (C != 1 && C != 2)) return GFX_EINVAL;
+    if (knee < 0 || knee > 2 || (knee != 0 && !log_knee) || param_rows < 1 || param_rows > R) return GFX_EINVAL;
+    auto al = [](const void* p, const gfx_rowmap_t& m) {
+        return ((uintptr_t)p & 15) == 0 && m.stride_outer % 4 == 0 && m.stride_inner % 4 == 0 && m.stride_ch % 4 == 0;
+    };
+    const int vec = L % 4 == 0 && al(x, xmap) && al(y, ymap) && ((uintptr_t)env & 15) == 0;
+    int64_t bx = (L + 4 * 256 - 1) / (4 * 256);
+    if (bx > 128) bx = 128;
+    hipLaunchKernelGGL(dyn_gain_apply_kernel, dim3((unsigned)bx, (unsigned)(R > 65535 ? 65535 : R)), dim3(256), 0,
+                       (hipStream_t)stream, x, xmap, env, y, ymap, log_threshold, log_ratio, log_knee, R, L, (int)C, knee,
+                       gate, (unsigned)param_rows, vec);
     return GFX_LAUNCH_OK();
 }
 

@@ -535,6 +535,8 @@ def _rowvec(p, R):
 # gfx_dynamics_fused_ws_f32) and as one workgroup per row for the others; "rows" forces one workgroup per row.
 MIX_FUSION = True          # dynamics stages take the routing sum that follows them (see dynamics_fused(mix=))
 DYN_SCHEDULE = "oneshot"
+# rows with a long smoother memory stay on the tile grid (gfx_dynamics_ws_bytes_ex); False / GRAFX_DYN_LOOKBACK=0: round 4
+DYN_LOOKBACK = os.environ.get("GRAFX_DYN_LOOKBACK", "1") != "0"
 
 
 def mix_schedule(dest_sources, n):
@@ -600,7 +602,8 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
             raise ValueError("dynamics_fused: u1_out must be contiguous and needs the one-pole smoother")
     ws = None
     if smoother == 1 and schedule == "oneshot":
-        ws = torch.empty(lib().gfx_dynamics_ws_bytes(P), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(lib().gfx_dynamics_ws_bytes_ex(P, R, L) if DYN_LOOKBACK else lib().gfx_dynamics_ws_bytes(P),
+                         dtype=torch.uint8, device=x.device)
     args = (_ptr(x), xmap, _ptr(out), ymap, pin(_rowvec(log_threshold, P)), pin(_rowvec(log_ratio, P)),
             pin(_rowvec(log_knee, P)), pin(_rowvec(z_alpha, P)), P, R, C, L, smoother, iir_len, KNEES[knee], int(gate),
             _ptr(u1_out), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
@@ -746,16 +749,49 @@ def onepole_fir(z_alpha, iir_len):
     return h
 
 
+BALLISTICS_SCHEDULE = "chunks"   # "chunks": rows cut into verified chunks (gfx_ballistics_ws_f32); "rows": whole rows only
+
+
 @_on_device
-def ballistics(u, z_alpha):
+def ballistics(u, z_alpha, coefficients=False, schedule=None):
+    """Ballistics.forward (core/envelope.py:84-101) on (R, L) rows: the float32 sequential recursion, bit for bit, whichever
+    schedule produces it.  ``coefficients``: ``z_alpha`` holds (at, rt) themselves instead of their logits."""
+    schedule = BALLISTICS_SCHEDULE if schedule is None else schedule
+    if schedule not in ("chunks", "rows"):
+        raise ValueError(f"ballistics: unknown schedule {schedule!r}")
     _require_gpu(u, z_alpha)
     u, z_alpha = u.contiguous(), z_alpha.contiguous()
     R, L = u.shape
     if z_alpha.shape != (R, 2):
         raise ValueError(f"z_alpha must be ({R}, 2), got {tuple(z_alpha.shape)}")
     y = torch.empty_like(u)
-    check(lib().gfx_ballistics_f32(_ptr(u), _ptr(z_alpha), _ptr(y), R, L, _stream()), "gfx_ballistics_f32")
+    ws = None
+    if schedule == "chunks":
+        ws = torch.empty(lib().gfx_ballistics_ws_bytes(R), dtype=torch.uint8, device=u.device)
+    with _timed("ballistics_walk_kernel", 8 * R * L):
+        check(lib().gfx_ballistics_ws_f32(_ptr(u), _ptr(z_alpha), int(coefficients), _ptr(y), R, L, _ptr(ws),
+                                          0 if ws is None else ws.numel(), _stream()), "gfx_ballistics_ws_f32")
     return y
+
+
+@_on_device
+def ballistics_energy(x, z_alpha, coefficients=False, schedule=None):
+    """ballistics(mean_c x^2) in one pass over x ((R, C, L) or a strided (B, n, C, L) view) -> (R, L): the envelope of
+    Compressor / NoiseGate with energy_smoother="ballistics" (dynamics.py:390, core/envelope.py:84-101)."""
+    schedule = BALLISTICS_SCHEDULE if schedule is None else schedule
+    _require_gpu(x, z_alpha)
+    xmap, R, C, L = rowmap(x)
+    z_alpha = z_alpha.contiguous()
+    if z_alpha.shape != (R, 2):
+        raise ValueError(f"z_alpha must be ({R}, 2), got {tuple(z_alpha.shape)}")
+    env = torch.empty((R, L), dtype=torch.float32, device=x.device)
+    ws = None
+    if schedule == "chunks":
+        ws = torch.empty(lib().gfx_ballistics_ws_bytes(R), dtype=torch.uint8, device=x.device)
+    with _timed("ballistics_walk_kernel", 4 * R * (C + 1) * L):
+        check(lib().gfx_ballistics_energy_f32(_ptr(x), xmap, C, _ptr(z_alpha), int(coefficients), _ptr(env), R, L, _ptr(ws),
+                                              0 if ws is None else ws.numel(), _stream()), "gfx_ballistics_energy_f32")
+    return env
 
 
 @_on_device
@@ -799,6 +835,27 @@ def apply_gain(x, g, exp_gain=False, out=None):
     elif rowmap(out)[1:] != (R, C, L):
         raise ValueError(f"apply_gain: output {tuple(out.shape)} does not match input rows/channels/length {(R, C, L)}")
     check(lib().gfx_apply_gain_f32(_ptr(x), xmap, _ptr(g), _ptr(out), rowmap(out)[0], R, C, L, int(exp_gain), _stream()), "gfx_apply_gain_f32")
+    return out
+
+
+@_on_device
+def dyn_gain_apply(x, env, log_threshold, log_ratio, log_knee, knee, gate, out=None, param_rows=None):
+    """y = exp(g(log(env + 1e-5)))[:, None, :] * x in one pass (dynamics.py:394-405): ``env`` (R, L) is the smoothed energy,
+    ``x`` / ``out`` (R, C, L) tensors or strided (B, n, C, L) views."""
+    _require_gpu(x, env, out)
+    xmap, R, C, L = rowmap(x)
+    _expect(env, (R, L), "dyn_gain_apply: envelope")
+    env = env.contiguous()
+    P = R if param_rows is None else param_rows
+    if out is None:
+        out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    elif rowmap(out)[1:] != (R, C, L):
+        raise ValueError(f"dyn_gain_apply: output {tuple(out.shape)} does not match input rows/channels/length {(R, C, L)}")
+    pin = _Pin()
+    with _timed("dyn_gain_apply_kernel", 4 * R * L * (2 * C + 1)):
+        check(lib().gfx_dyn_gain_apply_f32(_ptr(x), xmap, _ptr(env), _ptr(out), rowmap(out)[0], pin(_rowvec(log_threshold, P)),
+                                           pin(_rowvec(log_ratio, P)), pin(_rowvec(log_knee, P)), P, R, C, L, KNEES[knee],
+                                           int(gate), _stream()), "gfx_dyn_gain_apply_f32")
     return out
 
 

@@ -86,12 +86,15 @@ class _Dynamics(BufferIO, nn.Module):
         # unfused configurations (a gain smoother, ballistics, or an energy smoother whose convolve() aliases): the energy
         # and the gain kernels read / write the (B, n, C, L) buffer views in place through their row maps, the smoothers
         # work on the (rows, L) envelope in between -- no flattened copy of the input, no copy of the output
-        energy = ops.energy(input_signals)
-        if self.energy_smoother is not None:
-            energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)
-        if self.gain_smoother is None:
-            gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
-            return ops.apply_gain(input_signals, gain, out=_out)
+        if self.energy_smoother == "ballistics":   # energy and recursion in one pass over the signal (ballistics.hip)
+            energy = ops.ballistics_energy(input_signals, z_alpha_pre)
+        else:
+            energy = ops.energy(input_signals)
+            if self.energy_smoother is not None:
+                energy = self.energy_smoother_module(energy, z_alpha=z_alpha_pre)
+        if self.gain_smoother is None:   # gain computer and gain stage in one pass over the envelope
+            return ops.dyn_gain_apply(input_signals, energy, log_threshold, log_ratio, log_knee, self.knee, self._gate,
+                                      out=_out)
         if self.gain_smooth_in_log:  # dynamics.py:411-414
             g = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=True)
             return ops.apply_gain(input_signals, self.gain_smoother_module(g, z_alpha=z_alpha_post), exp_gain=True, out=_out)

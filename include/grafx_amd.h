@@ -248,8 +248,8 @@ int gfx_peq_coeffs_bwd_f32(const float* w0, const float* q_inv, const float* log
  *   gfx_onepole_f32      TruncatedOnePoleIIRFilter on (R,L) rows -> (R,Lout), optional relu
  *                        core/envelope.py:34-60 (Lout = L + iir_len - 1 gives the full convolution)
  *   gfx_onepole_fir_f32  its taps h[n] = (1-a) exp(n log a)              core/envelope.py:51-60
- *   gfx_ballistics_f32   Ballistics / torchcomp.compressor_core          core/envelope.py:84-101
- *                        (z_alpha: (R,2); recursion recalled — parity unpinned)
+ *   gfx_ballistics_*     Ballistics / torchcomp.compressor_core          core/envelope.py:84-101
+ *                        (z_alpha: (R,2); the recursion is torchcomp's published one, the wheel is absent: see DESIGN.md)
  *   gfx_dyn_gain_f32     env -> gain: log(env+1e-5) -> knee [-> exp unless log_out]
  *   gfx_apply_gain_f32   y = (exp_gain ? exp(g) : g)[:,None,:] * x        dynamics.py:405
  *   gfx_stereo_gain_f32  StereoGain.forward                               stereo.py:38-41
@@ -272,6 +272,16 @@ int gfx_dynamics_fused_ex_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
  * streams.  Rows whose history does not fit (H > 256, or a live a^N truncation term) are picked out on the device from
  * a per-row pole table and produced by the row kernel in the same call; no host synchronisation. */
 size_t gfx_dynamics_ws_bytes(int64_t param_rows);
+/* The workspace that also keeps rows with a LONG smoother memory on the tile grid (round 5): with
+ * gfx_dynamics_ws_bytes_ex(param_rows, R, L) bytes -- the pole table, 64 bytes of counters and 8 bytes per row and
+ * 512-sample tile -- a row whose history is longer than a tile may re-read (256 < H <= 64 * 512 samples, truncation term
+ * dead) gets the state entering each tile from the AGGREGATES of the tiles before it: every tile publishes the state it
+ * would leave from a zero entry state as soon as its own samples are scanned, then reads the ceil(H / 512) aggregates
+ * before it (an in-launch hand-off through 8-byte granules, zeroed by a memset on the stream in front of the launch;
+ * workgroups take their logical index from a ticket counter, so no tile ever waits for a workgroup that has not
+ * started).  Only rows with a LIVE truncation term (a^iir_len > 1e-12) are left to the row kernel.  A workspace of
+ * gfx_dynamics_ws_bytes(param_rows) bytes keeps the round-4 behaviour (those rows on the row kernel too). */
+size_t gfx_dynamics_ws_bytes_ex(int64_t param_rows, int64_t R, int64_t L);
 int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap,
                               const float* log_threshold, const float* log_ratio, const float* log_knee,
                               const float* z_alpha, int64_t param_rows, int64_t R, int64_t C, int64_t L,
@@ -303,7 +313,24 @@ int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);
 int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_len, void* stream);
+/* Ballistics.forward (core/envelope.py:84-101): at, rt = sigmoid(z_alpha[:, 0]), sigmoid(z_alpha[:, 1]);  y[-1] = 1;
+ * c = at if u[n] < y[n-1] else rt;  y[n] = (1 - c) y[n-1] + c u[n], the two products and the sum rounded separately
+ * (torchcomp's CPU loop).  u, y: (R, L).  This entry walks every row whole, one lane per row. */
 int gfx_ballistics_f32(const float* u, const float* z_alpha, float* y, int64_t R, int64_t L, void* stream);
+/* The same values, bit for bit, produced from chunks of the rows: with a workspace of gfx_ballistics_ws_bytes(R) bytes
+ * (scratch for this call: one flag per row) a row is cut into up to 64 chunks that start from a warmed-up guess and are
+ * accepted only if every chunk is entered with exactly the state its left neighbour ends with; rows that fail that
+ * check, or whose slower coefficient needs a longer warm-up than a chunk, are walked whole by a second launch in the same
+ * call (no host synchronisation).  ws == NULL: gfx_ballistics_f32.  `is_coef` != 0: z_alpha holds at, rt themselves (no
+ * sigmoid) -- how the parity tests hand the oracle's coefficients over. */
+size_t gfx_ballistics_ws_bytes(int64_t R);
+int gfx_ballistics_ws_f32(const float* u, const float* z_alpha, int is_coef, float* y, int64_t R, int64_t L, void* ws,
+                          size_t ws_bytes, void* stream);
+/* The same recursion over the energy of a signal, env = ballistics(mean_c x^2) (dynamics.py:390 followed by
+ * core/envelope.py:84-101 -- Compressor / NoiseGate with energy_smoother="ballistics"): x (R, C, L) addressed through xmap
+ * is read once, the energy never reaches memory.  env: (R, L). */
+int gfx_ballistics_energy_f32(const float* x, gfx_rowmap_t xmap, int64_t C, const float* z_alpha, int is_coef, float* env,
+                              int64_t R, int64_t L, void* ws, size_t ws_bytes, void* stream);
 /* Adjoint of the recursion above given the forward input x, output y and g = dL/dy:
  * gx = dL/dx (R, L), gz = dL/dz_alpha (R, 2).  The attack/release choice is treated as locally constant. */
 int gfx_ballistics_bwd_f32(const float* x, const float* y, const float* g, const float* z_alpha, float* gx, float* gz,
@@ -366,6 +393,11 @@ int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const flo
                        int64_t L, int64_t N, void* stream);
 int gfx_apply_gain_f32(const float* x, gfx_rowmap_t xmap, const float* g, float* y, gfx_rowmap_t ymap,
                        int64_t R, int64_t C, int64_t L, int exp_gain, void* stream);
+/* Gain computer and gain stage in one pass over an envelope a smoother left in memory (dynamics.py:394-405):
+ * y[r,c,n] = exp(g(log(env[r,n] + 1e-5))) * x[r,c,n], g the knee of gfx_dyn_gain_f32; row r reads parameter row r % param_rows. */
+int gfx_dyn_gain_apply_f32(const float* x, gfx_rowmap_t xmap, const float* env, float* y, gfx_rowmap_t ymap,
+                           const float* log_threshold, const float* log_ratio, const float* log_knee, int64_t param_rows,
+                           int64_t R, int64_t C, int64_t L, int knee, int gate, void* stream);
 int gfx_stereo_gain_f32(const float* x, gfx_rowmap_t xmap, const float* log_gain, float* y, gfx_rowmap_t ymap,
                         int64_t R, int64_t C_in, int64_t L, void* stream);
 /* StereoGain with the routing sum behind it fused in (the gain / pan stage in front of a bus): y as above, and the mix

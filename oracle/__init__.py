@@ -10,9 +10,10 @@ build container by ``tests/golden/make_golden.py`` (which imports
 ``/root/reference/src`` with four third-party shims) and committed as
 ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every oracle
 function against them.  One exception is stated where it applies:
-``ballistics`` follows the *recalled* recursion of the third-party
-``torchcomp.compressor_core`` (unpinned upstream, wheel absent here) —
-"parity unpinned" for that function only.
+``ballistics`` restates the published algorithm of the third-party
+``torchcomp.compressor_core`` (Yu et al., DAFx 2024; unpinned upstream, wheel
+absent here, no upstream golden vector) — "parity unpinned" for that function
+only; see its docstring.
 """
 from .lti import convolve, iir_fsm_fir, iir_fsm, one_pole_fir, truncated_one_pole  # noqa: F401
 from .processors import (  # noqa: F401
@@ -24,6 +25,7 @@ from .processors import (  # noqa: F401
     OracleSTFTMaskedNoiseReverb,
     OracleStereoGain,
     ballistics,
+    ballistics_coefficients,
     ballistics_docstring_reading,
     lr_to_ms,
     ms_to_lr,

@@ -35,20 +35,45 @@ def normalize_impulse(ir, eps=1e-12):
 
 
 def ballistics(x, z_alpha):
-    """core/envelope.py:84-101 -> torchcomp.compressor_core (third-party, absent).
+    """core/envelope.py:84-101 -> ``torchcomp.compressor_core(x, zi, at, rt)`` with ``at, rt = sigmoid(z)[..., 0],
+    sigmoid(z)[..., 1]`` and ``zi = 1``.
 
-    PARITY UNPINNED.  Reading "T" (implemented here and by gfx_ballistics_f32): the recursion of torchcomp's
-    ``compressor_core(x, zi, at, rt)`` as recalled from the public algorithm (Yu et al. 2024), which is what the
-    reference's *code* calls with ``at, rt = sigmoid(z)[..., 0], sigmoid(z)[..., 1]`` and ``zi = 1``:
-        y[-1] = 1;  c = at if x[n] < y[n-1] else rt;  y[n] = (1 - c) y[n-1] + c x[n].
+    The arithmetic lives in a third-party dependency that is ABSENT from /root/reference and from this image:
+    ``torchcomp`` (pyproject.toml:19, no version pinned; the package of Yu et al., "Differentiable All-pole Filters for
+    Time-varying Audio Systems", DAFx 2024 -- cited by the reference at core/envelope.py:77 and dynamics.py:226).  Its
+    published algorithm, restated (torchcomp/core.py ``compressor_kernel``, the numba loop behind ``compressor_core`` on
+    CPU; the paper's feed-forward compressor smooths the gain with g^[n] = alpha g^[n-1] + (1 - alpha) g[n], alpha the
+    attack constant when g[n] < g^[n-1] and the release constant otherwise, and torchcomp passes ``at = 1 - alpha_at``,
+    ``rt = 1 - alpha_rt``, its ``ms2coef``):
+
+        g = zi[b]
+        for t in range(T):
+            f = x[b, t]
+            coeff = at[b] if f < g else rt[b]
+            g *= 1 - coeff
+            g += coeff * f            # two products and one sum, each rounded (numba does not contract them)
+            y[b, t] = g
+
+    i.e. reading "T":  y[-1] = 1;  c = at if x[n] < y[n-1] else rt;  y[n] = (1 - c) y[n-1] + c x[n].
+
+    PARITY UNPINNED: no wheel, no upstream golden vector and no upstream numeric test exist for this call (the reference's
+    tests only smoke-test it on CUDA, tests/processors/test_dynamics.py:41-98), so nothing here can be checked against the
+    third-party code itself; tests that depend on it carry the ``provisional`` marker.  What IS anchored: the call site
+    (argument order, sigmoid, zi = 1: core/envelope.py:97-100) and the closed forms of tests/test_ballistics_readings.py.
     The reference's *docstring* (core/envelope.py:68-73) describes the smoother the other way round -- reading "D",
-    :func:`ballistics_docstring_reading` -- coefficient on y[n-1], and the *release* coefficient when u[n] < y[n-1].
-    The two are different functions of z_alpha; "T" is implemented because the code path, not the prose, is what a
-    user's parameters go through.  Nothing external checks the recalled recursion; tests that depend on it carry
-    the ``provisional`` marker and are reported separately.
+    :func:`ballistics_docstring_reading`: coefficient on y[n-1], and the *release* coefficient when u[n] < y[n-1].  The
+    two are different functions of z_alpha; "T" is implemented because the code path, not the prose, is what a user's
+    parameters go through.
     """
     ts = torch.sigmoid(z_alpha)
     at, rt = ts[..., 0], ts[..., 1]
+    return _attack_release(x, at, rt, on_input=True)
+
+
+def ballistics_coefficients(x, at, rt):
+    """The recursion of :func:`ballistics` for given coefficients ``at``, ``rt`` (R,), in x's dtype: for float32 input this
+    is the float32 sequential loop -- (1 - c), its product with the state, c * x and the sum each rounded once -- which
+    the HIP kernels reproduce bit for bit (tests/test_gpu_ballistics.py hands the same float32 coefficients to both)."""
     return _attack_release(x, at, rt, on_input=True)
 
 

@@ -1,5 +1,6 @@
 """python tools/mix_bench.py: the compressor stage + routing sum of the console graph (8192 rows, 32 per graph -> 4 buses +
 send) as two kernels and as the fused one; HIP-event time per call."""
+import os
 import sys
 
 import torch
@@ -14,6 +15,10 @@ buf = torch.empty(B, 2 * n + J, C, L, device=dev)
 buf[:, :n].normal_()
 x, y, mo = buf[:, :n], buf[:, n : 2 * n], buf[:, 2 * n :]
 p = [torch.randn(n, 1, device=dev) * 0.1 for _ in range(4)]
+if os.environ.get("MIX_BENCH_Z"):   # every smoother logit at this value (6 -> pole 0.9975: the long-memory rows)
+    p[3] = torch.full_like(p[3], float(os.environ["MIX_BENCH_Z"]))
+print(f"z_alpha = {os.environ.get('MIX_BENCH_Z', 'randn*0.1')}  lookback={ops.DYN_LOOKBACK}  "
+      f"GRAFX_DYN_DEFER={os.environ.get('GRAFX_DYN_DEFER', 'auto')}  lib={os.environ.get('GRAFX_AMD_LIB', 'default')}")
 dests = [list(range(8 * k, 8 * k + 8)) for k in range(4)] + [list(range(n))]
 codes, n_acc, _, _ = ops.mix_schedule(dests, n)
 sched = torch.tensor(codes, device=dev)
