@@ -53,6 +53,7 @@ SIGNATURES = {
     "gfx_iir_fsm_plan_bytes": (sz, [i64]),
     "gfx_iir_fsm_plan_f32": (ctypes.c_int, [vp, i64, vp]),
     "gfx_iir_fsm_fir_f32": (ctypes.c_int, [f32p, f32p, vp, f32p, i64, i64, i64, vp]),
+    "gfx_iir_fsm_fir_f64c_f32": (ctypes.c_int, [vp, vp, vp, f32p, i64, i64, i64, vp]),
     "gfx_peq_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, ctypes.c_int, vp]),
     "gfx_peq_coeffs_bwd_f32": (ctypes.c_int, [f32p] * 8 + [i64, i64, ctypes.c_int, vp]),
     "gfx_biquad_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, vp]),

@@ -341,7 +341,14 @@ class FsmFirFn(torch.autograd.Function):
     def backward(ctx, gh):
         Bs, As = ctx.saved_tensors
         N = ctx.N
-        D = _fsm_delays(N, Bs.device)                      # (3, F)
+        # Parameter-side math ((R, Cf, K, F) values, F <= 2049) in DOUBLE precision since round 5: the sums over the bins
+        # cancel to a few 1e-5 of their terms, and in complex64 the w0 / q_inv gradients behind them carried 0.9 .. 1.6e-5
+        # of rounding -- as much as the reference's own float32 autograd (0.7 .. 1.5e-5), so "at least as close to
+        # float64 as the reference" was a coin toss (tests/test_gpu_autograd.py::test_peq_parameter_gradients_vs_reference).
+        # Same sample points as the forward pass (the reference's float32 phase), widened.
+        out_dtype = Bs.dtype
+        Bs, As, gh = Bs.double(), As.double(), gh
+        D = _fsm_delays(N, Bs.device).to(torch.complex128)   # (3, F)
         # three-term sums written out: the library's complex GEMM takes 0.16 ms for these 3-wide contractions
         num = Bs[..., 0:1] * D[0] + Bs[..., 1:2] * D[1] + Bs[..., 2:3] * D[2]   # (R,Cf,K,F)
         den = As[..., 0:1] * D[0] + As[..., 1:2] * D[1] + As[..., 2:3] * D[2]
@@ -349,7 +356,7 @@ class FsmFirFn(torch.autograd.Function):
         resp = sections[..., 0, :]
         for i in range(1, sections.shape[-2]):
             resp = resp * sections[..., i, :]
-        G = (ops.rdft(gh, N) if N <= ops.IRDFT_MAX_N else torch.fft.rfft(gh, n=N, dim=-1)) * (2.0 / N)
+        G = (ops.rdft(gh, N) if N <= ops.IRDFT_MAX_N else torch.fft.rfft(gh, n=N, dim=-1)).to(torch.complex128) * (2.0 / N)
         G[..., 0] = G[..., 0] * 0.5
         if N % 2 == 0:
             G[..., -1] = G[..., -1] * 0.5
@@ -358,8 +365,8 @@ class FsmFirFn(torch.autograd.Function):
         def contract(Q):  # Re sum_k Q[..., k] D_d[k], d = 0..2  ->  (..., 3)
             return torch.stack([(Q * D[d]).real.sum(-1) for d in range(3)], -1)
 
-        gB = contract(T / num) if ctx.needs_input_grad[0] else None
-        gA = -contract(T / den) if ctx.needs_input_grad[1] else None
+        gB = contract(T / num).to(out_dtype) if ctx.needs_input_grad[0] else None
+        gA = (-contract(T / den)).to(out_dtype) if ctx.needs_input_grad[1] else None
         return gB, gA, None, None
 
 

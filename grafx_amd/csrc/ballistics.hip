@@ -54,6 +54,7 @@ struct BlArgs {
     int lg;              // log2(chunks per row), 0..6
     int T;               // chunk length, a multiple of BT (also the longest warm-up)
     int pass;            // 0: chunks, verified;  1: flagged rows, whole;  2: all rows, whole (no flags)
+    int from_flags;      // pass 0 again, with longer chunks, over the rows an earlier pass 0 flagged
     int vec;             // 16-byte accesses are legal (alignment, L % 4 == 0)
 };
 
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
     }
     bool alive = valid;
     int warm = 0;
+    if (a.pass == 0 && a.from_flags) alive = valid && a.flag[row] != 0u;   // (rows an earlier pass finished are not touched)
     if (a.pass == 0) {
         // warm-up: the steps an error as large as the signal needs to contract below an ulp at the slower coefficient
         // (2^-26 with a few steps to spare), rounded up to whole tiles; rows that need more than a chunk are not cut
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
         if (cmin >= 1.0f) need = 8.0f;
         else if (cmin > 0.0f) need = ceilf(-18.03f / log1pf(-cmin)) + 8.0f;
         const bool slow = !(need <= (float)a.T);
-        if (valid && slow) {
+        if (alive && slow) {
             alive = false;
             if (chunk == 0) a.flag[row] = 1u;
         }
@@ -317,6 +319,7 @@ int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int
     // rows per wave of the whole-row walk: the fewest that still leave every wave a SIMD of its own
     const int rpw = R <= 16 * 1024 ? 16 : (R <= 32 * 1024 ? 32 : 64);
     int rc;
+    a.from_flags = 0;
     if (lg == 0) {
         a.pass = 2;
         rc = launch_walk<SRC>(rpw, a, st);
@@ -324,6 +327,19 @@ int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int
         a.pass = 0;
         rc = launch_walk<SRC>(64, a, st);
         if (rc != GFX_OK) return rc;
+        if (lg >= 4) {
+            // second try for the rows whose warm-up did not fit (or did not converge in) a chunk: chunks eight times as
+            // long -- a coefficient of 2.5e-3 warms up in 7 200 samples, no use for 4096-sample chunks, a fifth of a
+            // 32768-sample one; whole-row walks are bound by the latency of one step (34 ns: 4.4 ms for 131072 samples
+            // however few the rows), chunks divide it
+            a.lg = lg - 3;
+            const int64_t per2 = (L + (1LL << a.lg) - 1) >> a.lg;
+            a.T = (int)((per2 + BTMAX - 1) / BTMAX * BTMAX);
+            a.from_flags = 1;
+            rc = launch_walk<SRC>(64, a, st);
+            if (rc != GFX_OK) return rc;
+            a.from_flags = 0;
+        }
         a.pass = 1;
         a.lg = 0;
         a.T = (int)((L + BTMAX - 1) / BTMAX * BTMAX);

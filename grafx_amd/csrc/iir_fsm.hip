@@ -84,9 +84,42 @@ __device__ __forceinline__ void sample_points(int k, int N, float2& d1, float2& 
     d2 = make_float2(c2, -s2);
 }
 
+// Coefficients given in DOUBLE precision (gfx_iir_fsm_fir_f64c_f32; the third-octave GraphicEqualizer: 31 sections, the
+// lowest with poles within 1e-3 of the unit circle): the response is evaluated in double precision at the exact sample
+// points exp(-2 pi i d k / N) and rounded once.  What separates the reference from a float64 evaluation of its formulas
+// there (1.3e-4 .. 3.6e-4 of the output) is the float32 REPRESENTATION of the coefficients -- 1 +- beta with beta = 6.5e-4
+// keeps four digits of the bandwidth -- far more than the float32 phase of the sample points or the complex64 product
+// (measured, round 5: double-precision sections and exact sample points on float32 coefficients both left the mid/side
+// case at 3.40e-4 against the reference's 3.30e-4, the one row of the parity table where "ours <= reference" did not
+// hold).  The parity rule for a reference that is itself > 1e-5 from float64 is "at least as close to float64 as the
+// reference" (SURVEY H6): with the band design carried in double precision up to here the result is the float64
+// evaluation, ~1e-6.  float32 coefficients keep the reference's float32 sample points and complex64 arithmetic at every
+// cascade length, which meet it at 1e-5 directly.
+__device__ __forceinline__ float2 cascade_response_f64(const double* __restrict__ B, const double* __restrict__ A, int K, int k,
+                                                       int N) {
+    double d1y, d1x, d2y, d2x;
+    sincospi(-2.0 * (double)k / (double)N, &d1y, &d1x);
+    sincospi(-4.0 * (double)k / (double)N, &d2y, &d2x);
+    double hr = 1.0, hi = 0.0;
+    for (int i = 0; i < K; ++i) {
+        const double b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
+        const double a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
+        const double nr = b0 + b1 * d1x + b2 * d2x, ni = b1 * d1y + b2 * d2y;
+        const double dr = a0 + a1 * d1x + a2 * d2x, di = a1 * d1y + a2 * d2y;
+        const double inv = 1.0 / (dr * dr + di * di);
+        const double qr = (nr * dr + ni * di) * inv, qi = (ni * dr - nr * di) * inv;
+        const double tr = hr * qr - hi * qi;
+        hi = hr * qi + hi * qr;
+        hr = tr;
+    }
+    return make_float2((float)hr, (float)hi);
+}
+
 // cascade response from the sample points (0 <= k <= N/2)
 __device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, const float* __restrict__ A, int K,
-                                                   float2 d1, float2 d2) {
+                                                   float2 d1, float2 d2, int k, int N, const double* __restrict__ Bd = nullptr,
+                                                   const double* __restrict__ Ad = nullptr) {
+    if (Bd) return cascade_response_f64(Bd, Ad, K, k, N);   // uniform
     float2 H = make_float2(1.0f, 0.0f);
     for (int i = 0; i < K; ++i) {
         const float b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
@@ -101,12 +134,15 @@ __device__ __forceinline__ float2 cascade_response(const float* __restrict__ B, 
 
 __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
                                                             const float2* __restrict__ plan, float* __restrict__ h,
-                                                            int K, int N, const float2* __restrict__ twtab) {
+                                                            int K, int N, const float2* __restrict__ twtab,
+                                                            const double* __restrict__ Bs64, const double* __restrict__ As64) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const int64_t rc = blockIdx.x;
-    const float* B = Bs + rc * K * 3;
-    const float* A = As + rc * K * 3;
+    const float* B = Bs ? Bs + rc * K * 3 : nullptr;
+    const float* A = As ? As + rc * K * 3 : nullptr;
+    const double* Bd = Bs64 ? Bs64 + rc * K * 3 : nullptr;
+    const double* Ad = As64 ? As64 + rc * K * 3 : nullptr;
     const int half = N / 2;
     const bool even = (N & 1) == 0;
 
@@ -120,7 +156,7 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
         const int k = t + 256 * a;
         if (k <= half) {
             const float4 d = reinterpret_cast<const float4*>(plan + PLAN_D)[k];
-            lds[k] = to_cx(cascade_response(B, A, K, make_float2(d.x, d.y), make_float2(d.z, d.w)));
+            lds[k] = to_cx(cascade_response(B, A, K, make_float2(d.x, d.y), make_float2(d.z, d.w), k, N, Bd, Ad));
         }
     }
     __syncthreads();
@@ -164,12 +200,16 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_kernel(const float* __restr
 // conj(Y[M-k])) / 2,  Z'[k] = Ye + i Yo,  Z'[M-k] = conj(Ye - i Yo)  (M = 8192; fft_tile.hpp, pair_merge).
 __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_pow2_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
                                                                  float* __restrict__ h, int K, int N,
-                                                                 const float2* __restrict__ twtab) {
+                                                                 const float2* __restrict__ twtab,
+                                                                 const double* __restrict__ Bs64,
+                                                                 const double* __restrict__ As64) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const int64_t rc = blockIdx.x;
-    const float* B = Bs + rc * K * 3;
-    const float* A = As + rc * K * 3;
+    const float* B = Bs ? Bs + rc * K * 3 : nullptr;
+    const float* A = As ? As + rc * K * 3 : nullptr;
+    const double* Bd = Bs64 ? Bs64 + rc * K * 3 : nullptr;
+    const double* Ad = As64 ? As64 + rc * K * 3 : nullptr;
     const int stride = TILE_F / N;
     TileTw tw;
     tile_twiddles(tw, twtab, t);
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(TILE_T, 2) void iir_fsm_pow2_kernel(const float* __
         const int k = bin / stride;
         float2 d1, d2;
         sample_points(k, N, d1, d2);
-        cx r = to_cx(cascade_response(B, A, K, d1, d2));
+        cx r = to_cx(cascade_response(B, A, K, d1, d2, k, N, Bd, Ad));
         if (k == 0 || k == N / 2) r.y = 0.0f;   // a c2r transform ignores the imaginary parts of DC and Nyquist
         return r;
     };
@@ -341,15 +381,15 @@ int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream) {
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
-int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h, int64_t RC, int64_t K,
-                        int64_t N, void* stream) {
-    if (!Bs || !As || !h || RC <= 0 || K <= 0 || N < 1 || RC > 0x7fffffffLL) return GFX_EINVAL;
+static int iir_fsm_fir_launch(const float* Bs, const float* As, const double* Bs64, const double* As64, const void* plan,
+                              float* h, int64_t RC, int64_t K, int64_t N, void* stream) {
+    if (!h || RC <= 0 || K <= 0 || N < 1 || RC > 0x7fffffffLL) return GFX_EINVAL;
     if (fsm_pow2(N)) {  // no plan needed
         if (allow_lds(iir_fsm_pow2_kernel)) return GFX_ELAUNCH;
         const float2* tw2 = tile_twiddle_table((hipStream_t)stream);
         if (!tw2) return GFX_ELAUNCH;
         hipLaunchKernelGGL(iir_fsm_pow2_kernel, dim3((unsigned)RC), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream, Bs,
-                           As, h, (int)K, (int)N, tw2);
+                           As, h, (int)K, (int)N, tw2, Bs64, As64);
         return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
     }
     if (!plan || N > FSM_MAX_N) return GFX_EINVAL;
@@ -357,8 +397,20 @@ int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, floa
     const float2* tw = tile_twiddle_table((hipStream_t)stream);
     if (!tw) return GFX_ELAUNCH;
     hipLaunchKernelGGL(iir_fsm_kernel, dim3((unsigned)RC), dim3(TILE_T), TILE_LDS_BYTES, (hipStream_t)stream, Bs, As,
-                       (const float2*)plan, h, (int)K, (int)N, tw);
+                       (const float2*)plan, h, (int)K, (int)N, tw, Bs64, As64);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h, int64_t RC, int64_t K,
+                        int64_t N, void* stream) {
+    if (!Bs || !As) return GFX_EINVAL;
+    return iir_fsm_fir_launch(Bs, As, nullptr, nullptr, plan, h, RC, K, N, stream);
+}
+
+int gfx_iir_fsm_fir_f64c_f32(const double* Bs, const double* As, const void* plan, float* h, int64_t RC, int64_t K,
+                             int64_t N, void* stream) {
+    if (!Bs || !As) return GFX_EINVAL;
+    return iir_fsm_fir_launch(nullptr, nullptr, Bs, As, plan, h, RC, K, N, stream);
 }
 
 int gfx_peq_coeffs_f32(const float* w0, const float* q_inv, const float* log_gain, float* Bs, float* As, int64_t n,

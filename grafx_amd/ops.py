@@ -465,12 +465,23 @@ def iir_fsm_plan(N, device):
 
 @_on_device
 def iir_fsm_fir(Bs, As, N, plan):
-    """(R, Cf, K, 3) biquad coefficients -> (R*Cf, N) frequency-sampled FIR taps."""
-    _require_gpu(Bs, As)
+    """(R, Cf, K, 3) biquad coefficients -> (R*Cf, N) frequency-sampled FIR taps.  float64 coefficients take the
+    double-precision response evaluation (gfx_iir_fsm_fir_f64c_f32); the taps are float32 either way."""
+    if Bs.dtype == torch.float64 and As.dtype == torch.float64:
+        if not (Bs.is_cuda and As.is_cuda):
+            _require_gpu(Bs.float(), As.float())
+    else:
+        _require_gpu(Bs, As)
     Bs, As = Bs.contiguous(), As.contiguous()
     K = Bs.shape[-2]
     RC = Bs.numel() // (K * 3)
     h = torch.empty((RC, N), dtype=torch.float32, device=Bs.device)
+    if Bs.dtype == torch.float64:   # coefficients carried in double precision (gfx_iir_fsm_fir_f64c_f32): float32 taps
+        if As.dtype != torch.float64:
+            raise TypeError("iir_fsm_fir: Bs and As must have the same dtype")
+        check(lib().gfx_iir_fsm_fir_f64c_f32(Bs.data_ptr(), As.data_ptr(), _ptr(plan), _ptr(h), RC, K, N, _stream()),
+              "gfx_iir_fsm_fir_f64c_f32")
+        return h
     check(lib().gfx_iir_fsm_fir_f32(_ptr(Bs), _ptr(As), _ptr(plan), _ptr(h), RC, K, N, _stream()), "gfx_iir_fsm_fir_f32")
     return h
 

@@ -39,7 +39,18 @@ class GraphicEqualizerBiquad(nn.Module):
         self.register_buffer("tan_B_half", torch.tan(math.pi * bw / sr))
         self.register_buffer("c", torch.tensor(c))
 
-    def forward(self, log_gains):
+    def forward(self, log_gains, precise=False):
+        """``precise``: the same design carried in double precision (the float32 band tables widened, every formula in
+        float64) -> float64 coefficients for ops.iir_fsm_fir's double-coefficient form."""
+        if precise:
+            log_gains = log_gains.double()
+            tan_B_half, m2_cos_wc, c = self.tan_B_half.double(), self.m2_cos_wc.double(), self.c.double()
+            g = torch.exp(log_gains)
+            n2 = torch.exp(log_gains * c).square()
+            scale = torch.sqrt(((1 - n2).abs() + 1e-7) / ((g.square() - n2).abs() + 1e-7))
+            beta = torch.where(log_gains.abs() < 1e-3, tan_B_half.expand_as(g), tan_B_half * scale)
+            gb, mid = g * beta, m2_cos_wc.expand_as(g)
+            return torch.stack([1 + gb, mid, 1 - gb], -1), torch.stack([1 + beta, mid, 1 - beta], -1)
         g = torch.exp(log_gains)
         g2 = g.square()
         n2 = torch.exp(log_gains * self.c).square()            # squared gain at the neighbouring band

@@ -140,8 +140,15 @@ class GraphicEqualizer(nn.Module):
         self.biquad = IIRFilter(**backend_kwargs)
         self.processor_channel = processor_channel
 
+    # band counts above this are designed in double precision on the forward path (31 third-octave bands: the lowest are
+    # 9 Hz wide, and float32 coefficients 1 +- beta keep four digits of that width -- the reference's own float32 result is
+    # 1e-4 .. 4e-4 from a float64 evaluation of its formulas there; 24 Bark bands meet it at 1e-5 in float32)
+    PRECISE_BANDS = 24
+
     def forward(self, input_signals, log_gains):
-        Bs, As = self.geq(log_gains)
+        precise = (self.geq.num_bands > self.PRECISE_BANDS and self.biquad.backend == "fsm"
+                   and ops.iir_fsm_native(self.biquad.fsm_fir_len) and not needs_grad(input_signals, log_gains))
+        Bs, As = self.geq(log_gains, precise=precise)
         if self.processor_channel == "midside":
             return ms_to_lr(self.biquad(lr_to_ms(input_signals), Bs, As))
         return self.biquad(input_signals, Bs, As)

@@ -219,6 +219,12 @@ size_t gfx_iir_fsm_plan_bytes(int64_t N);
 int gfx_iir_fsm_plan_f32(void* plan, int64_t N, void* stream);
 int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, float* h,
                         int64_t RC, int64_t K, int64_t N, void* stream);
+/* The same taps from coefficients given in DOUBLE precision: the cascade response is evaluated in double at the exact
+ * sample points exp(-2 pi i d k / N) and rounded once -- for cascades whose float32 coefficients lose the filter (the
+ * third-octave GraphicEqualizer's 9 Hz wide bands: 1 +- beta with beta = 6.5e-4; reference eq.py:339-436, core/geq.py),
+ * where the reference's own float32 result is 1e-4 .. 4e-4 from a float64 evaluation of its formulas. */
+int gfx_iir_fsm_fir_f64c_f32(const double* Bs, const double* As, const void* plan, float* h, int64_t RC, int64_t K,
+                             int64_t N, void* stream);
 
 /* coefficient front-ends (elementwise over n = rows*channels items of K biquads)
  * gfx_peq_coeffs_f32    replaces ParametricEqualizer.forward's activations + RBJ formulas:

@@ -3,7 +3,21 @@ gradients computed by the reference itself (tests/golden) and against torch.fft 
 import pytest
 import torch
 
-from conftest import assert_close
+from conftest import assert_close, assert_parity
+
+
+# Comparisons against a float64 evaluation only (no float32 reference to arbitrate): three times the largest error measured
+# on MI355X (gpurun_out/measured_errors.json of round 5), never below the north star's 1e-5 -- an order-of-magnitude
+# regression of a backward kernel fails.
+GRAD_TOL = {"ballistics gx": 1e-5, "ballistics gz": 1e-5, "fsm taps": 1e-5}   # measured: 1.4e-7, 5.6e-7, 1.4e-6
+
+
+def _oracle_grads64(o, x, p, w):
+    """float64 arbiter of a parameter-gradient comparison: the oracle (the reference's formulas) evaluated and
+    differentiated in double precision on the same inputs -> gradients in the order of p."""
+    p64 = {k: v.detach().cpu().double().requires_grad_() for k, v in p.items()}
+    y = o(x.detach().cpu().double(), **p64)
+    return [g.float() for g in torch.autograd.grad((y * w.detach().cpu().double()).sum(), list(p64.values()))]
 
 pytestmark = pytest.mark.gpu
 
@@ -46,8 +60,14 @@ def test_peq_parameter_gradients_vs_reference(golden, ch, N):
     y = m(g[f"x_{tag}"].cuda(), **p)
     assert_close(y.detach().cpu(), g[f"y_{tag}"], 1e-5, "peq y (grad mode)")
     grads = torch.autograd.grad((y * g[f"w_{tag}"].cuda()).sum(), list(p.values()))
-    for k, gr in zip(p, grads):
-        assert_close(gr.cpu(), g[f"grad_{k}_{tag}"], 2e-4, f"peq grad {k}")
+    import oracle
+
+    g64 = _oracle_grads64(oracle.OracleParametricEqualizer(num_filters=6, processor_channel=ch, fsm_fir_len=N), g[f"x_{tag}"], p,
+                          g[f"w_{tag}"])
+    for k, gr, r64 in zip(p, grads, g64):   # vs the reference's own float32 gradient, float64 as the tie-breaker
+        # (w0 / q_inv gradients: both float32 chains carry ~1e-5 of rounding -- the reference's own is 0.7 .. 1.5e-5 from
+        # float64, ours 0.9 .. 1.6e-5 -- so the bound on the difference is 5e-5, twice the largest measured 2.7e-5)
+        assert_parity(gr.cpu(), g[f"grad_{k}_{tag}"], r64, 1e-5 if k == "log_gain" else 5e-5, f"peq grad {k}")
 
 
 @pytest.mark.parametrize("ir_len", [3000, 3001])
@@ -61,8 +81,11 @@ def test_reverb_parameter_gradients_vs_reference(golden, ir_len):
     y = m(g[f"x_{tag}"].cuda(), **p)
     assert_close(y.detach().cpu(), g[f"y_{tag}"], 1e-5, "reverb y (grad mode)")
     grads = torch.autograd.grad((y * g[f"w_{tag}"].cuda()).sum(), list(p.values()))
-    for k, gr in zip(p, grads):
-        assert_close(gr.cpu(), g[f"grad_{k}_{tag}"], 2e-4, f"reverb grad {k}")
+    import oracle
+
+    g64 = _oracle_grads64(oracle.OracleSTFTMaskedNoiseReverb(ir_len=ir_len), g[f"x_{tag}"], p, g[f"w_{tag}"])
+    for k, gr, r64 in zip(p, grads, g64):
+        assert_parity(gr.cpu(), g[f"grad_{k}_{tag}"], r64, 1e-5, f"reverb grad {k}")
 
 
 def test_compressor_parameter_gradients_vs_reference(golden):
@@ -75,8 +98,12 @@ def test_compressor_parameter_gradients_vs_reference(golden):
     y = m(g["x_shared"].cuda(), **p)
     assert_close(y.detach().cpu(), g[f"y_{tag}"], 1e-5, "compressor y (grad mode)")
     grads = torch.autograd.grad((y * g[f"w_{tag}"].cuda()).sum(), list(p.values()))
-    for k, gr in zip(p, grads):
-        assert_close(gr.cpu(), g[f"grad_{k}_{tag}"], 5e-4, f"compressor grad {k}")
+    import oracle
+
+    g64 = _oracle_grads64(oracle.OracleCompressor(energy_smoother="iir", knee="quadratic", iir_len=511), g["x_shared"], p,
+                          g[f"w_{tag}"])
+    for k, gr, r64 in zip(p, grads, g64):
+        assert_parity(gr.cpu(), g[f"grad_{k}_{tag}"], r64, 1e-5, f"compressor grad {k}")
 
 
 def test_training_step_through_render_grafx():
@@ -106,13 +133,18 @@ def test_training_step_through_render_grafx():
     ref_grads = [p.grad.clone() for p in params.parameters()]
     for p in params.parameters():
         p.grad = None
+    import copy
+
+    params64 = copy.deepcopy(params).double()   # the same render differentiated in float64: the tie-breaker
+    render_grafx(cpu, x.double(), params64, rd)[0].square().mean().backward()
+    grads64 = [p.grad.float() for p in params64.parameters()]
     params_gpu = params.cuda()
     rd_gpu = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
     y, _, _ = render_grafx(hip, x.cuda(), params_gpu, rd_gpu)
     y.square().mean().backward()
     assert_close(y.detach().cpu(), y_ref.detach(), 2e-5, "y")
-    for gp, rg in zip(params_gpu.parameters(), ref_grads):
-        assert_close(gp.grad.cpu(), rg, 1e-3, "parameter gradient")
+    for (name, gp), rg, r64 in zip(params_gpu.named_parameters(), ref_grads, grads64):
+        assert_parity(gp.grad.cpu(), rg, r64, 1e-5, f"gradient of {name}")
 
 
 def test_training_backward_runs_under_the_callers_exact_convolution_setting():
@@ -197,11 +229,16 @@ def test_native_dynamics_backward_matches_torch_autograd_of_the_same_formulas(ga
     g = diff.log_gain(torch.log(e + 1e-5), p["log_threshold"] - 6, p["log_ratio"], p["log_knee"], knee, gate)
     y_torch = torch.exp(g)[:, None, :] * x
     assert (y_native - y_torch).abs().max() <= 2e-5 * y_torch.abs().max()
+    # No float64 arbiter here: a double-precision evaluation of the same expressions takes the other knee branch for the
+    # few samples that sit on a boundary, and the gradients jump there (measured: both float32 results 3e-2 .. 3e-1 of
+    # the peak away from it, 1e-5 from each other).  Flat bounds instead, at three times the largest error measured on
+    # MI355X (round 5: 3.5e-5 for the input gradient, 1.1e-5 for the parameters; most configurations ~1e-6) -- they were
+    # 2e-3 through round 4.
     for name, a, b in zip(["x"] + list(p), grads(y_native), grads(y_torch)):
         if b is None or (knee == "hard" and name == "log_knee") or (not smoother and name == "z"):
             continue
-        scale = b.abs().max().clamp_min(1e-6)
-        assert (a - b).abs().max() <= 2e-3 * scale, f"{name}: {(a - b).abs().max().item():.3e} vs scale {scale.item():.3e}"
+        assert_close(a.cpu(), b.cpu(), 1e-4 if name == "x" else 3e-5,
+                     f"dynamics backward {name} gate={gate} knee={knee} smoother={smoother}")
 
 
 @pytest.mark.gpu
@@ -230,9 +267,9 @@ def test_native_ballistics_backward_matches_torch_autograd_of_the_recursion(L):
     xg, zg = x.cuda().requires_grad_(True), z.cuda().requires_grad_(True)
     y = Ballistics()(xg, zg)
     gx, gz = torch.autograd.grad((y * w.cuda()).sum(), [xg, zg])
-    assert (y.detach().cpu() - y64.float()).abs().max() <= 1e-5 * y64.abs().max()
-    assert (gx.cpu() - gx64.float()).abs().max() <= 1e-4 * gx64.abs().max()
-    assert (gz.cpu() - gz64.float()).abs().max() <= 1e-3 * gz64.abs().max()
+    assert_close(y.detach().cpu(), y64.float(), 1e-5, f"ballistics y L={L}")
+    assert_close(gx.cpu(), gx64.float(), GRAD_TOL["ballistics gx"], f"ballistics gx L={L}")
+    assert_close(gz.cpu(), gz64.float(), GRAD_TOL["ballistics gz"], f"ballistics gz L={L}")
 
 
 @pytest.mark.gpu
@@ -300,7 +337,7 @@ def test_fsm_taps_backward_matches_torch_autograd(N):
     got = torch.autograd.grad((h * w).sum(), (Bs, As))
     want = torch.autograd.grad((h64 * w.double()).sum(), (B64, A64))
     for g, wv, name in zip(got, want, ("Bs", "As")):
-        assert (g - wv.float()).abs().max() <= 2e-4 * wv.abs().max(), f"{name}: {(g - wv.float()).abs().max().item():.3e}"
+        assert_close(g.cpu(), wv.float().cpu(), GRAD_TOL["fsm taps"], f"fsm taps grad {name} N={N}")
 
 
 @pytest.mark.gpu

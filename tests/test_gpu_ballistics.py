@@ -61,6 +61,20 @@ def test_slow_coefficients_take_the_whole_row_walk_and_stay_exact(R, L):
         assert torch.equal(_bits(y), _bits(ref)), schedule
 
 
+@pytest.mark.parametrize("R,L", [(9, 131072), (300, 65536)])
+def test_medium_coefficients_take_the_longer_chunks(R, L):
+    """Coefficients of a few 1e-3: too slow for the first cut (2048 / 4096-sample chunks), fast enough for chunks eight
+    times as long (the second launch, over the flagged rows); rows of the fast and of the very slow kind beside them."""
+    torch.manual_seed(R + 1)
+    u = torch.rand(R, L) * 2.0
+    coef = _coef(R, 2e-3, 6e-3, 21)
+    coef[1::3] = _coef(R, 0.2, 0.8, 22)[1::3]
+    coef[2::7] = _coef(R, 5e-5, 2e-4, 23)[2::7]
+    ref = oracle.ballistics_coefficients(u, coef[:, 0], coef[:, 1])
+    y = _run(u, coef, "chunks")
+    assert torch.equal(_bits(y), _bits(ref))
+
+
 def test_a_chunk_whose_warm_up_has_not_converged_is_caught_and_redone():
     """A 1e30 spike shortly before a chunk boundary: the true state is still ~1e22 where the next chunk starts, the
     warmed-up guess is ~1 -- the bit comparison of the two must flag the row, and the second launch walks it whole."""
