@@ -89,6 +89,8 @@ SIGNATURES = {
     "gfx_ballistics_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, vp]),
     "gfx_dyn_gain_apply_f32": (ctypes.c_int, [f32p, RowMap, f32p, f32p, RowMap, f32p, f32p, f32p, i64, i64, i64, i64,
                                               ctypes.c_int, ctypes.c_int, vp]),
+    "gfx_dynamics_ballistics_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                                   ctypes.c_int, ctypes.c_int, vp, sz, vp]),
     "gfx_ballistics_ws_bytes": (sz, [i64]),
     "gfx_ballistics_ws_f32": (ctypes.c_int, [f32p, f32p, ctypes.c_int, f32p, i64, i64, vp, sz, vp]),
     "gfx_ballistics_energy_f32": (ctypes.c_int, [f32p, RowMap, i64, f32p, ctypes.c_int, f32p, i64, i64, vp, sz, vp]),

@@ -29,6 +29,7 @@
 #include <cstdint>
 
 #include "../../include/grafx_amd.h"
+#include "dyn_gain.hpp"
 
 // every product and sum of this file rounds on its own, as numpy / numba / torch's CPU kernels do: a fused multiply-add
 // in the recursion (or in the energy x_l^2 + x_r^2) would change bits
@@ -56,6 +57,12 @@ struct BlArgs {
     int pass;            // 0: chunks, verified;  1: flagged rows, whole;  2: all rows, whole (no flags)
     int from_flags;      // pass 0 again, with longer chunks, over the rows an earlier pass 0 flagged
     int vec;             // 16-byte accesses are legal (alignment, L % 4 == 0)
+    // DST 1 (the whole compressor / gate in this kernel): y is the OUTPUT SIGNAL, addressed through ymap like x, and the
+    // gain computer's per-row parameters (row r reads parameter row r % prows; z likewise)
+    gfx_rowmap_t ymap;
+    const float *log_threshold, *log_ratio, *log_knee;
+    int knee, gate;
+    unsigned prows;
 };
 
 __device__ __forceinline__ int64_t row_off(const gfx_rowmap_t& m, int64_t r, int c) {
@@ -104,13 +111,19 @@ __device__ __forceinline__ f4 load_f4(const float* __restrict__ base, int64_t of
 // i.e. 32 + 32 prefetch registers and 32 of offsets -- the 64 x 64 tile needs 256 VGPRs with the energy source)
 // PF tiles are requested ahead of the one being walked (register sets): the whole-row walk is a handful of waves with
 // nothing else on their SIMD to cover a load's round trip, and one tile ahead (a 64-step walk, ~0.4 us) is shorter than it.
-template <int RPW, int BT, int SRC, bool VEC, int PF>
+// DST 0: the smoothed rows are the output.  DST 1 (with SRC 1): the gain computer and the gain stage ride on the walk --
+// the tile keeps the signal's channels in LDS instead of their energy, a lane forms the energy of its sample, steps the
+// recursion and at once turns the new state into the gain (log -> knee -> exp, dynamics.py:394-405) that scales the
+// sample in place; the tile then leaves as the compressor's output.  Energy -> envelope -> gain -> output in one pass over
+// x: 16 bytes per stereo sample instead of the 32 of "envelope kernel + gain kernel" (48 through round 4's four launches).
+template <int RPW, int BT, int SRC, bool VEC, int PF, int DST>
 __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
     constexpr int PITCH = BT + 4;              // LDS row pitch in floats: 16-byte row reads of 16 neighbouring lanes cover all banks
     constexpr int LPR = BT / 4;                // lanes per row in a cooperative pass
     constexpr int RPP = 64 / LPR;              // rows per pass
     constexpr int NP = RPW / RPP;              // cooperative passes
-    __shared__ __attribute__((aligned(16))) float tile[RPW * PITCH];
+    constexpr int PLANE = RPW * PITCH;         // DST 1: one LDS plane per channel
+    __shared__ __attribute__((aligned(16))) float tile[(DST == 1 ? 2 : 1) * PLANE];
     const int lane = threadIdx.x;
     const int nchunk = 1 << a.lg;
     const int64_t nvr = a.R << a.lg;             // virtual rows: (row, chunk)
@@ -120,8 +133,14 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
     const int64_t row = valid ? (vr >> a.lg) : 0;
     const int chunk = (int)(vr & (nchunk - 1));
     v2f c = {0.0f, 0.0f}, om = {1.0f, 1.0f};
+    Knee q;
+    if (DST == 1) {
+        const unsigned pr = valid ? (unsigned)(row % a.prows) : 0u;
+        knee_setup(q, a.log_threshold[pr], a.log_ratio[pr], a.log_knee ? a.log_knee[pr] : 0.0f, a.knee, a.gate);
+    }
     if (valid) {
-        float at = a.z[2 * row], rt = a.z[2 * row + 1];
+        const int64_t zr = DST == 1 ? row % a.prows : row;
+        float at = a.z[2 * zr], rt = a.z[2 * zr + 1];
         if (!a.is_coef) {
             at = 1.0f / (1.0f + expf(-at));
             rt = 1.0f / (1.0f + expf(-rt));
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
         const int64_t v = vbase + p * RPP + cr;
         const int64_t rrow = v >> a.lg;
         const int64_t pos0 = (int64_t)(int)(v & (nchunk - 1)) * a.T - warm + cc;
-        yoff[p] = rrow * a.L + pos0;
+        yoff[p] = DST == 1 ? row_off(a.ymap, rrow < a.R ? rrow : 0, 0) + pos0 : rrow * a.L + pos0;
         if (SRC == 1) soff[p] = row_off(a.xmap, rrow < a.R ? rrow : 0, 0) + pos0;
     }
     const unsigned chunk_c = (unsigned)((vbase + cr) & (nchunk - 1));
@@ -200,7 +219,9 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             f4 v = bx[p];
-            if (SRC == 1) {   // energy = mean_c x^2: squares, sum and the division by C each rounded (dynamics.py:390)
+            if (DST == 1) {   // the channels themselves: the walk forms the energy and scales them in place
+                if (a.C == 2) *reinterpret_cast<f4*>(&tile[PLANE + (p * RPP + cr) * PITCH + cc]) = bz[p];
+            } else if (SRC == 1) {   // energy = mean_c x^2: squares, sum and the division by C each rounded (dynamics.py:390)
                 const f4 w = bz[p];
                 v = a.C == 2 ? (v * v + w * w) * invC : v * v;
             }
@@ -212,10 +233,37 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
         const int64_t n0 = cstart - warm + (int64_t)ti * BT;          // this lane's position at step 0 of the tile
         int nv = 0;                                                    // steps this lane takes in this tile
         if (alive) nv = warming ? (chunk > 0 ? BT : 0) : (int)max((int64_t)0, min((int64_t)BT, cend - n0));
-        if (ti == 0 && chunk > 0) s = mine[0];
+        if (ti == 0 && chunk > 0) {
+            if (DST == 1) {
+                const float xa = mine[0], xb = mine[PLANE];
+                s = a.C == 2 ? (xa * xa + xb * xb) * invC : xa * xa;
+            } else {
+                s = mine[0];
+            }
+        }
         if (ti == warm_tiles) entry = s;
         const bool whole = __all(nv == BT || nv == 0);
         if (lane >= RPW) {
+        } else if (DST == 1) {
+            for (int j = 0; j < BT; j += 4) {
+                f4 xa = *reinterpret_cast<f4*>(mine + j), xb = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (a.C == 2) xb = *reinterpret_cast<f4*>(mine + PLANE + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = a.C == 2 ? (xa[i] * xa[i] + xb[i] * xb[i]) * invC : xa[i] * xa[i];
+                    const float t = bstep(s, e, c, om);
+                    s = j + i < nv ? t : s;
+                    if (!warming) {   // uniform
+                        const float g = FastMath::exp(log_gain_m<FastMath>(q, FastMath::log(s + 1e-5f)));   // dynamics.py:394-403
+                        xa[i] *= g;
+                        xb[i] *= g;
+                    }
+                }
+                if (!warming) {
+                    *reinterpret_cast<f4*>(mine + j) = xa;
+                    if (a.C == 2) *reinterpret_cast<f4*>(mine + PLANE + j) = xb;
+                }
+            }
         } else if (whole) {
             float t = s;
 #pragma unroll 4
@@ -248,14 +296,18 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
                 bool live;
                 const int64_t n = pass_pos(p, ti, live);
                 if (live && n < a.L) {
-                    const f4 q = *reinterpret_cast<const f4*>(&tile[(p * RPP + cr) * PITCH + cc]);
-                    float* o = a.y + yoff[p] + (int64_t)ti * BT;
-                    if (VEC) {
-                        __builtin_nontemporal_store(q, reinterpret_cast<f4*>(o));
-                    } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (n + i < a.L) o[i] = q[i];
+                    for (int ch = 0; ch < (DST == 1 ? 2 : 1); ++ch) {
+                        if (ch == 1 && a.C != 2) break;
+                        const f4 v = *reinterpret_cast<const f4*>(&tile[ch * PLANE + (p * RPP + cr) * PITCH + cc]);
+                        float* o = a.y + yoff[p] + (int64_t)ti * BT + (ch ? a.ymap.stride_ch : 0);
+                        if (VEC) {
+                            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(o));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (n + i < a.L) o[i] = v[i];
+                        }
                     }
                 }
             }
@@ -281,7 +333,7 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
     }
 }
 
-template <int SRC>
+template <int SRC, int DST>
 int launch_walk(int rpw, const BlArgs& a, hipStream_t st) {
     const int64_t nvr = a.R << a.lg;
     const int64_t blocks = (nvr + rpw - 1) / rpw;
@@ -289,27 +341,30 @@ int launch_walk(int rpw, const BlArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)blocks), blk(64);
     if (!a.vec) {   // unaligned rows / L % 4 != 0: the element-wise form, one shape
         const dim3 g64((unsigned)((nvr + 63) / 64));
-        hipLaunchKernelGGL((ballistics_walk_kernel<64, 32, SRC, false, 1>), g64, blk, 0, st, a);
-    } else if (rpw == 16) hipLaunchKernelGGL((ballistics_walk_kernel<16, 64, SRC, true, 4>), grid, blk, 0, st, a);
-    else if (rpw == 32) hipLaunchKernelGGL((ballistics_walk_kernel<32, 64, SRC, true, 2>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((ballistics_walk_kernel<64, 32, SRC, true, 1>), grid, blk, 0, st, a);
+        hipLaunchKernelGGL((ballistics_walk_kernel<64, 32, SRC, false, 1, DST>), g64, blk, 0, st, a);
+    } else if (rpw == 16) hipLaunchKernelGGL((ballistics_walk_kernel<16, 64, SRC, true, DST ? 2 : 4, DST>), grid, blk, 0, st, a);
+    else if (rpw == 32) hipLaunchKernelGGL((ballistics_walk_kernel<32, 64, SRC, true, DST ? 1 : 2, DST>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((ballistics_walk_kernel<64, 32, SRC, true, 1, DST>), grid, blk, 0, st, a);
     return GFX_OK;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // u: SRC 0 rows / SRC 1 signal.  Without a workspace (the flags of the two-pass form) every row is walked whole.
-template <int SRC>
+template <int SRC, int DST = 0>
 int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int is_coef, float* y, int64_t R, int64_t L,
-                   void* ws, size_t ws_bytes, hipStream_t st) {
+                   void* ws, size_t ws_bytes, hipStream_t st, const BlArgs* gain = nullptr) {
     if (!u || !z || !y || R <= 0 || L <= 0 || R > 0x3fffffffLL || L > 0x7fffff00LL) return GFX_EINVAL;
     if (SRC == 1 && ((C != 1 && C != 2) || xmap.inner <= 0)) return GFX_EINVAL;
     if (ws && ws_bytes < gfx_ballistics_ws_bytes(R)) return GFX_ENOSPC;
     BlArgs a;
+    if (gain) a = *gain;    // DST 1: ymap and the gain computer's parameters
+    else { a.ymap = xmap; a.log_threshold = a.log_ratio = a.log_knee = nullptr; a.knee = a.gate = 0; a.prows = 1; }
     a.u = u; a.xmap = xmap; a.C = C; a.y = y; a.z = z; a.is_coef = is_coef; a.flag = reinterpret_cast<unsigned*>(ws);
     a.R = R; a.L = L;
     a.vec = (L % 4 == 0) && aligned16(u) && aligned16(y);
     if (SRC == 1) a.vec = a.vec && xmap.stride_outer % 4 == 0 && xmap.stride_inner % 4 == 0 && xmap.stride_ch % 4 == 0;
+    if (DST == 1) a.vec = a.vec && a.ymap.stride_outer % 4 == 0 && a.ymap.stride_inner % 4 == 0 && a.ymap.stride_ch % 4 == 0;
     // chunks per row: enough virtual rows for ~4 waves per SIMD, chunks no shorter than 256 samples, at most one wave per row
     int lg = 0;
     while (ws && lg < 6 && (R << lg) < 262144 && (L >> (lg + 1)) >= 256) ++lg;
@@ -322,10 +377,10 @@ int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int
     a.from_flags = 0;
     if (lg == 0) {
         a.pass = 2;
-        rc = launch_walk<SRC>(rpw, a, st);
+        rc = launch_walk<SRC, DST>(rpw, a, st);
     } else {
         a.pass = 0;
-        rc = launch_walk<SRC>(64, a, st);
+        rc = launch_walk<SRC, DST>(64, a, st);
         if (rc != GFX_OK) return rc;
         if (lg >= 4) {
             // second try for the rows whose warm-up did not fit (or did not converge in) a chunk: chunks eight times as
@@ -336,14 +391,14 @@ int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int
             const int64_t per2 = (L + (1LL << a.lg) - 1) >> a.lg;
             a.T = (int)((per2 + BTMAX - 1) / BTMAX * BTMAX);
             a.from_flags = 1;
-            rc = launch_walk<SRC>(64, a, st);
+            rc = launch_walk<SRC, DST>(64, a, st);
             if (rc != GFX_OK) return rc;
             a.from_flags = 0;
         }
         a.pass = 1;
         a.lg = 0;
         a.T = (int)((L + BTMAX - 1) / BTMAX * BTMAX);
-        rc = launch_walk<SRC>(rpw, a, st);
+        rc = launch_walk<SRC, DST>(rpw, a, st);
     }
     if (rc != GFX_OK) return rc;
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
@@ -367,6 +422,17 @@ int gfx_ballistics_ws_f32(const float* u, const float* z_alpha, int is_coef, flo
                           size_t ws_bytes, void* stream) {
     gfx_rowmap_t none = {1, 0, 0, 0};
     return ballistics_run<0>(u, none, 1, z_alpha, is_coef, y, R, L, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gfx_dynamics_ballistics_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                                const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                                int64_t R, int64_t C, int64_t L, int knee, int gate, void* ws, size_t ws_bytes, void* stream) {
+    if (!log_threshold || !log_ratio || knee < 0 || knee > 2 || (knee != 0 && !log_knee)) return GFX_EINVAL;
+    if (param_rows < 1 || param_rows > R || xmap.inner <= 0 || ymap.inner <= 0) return GFX_EINVAL;
+    BlArgs g;
+    g.ymap = ymap; g.log_threshold = log_threshold; g.log_ratio = log_ratio; g.log_knee = log_knee;
+    g.knee = knee; g.gate = gate; g.prows = (unsigned)param_rows;
+    return ballistics_run<1, 1>(x, xmap, (int)C, z_alpha, 0, y, R, L, ws, ws_bytes, (hipStream_t)stream, &g);
 }
 
 int gfx_ballistics_energy_f32(const float* x, gfx_rowmap_t xmap, int64_t C, const float* z_alpha, int is_coef, float* env,

@@ -15,6 +15,7 @@
 #include <cstdint>
 
 #include "../../include/grafx_amd.h"
+#include "dyn_gain.hpp"
 
 #ifdef GFX_NT_OFF
 #define GFX_NT_STORE(...) gfx_plain_store(__VA_ARGS__)
@@ -42,9 +43,6 @@ __device__ __forceinline__ int64_t drow_off(const gfx_rowmap_t& m, int64_t r, in
     const unsigned q = rr / inner, rem = rr - q * inner;
     return (int64_t)q * m.stride_outer + (int64_t)rem * m.stride_inner + (int64_t)c * m.stride_ch;
 }
-
-__device__ __forceinline__ float sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
-__device__ __forceinline__ float softplusf(float v) { return v > 20.0f ? v : log1pf(expf(v)); }  // torch threshold=20
 
 // a^k for integer k >= 0, rounded once from double (keeps long decays accurate)
 __device__ __forceinline__ float powk(double log_a, double k) { return (float)exp(k * log_a); }
@@ -111,88 +109,6 @@ __device__ __forceinline__ void scan_tile(const OnePole& p, const float (&e)[DE]
     const float pre = fmaf(p.a_lane, entering, excl);  // u just before this thread's first sample
 #pragma unroll
     for (int i = 0; i < DE; ++i) u[i] = fmaf(p.ap[i + 1], pre, loc[i]);
-}
-
-// ---- gain computer -----------------------------------------------------------------------------
-struct Knee {
-    float T, R, invR, W, k, er;  // threshold (already -6), ratio, 1/ratio, half knee width, exp knee, exp(log_ratio)
-    float inv4W, invk;           // 1 / (4 W), 1 / k: the per-sample divisions of the gain curves are multiplications by
-                                 // these per-row reciprocals (an IEEE division is ~11 instructions)
-    int kind;                    // 0 hard, 1 quadratic, 2 exponential
-    int gate;                    // 0 compressor, 1 noise gate
-};
-
-__device__ __forceinline__ void knee_setup(Knee& q, float log_threshold, float log_ratio, float log_knee, int kind,
-                                           int gate) {
-    q.T = log_threshold - 6.0f;            // dynamics.py:395 / 630
-    q.er = expf(log_ratio);
-    q.R = 1.0f + q.er;
-    q.invR = 1.0f / q.R;
-    q.k = expf(log_knee);
-    q.W = q.k / 2.0f;
-    q.inv4W = 1.0f / (4.0f * q.W);
-    q.invk = 1.0f / q.k;
-    q.kind = kind;
-    q.gate = gate;
-}
-
-// log-gain g(G) for log-energy G.  (The nested conditionals compile to an exec-masked region per sample; selects between
-// values computed for every sample were measured and are slower, 3.49 vs 3.32 ms for 8192 rows: a wave whose samples all
-// sit outside the knee skips the quadratic arm.)
-__device__ __forceinline__ float log_gain(const Knee& q, float G) {
-    const float d = G - q.T;
-    if (!q.gate) {
-        if (q.kind == 0) return fminf(G, q.T + d * q.invR) - G;                                // dynamics.py:444-453
-        if (q.kind == 1) {                                                                     // 456-475
-            const bool below = G < (q.T - q.W), above = G > (q.T + q.W);
-            const float mid = G + (q.invR - 1.0f) * ((d + q.W) * (d + q.W)) * q.inv4W;
-            const float out = below ? G : (above ? (q.T + d * q.invR) : mid);
-            return out - G;
-        }
-        return (q.invR - 1.0f) * softplusf(q.k * d) * q.invk;                                  // 478-489
-    }
-    if (q.kind == 0) return fminf(G, q.R * d + q.T) - G;                                       // 676-686
-    if (q.kind == 1) {                                                                         // 688-707
-        const bool below = G < (q.T - q.W), above = G > (q.T + q.W);
-        const float mid = G + (1.0f - q.R) * ((d - q.W) * (d - q.W)) * q.inv4W;
-        const float out = below ? (q.R * d + q.T) : (above ? G : mid);
-        return out - G;
-    }
-    return -q.er * softplusf(q.k * (-d)) * q.invk;                                             // 709-721
-}
-
-// Hardware log2 / exp2 forms (v_log_f32, v_exp_f32) for the forward kernels: the one-shot tiles run at copy speed once the
-// arithmetic is out of the way -- with the library logf / expf they take 3.46 ms where the grid moving the same bytes takes
-// 2.72 (8192 stereo rows, profiles/r3/dyn_oneshot_ablation.txt) -- and the row kernel uses the same forms so that a row
-// gives the same samples whichever kernel produces it.  Accuracy: the
-// envelope is >= 1e-5, so log() sees no denormals and is good to ~1e-7 absolute; exp(g) is good to (2 + |g| log2 e) ulp,
-// i.e. a relative 6e-8 |g| on a GAIN that is itself e^g: large |g| means a proportionally small output.
-struct FastMath {
-    // __logf without its special cases: the same v_log_f32 and the same compensated product with ln 2 (bit-identical for
-    // normal finite arguments), minus the denormal pre-scaling and the inf / nan pass-through -- 5 instructions instead of
-    // 12, on an argument that is env + 1e-5 >= 1e-5 (an infinite envelope gives nan here, as the gain curve would anyway).
-    // Worth 0.3 % on the one-shot tiles (3.308 vs 3.317 ms, same box): they are not bound by their instruction count.
-    static __device__ __forceinline__ float log(float v) {
-        const float y = __builtin_amdgcn_logf(v);
-        const float c = 0x1.62e42ep-1f, cl = 0x1.efa39ep-25f;
-        const float r = c * y;
-        float t = fmaf(y, c, -r);
-        t = fmaf(cl, y, t);
-        return fmaf(c, y, t);
-    }
-    static __device__ __forceinline__ float exp(float v) { return __expf(v); }
-    // softplus, torch threshold 20; below -15 log1p(e^v) = e^v to fp32 (and 1 + e^v would round to 1)
-    static __device__ __forceinline__ float softplus(float v) {
-        return v > 20.0f ? v : (v < -15.0f ? __expf(v) : __logf(1.0f + __expf(v)));
-    }
-};
-
-template <typename M>
-__device__ __forceinline__ float log_gain_m(const Knee& q, float G) {
-    if (q.kind != 2) return log_gain(q, G);       // hard / quadratic knees: no transcendental
-    const float d = G - q.T;
-    if (!q.gate) return (q.invR - 1.0f) * M::softplus(q.k * d) * q.invk;   // dynamics.py:478-489
-    return -q.er * M::softplus(q.k * (-d)) * q.invk;                         // 709-721
 }
 
 // ---- loads / stores of 4 consecutive samples with bounds -----------------------------------------
@@ -778,22 +694,64 @@ __global__ __launch_bounds__(DT, (DEFER && NA <= 2) ? GFX_DEFER_WAVES : 1) void 
     const int64_t n0 = s + DE * lane;
     // NA == 0: no routing sum at all -- the walk over groups of `inner` rows that produces the LOOK-BACK rows of a call
     // without a fused sum (every other row belongs to dyn_oneshot_kernel / dyn_fused_kernel and is skipped here)
-    float acc0[NA ? NA : 1][OS_SUB][DE], acc1[STEREO && NA ? NA : 1][OS_SUB][DE];
+    // The routing sums' accumulators: registers in the plain walk; in the deferred walk -- whose pending row costs it a wave
+    // per SIMD otherwise (155 VGPRs) -- in LDS, which these kernels do not use for anything else: one 16-byte entry per
+    // lane, accumulator, sub-tile and channel, lane-contiguous (conflict-free), 32 KB per workgroup for two stereo
+    // accumulators.  A row touches the accumulators it feeds with one read-add-write each: ~16 LDS instructions per row
+    // and lane against ~200 vector instructions.
+    constexpr bool ACC_LDS = DEFER && NA > 0;
+    constexpr int NCH = STEREO ? 2 : 1;
+    using f4 = float __attribute__((ext_vector_type(4)));
+    __shared__ f4 acc_lds[ACC_LDS ? NA * OS_SUB * NCH : 1][DT];
+    float acc0[(!ACC_LDS && NA) ? NA : 1][OS_SUB][DE], acc1[(!ACC_LDS && STEREO && NA) ? NA : 1][OS_SUB][DE];
+    if (ACC_LDS) {
 #pragma unroll
-    for (int c = 0; c < NA; ++c)
+        for (int i = 0; i < NA * OS_SUB * NCH; ++i) acc_lds[i][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
 #pragma unroll
-        for (int k = 0; k < OS_SUB; ++k)
+        for (int c = 0; c < NA; ++c)
 #pragma unroll
-            for (int i = 0; i < DE; ++i) {
-                acc0[c][k][i] = 0.0f;
-                if (STEREO) acc1[c][k][i] = 0.0f;
-            }
+            for (int k = 0; k < OS_SUB; ++k)
+#pragma unroll
+                for (int i = 0; i < DE; ++i) {
+                    acc0[c][k][i] = 0.0f;
+                    if (STEREO) acc1[c][k][i] = 0.0f;
+                }
+    }
     float* const obase = NA ? m.out + (int64_t)g * m.sb : nullptr;
     // add one row's tile to the accumulators `code` names, then store and clear the destinations it completes
     auto settle = [&](uint64_t code, const float (&ga)[OS_SUB][DE], const float (&gb)[OS_SUB][DE]) {
         const unsigned add = (unsigned)code & 15u;
 #pragma unroll
         for (int c = 0; c < NA; ++c) {
+            const unsigned fl = (unsigned)(code >> (8 + 8 * c)) & 255u;
+            if (ACC_LDS) {
+                if ((((add >> c) & 1u) | fl) == 0u) continue;      // uniform: the row neither feeds nor completes it
+                float* o0 = obase + (int64_t)(fl ? fl - 1u : 0u) * m.sv;
+                float* o1 = o0 + m.sc;
+#pragma unroll
+                for (int k = 0; k < OS_SUB; ++k) {
+                    f4 v0 = acc_lds[(c * OS_SUB + k) * NCH][t], v1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (STEREO) v1 = acc_lds[(c * OS_SUB + k) * NCH + 1][t];
+                    if ((add >> c) & 1u) {
+#pragma unroll
+                        for (int i = 0; i < DE; ++i) {
+                            v0[i] += ga[k][i];
+                            if (STEREO) v1[i] += gb[k][i];
+                        }
+                    }
+                    if (fl != 0u) {                   // this destination is complete: store, clear
+                        const float s0[DE] = {v0[0], v0[1], v0[2], v0[3]}, s1[DE] = {v1[0], v1[1], v1[2], v1[3]};
+                        st4<true>(o0, n0 + 256 * k, a.L, true, s0);
+                        if (STEREO) st4<true>(o1, n0 + 256 * k, a.L, true, s1);
+                        v0 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+                        v1 = v0;
+                    }
+                    acc_lds[(c * OS_SUB + k) * NCH][t] = v0;
+                    if (STEREO) acc_lds[(c * OS_SUB + k) * NCH + 1][t] = v1;
+                }
+                continue;
+            }
             if ((add >> c) & 1u) {                // uniform
 #pragma unroll
                 for (int k = 0; k < OS_SUB; ++k)
@@ -803,7 +761,6 @@ __global__ __launch_bounds__(DT, (DEFER && NA <= 2) ? GFX_DEFER_WAVES : 1) void 
                         if (STEREO) acc1[c][k][i] += gb[k][i];
                     }
             }
-            const unsigned fl = (unsigned)(code >> (8 + 8 * c)) & 255u;
             if (fl != 0u) {                       // uniform: this destination is complete
                 float* o0 = obase + (int64_t)(fl - 1u) * m.sv;
                 float* o1 = o0 + m.sc;

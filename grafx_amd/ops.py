@@ -786,6 +786,33 @@ def ballistics(u, z_alpha, coefficients=False, schedule=None):
 
 
 @_on_device
+def dynamics_ballistics(x, log_threshold, log_ratio, log_knee, z_alpha, knee, gate, out=None, param_rows=None, schedule=None):
+    """Compressor / NoiseGate with the ballistics energy smoother and no gain smoother in one pass over ``x`` ((R, C, L) or
+    a strided (B, n, C, L) view): gfx_dynamics_ballistics_f32.  ``z_alpha``: (param_rows, 2)."""
+    schedule = BALLISTICS_SCHEDULE if schedule is None else schedule
+    _require_gpu(x, out, z_alpha)
+    xmap, R, C, L = rowmap(x)
+    P = R if param_rows is None else param_rows
+    z_alpha = z_alpha.contiguous()
+    if z_alpha.shape != (P, 2):
+        raise ValueError(f"z_alpha must be ({P}, 2), got {tuple(z_alpha.shape)}")
+    if out is None:
+        out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
+    elif rowmap(out)[1:] != (R, C, L):
+        raise ValueError(f"dynamics_ballistics: output {tuple(out.shape)} does not match input rows/channels/length {(R, C, L)}")
+    ws = None
+    if schedule == "chunks":
+        ws = torch.empty(lib().gfx_ballistics_ws_bytes(R), dtype=torch.uint8, device=x.device)
+    pin = _Pin()
+    with _timed("ballistics_walk_kernel", 8 * R * C * L):
+        check(lib().gfx_dynamics_ballistics_f32(_ptr(x), xmap, _ptr(out), rowmap(out)[0], pin(_rowvec(log_threshold, P)),
+                                                pin(_rowvec(log_ratio, P)), pin(_rowvec(log_knee, P)), _ptr(z_alpha), P, R, C, L,
+                                                KNEES[knee], int(gate), _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+              "gfx_dynamics_ballistics_f32")
+    return out
+
+
+@_on_device
 def ballistics_energy(x, z_alpha, coefficients=False, schedule=None):
     """ballistics(mean_c x^2) in one pass over x ((R, C, L) or a strided (B, n, C, L) view) -> (R, L): the envelope of
     Compressor / NoiseGate with energy_smoother="ballistics" (dynamics.py:390, core/envelope.py:84-101)."""

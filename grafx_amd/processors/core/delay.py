@@ -5,6 +5,7 @@ with a straight-through gradient.  A (num_taps x N/2) front-end — torch ops on
 import torch
 import torch.nn as nn
 
+from ... import autograd as diff
 from ... import ops
 from ...autograd import needs_grad
 
@@ -40,8 +41,10 @@ class SurrogateDelay(nn.Module):
         z = z * torch.tanh(radius) / (radius + 1e-7)
         spec = (z[:, None] + 1e-7) ** self.arange_sin
         n = 2 * (spec.shape[-1] - 1)                                      # length 2*(N//2), as upstream
-        if spec.is_cuda and not needs_grad(z) and 1 <= n <= ops.IRDFT_MAX_N:
-            soft = ops.irdft(spec, n)                                     # direct-sum kernel, no FFT library
+        if spec.is_cuda and spec.dtype == torch.complex64 and 1 <= n <= ops.IRDFT_MAX_N:
+            # direct-sum kernels, no FFT library: gfx_irdft_f32, and with gradients its differentiable form (backward:
+            # gfx_rdft_f32)
+            soft = diff.irfft_small(spec.contiguous(), n) if needs_grad(z) else ops.irdft(spec, n)
         else:
             soft = torch.fft.irfft(spec)
         irs = self.apply_straight_through(soft) if self.straight_through else soft

@@ -10,12 +10,21 @@ from .fft_filterbank import TriangularFilterBank
 
 
 def _zerophase_ir(magnitude, fir_len, window):
-    """irfft(magnitude, n=fir_len) rolled to the centre and windowed (core/fir.py:20-27).  Inference on the GPU: the
-    direct-sum kernel gfx_irdft_f32 (any length, no FFT library); with gradients, or beyond its size, torch ops."""
-    if (magnitude.is_cuda and not needs_grad(magnitude) and fir_len <= ops.IRDFT_MAX_N
-            and magnitude.shape[-1] == fir_len // 2 + 1 and magnitude.dtype == torch.float32):
+    """irfft(magnitude, n=fir_len) rolled to the centre and windowed (core/fir.py:20-27).  On the GPU, up to 8192 taps:
+    the direct-sum kernels (any length, no FFT library) -- gfx_irdft_f32 with the roll and the window fused for
+    inference, and with gradients its differentiable form (autograd.IrdftFn: backward = gfx_rdft_f32) followed by the
+    roll and the window as torch ops; beyond that size, or on other dtypes, the FFT library."""
+    native = (magnitude.is_cuda and fir_len <= ops.IRDFT_MAX_N and magnitude.shape[-1] == fir_len // 2 + 1
+              and magnitude.dtype == torch.float32)
+    if native and not needs_grad(magnitude):
         return ops.irdft(magnitude, fir_len, roll=fir_len // 2, window=window)
-    ir = torch.roll(torch.fft.irfft(magnitude, n=fir_len), shifts=fir_len // 2, dims=-1)
+    if native:
+        from ... import autograd as diff
+
+        ir = diff.irfft_small(torch.complex(magnitude, torch.zeros_like(magnitude)), fir_len)
+    else:
+        ir = torch.fft.irfft(magnitude, n=fir_len)
+    ir = torch.roll(ir, shifts=fir_len // 2, dims=-1)
     return ir if window is None else ir * window[None, :]
 
 

@@ -53,7 +53,7 @@ class _Dynamics(BufferIO, nn.Module):
         autograd node, so that the backward does not have to scan the input again."""
         if _shared_rows is not None and (needs_grad(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre,
                                                     z_alpha_post) or self.gain_smoother is not None
-                                         or self.energy_smoother == "ballistics"
+                                         or (self.energy_smoother == "ballistics" and self.gain_smoother is not None)
                                          or (self.energy_smoother == "iir" and reference_aliases(
                                              input_signals.shape[-1], self.iir_len, self.flashfftconv))):
             reps = shared_reps(input_signals, _shared_rows)  # paths without row sharing: one parameter row per signal row
@@ -86,6 +86,10 @@ class _Dynamics(BufferIO, nn.Module):
         # unfused configurations (a gain smoother, ballistics, or an energy smoother whose convolve() aliases): the energy
         # and the gain kernels read / write the (B, n, C, L) buffer views in place through their row maps, the smoothers
         # work on the (rows, L) envelope in between -- no flattened copy of the input, no copy of the output
+        if self.energy_smoother == "ballistics" and self.gain_smoother is None:
+            # energy -> attack / release recursion -> gain computer -> gain stage in one pass (gfx_dynamics_ballistics_f32)
+            return ops.dynamics_ballistics(input_signals, log_threshold, log_ratio, log_knee, z_alpha_pre, self.knee, self._gate,
+                                           out=_out, param_rows=_shared_rows)
         if self.energy_smoother == "ballistics":   # energy and recursion in one pass over the signal (ballistics.hip)
             energy = ops.ballistics_energy(input_signals, z_alpha_pre)
         else:

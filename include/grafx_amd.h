@@ -337,6 +337,14 @@ int gfx_ballistics_ws_f32(const float* u, const float* z_alpha, int is_coef, flo
  * is read once, the energy never reaches memory.  env: (R, L). */
 int gfx_ballistics_energy_f32(const float* x, gfx_rowmap_t xmap, int64_t C, const float* z_alpha, int is_coef, float* env,
                               int64_t R, int64_t L, void* ws, size_t ws_bytes, void* stream);
+/* Compressor / NoiseGate with energy_smoother="ballistics" and no gain smoother as ONE pass over the signal
+ * (dynamics.py:390-405 with core/envelope.py:84-101 inside): energy -> attack / release recursion (the float32 sequential
+ * recursion exactly, as above) -> log -> knee -> exp -> y = gain * x.  x, y: (R, C, L) through their row maps (in-place
+ * slices of the render buffer); per-row parameters as gfx_dynamics_fused_ex_f32 (row r reads row r % param_rows),
+ * z_alpha: (param_rows, 2); ws: gfx_ballistics_ws_bytes(R) bytes, or NULL for the whole-row walk only. */
+int gfx_dynamics_ballistics_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                                const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                                int64_t R, int64_t C, int64_t L, int knee, int gate, void* ws, size_t ws_bytes, void* stream);
 /* Adjoint of the recursion above given the forward input x, output y and g = dL/dy:
  * gx = dL/dx (R, L), gz = dL/dz_alpha (R, 2).  The attack/release choice is treated as locally constant. */
 int gfx_ballistics_bwd_f32(const float* x, const float* y, const float* g, const float* z_alpha, float* gx, float* gz,

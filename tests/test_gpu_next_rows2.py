@@ -255,3 +255,44 @@ def test_small_inverse_real_dft_matches_torch_irfft(n):
     r = n // 2
     want = torch.roll(torch.fft.irfft(Xr.double(), n=n), shifts=r, dims=-1) * w.double()
     assert (ops.irdft(Xr, n, roll=r, window=w).double() - want).abs().max() <= 2e-6 * want.abs().max().clamp_min(1e-12)
+
+
+def test_zero_phase_fir_design_gradient_matches_float64_autograd():
+    """The design front-end under autograd (round 5: autograd.IrdftFn -- gfx_irdft_f32 forward, gfx_rdft_f32 backward --
+    instead of the FFT library's irfft; reference core/fir.py:20-27) against the same formulas differentiated in float64."""
+    from grafx_amd.processors.core.fir import ZeroPhaseFIR
+
+    torch.manual_seed(0)
+    bins = 257
+    m = ZeroPhaseFIR(num_magnitude_bins=bins).cuda()
+    lm = (torch.randn(3, 2, bins) * 0.3).cuda().requires_grad_()
+    w = torch.randn(3, 2, 2 * bins - 1).cuda()
+    h = m(lm)
+    (g,) = torch.autograd.grad((h * w).sum(), lm)
+    lm64 = lm.detach().cpu().double().requires_grad_()
+    n = 2 * bins - 1
+    ir = torch.roll(torch.fft.irfft(torch.exp(lm64), n=n), shifts=n // 2, dims=-1) * m.window.cpu().double()
+    (g64,) = torch.autograd.grad((ir * w.cpu().double()).sum(), lm64)
+    assert_close(h.detach().cpu(), ir.detach().float(), 1e-5, "zero-phase FIR taps (grad mode)")
+    assert_close(g.cpu(), g64.float(), 1e-5, "zero-phase FIR design gradient")
+
+
+def test_surrogate_delay_gradient_matches_float64_autograd():
+    """SurrogateDelay's soft impulse under autograd (core/delay.py:73-76) on the direct-sum kernels both ways."""
+    from grafx_amd.processors.core.delay import SurrogateDelay
+
+    torch.manual_seed(1)
+    N = 512
+    m = SurrogateDelay(N=N, straight_through=False, normalize_gradients=False).cuda()
+    z = torch.polar(torch.rand(6) * 0.9 + 0.5, torch.rand(6) * 6.0).to(torch.cfloat).cuda().requires_grad_()
+    w = torch.randn(6, N).cuda()
+    irs, _ = m(z)
+    (g,) = torch.autograd.grad((irs * w).sum(), z)
+    z64 = z.detach().cpu().to(torch.cdouble).requires_grad_()
+    r = z64.abs()
+    zz = z64 * torch.tanh(r) / (r + 1e-7)
+    spec = (zz[:, None] + 1e-7) ** torch.arange(N // 2 + 1)[None, :]
+    soft = torch.fft.irfft(spec)
+    (g64,) = torch.autograd.grad((soft * w.cpu().double()).sum(), z64)
+    assert_close(irs.detach().cpu(), soft.detach().float(), 1e-5, "surrogate delay impulse (grad mode)")
+    assert_close(torch.view_as_real(g.cpu()), torch.view_as_real(g64.to(torch.cfloat)), 2e-5, "surrogate delay gradient")
