@@ -44,6 +44,9 @@ def parse_args(argv=None):
     ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--config", choices=["cfg4", "cfg2", "cfg3"], default="cfg4",
                     help="cfg4: the headline console graph (default); cfg2 / cfg3: BASELINE configs[1] / configs[2]")
+    ap.add_argument("--console-variant", choices=["headline", "longpole", "ballistics"], default="headline",
+                    help="cfg4 only, for profiles of the secondary legs: longpole = every compressor's smoother logit at 6 "
+                         "(pole 0.9975), ballistics = Compressor(energy_smoother='ballistics'); the line's config says so")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only with --dry)")
     ap.add_argument("--dry", action="store_true",
@@ -309,7 +312,7 @@ def profile_traffic(kernel, B, L, lens):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rN/pmc_hbm_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied) -- a PROFILE figure,
     not one measured in this run; None when no committed profile matches the workload."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         pmc = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
         if not os.path.exists(pmc):
             continue
@@ -521,9 +524,13 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
     L = args.length or 131072
     G = console_graph()
     render_data = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam"))
-    procs = dry_processors() if args.dry else {k: v.to(dev) for k, v in hip_processors(args.reference_default_args).items()}
+    smoother = "ballistics" if args.console_variant == "ballistics" else "iir"
+    procs = dry_processors() if args.dry else {k: v.to(dev) for k, v in
+                                               hip_processors(args.reference_default_args, energy_smoother=smoother).items()}
     torch.manual_seed(1234)  # identical parameters on every rank (a shared mixing console)
     params_cpu = {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
+    if args.console_variant == "longpole":
+        params_cpu["compressor"]["z_alpha_pre"] = torch.full_like(params_cpu["compressor"]["z_alpha_pre"], 6.0)
     params = {t: {k: v.to(dev) for k, v in d.items()} for t, d in params_cpu.items()}
     torch.manual_seed(1000 + rank)  # each rank renders its own shard of the batch
     x = torch.randn(B, 32, 2, L, device=dev)
@@ -613,7 +620,7 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
                             "forward render, upstream default constructor arguments (flashfftconv=True falls back to the native convolve(), "
                             "even lengths: aliasing compatibility path)"
                             if args.reference_default_args else "forward render, reference-exact lengths (even L+N-1)"),
-                   "parallelism": f"batch-shard x{world}",
+                   "parallelism": f"batch-shard x{world}", "console_variant": args.console_variant,
                    "launch": "one captured HIP graph per step" if args.capture else "eager render loop"},
         "per_gpu_value": B * L * args.steps / elapsed,
         "world_size": world if dist is None else dist.get_world_size(),

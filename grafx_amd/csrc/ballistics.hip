@@ -36,7 +36,6 @@
 #pragma clang fp contract(off)
 
 namespace gfx {
-namespace {
 
 constexpr int BTMAX = 64;      // chunk lengths and warm-ups are multiples of this (tiles are 64 or 32 samples per row)
 
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
 }
 
 template <int SRC, int DST>
-int launch_walk(int rpw, const BlArgs& a, hipStream_t st) {
+static int launch_walk(int rpw, const BlArgs& a, hipStream_t st) {
     const int64_t nvr = a.R << a.lg;
     const int64_t blocks = (nvr + rpw - 1) / rpw;
     if (blocks > 0x7fffffffLL) return GFX_EINVAL;
@@ -348,11 +347,11 @@ int launch_walk(int rpw, const BlArgs& a, hipStream_t st) {
     return GFX_OK;
 }
 
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // u: SRC 0 rows / SRC 1 signal.  Without a workspace (the flags of the two-pass form) every row is walked whole.
 template <int SRC, int DST = 0>
-int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int is_coef, float* y, int64_t R, int64_t L,
+static int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int is_coef, float* y, int64_t R, int64_t L,
                    void* ws, size_t ws_bytes, hipStream_t st, const BlArgs* gain = nullptr) {
     if (!u || !z || !y || R <= 0 || L <= 0 || R > 0x3fffffffLL || L > 0x7fffff00LL) return GFX_EINVAL;
     if (SRC == 1 && ((C != 1 && C != 2) || xmap.inner <= 0)) return GFX_EINVAL;
@@ -404,7 +403,6 @@ int ballistics_run(const float* u, gfx_rowmap_t xmap, int C, const float* z, int
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
-}  // namespace
 }  // namespace gfx
 
 using namespace gfx;

@@ -699,7 +699,11 @@ __global__ __launch_bounds__(DT, (DEFER && NA <= 2) ? GFX_DEFER_WAVES : 1) void 
     // lane, accumulator, sub-tile and channel, lane-contiguous (conflict-free), 32 KB per workgroup for two stereo
     // accumulators.  A row touches the accumulators it feeds with one read-add-write each: ~16 LDS instructions per row
     // and lane against ~200 vector instructions.
+#ifdef GFX_ACC_LDS_ALL   // A/B: the plain walk with LDS accumulators too
+    constexpr bool ACC_LDS = NA > 0;
+#else
     constexpr bool ACC_LDS = DEFER && NA > 0;
+#endif
     constexpr int NCH = STEREO ? 2 : 1;
     using f4 = float __attribute__((ext_vector_type(4)));
     __shared__ f4 acc_lds[ACC_LDS ? NA * OS_SUB * NCH : 1][DT];

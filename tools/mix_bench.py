@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from grafx_amd import ops
 
 B, n, C, L, J = 256, 32, 2, 131072, 5

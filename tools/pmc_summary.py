@@ -18,11 +18,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r4"))
+DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r5"))
 
 
 def bare(name):
     name = re.sub(r"^void\s+", "", name)
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"<.*$", "", name)
     return name
@@ -45,25 +46,37 @@ def counter(dirname, cname):
 def main():
     os.makedirs(DST, exist_ok=True)
     bench = json.loads(open(os.path.join(RAW, "bench.json")).read().strip().splitlines()[-1])
-    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, f"bench_{os.environ.get('GRAFX_ROUND', 'r3')}.json"))
+    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, f"bench_{os.environ.get('GRAFX_ROUND', 'r5')}.json"))
     shutil.copy(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(DST, "bench_under_rocprof.json"))
     stats = glob.glob(os.path.join(RAW, "trace", "**", "*kernel_stats.csv"), recursive=True)
     shutil.copy(stats[0], os.path.join(DST, "rocprofv3_kernel_stats.csv"))
-    fetch, write = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_SIZE")
-    kernels = {}
-    for k in sorted(set(fetch) | set(write)):
-        if not k.startswith(("gfx::", "gfx_")):
-            continue
-        f = sum(fetch[k]) / max(len(fetch[k]), 1)
-        w = sum(write[k]) / max(len(write[k]), 1)
-        kernels[k] = {
-            "launches": len(fetch[k]),
-            "FETCH_SIZE_KB_avg_per_launch": f,
-            "WRITE_SIZE_KB_avg_per_launch": w,
-            "hbm_read_bytes_per_launch_corrected": 2 * f * 1024,
-            "hbm_write_bytes_per_launch": w * 1024,
-            "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
-        }
+    def traffic(suffix=""):
+        fetch, write = counter("pmc_fetch" + suffix, "FETCH_SIZE"), counter("pmc_write" + suffix, "WRITE_SIZE")
+        out = {}
+        for k in sorted(set(fetch) | set(write)):
+            if not k.startswith(("gfx::", "gfx_")):
+                continue
+            f = sum(fetch[k]) / max(len(fetch[k]), 1)
+            w = sum(write[k]) / max(len(write[k]), 1)
+            out[k] = {
+                "launches": len(fetch[k]),
+                "FETCH_SIZE_KB_avg_per_launch": f,
+                "WRITE_SIZE_KB_avg_per_launch": w,
+                "hbm_read_bytes_per_launch_corrected": 2 * f * 1024,
+                "hbm_write_bytes_per_launch": w * 1024,
+                "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+            }
+        return out
+
+    kernels = traffic()
+    # round 5: the same two passes for the console with long compressor poles / the ballistics smoother, and for the
+    # ballistics recursion alone (tools/ballistics_bench.py: 9216 x 131072 rows) -- launches of different sizes are averaged
+    # per kernel name, so read these next to the kernel statistics of the same runs
+    for suffix in ("_longpole", "_ballistics", "_ballistics_rows"):
+        if glob.glob(os.path.join(RAW, "pmc_fetch" + suffix, "**", "*counter_collection.csv"), recursive=True):
+            json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md; averages over the launches of the run, the single-graph "
+                               "warm-up launches dropped", "kernels": traffic(suffix)},
+                      open(os.path.join(DST, f"pmc_hbm_traffic{suffix}.json"), "w"), indent=1)
     cfg = bench["config"]
     rec = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
