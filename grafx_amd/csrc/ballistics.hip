@@ -151,12 +151,17 @@ __global__ __launch_bounds__(64) void ballistics_walk_kernel(BlArgs a) {
     int warm = 0;
     if (a.pass == 0 && a.from_flags) alive = valid && a.flag[row] != 0u;   // (rows an earlier pass finished are not touched)
     if (a.pass == 0) {
-        // warm-up: the steps an error as large as the signal needs to contract below an ulp at the slower coefficient
-        // (2^-26 with a few steps to spare), rounded up to whole tiles; rows that need more than a chunk are not cut
+        // warm-up: two things have to happen before a lane's state is THE row's state.  An error as large as the signal
+        // contracts below an ulp in 18 / c steps at the slower coefficient c (2^-26); from there the two trajectories are
+        // neighbouring floats, and a step rounds neighbours to the same float with probability ~c -- another 16 / c steps
+        // leave 1e-7 of the boundaries unmerged (one unmerged boundary sends its row to the whole-row walk, and one such
+        // row makes that launch take its full 4.4 ms: the margin is what keeps the verified chunks worth having at small
+        // c; with 18 / c alone every row of a launch at c = 2.5e-3 failed the check).  Rounded up to whole tiles; rows
+        // that need more than a chunk are not cut.
         const float cmin = fminf(c.x, c.y);
         float need = 3.0e38f;
         if (cmin >= 1.0f) need = 8.0f;
-        else if (cmin > 0.0f) need = ceilf(-18.03f / log1pf(-cmin)) + 8.0f;
+        else if (cmin > 0.0f) need = ceilf(-34.0f / log1pf(-cmin)) + 8.0f;
         const bool slow = !(need <= (float)a.T);
         if (alive && slow) {
             alive = false;

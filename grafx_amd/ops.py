@@ -764,9 +764,11 @@ BALLISTICS_SCHEDULE = "chunks"   # "chunks": rows cut into verified chunks (gfx_
 
 
 @_on_device
-def ballistics(u, z_alpha, coefficients=False, schedule=None):
+def ballistics(u, z_alpha, coefficients=False, schedule=None, flags=None):
     """Ballistics.forward (core/envelope.py:84-101) on (R, L) rows: the float32 sequential recursion, bit for bit, whichever
-    schedule produces it.  ``coefficients``: ``z_alpha`` holds (at, rt) themselves instead of their logits."""
+    schedule produces it.  ``coefficients``: ``z_alpha`` holds (at, rt) themselves instead of their logits.
+    ``flags``: a list that receives the per-row int32 flags of the chunked schedule (1 = the row was walked whole by the
+    last launch: its coefficient is too slow for a chunk, or a chunk boundary failed the bit check) -- diagnostics."""
     schedule = BALLISTICS_SCHEDULE if schedule is None else schedule
     if schedule not in ("chunks", "rows"):
         raise ValueError(f"ballistics: unknown schedule {schedule!r}")
@@ -782,6 +784,8 @@ def ballistics(u, z_alpha, coefficients=False, schedule=None):
     with _timed("ballistics_walk_kernel", 8 * R * L):
         check(lib().gfx_ballistics_ws_f32(_ptr(u), _ptr(z_alpha), int(coefficients), _ptr(y), R, L, _ptr(ws),
                                           0 if ws is None else ws.numel(), _stream()), "gfx_ballistics_ws_f32")
+    if flags is not None and ws is not None:
+        flags.append(ws.view(torch.int32))
     return y
 
 

@@ -75,6 +75,23 @@ def test_medium_coefficients_take_the_longer_chunks(R, L):
     assert torch.equal(_bits(y), _bits(ref))
 
 
+@pytest.mark.parametrize("lo,hi", [(0.3, 0.7), (0.01, 0.02), (2e-3, 4e-3)])
+def test_verified_chunks_actually_carry_the_rows(lo, hi):
+    """Exactness holds whichever path produces a row; SPEED needs the chunks to pass their bit check.  With the warm-up the
+    kernel gives itself (34 / c steps: contraction to an ulp, then the merge of neighbouring floats) no row of 9216 may
+    fall back to the whole-row walk at coefficients of 0.5 (first cut: 4096-sample chunks), 0.015 (still the first cut) and
+    3e-3 (the second cut: 32768-sample chunks) -- one flagged row costs the launch the full 4.4 ms."""
+    from grafx_amd import ops
+
+    R, L = 9216, 131072
+    torch.manual_seed(5)
+    u = torch.rand(R, L, device="cuda") * 2
+    coef = _coef(R, lo, hi, 3).cuda()
+    flags = []
+    ops.ballistics(u, coef, coefficients=True, schedule="chunks", flags=flags)
+    assert int(flags[0].sum()) == 0, f"{int(flags[0].sum())} of {R} rows were walked whole"
+
+
 def test_a_chunk_whose_warm_up_has_not_converged_is_caught_and_redone():
     """A 1e30 spike shortly before a chunk boundary: the true state is still ~1e22 where the next chunk starts, the
     warmed-up guess is ~1 -- the bit comparison of the two must flag the row, and the second launch walks it whole."""

@@ -1,3 +1,2 @@
-python -m pytest tests/test_gpu_processors.py tests/test_gpu_full_size.py tests/test_gpu_reverb_ir_fft.py tests/test_gpu_fftconv.py tests/test_gpu_captured_render.py -q -m gpu --tb=short -k "reverb or cfg3 or fftconv or captured" 2>&1 | tail -8
-python bench.py --config cfg3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3', d['ms_per_step'], d['roofline']['per_kernel_ms_per_step'])"
-python bench.py --config cfg3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3', d['ms_per_step'], d['roofline']['per_kernel_ms_per_step'])"
+python -m pytest tests/test_gpu_ballistics.py -q -m gpu --tb=short 2>&1 | tail -8
+python tools/ballistics_bench.py --rows 9216 1024 256 2>&1 | grep -v amdgpu.ids
