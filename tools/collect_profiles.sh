@@ -26,6 +26,8 @@ for v in longpole ballistics; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$v -- python3 $R/bench.py --console-variant $v --steps 2 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_fetch_$v.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$v -- python3 $R/bench.py --console-variant $v --steps 2 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_write_$v.err
 done
+# the long-pole console on round 4's path (row kernel + read-back) for the before / after of DESIGN section 4.5
+GRAFX_DYN_LOOKBACK=0 python3 $R/bench.py --console-variant longpole --steps 10 --warmup 3 $LEAN > $OUT/bench_longpole_r4path.json 2> $OUT/bench_longpole_r4path.err
 # the ballistics recursion on its own (9216 x 131072 rows, both coefficient regimes, both schedules)
 python3 $R/tools/ballistics_bench.py --old-lib $R/grafx_amd/lib/r4base.so > $OUT/ballistics_bench.md 2> $OUT/ballistics_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ballistics_rows -- python3 $R/tools/ballistics_bench.py --rows 9216 --iters 3 > /dev/null 2> $OUT/trace_ballistics_rows.err

@@ -14,6 +14,7 @@ f="$(ls -t $RAW/trace_compat/*/*kernel_stats.csv | head -1)"; cp "$f" $D/rocprof
 cp $RAW/bench_compat.json $D/bench_cfg4_compat.json
 cp $RAW/bench_longpole.json $D/bench_cfg4_longpole.json
 cp $RAW/bench_ballistics.json $D/bench_cfg4_ballistics.json
+cp $RAW/bench_longpole_r4path.json $D/bench_cfg4_longpole_r4path.json
 cp $RAW/ballistics_bench.md $D/ballistics_bench.md
 grep -v amdgpu.ids $RAW/mix_bench.txt > $D/mix_bench_longpole.txt
 [ -f gpurun_out/parity_exceptions.md ] && cp gpurun_out/parity_exceptions.md $D/parity_exceptions.md
