@@ -743,7 +743,7 @@ def call_roofline(R, C, L, ms_per_step):
     return {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
 
 
-def console_case(torch, dev, B, L, lens, seed=1234, energy_smoother="iir", z_alpha_pre=None):
+def console_case(torch, dev, B, L, lens, seed=1234, energy_smoother="iir", z_alpha_pre=None, keep_signal_buffer=True):
     """The headline console graph on a resident batch of B graphs as a step function (forward render).
     ``energy_smoother``: the compressors' envelope follower ("iir" as in the headline, or "ballistics");
     ``z_alpha_pre``: set every compressor's smoother logit to this value instead of randn * 0.1 (6 -> a pole at 0.9975,
@@ -763,7 +763,7 @@ def console_case(torch, dev, B, L, lens, seed=1234, energy_smoother="iir", z_alp
 
     def step():
         with torch.no_grad():
-            return render_grafx(procs, x, params, rd, parameters_grad=False)[0]
+            return render_grafx(procs, x, params, rd, parameters_grad=False, keep_signal_buffer=keep_signal_buffer)[0]
 
     return step
 
@@ -779,6 +779,7 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
     out = {}
     legs = [("cfg2", "cfg2", None, steps, warmup), ("cfg3", "cfg3", None, steps, warmup),
             ("cfg4_longpole", "cfg4v", dict(z_alpha_pre=6.0), 10, 3), ("cfg4_ballistics", "cfg4v", dict(energy_smoother="ballistics"), 10, 3),
+            ("cfg4_output_only", "cfg4v", dict(keep_signal_buffer=False), 10, 3),
             ("cfg2_compat", "cfg2", REFERENCE_DEFAULT_LENS, 5, 2), ("cfg3_compat", "cfg3", REFERENCE_DEFAULT_LENS, 5, 2),
             ("cfg4_compat", "cfg4", REFERENCE_DEFAULT_LENS, 5, 2)]
     for key, cfg, lens, n, w in legs:
@@ -793,6 +794,10 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
                 step = console_case(torch, dev, R, L, LENS, **variant)
                 what = (f"BASELINE configs[3] console graph at batch {R}, L={L}, the headline's tap counts, "
                         + ("every compressor's smoother logit z_alpha_pre = 6 (pole 0.9975)" if "z_alpha_pre" in variant
+                           else "the headline's processors and parameters, render_grafx(keep_signal_buffer=False): the output node "
+                                "only -- an EXTENSION of upstream's API (which always returns every node's signal), not the headline: "
+                                "rows nothing reads are not written (the sources' copy, the channel strips' and bus compressors' "
+                                "outputs, which only feed the fused routing sums)" if "keep_signal_buffer" in variant
                            else "Compressor(energy_smoother='ballistics') (attack / release recursion, z_alpha_pre ~ randn * 0.1)"))
                 unit, units = "audio samples/s", R * L
                 call_bytes = 285 * R * 2 * L * 4

@@ -76,6 +76,9 @@ SIGNATURES = {
     "gfx_dynamics_fused_mix_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                   ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, f32p, vp, sz, vp, i64, i64,
                                                   f32p, i64, i64, i64, vp, i64, i64, vp]),
+    "gfx_dynamics_fused_mix_flags_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                                        ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, f32p, vp, sz, vp, i64, i64,
+                                                        f32p, i64, i64, i64, vp, i64, i64, ctypes.c_int, vp]),
     "gfx_ballistics_bwd_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, vp]),
     "gfx_dyn_gain_bwd_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, ctypes.c_int,
                                             ctypes.c_int, f32p, f32p, f32p, vp]),

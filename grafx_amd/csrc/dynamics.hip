@@ -546,8 +546,10 @@ __device__ __forceinline__ void os_emit(const DynArgs& a, const float (&xa)[OS_S
         }
         const int64_t n = n0 + 256 * k;
         if (u1row) st4<AL>(u1row, n, a.L, vu, raw);
-        st4<AL>(y0, n, a.L, vx, ga[k]);
-        if (stereo) st4<AL>(y1, n, a.L, vx, gb[k]);
+        if (y0) {                                     // (null: an output-only render that only sums this row)
+            st4<AL>(y0, n, a.L, vx, ga[k]);
+            if (stereo) st4<AL>(y1, n, a.L, vx, gb[k]);
+        }
     }
 }
 
@@ -585,8 +587,10 @@ __device__ __forceinline__ void os_emit_lean(const DynArgs& a, const float (&xa)
         }
         const int64_t n = n0 + 256 * k;
         if (u1row) st4<AL>(u1row, n, a.L, true, raw);
-        st4<AL>(y0, n, a.L, true, ga[k]);
-        if (stereo) st4<AL>(y1, n, a.L, true, gb[k]);
+        if (y0) {
+            st4<AL>(y0, n, a.L, true, ga[k]);
+            if (stereo) st4<AL>(y1, n, a.L, true, gb[k]);
+        }
     }
 }
 
@@ -662,6 +666,9 @@ struct MixArgs {
     // n_pre of them added before the stage's rows and n_post after -- the sum stays in increasing row order
     const int64_t* extras;
     int n_pre, n_post;
+    // the stage's own rows are consumed by the routing sums alone (an output-only render: nobody reads them afterwards), so
+    // the tiles do not store them -- rows the ROW kernel produces are still written (the tiles read them back from y)
+    int skip_rows;
 };
 
 // Knee kind and compressor / gate are template parameters: a wave runs the row body `inner` times, and with every gain curve
@@ -808,8 +815,8 @@ __global__ __launch_bounds__(DT, (DEFER && NA <= 2) ? GFX_DEFER_WAVES : 1) void 
                 knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
                 OsIn in;
                 os_load<true>(a, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, STEREO ? 1 : 0), true, tb, s, lane, in);
-                os_finish<true>(a, in, y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane, ga, gb,
-                                looks_back ? lb.gran + (size_t)r * lb.ntiles : nullptr);
+                os_finish<true>(a, in, m.skip_rows ? nullptr : y0, y1, true, u1 ? u1 + (int64_t)r * a.L : nullptr, tb, q, s, lane,
+                                ga, gb, looks_back ? lb.gran + (size_t)r * lb.ntiles : nullptr);
             } else if (((unsigned)code & 15u) != 0u) {   // the row kernel's row: read back what it wrote
 #pragma unroll
                 for (int k = 0; k < OS_SUB; ++k) {
@@ -839,7 +846,7 @@ __global__ __launch_bounds__(DT, (DEFER && NA <= 2) ? GFX_DEFER_WAVES : 1) void 
                 knee_setup(q, log_threshold[pr], log_ratio[pr], KIND != 0 ? log_knee[pr] : 0.0f, KIND, GATE ? 1 : 0);
                 const float carry = pkind == 2 ? os_lookback(tb, s, lane, lb.gran + (size_t)prow * lb.ntiles) : pcarry;
                 float ga[OS_SUB][DE], gb[OS_SUB][DE];
-                os_emit_lean<true>(a, pxa, pxb, pexcl, ptotal, carry, y + drow_off(a.ymap, prow, 0),
+                os_emit_lean<true>(a, pxa, pxb, pexcl, ptotal, carry, m.skip_rows ? nullptr : y + drow_off(a.ymap, prow, 0),
                                    y + drow_off(a.ymap, prow, STEREO ? 1 : 0), u1 ? u1 + (int64_t)prow * a.L : nullptr, tb, q, s,
                                    lane, ga, gb);
                 settle(pcode, ga, gb);
@@ -2050,7 +2057,7 @@ static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gf
         const unsigned nblocks = (unsigned)(units * ngroups);
         MixArgs none;
         none.sched = nullptr; none.out = nullptr; none.sb = none.sv = none.sc = 0; none.inner = LB_GROUP;
-        none.extras = nullptr; none.n_pre = none.n_post = 0;
+        none.extras = nullptr; none.n_pre = none.n_post = 0; none.skip_rows = 0;
         a.nchunks = 1;
         a.chunk_tiles = 1;
         lb.split = 1;
@@ -2138,6 +2145,17 @@ int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_
                                float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
                                float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
                                int64_t n_pre, int64_t n_post, void* stream) {
+    return gfx_dynamics_fused_mix_flags_f32(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L,
+                                            smoother, iir_len, knee, gate, u1, ws, ws_bytes, sched, inner, n_acc, mix, mix_sb,
+                                            mix_sv, mix_sc, extras, n_pre, n_post, 0, stream);
+}
+
+int gfx_dynamics_fused_mix_flags_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                                     const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                                     int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                                     float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
+                                     float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
+                                     int64_t n_pre, int64_t n_post, int flags, void* stream) {
     if (!sched || !mix || inner < 1 || inner > 65535 || n_acc < 1 || n_acc > 4 || R % inner != 0 || !ws || smoother != 1)
         return GFX_EINVAL;
     if (n_pre < 0 || n_post < 0 || n_pre + n_post > 65535 || (n_pre + n_post > 0 && !extras)) return GFX_EINVAL;
@@ -2149,6 +2167,7 @@ int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_
     MixArgs m;
     m.sched = sched; m.out = mix; m.sb = mix_sb; m.sv = mix_sv; m.sc = mix_sc; m.inner = (int)inner;
     m.extras = extras; m.n_pre = (int)n_pre; m.n_post = (int)n_post;
+    m.skip_rows = (flags & GFX_MIX_SKIP_ROWS) ? 1 : 0;
     return dynamics_fused_launch(x, xmap, y, ymap, log_threshold, log_ratio, log_knee, z_alpha, param_rows, R, C, L, smoother,
                                  iir_len, knee, gate, u1, ws, ws_bytes, stream, &m, (int)n_acc);
 }

@@ -623,13 +623,15 @@ def dynamics_fused(x, log_threshold, log_ratio, log_knee, z_alpha, smoother, iir
         n, J = x.shape[1], mo.shape[1]
         if (mo.shape == (x.shape[0], J, C, L) and mo.stride(-1) == 1 and sched.numel() == n and xmap.inner == n
                 and ymap.inner == n):
-            with _timed("dyn_fused_kernel", 8 * R * C * L + 4 * mo.numel() + (4 * R * L if u1_out is not None else 0)) as t:
+            own = 4 if mix.get("skip_rows") else 8
+            with _timed("dyn_fused_kernel", own * R * C * L + 4 * mo.numel() + (4 * R * L if u1_out is not None else 0)) as t:
                 ex = mix.get("extras")
                 n_ex = 0 if ex is None else ex.shape[0]
                 n_pre = mix.get("n_pre", 0)
-                rc = lib().gfx_dynamics_fused_mix_f32(*args[:-1], _ptr(sched), n, mix["n_acc"], _ptr(mo), mo.stride(0),
-                                                      mo.stride(1), mo.stride(2) if C == 2 else 0, _ptr(ex), n_pre,
-                                                      n_ex - n_pre, _stream())
+                # mix["skip_rows"]: nobody but these sums reads the stage's rows (an output-only render): do not store them
+                rc = lib().gfx_dynamics_fused_mix_flags_f32(*args[:-1], _ptr(sched), n, mix["n_acc"], _ptr(mo), mo.stride(0),
+                                                            mo.stride(1), mo.stride(2) if C == 2 else 0, _ptr(ex), n_pre,
+                                                            n_ex - n_pre, 1 if mix.get("skip_rows") else 0, _stream())
                 if rc == 0 and t.rec is not None:    # keyed by the kernel's own name, as a profile prints it
                     t.name = lib().gfx_dynamics_last_kernel().decode()
             if rc == 0:

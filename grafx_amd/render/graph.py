@@ -257,9 +257,13 @@ def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
     return True
 
 
-def _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters, aux=None):
+def _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters, aux=None,
+                      keep_signal_buffer=True):
     """render_grafx for HIP processors: every stage reads and writes the (B, V, C, L) signal buffer in place
     (no clone / index_select / reshape copies), routing sums run as one gather-sum kernel.
+    ``keep_signal_buffer=False`` (an output-only render; the third return value is None): rows that nothing reads are
+    not written -- the sources are not copied into the buffer unless a stage reads them from there, and a stage whose
+    rows only feed the routing sum fused into its kernel does not store them.
     ``aux``: a dict (training path) in which processors with ``accepts_aux`` keep per-stage by-products of the forward
     pass that their backward needs (key: the stage's order); the stage-wise backward hands it back to them."""
     from .. import ops
@@ -284,9 +288,11 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
     # copy runs on a side stream underneath the first (compute-bound) stages.
     # ... and a stage whose processor can "tee" (write its input through to a second destination from the
     # registers that hold it anyway) makes the copy of the rows it reads free.
-    teed = _tee_range(render_data, processors, n_src, x.device)
+    lean = not keep_signal_buffer
+    teed = None if lean else _tee_range(render_data, processors, n_src, x.device)
     main = torch.cuda.current_stream(x.device)
-    rest = _complement(teed, n_src)
+    rest = [] if lean else _complement(teed, n_src)
+    sources_in_buf = not lean          # lean: copied on demand (ensure_sources), on the main stream
     side = _side_stream(x.device) if rest else None
     if side is not None:
         side.wait_stream(main)
@@ -300,6 +306,14 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         # falls back to a fresh hipMalloc per step (seen as intermittent 150-800 ms steps).
     copied = False  # has the main stream joined the copy yet?
     out_view = None
+
+    def ensure_sources():
+        """Output-only render: a stage is about to read source rows from the buffer (a gathered read, a routing sum that
+        takes sources) -- put them there now."""
+        nonlocal sources_in_buf
+        if not sources_in_buf:
+            buf[:, :n_src].copy_(x)
+            sources_in_buf = True
 
     def stage_parameters(step, proc):
         nonlocal expanded_tree
@@ -364,6 +378,8 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         if side is not None and not from_inputs and not copied and _touches_inputs(src_read, n_src):
             main.wait_stream(side)
             copied = True
+        if lean and not from_inputs and _touches_inputs(src_read, n_src):
+            ensure_sources()
         if node_type not in processors:  # in / out / mix: the (summed) input is the output
             if plan is None:
                 a, b = step.source_reads[0].idx
@@ -399,9 +415,17 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
                 # copy, and the skipped mix stage is the one that would have joined it (a stage reading `x` directly has not)
                 main.wait_stream(side)
                 copied = True
+            if lean and any(r < n_src for r in sched["extra_rows"]):
+                ensure_sources()
             e0, e1 = nxt.dest_write.idx
             mix = extra["_mix"] = {"sched": sched["sched"], "n_acc": sched["n_acc"], "extras": sched["extras"],
                                    "n_pre": sched["n_pre"], "out": buf.narrow(1, e0, e1 - e0)}
+            # output-only render: rows that only the fused sum reads (not the last stage's, not read by any later stage
+            # other than the sum itself) are not stored
+            if lean and i != render_data.max_order and not any(
+                    _reads_rows(render_data.iter_list[k], d0, d1) for k in range(i + 1, render_data.max_order + 1)
+                    if k != mix_with and k not in done):
+                mix["skip_rows"] = True
         proc.render_into(x_view, out_v, **extra, **params, **common_i)
         launched += 1
         if prepared is None and PREPARE_MODE != "inline" and launched == (2 if PREPARE_MODE == "under_second" else 1):
@@ -454,6 +478,8 @@ def _render_buffer_io(processors, input_signals, per_type_parameters, render_dat
         # (declined: the stage in between has run early and the sum runs at its own place -- still a valid order)
     if side is not None and not copied:
         main.wait_stream(side)  # the returned buffer is complete on the caller's stream
+    if lean:
+        return (out_view[0] if squeeze else out_view), [], None
     if squeeze:
         return out_view[0], [], buf[0]
     return out_view, [], buf
@@ -723,14 +749,19 @@ def render_grafx(
     common_parameters=None,
     parameters_grad=True,
     input_signal_grad=False,
+    keep_signal_buffer=True,
 ):
+    """``keep_signal_buffer=False`` (an extension; upstream always returns the buffer): an output-only render on the HIP
+    path without gradients -- the third return value is None and rows that nothing reads are not written (the sources'
+    copy, the rows of a stage that only feed the routing sum fused into its kernel).  The output is the same bits."""
     method = render_data.method
     ndim = input_signals.ndim
     if ndim in (3, 4) and _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
         if _wants_grad(input_signals, per_type_parameters, common_parameters):
             return _render_buffer_io_with_grad(processors, input_signals, per_type_parameters, render_data,
                                                common_parameters)
-        return _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters)
+        return _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters,
+                                 keep_signal_buffer=keep_signal_buffer)
     if ndim == 3:
         node_dim, postprocess = 0, None
     elif ndim == 4:

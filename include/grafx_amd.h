@@ -315,6 +315,17 @@ int gfx_dynamics_fused_mix_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_
                                float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
                                float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
                                int64_t n_pre, int64_t n_post, void* stream);
+/* The same with flags.  GFX_MIX_SKIP_ROWS: the call's own rows are NOT stored by the tile kernels -- for a render whose
+ * caller wants the output node only (grafx_amd.render.render_grafx(keep_signal_buffer=False)) and a stage whose rows
+ * nothing but the fused routing sums reads: the stage then moves 8 instead of 16 bytes per stereo sample plus the sums.
+ * (Rows the pole table leaves to the row kernel are still written: the summing tiles read them back from y.) */
+#define GFX_MIX_SKIP_ROWS 1
+int gfx_dynamics_fused_mix_flags_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_rowmap_t ymap, const float* log_threshold,
+                                     const float* log_ratio, const float* log_knee, const float* z_alpha, int64_t param_rows,
+                                     int64_t R, int64_t C, int64_t L, int smoother, int64_t iir_len, int knee, int gate,
+                                     float* u1, void* ws, size_t ws_bytes, const int64_t* sched, int64_t inner, int64_t n_acc,
+                                     float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
+                                     int64_t n_pre, int64_t n_post, int flags, void* stream);
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);

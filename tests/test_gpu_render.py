@@ -163,3 +163,37 @@ def test_hip_processors_next_to_a_user_defined_torch_processor():
     assert set(g_ref) == set(g_hip)
     for key, wv in g_ref.items():
         assert (g_hip[key] - wv).abs().max() <= 5e-3 * wv.abs().max().clamp_min(1e-8), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_output_only_render_gives_the_same_output_bits(seed):
+    """render_grafx(keep_signal_buffer=False) (an extension: upstream always returns the buffer) must not change one bit
+    of the output node -- on the console (where the channel strips' rows are then never stored and the sources never
+    copied) and on random graphs (where some stage usually DOES read the rows again, or sums take source rows)."""
+    import random
+
+    import bench
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.utils import create_empty_parameters
+    from test_gpu_render_fuzz import build, random_graph
+
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    if seed == 0:
+        G = bench.console_graph()
+        procs = {k: v.cuda() for k, v in bench.hip_processors(lens=dict(fsm_fir_len=513, iir_len=1023, ir_len=3001)).items()}
+        x = torch.randn(2, 32, 2, 8192, device="cuda")
+    else:
+        G = random_graph(rng, n_src=rng.randint(1, 3), n_proc=rng.randint(3, 8))
+        procs, _ = build(0, 257, 255, 1501)
+        n_in = len([1 for _, d in G.nodes(data=True) if d["node_type"] == "in"])
+        x = torch.randn(rng.randint(1, 3), n_in, 2, rng.choice([2048, 4096, 6000]), device="cuda")
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to("cuda")
+    params = {t: {k: v.detach().cuda() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.3).items()}
+    with torch.no_grad():
+        y_full, _, buf = render_grafx(procs, x, params, rd, parameters_grad=False)
+        y_lean, _, none = render_grafx(procs, x, params, rd, parameters_grad=False, keep_signal_buffer=False)
+    assert none is None and buf is not None
+    assert torch.equal(y_full, y_lean)
