@@ -47,6 +47,15 @@ SIGNATURES = {
     "gfx_odd_alias_precise_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),
     "gfx_odd_alias_precise_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_odd_alias_precise_adjoint_f32": (ctypes.c_int, [f32p, i64, i64, i64, f32p, i64, i64, vp, vp, sz, vp]),
+    "gfx_odd_alias_pair_plan_bytes": (sz, [i64]),
+    "gfx_odd_alias_pair_workspace_bytes": (sz, [i64, i64]),
+    "gfx_odd_alias_pair_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),
+    "gfx_odd_alias_pair_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
+    "gfx_odd_alias_pair_rows_f32": (ctypes.c_int, [f32p, f32p, RowMap, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
+    "gfx_odd_alias_pair_precise_plan_bytes": (sz, [i64]),
+    "gfx_odd_alias_pair_precise_workspace_bytes": (sz, [i64, i64]),
+    "gfx_odd_alias_pair_precise_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),
+    "gfx_odd_alias_pair_precise_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_irdft_f32": (ctypes.c_int, [f32p, ctypes.c_int, f32p, i64, i64, i64, i64, f32p, vp]),
     "gfx_rdft_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, vp]),
     "gfx_iir_fsm_native": (ctypes.c_int, [i64]),

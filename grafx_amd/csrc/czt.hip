@@ -25,294 +25,9 @@
 #include <cstdint>
 #include <mutex>
 
-#include "../../include/grafx_amd.h"
-#include "fft_tile.hpp"
-#include "fft_tile_f64.hpp"
-#include "small_dft.hpp"
+#include "czt_core.hpp"
 
 namespace gfx {
-
-constexpr int CZT_MAXC = 32;
-// tiles per (sub-)transform: every size up to 32 with prime factors up to 7 (czt_geom picks the smallest that covers P)
-#define GFX_CZT_SIZES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(14) X(15) X(16) X(18) X(20) X(21) X(24) \
-    X(25) X(27) X(28) X(30) X(32)
-
-// Working precision of the transforms (the data in and out is fp32 either way): float = the packed-FP32 tile, double =
-// the `precise` form for the energy envelope (fft_tile_f64.hpp).  Tables, spectra and the workspace are T2 per point.
-template <typename T> struct Prec;
-template <> struct Prec<float> {
-    using cxt = cx;
-    using T2 = float2;
-    using Tw = TileTw;
-    static constexpr int lds_bytes = TILE_LDS_BYTES;
-    static __device__ __forceinline__ T2 make(float x, float y) { return make_float2(x, y); }
-};
-template <> struct Prec<double> {
-    using cxt = cxd;
-    using T2 = double2;
-    using Tw = TileTwD;
-    static constexpr int lds_bytes = TILE_LDS_BYTES_F64;
-    static __device__ __forceinline__ T2 make(double x, double y) { return make_double2(x, y); }
-};
-
-struct CztGeom {
-    int64_t P, Q, K, NFFT;   // NFFT = S * C * 8192
-    int C, S;                // C <= 32 columns per sub-transform; S = 4^levels sub-transforms under `levels` outer radix-4 levels
-    int levels;
-    // where the real output rows go: row r of the call at y + r * ldy (yC == 0), or -- gfx_odd_alias_rows_f32 -- row
-    // (row0 + r) of a (rows / yC, yC, len) signal addressed through a row map (a strided view of the render's buffer)
-    int yC;
-    int64_t row0;
-    gfx_rowmap_t ymap;
-};
-
-__device__ __forceinline__ float* czt_out_row(const CztGeom& g, float* y, int64_t ldy, int64_t row) {
-    if (g.yC == 0) return y + row * ldy;
-    const int64_t q = g.row0 + row;
-    const unsigned r = (unsigned)(q / g.yC);
-    const int c = (int)(q - (int64_t)r * g.yC);
-    const unsigned inner = (unsigned)g.ymap.inner, o = r / inner, rem = r - o * inner;
-    return y + (int64_t)o * g.ymap.stride_outer + (int64_t)rem * g.ymap.stride_inner + (int64_t)c * g.ymap.stride_ch;
-}
-
-constexpr int CZT_MAX_LEVELS = 3;   // NFFT <= 2^24: P <= 11,184,811 (233 s of audio at 48 kHz plus the filter)
-
-static inline bool czt_geom(int64_t P, CztGeom& g) {
-    if (P < 3 || (P & 1) == 0) return false;
-    g.yC = 0;
-    g.row0 = 0;
-    g.ymap = gfx_rowmap_t{1, 0, 0, 0};
-    g.P = P;
-    g.Q = P - 1;
-    g.K = (P + 1) / 2;
-    const int64_t need = P + g.K - 1;
-    const int64_t tiles = (need + TILE_M - 1) / TILE_M;
-    // C <= 32 tiles per (sub-)transform with prime factors up to 7 (small_dft.hpp); beyond 32, outer radix-4 levels
-    g.levels = 0;
-    int64_t per = tiles;
-    while (per > CZT_MAXC) {
-        per = (per + 3) / 4;
-        ++g.levels;
-    }
-    int64_t C = per;
-    while (!sd_supported((int)C)) ++C;       // (32 is supported: the loop ends)
-    if (g.levels > CZT_MAX_LEVELS || C < 1) return false;
-    g.S = 1 << (2 * g.levels);
-    g.C = (int)C;
-    g.NFFT = (int64_t)g.S * C * TILE_M;
-    return true;
-}
-
-// plan layout (float2 units): cP[P] | cQ[Q] | spectra [NFFT] each of bP, bQ (forward) and of bQ, bP placed for the
-// adjoint (same chirps, mirrored support: the adjoint's first transform has Q inputs and K outputs, its second K
-// inputs and P outputs)
-static inline size_t czt_plan_f2(const CztGeom& g) { return (size_t)(g.P + g.Q + 4 * g.NFFT); }
-
-// b[j] = exp(sign i pi j^2 / den) at circular index j mod NFFT for j in [-lo, hi], zero elsewhere
-struct ChirpSeq {
-    int64_t lo, hi, den;
-    double sign;
-};
-
-template <typename T>
-__device__ __forceinline__ typename Prec<T>::T2 chirp_d(int64_t j, int64_t den, double sign) {   // exp(sign i pi j^2 / den)
-    const int64_t r = (j * j) % (2 * den);
-    double s, c;
-    sincospi((double)r / (double)den, &s, &c);
-    return Prec<T>::make((T)c, (T)(sign * s));
-}
-
-template <typename T>
-__global__ void czt_chirp_table_kernel(typename Prec<T>::T2* __restrict__ tab, int64_t n, int64_t den, float sign) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tab[i] = chirp_d<T>(i, den, sign);
-}
-
-// e^{-+ 2 pi i r / N} for 0 <= r < N, N a multiple of 4 (N = C x 8192, not a power of two in general): the quarter turn is
-// taken off in integers and the rest, rem / (N / 2) <= 1/2 half-turns with rem < 2^24 exact, goes to sincospif -- the phase
-// is good to 1e-7 rad whatever N (for a power of two the quotient is exact, as before).
-__device__ __forceinline__ cx unit_root_f(int r, int N, bool conj) {
-    const int quarter = N >> 2;
-    const int q = r / quarter, rem = r - q * quarter;
-    float s, c;
-    sincospif((float)rem / (float)(N >> 1), &s, &c);
-    const float cr = (q & 1) ? ((q & 2) ? s : -s) : ((q & 2) ? -c : c);     // cos of the full angle
-    const float sr = (q & 1) ? ((q & 2) ? -c : c) : ((q & 2) ? -s : s);     // sin of the full angle
-    return cx{cr, conj ? sr : -sr};
-}
-__device__ __forceinline__ cxd col_twiddle(int n2, int k1, double inv_half_nfft, bool conj) {
-    double s, c;
-    sincospi((double)(n2 * k1) * inv_half_nfft, &s, &c);
-    return cxd{c, conj ? s : -s};
-}
-
-// The column twiddles W_NS^(n2 k1), k1 = 1, 2, ... C-1 IN TURN.  float: n2 k1 mod NS carried incrementally, one sincospif
-// each; double: powers of W^(n2) by repeated multiplication (31 steps lose ~1e-15, and a double sincospi per point would
-// make the column kernels compute-bound).
-template <typename T> struct ColTw;
-template <> struct ColTw<float> {
-    int n2, NS, r;
-    bool conj;
-    __device__ __forceinline__ ColTw(int n2_, int NS_, bool conj_) : n2(n2_), NS(NS_), r(0), conj(conj_) {}
-    __device__ __forceinline__ cx at(int) {
-        r += n2;
-        r -= r >= NS ? NS : 0;
-        return unit_root_f(r, NS, conj);
-    }
-};
-template <> struct ColTw<double> {
-    cxd w1, w;
-    __device__ __forceinline__ ColTw(int n2, int NS, bool conj) : w1(col_twiddle(n2, 1, 2.0 / (double)NS, conj)), w(cxd{1.0, 0.0}) {}
-    __device__ __forceinline__ cxd at(int) { w = cmul(w, w1); return w; }
-};
-
-// C-point DFT of a column in registers: the power-of-two sizes on the tile's radix-2 codelet (bit-identical with the
-// rounds before), the others on small_dft.hpp; either way frequency k ends up at v[spos(C, k)].
-template <int C, bool INV, typename V>
-__device__ __forceinline__ void col_dft(V (&v)[C]) {
-    if constexpr ((C & (C - 1)) == 0) dif<C, INV>(v);
-    else sdft<C, INV>(v);
-}
-
-// MODE 0: real rows, z[row, i - lo] tab[i] for lo <= i < lo + len (row stride ldz), zero elsewhere;  MODE 1: the complex
-// buffer itself;  MODE 2: a chirp sequence (plan building)
-template <typename T, int C, int MODE>
-__global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restrict__ z,
-                                                          const typename Prec<T>::T2* __restrict__ tab,
-                                                          typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t ldz,
-                                                          int64_t lo, int64_t len, ChirpSeq cs) {
-    using cx = typename Prec<T>::cxt;
-    const int n2 = blockIdx.x * 256 + threadIdx.x;          // column 0..8191
-    const int64_t row = blockIdx.y;                        // signal row * S + sub-transform
-    const int64_t NS = g.NFFT / g.S;                       // points of one sub-transform
-    typename Prec<T>::T2* b = buf + row * NS;
-    cx v[C];
-#pragma unroll
-    for (int n1 = 0; n1 < C; ++n1) {
-        const int64_t i = (int64_t)n1 * TILE_M + n2;
-        cx e = {0, 0};
-        if (MODE == 0) {
-            if (i >= lo && i < lo + len) e = to_cx(tab[i]) * (T)z[row * ldz + (i - lo)];
-        } else if (MODE == 1) {
-            e = to_cx(b[i]);
-        } else {
-            if (i <= cs.hi) e = to_cx(chirp_d<T>(i, cs.den, cs.sign));
-            else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d<T>(g.NFFT - i, cs.den, cs.sign));
-        }
-        v[n1] = e;
-    }
-    col_dft<C, false>(v);
-    ColTw<T> tw(n2, (int)NS, false);
-#pragma unroll
-    for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = v[spos(C, k1)];
-        const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
-        b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
-    }
-}
-
-// One tile per (row, k1): forward, times the chirp spectrum, inverse -- in place.  PLAN: forward only, spectrum stored
-// in thread layout.
-template <typename T, bool PLAN>
-__global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kernel(
-    typename Prec<T>::T2* __restrict__ buf, const typename Prec<T>::T2* __restrict__ spec,
-    typename Prec<T>::T2* __restrict__ spec_out, int C, const typename Prec<T>::T2* __restrict__ twtab) {
-    using cx = typename Prec<T>::cxt;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    cx* lds = reinterpret_cast<cx*>(lds_raw);
-    const int t = threadIdx.x;
-    const int64_t tile = blockIdx.x;                    // row * C + k1
-    const int k1 = (int)(tile % C);                       // C here = tiles per signal row = S * C
-    cx* b = reinterpret_cast<cx*>(buf) + tile * TILE_M;
-    typename Prec<T>::Tw tw;
-    tile_twiddles(tw, twtab, t);
-    cx v[32], w[2][16];
-#pragma unroll
-    for (int a = 0; a < 32; ++a) v[a] = b[t + 256 * a];
-    tile_forward(v, w, tw, lds, t);
-    if (PLAN) {
-        cx* o = reinterpret_cast<cx*>(spec_out) + (int64_t)k1 * TILE_M;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) o[q * TILE_T + t] = w[q >> 4][q & 15];
-        return;
-    }
-    const cx* sp = reinterpret_cast<const cx*>(spec) + (int64_t)k1 * TILE_M;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], sp[q * TILE_T + t]);
-    __syncthreads();
-    tile_inverse(w, v, tw, lds, t);
-#pragma unroll
-    for (int a = 0; a < 32; ++a) b[t + 256 * a] = v[brev(a, 5)];
-}
-
-// MODE 0 (after the first convolution): buf[k] <- conv[k] cP[k] w_k cQ[k] / NFFT for k < K, zero beyond
-// MODE 1 (after the second):            y[row, n - lo] <- Re(conv[n] cQ[n]) / (NFFT Q)  for lo <= n < lo + len
-// MODE 3: MODE 0 and the second convolution's column pass (cols_fwd MODE 1) in one -- the same thread owns the column in
-//         both, so the buffer is read and written once instead of twice
-// (the adjoint passes cP in cQ's place for MODE 1: its output lives on the P grid, still divided by Q)
-template <typename T, int C, int MODE>
-__global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2* __restrict__ buf,
-                                                          const typename Prec<T>::T2* __restrict__ cP,
-                                                          const typename Prec<T>::T2* __restrict__ cQ,
-                                                          float* __restrict__ y, int64_t ldy, int64_t lo, int64_t len,
-                                                          CztGeom g) {
-    using cx = typename Prec<T>::cxt;
-    const int n2 = blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = blockIdx.y;
-    const int64_t NS = g.NFFT / g.S;
-    typename Prec<T>::T2* b = buf + row * NS;
-    cx v[C];
-    ColTw<T> twi(n2, (int)NS, true);
-#pragma unroll
-    for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
-        v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
-    }
-    col_dft<C, true>(v);
-    const T sc = (T)1 / (T)NS;
-    if (MODE == 3) {   // the step between the two convolutions (S = 1): MODE 0's values, then cols_fwd's MODE 1 on them
-        cx u[C];
-#pragma unroll
-        for (int n1 = 0; n1 < C; ++n1) {
-            const int64_t i = (int64_t)n1 * TILE_M + n2;
-            cx o = {0, 0};
-            if (i < g.K) {
-                const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
-                o = cmul(cmul(v[spos(C, n1)] * sc, to_cx(cP[i])), to_cx(cQ[i])) * wk;
-            }
-            u[n1] = o;
-        }
-        col_dft<C, false>(u);
-        ColTw<T> twf(n2, (int)NS, false);
-#pragma unroll
-        for (int k1 = 0; k1 < C; ++k1) {
-            const cx e = u[spos(C, k1)];
-            const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
-            b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
-        }
-        return;
-    }
-#pragma unroll
-    for (int n1 = 0; n1 < C; ++n1) {
-        const int64_t i = (int64_t)n1 * TILE_M + n2;
-        const cx e = v[spos(C, n1)] * sc;
-        if (MODE == 2) {                                   // plain inverse of a sub-transform (outer level follows)
-            b[i] = Prec<T>::make(e.x, e.y);
-        } else if (MODE == 0) {
-            cx o = {0, 0};
-            if (i < g.K) {
-                const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
-                o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
-            }
-            b[i] = Prec<T>::make(o.x, o.y);
-        } else {
-            if (i >= lo && i < lo + len) {
-                const cx c = to_cx(cQ[i]);
-                czt_out_row(g, y, ldy, row)[i - lo] = (float)((e.x * c.x - e.y * c.y) / (T)g.Q);
-            }
-        }
-    }
-}
 
 // ---- outer radix-4 level (S = 4): NFFT = 4 NS, n = n3 NS + n', k = k3 + 4 k' ---------------------------------------
 //   forward:  sub[k3][n'] = ( sum_n3 x[n3 NS + n'] W_4^(n3 k3) ) W_NFFT^(n' k3)      then four NS-point transforms
@@ -445,12 +160,6 @@ static void launch_cols_inv(const CztGeom& g, typename Prec<T>::T2* buf, const t
 #undef GFX_CI
 }
 
-template <typename K>
-static bool czt_allow_lds(K kernel, int bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
-           hipSuccess;
-}
-
 // the double tile's twiddles: TW_ROWS x 256 double2 (rows as in fft_tile.hpp), one table per device
 __global__ void czt_twiddle_table_f64_kernel(double2* __restrict__ table) {
     const int t = threadIdx.x, row = blockIdx.x;
@@ -465,7 +174,7 @@ __global__ void czt_twiddle_table_f64_kernel(double2* __restrict__ table) {
     table[row * TILE_T + t] = make_double2(c, -s);
 }
 
-static const double2* tile_twiddle_table_f64(hipStream_t stream) {
+const double2* tile_twiddle_table_f64(hipStream_t stream) {
     static std::mutex mu;
     static double2* tables[64] = {nullptr};
     int dev = 0;
@@ -483,10 +192,6 @@ static const double2* tile_twiddle_table_f64(hipStream_t stream) {
     }
     return tables[dev];
 }
-
-template <typename T> static const typename Prec<T>::T2* czt_twiddles(hipStream_t st);
-template <> const float2* czt_twiddles<float>(hipStream_t st) { return tile_twiddle_table(st); }
-template <> const double2* czt_twiddles<double>(hipStream_t st) { return tile_twiddle_table_f64(st); }
 
 // The levels below the outermost one and the column pass: every 4^lvl-th part of the buffer is its own transform
 template <typename T>

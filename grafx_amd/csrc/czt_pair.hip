@@ -1,0 +1,312 @@
+// The odd-length aliasing y = irfft_{P-1}(rfft_P(z)) (czt.hip) for TWO real rows per complex chirp-z transform.
+//
+// The aliasing A is a real-linear map of a row, and the transforms of czt.hip are complex anyway (Bluestein), so the
+// pair z1 + i z2 goes through as ONE complex row and comes out as A z1 + i A z2 -- provided the spectrum is kept on both
+// sides (a real row's one-sided bins k < K with weights 1, 2, ..., 2, 1 rely on Z[-k] = conj Z[k], which a complex row
+// does not have):
+//
+//   Z[k'] = cP[|k'|] sum_m (z[m] cP[m]) bP[k' - m],          k' = -(K-1) .. K-1  (P = 2K - 1 bins),  z = z1 + i z2
+//   v[n]  = cQ[n] sum_k' (w_k' Z[k'] cQ[|k'|]) bQ[n - k'] / Q,   w = 1/2 at |k'| = K - 1 (the Nyquist bin of the Q grid), else 1
+//   y1 = Re v,  y2 = Im v
+//
+// (chirps as in czt.hip; reference: core/convolution.py:119-134, rfft(n=P) ... irfft() without n).  With the bins stored
+// at position k' + (K - 1), the first convolution takes its input at positions m + (K - 1) and the second delivers y[n] at
+// position n + (K - 1): both chirp kernels span 2P - 1 points and NFFT = C x 8192 >= 2P - 1 is enough (no wrapped term
+// reaches a position that is read).  Against one transform per row that is 2P - 1 points per PAIR instead of
+// 2 x (3P - 1) / 2: a third fewer bytes through every pass (P = 135 071: 35 tiles per pair against 2 x 25), for the same
+// five passes.  C <= 63 tiles (P <= 258 048: 5.4 s of audio at 48 kHz); longer rows stay on czt.hip, and so does the
+// adjoint.  The rounding error of a row now carries eps times the LARGER of the two rows -- the callers pair neighbouring
+// rows of one call (the two channels of a stereo signal, or neighbouring tracks' envelopes in double precision).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "czt_core.hpp"
+
+namespace gfx {
+
+constexpr int CZT_PAIR_MAXC = 63;
+#ifdef GFX_PAIR_DEV_SIZES
+#define GFX_CZT_PAIR_SIZES(X) X(2) X(3) X(35) X(36) X(48)
+#else
+#define GFX_CZT_PAIR_SIZES(X) GFX_CZT_SIZES(X) X(35) X(36) X(40) X(42) X(45) X(48) X(49) X(50) X(54) X(56) X(60) X(63)
+#endif
+
+// the middle pass keeps two columns of C points in registers when fused with the next column pass: above 36 tiles (28 in
+// double precision) that no longer fits two waves per SIMD and it goes in two passes instead (one more sweep over the buffer)
+template <typename T, int C> constexpr bool pair_mid_fused() { return sizeof(T) == 4 ? C <= 36 : C <= 28; }
+
+static inline bool czt_pair_geom(int64_t P, CztGeom& g) {
+    if (P < 3 || (P & 1) == 0) return false;
+    g.yC = 0;
+    g.row0 = 0;
+    g.ymap = gfx_rowmap_t{1, 0, 0, 0};
+    g.P = P;
+    g.Q = P - 1;
+    g.K = (P + 1) / 2;
+    const int64_t tiles = (2 * P - 1 + TILE_M - 1) / TILE_M;
+    if (tiles > CZT_PAIR_MAXC) return false;
+    int C = (int)tiles;
+    while (!sd_supported(C) || C == 64) ++C;      // (63 = 3 * 3 * 7 is supported: the loop ends at or below it)
+    g.levels = 0;
+    g.S = 1;
+    g.C = C;
+    g.NFFT = (int64_t)C * TILE_M;
+    return true;
+}
+
+// plan layout (T2 units): cP[P] | cQ[Q] | mid[P] | spectrum of bP over [-(P + K - 2), K - 1] | spectrum of bQ over
+// [-(K - 1), Q + K - 2];  mid[i] = cP[|k'|] cQ[|k'|] w_k' / NFFT for the bin k' = i - (K - 1) stored at position i
+static inline size_t czt_pair_plan_t2(const CztGeom& g) { return (size_t)(g.P + g.Q + g.P + 2 * g.NFFT); }
+
+template <typename T>
+__global__ void czt_pair_mid_table_kernel(typename Prec<T>::T2* __restrict__ mid, int64_t P, int64_t NFFT) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int64_t off = (P - 1) / 2, kp = i - off, a = kp < 0 ? -kp : kp;
+    const double2 p = chirp_d<double>(a, P, -1.0), q = chirp_d<double>(a, P - 1, 1.0);
+    const double w = (a == off ? 0.5 : 1.0) / (double)NFFT;
+    mid[i] = Prec<T>::make((T)((p.x * q.x - p.y * q.y) * w), (T)((p.x * q.y + p.y * q.x) * w));
+}
+
+// first column pass: (z1[m] + i z2[m]) cP[m] at position m + K - 1, zero elsewhere
+template <typename T, int C>
+__global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restrict__ z, const typename Prec<T>::T2* __restrict__ cP,
+                                                         typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t rows) {
+    using cx = typename Prec<T>::cxt;
+    const int n2 = blockIdx.x * 256 + threadIdx.x;
+    const int64_t pr = blockIdx.y;
+    typename Prec<T>::T2* b = buf + pr * g.NFFT;
+    const int64_t off = g.K - 1;
+    const bool two = 2 * pr + 1 < rows;
+    const float* z1 = z + 2 * pr * g.P;
+    const float* z2 = z1 + (two ? g.P : 0);
+    cx v[C];
+#pragma unroll
+    for (int n1 = 0; n1 < C; ++n1) {
+        const int64_t m = (int64_t)n1 * TILE_M + n2 - off;
+        cx e = {0, 0};
+        if (m >= 0 && m < g.P) {
+            const cx c = to_cx(cP[m]);
+            const T a = (T)z1[m], bb = two ? (T)z2[m] : (T)0;
+            e = cx{c.x * a - c.y * bb, c.x * bb + c.y * a};
+        }
+        v[n1] = e;
+    }
+    col_dft<C, false>(v);
+    ColTw<T> tw(n2, (int)g.NFFT, false);
+#pragma unroll
+    for (int k1 = 0; k1 < C; ++k1) {
+        const cx e = v[spos(C, k1)];
+        const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
+        b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+    }
+}
+
+// between the convolutions: the inverse column pass of the first, the bins' factors mid[i] (zero beyond the P bins), and
+// -- FUSED -- the forward column pass of the second
+template <typename T, int C, bool FUSED>
+__global__ __launch_bounds__(256, 2) void czt_pair_mid_kernel(typename Prec<T>::T2* __restrict__ buf,
+                                                          const typename Prec<T>::T2* __restrict__ mid, CztGeom g) {
+    using cx = typename Prec<T>::cxt;
+    const int n2 = blockIdx.x * 256 + threadIdx.x;
+    typename Prec<T>::T2* b = buf + (int64_t)blockIdx.y * g.NFFT;
+    cx v[C];
+    ColTw<T> twi(n2, (int)g.NFFT, true);
+#pragma unroll
+    for (int k1 = 0; k1 < C; ++k1) {
+        const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
+        v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
+    }
+    col_dft<C, true>(v);
+    if constexpr (FUSED) {
+        cx u[C];
+#pragma unroll
+        for (int n1 = 0; n1 < C; ++n1) {
+            const int64_t i = (int64_t)n1 * TILE_M + n2;
+            u[n1] = i < g.P ? cmul(v[spos(C, n1)], to_cx(mid[i])) : cx{0, 0};
+        }
+        col_dft<C, false>(u);
+        ColTw<T> twf(n2, (int)g.NFFT, false);
+#pragma unroll
+        for (int k1 = 0; k1 < C; ++k1) {
+            const cx e = u[spos(C, k1)];
+            const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
+            b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+        }
+    } else {
+#pragma unroll
+        for (int n1 = 0; n1 < C; ++n1) {
+            const int64_t i = (int64_t)n1 * TILE_M + n2;
+            const cx o = i < g.P ? cmul(v[spos(C, n1)], to_cx(mid[i])) : cx{0, 0};
+            b[i] = Prec<T>::make(o.x, o.y);
+        }
+    }
+}
+
+// last column pass: v[n] = conv[n + K - 1] cQ[n] / (NFFT Q) for lo <= n < lo + len; real part to the pair's first row,
+// imaginary part to its second
+template <typename T, int C>
+__global__ __launch_bounds__(256, 2) void czt_pair_out_kernel(const typename Prec<T>::T2* __restrict__ buf,
+                                                          const typename Prec<T>::T2* __restrict__ cQ, float* __restrict__ y,
+                                                          int64_t ldy, int64_t lo, int64_t len, CztGeom g, int64_t rows) {
+    using cx = typename Prec<T>::cxt;
+    const int n2 = blockIdx.x * 256 + threadIdx.x;
+    const int64_t pr = blockIdx.y;
+    const typename Prec<T>::T2* b = buf + pr * g.NFFT;
+    const int64_t off = g.K - 1;
+    const bool two = 2 * pr + 1 < rows;
+    cx v[C];
+    ColTw<T> twi(n2, (int)g.NFFT, true);
+#pragma unroll
+    for (int k1 = 0; k1 < C; ++k1) {
+        const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
+        v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
+    }
+    col_dft<C, true>(v);
+    const T sc = (T)1 / ((T)g.NFFT * (T)g.Q);
+    float* y1 = czt_out_row(g, y, ldy, 2 * pr);
+    float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
+#pragma unroll
+    for (int n1 = 0; n1 < C; ++n1) {
+        const int64_t n = (int64_t)n1 * TILE_M + n2 - off;
+        if (n >= lo && n < lo + len) {
+            const cx o = cmul(v[spos(C, n1)], to_cx(cQ[n])) * sc;
+            y1[n - lo] = (float)o.x;
+            if (two) y2[n - lo] = (float)o.y;
+        }
+    }
+}
+
+template <typename T, int MODE>
+static void pair_cols_fwd(const CztGeom& g, typename Prec<T>::T2* buf, int64_t pairs, hipStream_t st, ChirpSeq cs) {
+    using T2 = typename Prec<T>::T2;
+    const dim3 grid(TILE_M / 256, (unsigned)pairs), blk(256);
+#define GFX_PF(CC) case CC: hipLaunchKernelGGL((czt_cols_fwd_kernel<T, CC, MODE>), grid, blk, 0, st, (const float*)nullptr, (const T2*)nullptr, \
+                                               buf, g, (int64_t)0, (int64_t)0, (int64_t)0, cs); break;
+    switch (g.C) { GFX_CZT_PAIR_SIZES(GFX_PF) default: break; }
+#undef GFX_PF
+}
+
+template <typename T>
+static int czt_pair_plan(void* plan, int64_t P, void* ws, size_t ws_bytes, hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    CztGeom g;
+    if (!plan || !czt_pair_geom(P, g)) return GFX_EINVAL;
+    if (!ws || ws_bytes < (size_t)g.NFFT * sizeof(T2)) return GFX_ENOSPC;
+    const T2* tw = czt_twiddles<T>(st);
+    if (!tw || !czt_allow_lds(czt_rows_kernel<T, true>, Prec<T>::lds_bytes)) return GFX_ELAUNCH;
+    T2* cP = (T2*)plan;
+    T2* cQ = cP + g.P;
+    T2* mid = cQ + g.Q;
+    T2* spec = mid + g.P;
+    hipLaunchKernelGGL(czt_pair_mid_table_kernel<T>, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, mid, g.P, g.NFFT);
+    hipLaunchKernelGGL(czt_chirp_table_kernel<T>, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, cP, g.P, g.P, -1.0f);
+    hipLaunchKernelGGL(czt_chirp_table_kernel<T>, dim3((unsigned)((g.Q + 255) / 256)), dim3(256), 0, st, cQ, g.Q, g.Q, 1.0f);
+    T2* buf = (T2*)ws;
+    const ChirpSeq seqs[2] = {{g.P + g.K - 2, g.K - 1, g.P, 1.0}, {g.K - 1, g.Q + g.K - 2, g.Q, -1.0}};
+    for (int i = 0; i < 2; ++i) {
+        pair_cols_fwd<T, 2>(g, buf, 1, st, seqs[i]);
+        hipLaunchKernelGGL((czt_rows_kernel<T, true>), dim3((unsigned)g.C), dim3(TILE_T), Prec<T>::lds_bytes, st, buf,
+                           (const T2*)nullptr, spec + (int64_t)i * g.NFFT, g.C, tw);
+    }
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+template <typename T, int CC>
+static void pair_chain(const CztGeom& g, const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows,
+                       const typename Prec<T>::T2* cP, const typename Prec<T>::T2* cQ, const typename Prec<T>::T2* mid,
+                       const typename Prec<T>::T2* spec,
+                       typename Prec<T>::T2* buf, const typename Prec<T>::T2* tw, hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    constexpr int LDS = Prec<T>::lds_bytes;
+    constexpr bool FUSED = pair_mid_fused<T, CC>();
+    const int64_t pairs = (rows + 1) / 2;
+    const dim3 grid(TILE_M / 256, (unsigned)pairs), blk(256);
+    const unsigned tiles = (unsigned)(pairs * g.C);
+    hipLaunchKernelGGL((czt_pair_in_kernel<T, CC>), grid, blk, 0, st, z, cP, buf, g, rows);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec, (T2*)nullptr, g.C, tw);
+    hipLaunchKernelGGL((czt_pair_mid_kernel<T, CC, FUSED>), grid, blk, 0, st, buf, mid, g);
+    if constexpr (!FUSED)
+        hipLaunchKernelGGL((czt_cols_fwd_kernel<T, CC, 1>), grid, blk, 0, st, (const float*)nullptr, (const T2*)nullptr, buf, g,
+                           (int64_t)0, (int64_t)0, (int64_t)0, ChirpSeq{0, 0, 1, 1.0});
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec + g.NFFT, (T2*)nullptr, g.C, tw);
+    hipLaunchKernelGGL((czt_pair_out_kernel<T, CC>), grid, blk, 0, st, (const T2*)buf, cQ, y, ldy, lo, len, g, rows);
+}
+
+template <typename T>
+static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                          const void* plan, void* ws, size_t ws_bytes, void* stream, const gfx_rowmap_t* ymap = nullptr,
+                          int yC = 0, int64_t row0 = 0) {
+    using T2 = typename Prec<T>::T2;
+    CztGeom g;
+    if (!z || !y || !plan || rows <= 0 || rows > 131070 || !czt_pair_geom(P, g)) return GFX_EINVAL;
+    if (ymap) {
+        if (yC < 1 || row0 < 0 || ymap->inner <= 0 || ymap->inner > 0x7fffffffLL || (row0 + rows) / yC > 0x7fffffffLL)
+            return GFX_EINVAL;
+        g.yC = yC;
+        g.ymap = *ymap;
+        g.row0 = row0;
+    }
+    if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
+    const int64_t pairs = (rows + 1) / 2;
+    if (!ws || ws_bytes < (size_t)pairs * g.NFFT * sizeof(T2)) return GFX_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    const T2* tw = czt_twiddles<T>(st);
+    if (!tw || !czt_allow_lds(czt_rows_kernel<T, false>, Prec<T>::lds_bytes)) return GFX_ELAUNCH;
+    const T2* cP = (const T2*)plan;
+    const T2* cQ = cP + g.P;
+    const T2* mid = cQ + g.Q;
+    const T2* spec = mid + g.P;
+#define GFX_PC(CC) case CC: pair_chain<T, CC>(g, z, y, ldy, lo, len, rows, cP, cQ, mid, spec, (T2*)ws, tw, st); break;
+    switch (g.C) { GFX_CZT_PAIR_SIZES(GFX_PC) default: return GFX_EINVAL; }
+#undef GFX_PC
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+}  // namespace gfx
+
+using namespace gfx;
+
+extern "C" {
+
+size_t gfx_odd_alias_pair_plan_bytes(int64_t P) {
+    CztGeom g;
+    return czt_pair_geom(P, g) ? czt_pair_plan_t2(g) * sizeof(float2) : 0;
+}
+
+size_t gfx_odd_alias_pair_workspace_bytes(int64_t rows, int64_t P) {
+    CztGeom g;
+    if (rows <= 0 || !czt_pair_geom(P, g)) return 0;
+    return (size_t)((rows + 1) / 2) * g.NFFT * sizeof(float2);
+}
+
+int gfx_odd_alias_pair_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream) {
+    return czt_pair_plan<float>(plan, P, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gfx_odd_alias_pair_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                           const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    return czt_pair_alias<float>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream);
+}
+
+int gfx_odd_alias_pair_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo, int64_t len,
+                                int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    if (C < 1 || C > 0x7fffffffLL || (row0 & 1)) return GFX_EINVAL;
+    return czt_pair_alias<float>(z, y, len, lo, len, rows, P, plan, ws, ws_bytes, stream, &ymap, (int)C, row0);
+}
+
+size_t gfx_odd_alias_pair_precise_plan_bytes(int64_t P) { return 2 * gfx_odd_alias_pair_plan_bytes(P); }
+
+size_t gfx_odd_alias_pair_precise_workspace_bytes(int64_t rows, int64_t P) { return 2 * gfx_odd_alias_pair_workspace_bytes(rows, P); }
+
+int gfx_odd_alias_pair_precise_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream) {
+    return czt_pair_plan<double>(plan, P, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int gfx_odd_alias_pair_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                                   const void* plan, void* ws, size_t ws_bytes, void* stream) {
+    return czt_pair_alias<double>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

@@ -326,17 +326,29 @@ def odd_alias_supported(P):
     return lib().gfx_odd_alias_plan_bytes(P) > 0
 
 
-def _alias_fns(precise):
-    """(plan_bytes, workspace_bytes, plan, forward, adjoint) of the fp32 or the double-precision transforms."""
-    L, tag = lib(), "gfx_odd_alias_precise_" if precise else "gfx_odd_alias_"
+# Two real rows per complex chirp-z transform (csrc/czt_pair.hip) in odd_alias's forward calls: a third fewer bytes
+# through every pass.  GRAFX_ALIAS_PAIRS=0 keeps one transform per row (round 4's path; also what rows beyond
+# P = 258 048 and every adjoint take).
+ALIAS_PAIRS = os.environ.get("GRAFX_ALIAS_PAIRS", "1") != "0"
+
+
+def _alias_fns(precise, pairs=False):
+    """(plan_bytes, workspace_bytes, plan, forward, adjoint, tag) of the fp32 or the double-precision transforms; ``pairs``:
+    the two-rows-per-transform forms (forward only: adjoint is None)."""
+    L, tag = lib(), "gfx_odd_alias_" + ("pair_" if pairs else "") + ("precise_" if precise else "")
     return (getattr(L, tag + "plan_bytes"), getattr(L, tag + "workspace_bytes"), getattr(L, tag + "plan_f32"),
-            getattr(L, tag + "f32"), getattr(L, tag + "adjoint_f32"), tag)
+            getattr(L, tag + "f32"), None if pairs else getattr(L, tag + "adjoint_f32"), tag)
 
 
-def _alias_plan(P, device, precise=False):
+def _alias_pairs(P, rows):
+    """Whether a forward call of `rows` rows of length P goes two rows per transform."""
+    return ALIAS_PAIRS and rows >= 2 and lib().gfx_odd_alias_pair_plan_bytes(P) > 0
+
+
+def _alias_plan(P, device, precise=False, pairs=False):
     """The per-P chirp plan of the aliasing kernels (LRU of _ALIAS_PLANS_MAX, built on first use)."""
-    plan_bytes, ws_bytes, build, _, _, tag = _alias_fns(precise)
-    key = (P, device.type, device.index, bool(precise))
+    plan_bytes, ws_bytes, build, _, _, tag = _alias_fns(precise, pairs)
+    key = (P, device.type, device.index, bool(precise), bool(pairs))
     plan = _ALIAS_PLANS.pop(key, None)
     if plan is not None:
         _ALIAS_PLANS[key] = plan   # back in as the most recent
@@ -371,19 +383,22 @@ def set_alias_workspace_cap(nbytes):
     return old
 
 
-def _alias_chunks(rows, P, rows_per_chunk, device, precise):
-    ws_bytes = _alias_fns(precise)[1]
+def _alias_chunks(rows, P, rows_per_chunk, device, precise, pairs=False):
+    ws_bytes = _alias_fns(precise, pairs)[1]
     cap = ALIAS_WS_CAP
     if not torch.cuda.is_current_stream_capturing():
         cap = min(cap, max(torch.cuda.mem_get_info(device)[0] // 4, 1))
-    chunk = max(1, min(rows, rows_per_chunk, cap // ws_bytes(1, P)))
+    unit = 2 if pairs else 1            # chunks of whole pairs: row 2r stays with row 2r + 1
+    chunk = max(unit, min(rows, rows_per_chunk, unit * (cap // ws_bytes(unit, P))) // unit * unit)
+    if chunk >= rows:
+        chunk = rows
     while True:
         try:
             return chunk, torch.empty(ws_bytes(chunk, P), dtype=torch.uint8, device=device)
         except torch.OutOfMemoryError:
-            if chunk == 1:
+            if chunk <= unit:
                 raise
-            chunk = max(1, chunk // 2)
+            chunk = max(unit, chunk // 2 // unit * unit)
 
 
 @_on_device
@@ -396,11 +411,12 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False, out=None
     P = z.shape[-1]
     Q = P - 1
     length = Q - lo if length is None else length
-    plan = _alias_plan(P, z.device, precise)
-    fwd, tag = _alias_fns(precise)[3], _alias_fns(precise)[5]
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
-    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise)
+    pairs = _alias_pairs(P, rows)
+    plan = _alias_plan(P, z.device, precise, pairs)
+    fwd, tag = _alias_fns(precise, pairs)[3], _alias_fns(precise, pairs)[5]
+    chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise, pairs)
     if out is not None:
         # ``out``: a (R, C, length) tensor or a strided (B, n, C, length) view whose rows, channels flattened, are z's
         # rows: the last column pass writes them in place (gfx_odd_alias_rows_f32; float transforms only)
@@ -408,16 +424,19 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False, out=None
         omap, Ro, Co, Lo = rowmap(out)
         if precise or Ro * Co != rows or Lo != length:
             raise ValueError(f"odd_alias: out {tuple(out.shape)} does not take {rows} rows of {length} samples")
-        name = "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel<float>"
+        name = ("czt_pair_in_kernel+czt_rows_kernel+czt_pair_mid_kernel+czt_pair_out_kernel<float>" if pairs
+                else "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel<float>")
+        rows_fn = lib().gfx_odd_alias_pair_rows_f32 if pairs else lib().gfx_odd_alias_rows_f32
         for i in range(0, rows, chunk):
             n = min(chunk, rows - i)
             with _timed(name, 4 * n * (P + length)):
-                check(lib().gfx_odd_alias_rows_f32(_ptr(flat[i : i + n]), _ptr(out), omap, Co, i, lo, length, n, P, _ptr(plan),
-                                                   _ptr(ws), ws.numel(), _stream()), "gfx_odd_alias_rows_f32")
+                check(rows_fn(_ptr(flat[i : i + n]), _ptr(out), omap, Co, i, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
+                              _stream()), tag + "rows_f32")
         return out
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
     # one record per chunk: the column / tile / column passes of the two chirp-z transforms (czt.hip), read z + write y
-    name = "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel" + ("<double>" if precise else "<float>")
+    name = (("czt_pair_in_kernel+czt_rows_kernel+czt_pair_mid_kernel+czt_pair_out_kernel" if pairs
+             else "czt_cols_fwd_kernel+czt_rows_kernel+czt_cols_inv_kernel") + ("<double>" if precise else "<float>"))
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
         with _timed(name, 4 * n * (P + length)):

@@ -191,6 +191,27 @@ int gfx_odd_alias_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo,
                               const void* plan, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_precise_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, int64_t len, float* gz, int64_t rows,
                                       int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream);
+/* The forward maps with TWO real rows per complex transform (csrc/czt_pair.hip): the pair z1 + i z2 goes through the
+ * two chirp-z transforms as one complex row with the spectrum kept on both sides (P bins) and comes out as
+ * A z1 + i A z2 -- 2P - 1 points per pair instead of (3P - 1) / 2 per row, a third fewer bytes through each of the same
+ * passes.  Rows 2r and 2r + 1 of a call form a pair (an odd row count leaves the last row alone); each row's rounding error
+ * scales with the larger row of its pair.  3 <= P <= 258 048 odd, else the size queries return 0 and the calls
+ * GFX_EINVAL (use the one-row forms above); own plan (gfx_odd_alias_pair_plan_f32, workspace of
+ * gfx_odd_alias_pair_workspace_bytes(1, P)) and workspace (gfx_odd_alias_pair_workspace_bytes(rows, P)); rows <= 131070 per
+ * call; for gfx_odd_alias_pair_rows_f32 row0 must be even.  The `precise` forms carry the transforms in double (plan and
+ * workspace twice the size).  Same results as the one-row forms up to rounding (tests/test_gpu_odd_alias_pair.py). */
+size_t gfx_odd_alias_pair_plan_bytes(int64_t P);
+size_t gfx_odd_alias_pair_workspace_bytes(int64_t rows, int64_t P);
+int gfx_odd_alias_pair_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_pair_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                           const void* plan, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_pair_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo, int64_t len,
+                                int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream);
+size_t gfx_odd_alias_pair_precise_plan_bytes(int64_t P);
+size_t gfx_odd_alias_pair_precise_workspace_bytes(int64_t rows, int64_t P);
+int gfx_odd_alias_pair_precise_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_pair_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                                   const void* plan, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- small inverse real DFT (parameter-side front-ends) ---------------------------------------
  * y = irfft(X, n) for any n <= 8192 as a direct sum (twiddles tabulated in LDS), K = n/2 + 1 bins per row, X complex

@@ -1,0 +1,141 @@
+"""Two real rows per complex chirp-z transform (csrc/czt_pair.hip) against torch.fft in float64 and against the one-row
+transforms of czt.hip (reference: core/convolution.py:119-134, y = irfft_{P-1}(rfft_P(z))).
+
+ops.odd_alias takes this form by default for calls of two rows or more (P <= 258 048), so tests/test_gpu_odd_alias.py and
+every compat-length processor test run on it too; here: every tile count of the pair form, odd row counts (the last row
+alone in its transform), rows of very different size in one pair, slices, strided in-place output, the double-precision
+form, and the switch back to one transform per row."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _want(z):
+    return torch.fft.irfft(torch.fft.rfft(z.double()))
+
+
+def _one_row_form(fn):
+    from grafx_amd import ops
+
+    old = ops.ALIAS_PAIRS
+    ops.ALIAS_PAIRS = False
+    try:
+        return fn()
+    finally:
+        ops.ALIAS_PAIRS = old
+
+
+# P just below / above each boundary 2P - 1 = C x 8192 of the pair form's tile counts (C = 1 .. 63 with factors <= 7)
+PAIR_SIZES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 15, 16, 18, 20, 21, 24, 25, 27, 28, 30, 32, 35, 36, 40, 42, 45, 48, 49, 50,
+              54, 56, 60, 63]
+
+
+@pytest.mark.parametrize("C", PAIR_SIZES)
+def test_every_tile_count_of_the_pair_form(C):
+    from grafx_amd import ops
+    from grafx_amd._lib import lib
+
+    P = (C * 8192 + 1) // 2                     # the largest P with 2P - 1 <= C x 8192 ...
+    P -= 1 - (P & 1)                            # ... that is odd
+    assert lib().gfx_odd_alias_pair_workspace_bytes(2, P) == C * 8192 * 8, (C, P)
+    torch.manual_seed(C)
+    z = torch.randn(5, P, device="cuda")        # an odd row count: two pairs and a single
+    got = ops.odd_alias(z)
+    want = _want(z)
+    err = (got.double() - want).abs().max() / want.abs().max()
+    assert err <= 3e-6, f"C={C} P={P}: {err:.2e}"
+    single = _one_row_form(lambda: ops.odd_alias(z))
+    assert (got - single).abs().max() <= 3e-6 * single.abs().max()
+
+
+@pytest.mark.parametrize("P", [3, 5, 7, 101, 4001, 8191, 8193, 135071, 147455, 191071, 258047])
+def test_pairs_match_float64_fft_and_slices_are_bit_equal(P):
+    from grafx_amd import ops
+
+    torch.manual_seed(P)
+    z = torch.randn(3, 2, P, device="cuda")
+    got = ops.odd_alias(z)
+    want = _want(z)
+    assert got.shape == want.shape
+    err = (got.double() - want).abs().max() / want.abs().max()
+    assert err <= 3e-6, f"P={P}: {err:.2e}"
+    lo, n = P // 3, max(1, P // 5)
+    assert torch.equal(ops.odd_alias(z, lo, n), got[..., lo : lo + n])
+
+
+def test_longer_rows_fall_back_to_one_transform_per_row():
+    from grafx_amd import ops
+    from grafx_amd._lib import lib
+
+    P = 258049
+    assert lib().gfx_odd_alias_pair_plan_bytes(P) == 0 and lib().gfx_odd_alias_pair_plan_bytes(P - 2) > 0
+    assert lib().gfx_odd_alias_pair_plan_bytes(4000) == 0              # even lengths do not alias
+    torch.manual_seed(0)
+    z = torch.randn(2, P, device="cuda")
+    got = ops.odd_alias(z)
+    want = _want(z)
+    assert (got.double() - want).abs().max() / want.abs().max() <= 3e-6
+
+
+def test_a_loud_and_a_quiet_row_in_one_pair():
+    """Each row's error scales with the LARGER row of its pair (one complex transform carries both): a row 1e-3 as loud as
+    its partner keeps a relative error of eps x 1e3, which the callers' per-call tolerance (1e-5 of the call's peak)
+    covers -- stated here as what it is."""
+    from grafx_amd import ops
+
+    P = 135071
+    torch.manual_seed(1)
+    z = torch.randn(2, P, device="cuda")
+    z[1] *= 1e-3
+    got = ops.odd_alias(z)
+    want = _want(z)
+    assert (got[0].double() - want[0]).abs().max() <= 3e-6 * want[0].abs().max()
+    assert (got[1].double() - want[1]).abs().max() <= 3e-6 * want[0].abs().max()      # (of the pair's peak)
+    alone = _one_row_form(lambda: ops.odd_alias(z))
+    assert (alone[1].double() - want[1]).abs().max() <= 3e-6 * want[1].abs().max()    # one row per transform: of its own
+
+
+@pytest.mark.parametrize("P", [101, 135071, 147455])
+def test_precise_pairs_are_float64_accurate(P):
+    """The double-precision form (the energy envelope's): fp32 rounding of the output only, even across a pair whose rows
+    differ by 1e4 in size."""
+    from grafx_amd import ops
+
+    torch.manual_seed(P)
+    z = torch.randn(7, P, device="cuda").abs()
+    z[1] *= 1e-4
+    got = ops.odd_alias(z, precise=True)
+    want = _want(z)
+    for r in range(z.shape[0]):
+        assert (got[r].double() - want[r]).abs().max() <= 1.5e-7 * want[r].abs().max(), r
+    lo, n = P // 4, P // 2
+    assert torch.equal(ops.odd_alias(z, lo, n, precise=True), got[..., lo : lo + n])
+
+
+@pytest.mark.parametrize("P,C", [(4001, 2), (135071, 2), (9001, 1), (9001, 3)])
+def test_pairs_write_strided_buffer_rows_in_place(P, C):
+    """gfx_odd_alias_pair_rows_f32: rows 2r, 2r + 1 of the call -> row q / C, channel q % C of a strided (B, n, C, len) view
+    (the render's signal buffer); odd C makes pairs straddle signal rows; chunks keep pairs whole."""
+    from grafx_amd import ops
+
+    B, V, n, L = 2, 5, 3, P - 1 - 7
+    torch.manual_seed(P + C)
+    buf = torch.zeros(B, V, C, L, device="cuda")
+    view = buf[:, 1 : 1 + n]
+    z = torch.randn(B * n * C, P, device="cuda")
+    ops.odd_alias(z, 3, L, out=view, rows_per_chunk=4)
+    want = ops.odd_alias(z, 3, L).view(B, n, C, L)
+    assert torch.equal(view, want)
+    assert float(buf[:, 0].abs().max()) == 0.0 and float(buf[:, 1 + n :].abs().max()) == 0.0
+
+
+def test_chunked_calls_give_the_same_bits():
+    from grafx_amd import ops
+
+    P = 20001
+    torch.manual_seed(2)
+    z = torch.randn(11, P, device="cuda")
+    whole = ops.odd_alias(z)
+    for per in (2, 3, 4, 10):
+        assert torch.equal(ops.odd_alias(z, rows_per_chunk=per), whole), per
