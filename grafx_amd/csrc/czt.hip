@@ -33,18 +33,6 @@ namespace gfx {
 //   forward:  sub[k3][n'] = ( sum_n3 x[n3 NS + n'] W_4^(n3 k3) ) W_NFFT^(n' k3)      then four NS-point transforms
 //   inverse:  x[n3 NS + n'] = (1/4) sum_k3 ( sub[k3][n'] conj W_NFFT^(n' k3) ) W_4^(-n3 k3)
 // in place (a thread owns the four positions n' + n3 NS).  Input / output modes as in the column kernels.
-template <typename T>
-__device__ __forceinline__ typename Prec<T>::cxt outer_twiddle(int64_t np, int k3, int64_t NFFT, bool conj) {
-    // W_NFFT^(np k3), np k3 < NFFT <= 2^24
-    if constexpr (sizeof(T) == 4) {
-        return unit_root_f((int)(np * k3), (int)NFFT, conj);
-    } else {
-        double s, c;
-        sincospi(2.0 * (double)(np * k3) / (double)NFFT, &s, &c);
-        return cxd{c, conj ? s : -s};
-    }
-}
-
 template <typename T, int MODE>   // 0: real rows times a chirp table; 1: complex buffer; 2: a chirp sequence (plan)
 __global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restrict__ z,
                                                            const typename Prec<T>::T2* __restrict__ tab,
@@ -251,6 +239,33 @@ static int czt_plan(void* plan, int64_t P, void* ws, size_t ws_bytes, hipStream_
                            (const T2*)nullptr, spec + (int64_t)i * g.NFFT, ctot, tw);
     }
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+// what czt_pair.hip shares with this file when its transforms need outer levels (declared in czt_core.hpp)
+template <typename T>
+static void czt_chirp_spectrum(const CztGeom& g, ChirpSeq cs, typename Prec<T>::T2* buf, typename Prec<T>::T2* spec,
+                               const typename Prec<T>::T2* tw, hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    const int ctot = g.S * g.C;
+    hipLaunchKernelGGL((czt_outer_fwd_kernel<T, 2>), dim3((unsigned)(g.NFFT / 4 / 256), 1), dim3(256), 0, st, (const float*)nullptr,
+                       (const T2*)nullptr, buf, g, (int64_t)0, (int64_t)0, (int64_t)0, cs);
+    czt_inner_fwd<T>(g, buf, 1, st);
+    hipLaunchKernelGGL((czt_rows_kernel<T, true>), dim3((unsigned)ctot), dim3(TILE_T), Prec<T>::lds_bytes, st, buf,
+                       (const T2*)nullptr, spec, ctot, tw);
+}
+void czt_levels_fwd(const CztGeom& g, float2* buf, int64_t rows, hipStream_t st) { czt_inner_fwd<float>(g, buf, rows, st); }
+void czt_levels_fwd(const CztGeom& g, double2* buf, int64_t rows, hipStream_t st) { czt_inner_fwd<double>(g, buf, rows, st); }
+void czt_levels_inv(const CztGeom& g, float2* buf, int64_t rows, hipStream_t st) {
+    czt_inner_inv<float>(g, buf, nullptr, nullptr, rows, st);
+}
+void czt_levels_inv(const CztGeom& g, double2* buf, int64_t rows, hipStream_t st) {
+    czt_inner_inv<double>(g, buf, nullptr, nullptr, rows, st);
+}
+void czt_levels_chirp_spectrum(const CztGeom& g, ChirpSeq cs, float2* buf, float2* spec, const float2* tw, hipStream_t st) {
+    czt_chirp_spectrum<float>(g, cs, buf, spec, tw, st);
+}
+void czt_levels_chirp_spectrum(const CztGeom& g, ChirpSeq cs, double2* buf, double2* spec, const double2* tw, hipStream_t st) {
+    czt_chirp_spectrum<double>(g, cs, buf, spec, tw, st);
 }
 
 // The two chirp-z transforms of one direction: rows of `in` (slice [ilo, ilo + ilen) of the first grid, times tab1) ->

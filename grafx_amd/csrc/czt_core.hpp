@@ -295,6 +295,30 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
     }
 }
 
+// ---- outer radix-4 levels (NFFT = 4 NS, n = n3 NS + n', k = k3 + 4 k'): the twiddle W_NFFT^(n' k3) --------------------
+template <typename T>
+__device__ __forceinline__ typename Prec<T>::cxt outer_twiddle(int64_t np, int k3, int64_t NFFT, bool conj) {
+    // W_NFFT^(np k3), np k3 < NFFT <= 2^24
+    if constexpr (sizeof(T) == 4) {
+        return unit_root_f((int)(np * k3), (int)NFFT, conj);
+    } else {
+        double s, c;
+        sincospi(2.0 * (double)(np * k3) / (double)NFFT, &s, &c);
+        return cxd{c, conj ? s : -s};
+    }
+}
+
+// the passes below the outermost level of a transform with outer levels (g.levels >= 1), in place on `rows` buffers of
+// g.NFFT points: inner radix-4 levels and the column pass (forward), the inverse column pass and the inner levels
+// (inverse, scaled by 4^(levels-1) / NFFT: the outermost level's 1/4 is the caller's); and a chirp sequence's spectrum
+// in the tile pass's layout.  Defined in czt.hip.
+void czt_levels_fwd(const CztGeom& g, float2* buf, int64_t rows, hipStream_t st);
+void czt_levels_fwd(const CztGeom& g, double2* buf, int64_t rows, hipStream_t st);
+void czt_levels_inv(const CztGeom& g, float2* buf, int64_t rows, hipStream_t st);
+void czt_levels_inv(const CztGeom& g, double2* buf, int64_t rows, hipStream_t st);
+void czt_levels_chirp_spectrum(const CztGeom& g, ChirpSeq cs, float2* buf, float2* spec, const float2* tw, hipStream_t st);
+void czt_levels_chirp_spectrum(const CztGeom& g, ChirpSeq cs, double2* buf, double2* spec, const double2* tw, hipStream_t st);
+
 template <typename K>
 static bool czt_allow_lds(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==

@@ -14,8 +14,9 @@
 // position n + (K - 1): both chirp kernels span 2P - 1 points and NFFT = C x 8192 >= 2P - 1 is enough (no wrapped term
 // reaches a position that is read).  Against one transform per row that is 2P - 1 points per PAIR instead of
 // 2 x (3P - 1) / 2: a third fewer bytes through every pass (P = 135 071: 35 tiles per pair against 2 x 25), for the same
-// five passes.  C <= 63 tiles (P <= 258 048: 5.4 s of audio at 48 kHz); longer rows stay on czt.hip, and so does the
-// adjoint.  The rounding error of a row now carries eps times the LARGER of the two rows -- the callers pair neighbouring
+// five passes.  Up to 63 tiles in one column pass (P <= 258 048: 5.4 s of audio at 48 kHz); longer rows take outer radix-4
+// levels around czt.hip's column passes of up to 32 tiles, as there (2P - 1 <= 2^24: P <= 8 388 607); the adjoint stays on
+// czt.hip.  The rounding error of a row now carries eps times the LARGER of the two rows -- the callers pair neighbouring
 // rows of one call (the two channels of a stereo signal, or neighbouring tracks' envelopes in double precision).
 #include <hip/hip_runtime.h>
 
@@ -45,29 +46,42 @@ static inline bool czt_pair_geom(int64_t P, CztGeom& g) {
     g.Q = P - 1;
     g.K = (P + 1) / 2;
     const int64_t tiles = (2 * P - 1 + TILE_M - 1) / TILE_M;
-    if (tiles > CZT_PAIR_MAXC) return false;
-    int C = (int)tiles;
-    while (!sd_supported(C) || C == 64) ++C;      // (63 = 3 * 3 * 7 is supported: the loop ends at or below it)
+    // up to 63 tiles in one column pass; beyond, outer radix-4 levels around sub-transforms of C <= 32 tiles as in czt.hip
+    // (the column kernels of that size range are czt.hip's)
     g.levels = 0;
-    g.S = 1;
+    int64_t per = tiles;
+    if (tiles > CZT_PAIR_MAXC)
+        while (per > CZT_MAXC) {
+            per = (per + 3) / 4;
+            ++g.levels;
+        }
+    if (g.levels > CZT_MAX_LEVELS) return false;
+    int C = (int)per;
+    while (!sd_supported(C) || C == 64) ++C;      // (63 = 3 * 3 * 7 and 32 are supported: the loop ends at or below them)
+    g.S = 1 << (2 * g.levels);
     g.C = C;
-    g.NFFT = (int64_t)C * TILE_M;
+    g.NFFT = (int64_t)g.S * C * TILE_M;
     return true;
 }
 
 // plan layout (T2 units): cP[P] | cQ[Q] | mid[P] | spectrum of bP over [-(P + K - 2), K - 1] | spectrum of bQ over
-// [-(K - 1), Q + K - 2];  mid[i] = cP[|k'|] cQ[|k'|] w_k' / NFFT for the bin k' = i - (K - 1) stored at position i
+// [-(K - 1), Q + K - 2];  mid[i] = cP[|k'|] cQ[|k'|] w_k' for the bin k' = i - (K - 1) stored at position i (times
+// 1 / NFFT when the transform has no outer levels: its inverse column pass leaves the scaling to this table)
 static inline size_t czt_pair_plan_t2(const CztGeom& g) { return (size_t)(g.P + g.Q + g.P + 2 * g.NFFT); }
 
 template <typename T>
-__global__ void czt_pair_mid_table_kernel(typename Prec<T>::T2* __restrict__ mid, int64_t P, int64_t NFFT) {
+__global__ void czt_pair_mid_table_kernel(typename Prec<T>::T2* __restrict__ mid, int64_t P, double scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const int64_t off = (P - 1) / 2, kp = i - off, a = kp < 0 ? -kp : kp;
     const double2 p = chirp_d<double>(a, P, -1.0), q = chirp_d<double>(a, P - 1, 1.0);
-    const double w = (a == off ? 0.5 : 1.0) / (double)NFFT;
+    const double w = (a == off ? 0.5 : 1.0) * scale;
     mid[i] = Prec<T>::make((T)((p.x * q.x - p.y * q.y) * w), (T)((p.x * q.y + p.y * q.x) * w));
 }
+
+// the instruction scheduler may not move anything across this point: keeps the loads and twiddles of the NEXT phase of a
+// column kernel from being hoisted above the C-point transform, where they would be live on top of the column itself
+__device__ __forceinline__ void pair_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // first column pass: (z1[m] + i z2[m]) cP[m] at position m + K - 1, zero elsewhere
 template <typename T, int C>
@@ -103,10 +117,13 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
     }
 }
 
+// (launch bounds of the two kernels below, measured at 4096 rows, tools/alias_bench.py: in float two workgroups per CU with a
+// few spilled registers beat one without -- 13.8 against 15.6 ms at P = 135 071; in double it is the other way round, 14.6
+// against 15.3 ms per 2048 rows, and 20.0 against 27.6 at 48 tiles)
 // between the convolutions: the inverse column pass of the first, the bins' factors mid[i] (zero beyond the P bins), and
 // -- FUSED -- the forward column pass of the second
 template <typename T, int C, bool FUSED>
-__global__ __launch_bounds__(256, 2) void czt_pair_mid_kernel(typename Prec<T>::T2* __restrict__ buf,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kernel(typename Prec<T>::T2* __restrict__ buf,
                                                           const typename Prec<T>::T2* __restrict__ mid, CztGeom g) {
     using cx = typename Prec<T>::cxt;
     const int n2 = blockIdx.x * 256 + threadIdx.x;
@@ -118,7 +135,9 @@ __global__ __launch_bounds__(256, 2) void czt_pair_mid_kernel(typename Prec<T>::
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
+    pair_sched_fence();
     col_dft<C, true>(v);
+    pair_sched_fence();   // (the factors' loads and the next pass's twiddles stay behind the transform: they would be live across it)
     if constexpr (FUSED) {
         cx u[C];
 #pragma unroll
@@ -126,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void czt_pair_mid_kernel(typename Prec<T>::
             const int64_t i = (int64_t)n1 * TILE_M + n2;
             u[n1] = i < g.P ? cmul(v[spos(C, n1)], to_cx(mid[i])) : cx{0, 0};
         }
+        pair_sched_fence();
         col_dft<C, false>(u);
+        pair_sched_fence();
         ColTw<T> twf(n2, (int)g.NFFT, false);
 #pragma unroll
         for (int k1 = 0; k1 < C; ++k1) {
@@ -147,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void czt_pair_mid_kernel(typename Prec<T>::
 // last column pass: v[n] = conv[n + K - 1] cQ[n] / (NFFT Q) for lo <= n < lo + len; real part to the pair's first row,
 // imaginary part to its second
 template <typename T, int C>
-__global__ __launch_bounds__(256, 2) void czt_pair_out_kernel(const typename Prec<T>::T2* __restrict__ buf,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_out_kernel(const typename Prec<T>::T2* __restrict__ buf,
                                                           const typename Prec<T>::T2* __restrict__ cQ, float* __restrict__ y,
                                                           int64_t ldy, int64_t lo, int64_t len, CztGeom g, int64_t rows) {
     using cx = typename Prec<T>::cxt;
@@ -163,7 +184,9 @@ __global__ __launch_bounds__(256, 2) void czt_pair_out_kernel(const typename Pre
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
+    pair_sched_fence();
     col_dft<C, true>(v);
+    pair_sched_fence();
     const T sc = (T)1 / ((T)g.NFFT * (T)g.Q);
     float* y1 = czt_out_row(g, y, ldy, 2 * pr);
     float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
@@ -176,6 +199,123 @@ __global__ __launch_bounds__(256, 2) void czt_pair_out_kernel(const typename Pre
             if (two) y2[n - lo] = (float)o.y;
         }
     }
+}
+
+// ---- transforms with outer radix-4 levels (more than 63 tiles per pair): the outermost level's three passes in pair form;
+// the levels below and the column passes are czt.hip's (czt_levels_fwd / czt_levels_inv) ---------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void czt_pair_outer_in_kernel(const float* __restrict__ z, const typename Prec<T>::T2* __restrict__ cP,
+                                                               typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t rows) {
+    using cx = typename Prec<T>::cxt;
+    const int64_t NS = g.NFFT / 4;
+    const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pr = blockIdx.y;
+    typename Prec<T>::T2* b = buf + pr * g.NFFT;
+    const int64_t off = g.K - 1;
+    const bool two = 2 * pr + 1 < rows;
+    const float* z1 = z + 2 * pr * g.P;
+    const float* z2 = z1 + (two ? g.P : 0);
+    cx v[4];
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) {
+        const int64_t m = n3 * NS + np - off;
+        cx e = {0, 0};
+        if (m >= 0 && m < g.P) {
+            const cx c = to_cx(cP[m]);
+            const T a = (T)z1[m], bb = two ? (T)z2[m] : (T)0;
+            e = cx{c.x * a - c.y * bb, c.x * bb + c.y * a};
+        }
+        v[n3] = e;
+    }
+    dif<4, false>(v);
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const cx e = v[brev(k3, 2)];
+        const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
+        b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void czt_pair_outer_mid_kernel(typename Prec<T>::T2* __restrict__ buf,
+                                                                const typename Prec<T>::T2* __restrict__ mid, CztGeom g) {
+    using cx = typename Prec<T>::cxt;
+    const int64_t NS = g.NFFT / 4;
+    const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    typename Prec<T>::T2* b = buf + (int64_t)blockIdx.y * g.NFFT;
+    cx v[4], u[4];
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const cx e = to_cx(b[k3 * NS + np]);
+        v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
+    }
+    dif<4, true>(v);
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) {
+        const int64_t i = n3 * NS + np;
+        u[n3] = i < g.P ? cmul(v[brev(n3, 2)] * (T)0.25, to_cx(mid[i])) : cx{0, 0};
+    }
+    dif<4, false>(u);
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const cx e = u[brev(k3, 2)];
+        const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
+        b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void czt_pair_outer_out_kernel(const typename Prec<T>::T2* __restrict__ buf,
+                                                                const typename Prec<T>::T2* __restrict__ cQ, float* __restrict__ y,
+                                                                int64_t ldy, int64_t lo, int64_t len, CztGeom g, int64_t rows) {
+    using cx = typename Prec<T>::cxt;
+    const int64_t NS = g.NFFT / 4;
+    const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pr = blockIdx.y;
+    const typename Prec<T>::T2* b = buf + pr * g.NFFT;
+    const int64_t off = g.K - 1;
+    const bool two = 2 * pr + 1 < rows;
+    cx v[4];
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) {
+        const cx e = to_cx(b[k3 * NS + np]);
+        v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
+    }
+    dif<4, true>(v);
+    const T sc = (T)0.25 / (T)g.Q;
+    float* y1 = czt_out_row(g, y, ldy, 2 * pr);
+    float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) {
+        const int64_t n = n3 * NS + np - off;
+        if (n >= lo && n < lo + len) {
+            const cx o = cmul(v[brev(n3, 2)], to_cx(cQ[n])) * sc;
+            y1[n - lo] = (float)o.x;
+            if (two) y2[n - lo] = (float)o.y;
+        }
+    }
+}
+
+template <typename T>
+static void pair_chain_levels(const CztGeom& g, const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows,
+                              const typename Prec<T>::T2* cP, const typename Prec<T>::T2* cQ, const typename Prec<T>::T2* mid,
+                              const typename Prec<T>::T2* spec, typename Prec<T>::T2* buf, const typename Prec<T>::T2* tw,
+                              hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    constexpr int LDS = Prec<T>::lds_bytes;
+    const int64_t pairs = (rows + 1) / 2;
+    const dim3 og((unsigned)(g.NFFT / 4 / 256), (unsigned)pairs), blk(256);
+    const int ctot = g.S * g.C;
+    const unsigned tiles = (unsigned)(pairs * ctot);
+    hipLaunchKernelGGL((czt_pair_outer_in_kernel<T>), og, blk, 0, st, z, cP, buf, g, rows);
+    czt_levels_fwd(g, buf, pairs, st);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec, (T2*)nullptr, ctot, tw);
+    czt_levels_inv(g, buf, pairs, st);
+    hipLaunchKernelGGL((czt_pair_outer_mid_kernel<T>), og, blk, 0, st, buf, mid, g);
+    czt_levels_fwd(g, buf, pairs, st);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec + g.NFFT, (T2*)nullptr, ctot, tw);
+    czt_levels_inv(g, buf, pairs, st);
+    hipLaunchKernelGGL((czt_pair_outer_out_kernel<T>), og, blk, 0, st, (const T2*)buf, cQ, y, ldy, lo, len, g, rows);
 }
 
 template <typename T, int MODE>
@@ -200,12 +340,17 @@ static int czt_pair_plan(void* plan, int64_t P, void* ws, size_t ws_bytes, hipSt
     T2* cQ = cP + g.P;
     T2* mid = cQ + g.Q;
     T2* spec = mid + g.P;
-    hipLaunchKernelGGL(czt_pair_mid_table_kernel<T>, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, mid, g.P, g.NFFT);
+    hipLaunchKernelGGL(czt_pair_mid_table_kernel<T>, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, mid, g.P,
+                       g.levels == 0 ? 1.0 / (double)g.NFFT : 1.0);
     hipLaunchKernelGGL(czt_chirp_table_kernel<T>, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, st, cP, g.P, g.P, -1.0f);
     hipLaunchKernelGGL(czt_chirp_table_kernel<T>, dim3((unsigned)((g.Q + 255) / 256)), dim3(256), 0, st, cQ, g.Q, g.Q, 1.0f);
     T2* buf = (T2*)ws;
     const ChirpSeq seqs[2] = {{g.P + g.K - 2, g.K - 1, g.P, 1.0}, {g.K - 1, g.Q + g.K - 2, g.Q, -1.0}};
     for (int i = 0; i < 2; ++i) {
+        if (g.levels > 0) {
+            czt_levels_chirp_spectrum(g, seqs[i], buf, spec + (int64_t)i * g.NFFT, tw, st);
+            continue;
+        }
         pair_cols_fwd<T, 2>(g, buf, 1, st, seqs[i]);
         hipLaunchKernelGGL((czt_rows_kernel<T, true>), dim3((unsigned)g.C), dim3(TILE_T), Prec<T>::lds_bytes, st, buf,
                            (const T2*)nullptr, spec + (int64_t)i * g.NFFT, g.C, tw);
@@ -240,13 +385,12 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
                           int yC = 0, int64_t row0 = 0) {
     using T2 = typename Prec<T>::T2;
     CztGeom g;
-    if (!z || !y || !plan || rows <= 0 || rows > 131070 || !czt_pair_geom(P, g)) return GFX_EINVAL;
+    if (!z || !y || !plan || rows <= 0 || !czt_pair_geom(P, g)) return GFX_EINVAL;
     if (ymap) {
         if (yC < 1 || row0 < 0 || ymap->inner <= 0 || ymap->inner > 0x7fffffffLL || (row0 + rows) / yC > 0x7fffffffLL)
             return GFX_EINVAL;
         g.yC = yC;
         g.ymap = *ymap;
-        g.row0 = row0;
     }
     if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
     const int64_t pairs = (rows + 1) / 2;
@@ -258,9 +402,21 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
     const T2* cQ = cP + g.P;
     const T2* mid = cQ + g.Q;
     const T2* spec = mid + g.P;
-#define GFX_PC(CC) case CC: pair_chain<T, CC>(g, z, y, ldy, lo, len, rows, cP, cQ, mid, spec, (T2*)ws, tw, st); break;
-    switch (g.C) { GFX_CZT_PAIR_SIZES(GFX_PC) default: return GFX_EINVAL; }
+    const int64_t step = 65535 / g.S;        // pairs * S sub-transforms ride on a grid dimension
+    for (int64_t p0 = 0; p0 < pairs; p0 += step) {
+        const int64_t n = rows - 2 * p0 < 2 * step ? rows - 2 * p0 : 2 * step;   // rows of this launch chain
+        const float* zc = z + 2 * p0 * g.P;
+        float* yc = ymap ? y : y + 2 * p0 * ldy;
+        T2* buf = (T2*)ws + p0 * g.NFFT;
+        g.row0 = row0 + 2 * p0;
+        if (g.levels > 0) {
+            pair_chain_levels<T>(g, zc, yc, ldy, lo, len, n, cP, cQ, mid, spec, buf, tw, st);
+            continue;
+        }
+#define GFX_PC(CC) case CC: pair_chain<T, CC>(g, zc, yc, ldy, lo, len, n, cP, cQ, mid, spec, buf, tw, st); break;
+        switch (g.C) { GFX_CZT_PAIR_SIZES(GFX_PC) default: return GFX_EINVAL; }
 #undef GFX_PC
+    }
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 
@@ -269,6 +425,8 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
 using namespace gfx;
 
 extern "C" {
+
+#ifndef GFX_CZT_PAIR_F64   // this file compiles the float transforms; czt_pair_f64.hip includes it for the double ones
 
 size_t gfx_odd_alias_pair_plan_bytes(int64_t P) {
     CztGeom g;
@@ -296,6 +454,8 @@ int gfx_odd_alias_pair_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int
     return czt_pair_alias<float>(z, y, len, lo, len, rows, P, plan, ws, ws_bytes, stream, &ymap, (int)C, row0);
 }
 
+#else
+
 size_t gfx_odd_alias_pair_precise_plan_bytes(int64_t P) { return 2 * gfx_odd_alias_pair_plan_bytes(P); }
 
 size_t gfx_odd_alias_pair_precise_workspace_bytes(int64_t rows, int64_t P) { return 2 * gfx_odd_alias_pair_workspace_bytes(rows, P); }
@@ -308,5 +468,7 @@ int gfx_odd_alias_pair_precise_f32(const float* z, float* y, int64_t ldy, int64_
                                    const void* plan, void* ws, size_t ws_bytes, void* stream) {
     return czt_pair_alias<double>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream);
 }
+
+#endif
 
 }  // extern "C"

@@ -328,7 +328,7 @@ def odd_alias_supported(P):
 
 # Two real rows per complex chirp-z transform (csrc/czt_pair.hip) in odd_alias's forward calls: a third fewer bytes
 # through every pass.  GRAFX_ALIAS_PAIRS=0 keeps one transform per row (round 4's path; also what rows beyond
-# P = 258 048 and every adjoint take).
+# P = 8 388 607 and every adjoint take).
 ALIAS_PAIRS = os.environ.get("GRAFX_ALIAS_PAIRS", "1") != "0"
 
 

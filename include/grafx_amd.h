@@ -195,10 +195,10 @@ int gfx_odd_alias_precise_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, 
  * two chirp-z transforms as one complex row with the spectrum kept on both sides (P bins) and comes out as
  * A z1 + i A z2 -- 2P - 1 points per pair instead of (3P - 1) / 2 per row, a third fewer bytes through each of the same
  * passes.  Rows 2r and 2r + 1 of a call form a pair (an odd row count leaves the last row alone); each row's rounding error
- * scales with the larger row of its pair.  3 <= P <= 258 048 odd, else the size queries return 0 and the calls
- * GFX_EINVAL (use the one-row forms above); own plan (gfx_odd_alias_pair_plan_f32, workspace of
- * gfx_odd_alias_pair_workspace_bytes(1, P)) and workspace (gfx_odd_alias_pair_workspace_bytes(rows, P)); rows <= 131070 per
- * call; for gfx_odd_alias_pair_rows_f32 row0 must be even.  The `precise` forms carry the transforms in double (plan and
+ * scales with the larger row of its pair.  3 <= P <= 8 388 607 odd (2P - 1 <= 2^24 points), else the size queries return
+ * 0 and the calls GFX_EINVAL (use the one-row forms above); own plan (gfx_odd_alias_pair_plan_f32, workspace of
+ * gfx_odd_alias_pair_workspace_bytes(1, P)) and workspace (gfx_odd_alias_pair_workspace_bytes(rows, P)); for
+ * gfx_odd_alias_pair_rows_f32 row0 must be even.  The `precise` forms carry the transforms in double (plan and
  * workspace twice the size).  Same results as the one-row forms up to rounding (tests/test_gpu_odd_alias_pair.py). */
 size_t gfx_odd_alias_pair_plan_bytes(int64_t P);
 size_t gfx_odd_alias_pair_workspace_bytes(int64_t rows, int64_t P);

@@ -57,6 +57,7 @@ int main() {
     srand(1);
 #define X(C) size<C>();
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(14) X(15) X(16) X(18) X(20) X(21) X(24) X(25) X(27) X(28) X(30) X(32)
+    X(35) X(36) X(40) X(42) X(45) X(48) X(49) X(50) X(54) X(56) X(60) X(63)   // the pair form's column passes (czt_pair.hip)
 #undef X
     // spos is a permutation
     for (int C : {6, 9, 25, 27, 28, 30}) {

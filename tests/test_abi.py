@@ -42,6 +42,19 @@ def test_size_queries_need_no_gpu():
     assert lib.gfx_fftconv_workspace_bytes(2, 2, 131072, 131072, 0, 60001) == 2 * 2 * (16 + 7) * 17 * 256 * 16
     assert lib.gfx_iir_fsm_plan_bytes(4001) == (8192 + 4096 + 2 * 2052) * 8 and lib.gfx_iir_fsm_plan_bytes(5000) == 0
     assert lib.gfx_istft_basis_bytes(384) == (388 * 384 + 193 * 2 * 208 + 2 * 384) * 4   # full basis, half basis, FFT factors
+    # the odd-length aliasing: one row per transform needs (3P - 1) / 2 points (25 tiles at P = 135 071), two rows per
+    # transform 2P - 1 per pair (35 tiles); the pair form ends at 2^24 points, even lengths do not alias at all
+    P = 131072 + 4000 - 1
+    assert lib.gfx_odd_alias_workspace_bytes(2, P) == 2 * 25 * 8192 * 8
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, P) == 35 * 8192 * 8 == lib.gfx_odd_alias_pair_workspace_bytes(1, P)
+    assert lib.gfx_odd_alias_pair_workspace_bytes(3, P) == 2 * 35 * 8192 * 8
+    assert lib.gfx_odd_alias_pair_plan_bytes(P) == (P + (P - 1) + P + 2 * 35 * 8192) * 8
+    assert lib.gfx_odd_alias_pair_precise_plan_bytes(P) == 2 * lib.gfx_odd_alias_pair_plan_bytes(P)
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 258047) == 63 * 8192 * 8          # the last length of one column pass
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 258049) == 4 * 16 * 8192 * 8      # then one outer radix-4 level
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 480000 + 4000 - 1) == 4 * 30 * 8192 * 8   # BASELINE configs[1], 4000 taps
+    assert lib.gfx_odd_alias_pair_plan_bytes(8388607) > 0 and lib.gfx_odd_alias_pair_plan_bytes(8388609) == 0
+    assert lib.gfx_odd_alias_pair_plan_bytes(4000) == 0 and lib.gfx_odd_alias_plan_bytes(8388609) > 0
 
 
 def test_processors_refuse_cpu_tensors_and_missing_library(monkeypatch):
