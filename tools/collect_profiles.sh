@@ -36,3 +36,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_
 # the compressor stage + routing sum alone, fast and long poles
 ( python3 $R/tools/mix_bench.py; MIX_BENCH_Z=6 python3 $R/tools/mix_bench.py; MIX_BENCH_Z=6 GRAFX_DYN_LOOKBACK=0 python3 $R/tools/mix_bench.py ) > $OUT/mix_bench.txt 2>&1
 ls $OUT | head -60
+# the odd-length aliasing alone: one row against two rows per chirp-z transform
+python3 $R/tools/alias_bench.py 2> /dev/null | grep "^|" > $OUT/alias_bench.md
+python3 $R/tools/alias_bench.py --rows 1024 --P 483999 299999 2> /dev/null | grep "^| [0-9]" >> $OUT/alias_bench.md

@@ -16,6 +16,7 @@ cp $RAW/bench_longpole.json $D/bench_cfg4_longpole.json
 cp $RAW/bench_ballistics.json $D/bench_cfg4_ballistics.json
 cp $RAW/bench_longpole_r4path.json $D/bench_cfg4_longpole_r4path.json
 cp $RAW/ballistics_bench.md $D/ballistics_bench.md
+[ -f $RAW/alias_bench.md ] && cp $RAW/alias_bench.md $D/alias_bench.md
 grep -v amdgpu.ids $RAW/mix_bench.txt > $D/mix_bench_longpole.txt
 [ -f gpurun_out/parity_exceptions.md ] && cp gpurun_out/parity_exceptions.md $D/parity_exceptions.md
 [ -f gpurun_out/measured_errors.json ] && cp gpurun_out/measured_errors.json $D/measured_errors.json
