@@ -127,21 +127,37 @@ __device__ __forceinline__ cxd col_twiddle(int n2, int k1, double inv_half_nfft,
     return cxd{c, conj ? s : -s};
 }
 
-// The column twiddles W_NS^(n2 k1), k1 = 1, 2, ... C-1 IN TURN.  float: n2 k1 mod NS carried incrementally, one sincospif
-// each; double: powers of W^(n2) by repeated multiplication (31 steps lose ~1e-15, and a double sincospi per point would
-// make the column kernels compute-bound).
-template <typename T> struct ColTw;
-template <> struct ColTw<float> {
-    int n2, NS, r;
-    bool conj;
-    __device__ __forceinline__ ColTw(int n2_, int NS_, bool conj_) : n2(n2_), NS(NS_), r(0), conj(conj_) {}
-    __device__ __forceinline__ cx at(int) {
-        r += n2;
-        r -= r >= NS ? NS : 0;
-        return unit_root_f(r, NS, conj);
+// The column twiddles W_NS^(n2 k1), k1 = 1 .. C-1 (asked for in turn, k1 a constant after unrolling).  float: two digits,
+// k1 = 8 a + b -- W^(n2 b) for b < 8 and W^(8 n2 a), each one sincospif on an exactly reduced phase, and one complex product
+// for the rest: 11 evaluations instead of 34 at 35 tiles (one per point made the float column passes instruction-bound:
+// ~50 of ~80 instructions per point; one more rounding, 6e-8).  double: powers of W^(n2) by repeated multiplication (31 steps
+// lose ~1e-15, and a double sincospi per point would make the column kernels compute-bound).
+template <typename T, int C> struct ColTw;
+template <int C> struct ColTw<float, C> {
+    static constexpr int NLO = C < 8 ? C : 8, NHI = (C - 1) / 8 + 1;
+    cx lo[NLO], hi[NHI];
+    __device__ __forceinline__ ColTw(int n2, int NS, bool conj) {
+        lo[0] = hi[0] = cx{1.0f, 0.0f};
+        int r = 0;
+#pragma unroll
+        for (int b = 1; b < NLO; ++b) {
+            r += n2;                                       // n2 b < 8 x 8192 <= NS whenever C >= 8; below, b < C keeps it under NS
+            lo[b] = unit_root_f(r, NS, conj);
+        }
+        r = 0;
+#pragma unroll
+        for (int a = 1; a < NHI; ++a) {
+            r += 8 * n2;                                   // (8 n2 < 65536 <= NS here: one subtraction reduces)
+            r -= r >= NS ? NS : 0;
+            hi[a] = unit_root_f(r, NS, conj);
+        }
+    }
+    __device__ __forceinline__ cx at(int k1) const {
+        const int a = k1 >> 3, b = k1 & 7;
+        return a == 0 ? lo[b] : b == 0 ? hi[a] : cmul(hi[a], lo[b]);
     }
 };
-template <> struct ColTw<double> {
+template <int C> struct ColTw<double, C> {
     cxd w1, w;
     __device__ __forceinline__ ColTw(int n2, int NS, bool conj) : w1(col_twiddle(n2, 1, 2.0 / (double)NS, conj)), w(cxd{1.0, 0.0}) {}
     __device__ __forceinline__ cxd at(int) { w = cmul(w, w1); return w; }
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
         v[n1] = e;
     }
     col_dft<C, false>(v);
-    ColTw<T> tw(n2, (int)NS, false);
+    ColTw<T, C> tw(n2, (int)NS, false);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[spos(C, k1)];
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
     const int64_t NS = g.NFFT / g.S;
     typename Prec<T>::T2* b = buf + row * NS;
     cx v[C];
-    ColTw<T> twi(n2, (int)NS, true);
+    ColTw<T, C> twi(n2, (int)NS, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
             u[n1] = o;
         }
         col_dft<C, false>(u);
-        ColTw<T> twf(n2, (int)NS, false);
+        ColTw<T, C> twf(n2, (int)NS, false);
 #pragma unroll
         for (int k1 = 0; k1 < C; ++k1) {
             const cx e = u[spos(C, k1)];

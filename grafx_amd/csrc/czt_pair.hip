@@ -33,9 +33,9 @@ constexpr int CZT_PAIR_MAXC = 63;
 #define GFX_CZT_PAIR_SIZES(X) GFX_CZT_SIZES(X) X(35) X(36) X(40) X(42) X(45) X(48) X(49) X(50) X(54) X(56) X(60) X(63)
 #endif
 
-// the middle pass keeps two columns of C points in registers when fused with the next column pass: above 36 tiles (28 in
+// the middle pass keeps two columns of C points in registers when fused with the next column pass: above 48 tiles (36 in
 // double precision) that no longer fits two waves per SIMD and it goes in two passes instead (one more sweep over the buffer)
-template <typename T, int C> constexpr bool pair_mid_fused() { return sizeof(T) == 4 ? C <= 36 : C <= 28; }
+template <typename T, int C> constexpr bool pair_mid_fused() { return sizeof(T) == 4 ? C <= 48 : C <= 36; }
 
 static inline bool czt_pair_geom(int64_t P, CztGeom& g) {
     if (P < 3 || (P & 1) == 0) return false;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
         v[n1] = e;
     }
     col_dft<C, false>(v);
-    ColTw<T> tw(n2, (int)g.NFFT, false);
+    ColTw<T, C> tw(n2, (int)g.NFFT, false);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[spos(C, k1)];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kern
     const int n2 = blockIdx.x * 256 + threadIdx.x;
     typename Prec<T>::T2* b = buf + (int64_t)blockIdx.y * g.NFFT;
     cx v[C];
-    ColTw<T> twi(n2, (int)g.NFFT, true);
+    ColTw<T, C> twi(n2, (int)g.NFFT, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kern
         pair_sched_fence();
         col_dft<C, false>(u);
         pair_sched_fence();
-        ColTw<T> twf(n2, (int)g.NFFT, false);
+        ColTw<T, C> twf(n2, (int)g.NFFT, false);
 #pragma unroll
         for (int k1 = 0; k1 < C; ++k1) {
             const cx e = u[spos(C, k1)];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_out_kern
     const int64_t off = g.K - 1;
     const bool two = 2 * pr + 1 < rows;
     cx v[C];
-    ColTw<T> twi(n2, (int)g.NFFT, true);
+    ColTw<T, C> twi(n2, (int)g.NFFT, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
