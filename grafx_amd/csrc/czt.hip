@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restr
         if (MODE == 0) {
             if (i >= lo && i < lo + len) e = to_cx(tab[i]) * (T)z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
-            e = to_cx(b[i]);
+            e = buf_load<T>(&b[i]);
         } else {
             if (i <= cs.hi) e = to_cx(chirp_d<T>(i, cs.den, cs.sign));
             else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d<T>(g.NFFT - i, cs.den, cs.sign));
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void czt_outer_fwd_kernel(const float* __restr
     for (int k3 = 0; k3 < 4; ++k3) {
         const cx e = v[brev(k3, 2)];
         const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
-        b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+        buf_store<T>(&b[k3 * NS + np], o);
     }
 }
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2
     cx v[4];
 #pragma unroll
     for (int k3 = 0; k3 < 4; ++k3) {
-        const cx e = to_cx(b[k3 * NS + np]);
+        const cx e = buf_load<T>(&b[k3 * NS + np]);
         v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
     }
     dif<4, true>(v);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2
         for (int k3 = 0; k3 < 4; ++k3) {
             const cx e = u[brev(k3, 2)];
             const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
-            b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+            buf_store<T>(&b[k3 * NS + np], o);
         }
         return;
     }
@@ -111,14 +111,14 @@ __global__ __launch_bounds__(256) void czt_outer_inv_kernel(typename Prec<T>::T2
         const int64_t i = n3 * NS + np;
         const cx e = v[brev(n3, 2)] * (T)0.25;
         if (MODE == 3) {                                   // plain inverse of an inner level
-            b[i] = Prec<T>::make(e.x, e.y);
+            buf_store<T>(&b[i], e);
         } else if (MODE == 0) {
             cx o = {0, 0};
             if (i < g.K) {
                 const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
                 o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
             }
-            b[i] = Prec<T>::make(o.x, o.y);
+            buf_store<T>(&b[i], o);
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);

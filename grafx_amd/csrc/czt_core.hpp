@@ -12,6 +12,19 @@
 
 namespace gfx {
 
+// the workspace streams through every pass once: non-temporal accesses keep it from evicting what IS reused (the chirp
+// spectrum, the twiddle tables).  -DGFX_CZT_NT=0 for A/B.
+#ifndef GFX_CZT_NT
+#define GFX_CZT_NT 1
+#endif
+#if GFX_CZT_NT
+#define GFX_CZT_LOAD(p) __builtin_nontemporal_load(p)
+#define GFX_CZT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define GFX_CZT_LOAD(p) (*(p))
+#define GFX_CZT_STORE(v, p) (*(p) = (v))
+#endif
+
 
 constexpr int CZT_MAXC = 32;
 // tiles per (sub-)transform: every size up to 32 with prime factors up to 7 (czt_geom picks the smallest that covers P)
@@ -88,6 +101,16 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
 // adjoint (same chirps, mirrored support: the adjoint's first transform has Q inputs and K outputs, its second K
 // inputs and P outputs)
 static inline size_t czt_plan_f2(const CztGeom& g) { return (size_t)(g.P + g.Q + 4 * g.NFFT); }
+
+// the workspace's points in the column passes (T2 in memory, the tile's complex type in registers)
+template <typename T>
+__device__ __forceinline__ typename Prec<T>::cxt buf_load(const typename Prec<T>::T2* p) {
+    return GFX_CZT_LOAD(reinterpret_cast<const typename Prec<T>::cxt*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void buf_store(typename Prec<T>::T2* p, typename Prec<T>::cxt v) {
+    GFX_CZT_STORE(v, reinterpret_cast<typename Prec<T>::cxt*>(p));
+}
 
 // b[j] = exp(sign i pi j^2 / den) at circular index j mod NFFT for j in [-lo, hi], zero elsewhere
 struct ChirpSeq {
@@ -191,7 +214,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
         if (MODE == 0) {
             if (i >= lo && i < lo + len) e = to_cx(tab[i]) * (T)z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
-            e = to_cx(b[i]);
+            e = buf_load<T>(&b[i]);
         } else {
             if (i <= cs.hi) e = to_cx(chirp_d<T>(i, cs.den, cs.sign));
             else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d<T>(g.NFFT - i, cs.den, cs.sign));
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[spos(C, k1)];
         const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
-        b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+        buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
     }
 }
 
@@ -225,7 +248,7 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
     tile_twiddles(tw, twtab, t);
     cx v[32], w[2][16];
 #pragma unroll
-    for (int a = 0; a < 32; ++a) v[a] = b[t + 256 * a];
+    for (int a = 0; a < 32; ++a) v[a] = GFX_CZT_LOAD(&b[t + 256 * a]);
     tile_forward(v, w, tw, lds, t);
     if (PLAN) {
         cx* o = reinterpret_cast<cx*>(spec_out) + (int64_t)k1 * TILE_M;
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
     __syncthreads();
     tile_inverse(w, v, tw, lds, t);
 #pragma unroll
-    for (int a = 0; a < 32; ++a) b[t + 256 * a] = v[brev(a, 5)];
+    for (int a = 0; a < 32; ++a) GFX_CZT_STORE(v[brev(a, 5)], &b[t + 256 * a]);
 }
 
 // MODE 0 (after the first convolution): buf[k] <- conv[k] cP[k] w_k cQ[k] / NFFT for k < K, zero beyond
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
     ColTw<T, C> twi(n2, (int)NS, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
+        const cx e = buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     col_dft<C, true>(v);
@@ -285,7 +308,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
         for (int k1 = 0; k1 < C; ++k1) {
             const cx e = u[spos(C, k1)];
             const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
-            b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+            buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
         }
         return;
     }
@@ -294,14 +317,14 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
         const int64_t i = (int64_t)n1 * TILE_M + n2;
         const cx e = v[spos(C, n1)] * sc;
         if (MODE == 2) {                                   // plain inverse of a sub-transform (outer level follows)
-            b[i] = Prec<T>::make(e.x, e.y);
+            buf_store<T>(&b[i], e);
         } else if (MODE == 0) {
             cx o = {0, 0};
             if (i < g.K) {
                 const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
                 o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
             }
-            b[i] = Prec<T>::make(o.x, o.y);
+            buf_store<T>(&b[i], o);
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[spos(C, k1)];
         const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
-        b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+        buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
     }
 }
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kern
     ColTw<T, C> twi(n2, (int)g.NFFT, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
+        const cx e = buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     pair_sched_fence();
@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kern
         for (int k1 = 0; k1 < C; ++k1) {
             const cx e = u[spos(C, k1)];
             const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
-            b[(int64_t)k1 * TILE_M + n2] = Prec<T>::make(o.x, o.y);
+            buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
         }
     } else {
 #pragma unroll
         for (int n1 = 0; n1 < C; ++n1) {
             const int64_t i = (int64_t)n1 * TILE_M + n2;
             const cx o = i < g.P ? cmul(v[spos(C, n1)], to_cx(mid[i])) : cx{0, 0};
-            b[i] = Prec<T>::make(o.x, o.y);
+            buf_store<T>(&b[i], o);
         }
     }
 }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_out_kern
     ColTw<T, C> twi(n2, (int)g.NFFT, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = to_cx(b[(int64_t)k1 * TILE_M + n2]);
+        const cx e = buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     pair_sched_fence();
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void czt_pair_outer_in_kernel(const float* __r
     for (int k3 = 0; k3 < 4; ++k3) {
         const cx e = v[brev(k3, 2)];
         const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
-        b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+        buf_store<T>(&b[k3 * NS + np], o);
     }
 }
 
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void czt_pair_outer_mid_kernel(typename Prec<T
     cx v[4], u[4];
 #pragma unroll
     for (int k3 = 0; k3 < 4; ++k3) {
-        const cx e = to_cx(b[k3 * NS + np]);
+        const cx e = buf_load<T>(&b[k3 * NS + np]);
         v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
     }
     dif<4, true>(v);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void czt_pair_outer_mid_kernel(typename Prec<T
     for (int k3 = 0; k3 < 4; ++k3) {
         const cx e = u[brev(k3, 2)];
         const cx o = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, false));
-        b[k3 * NS + np] = Prec<T>::make(o.x, o.y);
+        buf_store<T>(&b[k3 * NS + np], o);
     }
 }
 
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void czt_pair_outer_out_kernel(const typename 
     cx v[4];
 #pragma unroll
     for (int k3 = 0; k3 < 4; ++k3) {
-        const cx e = to_cx(b[k3 * NS + np]);
+        const cx e = buf_load<T>(&b[k3 * NS + np]);
         v[k3] = k3 == 0 ? e : cmul(e, outer_twiddle<T>(np, k3, g.NFFT, true));
     }
     dif<4, true>(v);
