@@ -330,6 +330,7 @@ def odd_alias_supported(P):
 # through every pass.  GRAFX_ALIAS_PAIRS=0 keeps one transform per row (round 4's path; also what rows beyond
 # P = 8 388 607 and every adjoint take).
 ALIAS_PAIRS = os.environ.get("GRAFX_ALIAS_PAIRS", "1") != "0"
+ALIAS_ROWS_PER_CHUNK = int(os.environ.get("GRAFX_ALIAS_ROWS", "1024"))   # rows of one launch chain (and ALIAS_WS_CAP bytes at most)
 
 
 def _alias_fns(precise, pairs=False):
@@ -402,7 +403,7 @@ def _alias_chunks(rows, P, rows_per_chunk, device, precise, pairs=False):
 
 
 @_on_device
-def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False, out=None):
+def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
     full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (1.6 MB of
     workspace per row at P ~ 135 k: 25 tiles of 8192 points).  ``precise``: transforms in double precision (twice the
@@ -413,6 +414,7 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=1024, precise=False, out=None
     length = Q - lo if length is None else length
     flat = z.reshape(-1, P).contiguous()
     rows = flat.shape[0]
+    rows_per_chunk = ALIAS_ROWS_PER_CHUNK if rows_per_chunk is None else rows_per_chunk
     pairs = _alias_pairs(P, rows)
     plan = _alias_plan(P, z.device, precise, pairs)
     fwd, tag = _alias_fns(precise, pairs)[3], _alias_fns(precise, pairs)[5]
