@@ -14,6 +14,9 @@ namespace gfx {
 
 // the workspace streams through every pass once: non-temporal accesses keep it from evicting what IS reused (the chirp
 // spectrum, the twiddle tables).  -DGFX_CZT_NT=0 for A/B.
+#ifndef GFX_CZT_EARLY_SPEC
+#define GFX_CZT_EARLY_SPEC 1
+#endif
 #ifndef GFX_CZT_NT
 #define GFX_CZT_NT 1
 #endif
@@ -102,6 +105,29 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
 // inputs and P outputs)
 static inline size_t czt_plan_f2(const CztGeom& g) { return (size_t)(g.P + g.Q + 4 * g.NFFT); }
 
+// Tile accesses through a buffer descriptor: base in SGPRs, one lane offset, the register row as the scalar offset -- a
+// global access with a 2048 a byte offset needs a 64-bit VGPR address per row (the immediate field ends at 4095), 64
+// registers of addresses per phase.  AUX 2 = non-temporal.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+template <int AUX> __device__ __forceinline__ cx tile_ld(__amdgpu_buffer_rsrc_t r, int t, int row, cx*) {
+    return __builtin_bit_cast(cx, __builtin_amdgcn_raw_buffer_load_b64(r, 8u * (uint32_t)t, (uint32_t)(row * 256 * 8), AUX));
+}
+template <int AUX> __device__ __forceinline__ cxd tile_ld(__amdgpu_buffer_rsrc_t r, int t, int row, cxd*) {
+    return __builtin_bit_cast(cxd, __builtin_amdgcn_raw_buffer_load_b128(r, 16u * (uint32_t)t, (uint32_t)(row * 256 * 16), AUX));
+}
+template <int AUX> __device__ __forceinline__ void tile_st(__amdgpu_buffer_rsrc_t r, int t, int row, cx v) {
+    using u2 = unsigned __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, 8u * (uint32_t)t, (uint32_t)(row * 256 * 8), AUX);
+}
+template <int AUX> __device__ __forceinline__ void tile_st(__amdgpu_buffer_rsrc_t r, int t, int row, cxd v) {
+    using u4 = unsigned __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, 16u * (uint32_t)t, (uint32_t)(row * 256 * 16), AUX);
+}
+
 // the workspace's points in the column passes (T2 in memory, the tile's complex type in registers)
 template <typename T>
 __device__ __forceinline__ typename Prec<T>::cxt buf_load(const typename Prec<T>::T2* p) {
@@ -111,6 +137,32 @@ template <typename T>
 __device__ __forceinline__ void buf_store(typename Prec<T>::T2* p, typename Prec<T>::cxt v) {
     GFX_CZT_STORE(v, reinterpret_cast<typename Prec<T>::cxt*>(p));
 }
+
+// A column pass's view of one transform's points: point (k1, n2) = b[k1 * 8192 + n2].  float: through a descriptor (lane
+// offset 8 n2, row k1 as the scalar offset) -- a global access per row costs a 64-bit VGPR address and its carry chain per
+// point, in kernels that are bound by vector-memory issue and the vector ALU; double: global accesses (measured equal).
+template <typename T> struct ColBuf {
+    using cx = typename Prec<T>::cxt;
+    static constexpr int NT = GFX_CZT_NT ? 2 : 0;
+    typename Prec<T>::T2* b;
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ ColBuf(const typename Prec<T>::T2* base, int64_t points)
+        : b(const_cast<typename Prec<T>::T2*>(base)), r(tile_rsrc(base, (uint32_t)(points * (int64_t)sizeof(typename Prec<T>::T2)))) {}
+    __device__ __forceinline__ cx ld(int k1, int n2) const {
+        if constexpr (sizeof(T) == 4)
+            return __builtin_bit_cast(cx, __builtin_amdgcn_raw_buffer_load_b64(r, 8u * (uint32_t)n2, (uint32_t)k1 * (TILE_M * 8u), NT));
+        else
+            return buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
+    }
+    __device__ __forceinline__ void st(int k1, int n2, cx v) const {
+        if constexpr (sizeof(T) == 4) {
+            using u2 = unsigned __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, 8u * (uint32_t)n2, (uint32_t)k1 * (TILE_M * 8u), NT);
+        } else {
+            buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], v);
+        }
+    }
+};
 
 // b[j] = exp(sign i pi j^2 / den) at circular index j mod NFFT for j in [-lo, hi], zero elsewhere
 struct ChirpSeq {
@@ -206,6 +258,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
     const int64_t row = blockIdx.y;                        // signal row * S + sub-transform
     const int64_t NS = g.NFFT / g.S;                       // points of one sub-transform
     typename Prec<T>::T2* b = buf + row * NS;
+    const ColBuf<T> cb(b, NS);
     cx v[C];
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
@@ -214,7 +267,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
         if (MODE == 0) {
             if (i >= lo && i < lo + len) e = to_cx(tab[i]) * (T)z[row * ldz + (i - lo)];
         } else if (MODE == 1) {
-            e = buf_load<T>(&b[i]);
+            e = cb.ld(n1, n2);
         } else {
             if (i <= cs.hi) e = to_cx(chirp_d<T>(i, cs.den, cs.sign));
             else if (i >= g.NFFT - cs.lo) e = to_cx(chirp_d<T>(g.NFFT - i, cs.den, cs.sign));
@@ -227,7 +280,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[spos(C, k1)];
         const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
-        buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
+        cb.st(k1, n2, o);
     }
 }
 
@@ -243,12 +296,30 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
     const int t = threadIdx.x;
     const int64_t tile = blockIdx.x;                    // row * C + k1
     const int k1 = (int)(tile % C);                       // C here = tiles per signal row = S * C
-    cx* b = reinterpret_cast<cx*>(buf) + tile * TILE_M;
+    constexpr uint32_t TILE_BYTES = TILE_M * sizeof(cx);
+    constexpr int NT = GFX_CZT_NT ? 2 : 0;
+    const __amdgpu_buffer_rsrc_t rb = tile_rsrc(reinterpret_cast<cx*>(buf) + tile * TILE_M, TILE_BYTES);
     typename Prec<T>::Tw tw;
     tile_twiddles(tw, twtab, t);
     cx v[32], w[2][16];
+    // (descriptor accesses in float: 10.1 -> 9.3 ms per 4096 rows; in double the global form measured 1 % better)
+    cx* b = reinterpret_cast<cx*>(buf) + tile * TILE_M;
 #pragma unroll
-    for (int a = 0; a < 32; ++a) v[a] = GFX_CZT_LOAD(&b[t + 256 * a]);
+    for (int a = 0; a < 32; ++a) {
+        if constexpr (sizeof(T) == 4) v[a] = tile_ld<NT>(rb, t, a, (cx*)nullptr);
+        else v[a] = GFX_CZT_LOAD(&b[t + 256 * a]);
+    }
+    // float: the spectrum's loads go out with the tile's, up front, as in fftconv1_kernel -- left to itself the compiler
+    // issues each one right before its product and waits for it, 32 L2 round trips in the middle of the tile (in double the
+    // 128 registers are not there)
+    constexpr bool EARLY = !PLAN && sizeof(T) == 4 && GFX_CZT_EARLY_SPEC;
+    cx sreg[EARLY ? 32 : 1];
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(reinterpret_cast<const cx*>(spec) + (PLAN ? 0 : (int64_t)k1 * TILE_M), TILE_BYTES);
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) sreg[q] = tile_ld<0>(rs, t, q, (cx*)nullptr);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     tile_forward(v, w, tw, lds, t);
     if (PLAN) {
         cx* o = reinterpret_cast<cx*>(spec_out) + (int64_t)k1 * TILE_M;
@@ -256,13 +327,16 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
         for (int q = 0; q < 32; ++q) o[q * TILE_T + t] = w[q >> 4][q & 15];
         return;
     }
-    const cx* sp = reinterpret_cast<const cx*>(spec) + (int64_t)k1 * TILE_M;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], sp[q * TILE_T + t]);
+    for (int q = 0; q < 32; ++q)
+        w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], EARLY ? sreg[EARLY ? q : 0] : tile_ld<0>(rs, t, q, (cx*)nullptr));
     __syncthreads();
     tile_inverse(w, v, tw, lds, t);
 #pragma unroll
-    for (int a = 0; a < 32; ++a) GFX_CZT_STORE(v[brev(a, 5)], &b[t + 256 * a]);
+    for (int a = 0; a < 32; ++a) {
+        if constexpr (sizeof(T) == 4) tile_st<NT>(rb, t, a, v[brev(a, 5)]);
+        else GFX_CZT_STORE(v[brev(a, 5)], &b[t + 256 * a]);
+    }
 }
 
 // MODE 0 (after the first convolution): buf[k] <- conv[k] cP[k] w_k cQ[k] / NFFT for k < K, zero beyond
@@ -281,11 +355,12 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
     const int64_t row = blockIdx.y;
     const int64_t NS = g.NFFT / g.S;
     typename Prec<T>::T2* b = buf + row * NS;
+    const ColBuf<T> cb(b, NS);
     cx v[C];
     ColTw<T, C> twi(n2, (int)NS, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
+        const cx e = cb.ld(k1, n2);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     col_dft<C, true>(v);
@@ -308,7 +383,7 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
         for (int k1 = 0; k1 < C; ++k1) {
             const cx e = u[spos(C, k1)];
             const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
-            buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
+            cb.st(k1, n2, o);
         }
         return;
     }
@@ -317,14 +392,14 @@ __global__ __launch_bounds__(256) void czt_cols_inv_kernel(typename Prec<T>::T2*
         const int64_t i = (int64_t)n1 * TILE_M + n2;
         const cx e = v[spos(C, n1)] * sc;
         if (MODE == 2) {                                   // plain inverse of a sub-transform (outer level follows)
-            buf_store<T>(&b[i], e);
+            cb.st(n1, n2, e);
         } else if (MODE == 0) {
             cx o = {0, 0};
             if (i < g.K) {
                 const T wk = (i == 0 || i == g.K - 1) ? (T)1 : (T)2;
                 o = cmul(cmul(e, to_cx(cP[i])), to_cx(cQ[i])) * wk;
             }
-            buf_store<T>(&b[i], o);
+            cb.st(n1, n2, o);
         } else {
             if (i >= lo && i < lo + len) {
                 const cx c = to_cx(cQ[i]);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
     using cx = typename Prec<T>::cxt;
     const int n2 = blockIdx.x * 256 + threadIdx.x;
     const int64_t pr = blockIdx.y;
-    typename Prec<T>::T2* b = buf + pr * g.NFFT;
+    const ColBuf<T> cb(buf + pr * g.NFFT, g.NFFT);
     const int64_t off = g.K - 1;
     const bool two = 2 * pr + 1 < rows;
     const float* z1 = z + 2 * pr * g.P;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
     for (int k1 = 0; k1 < C; ++k1) {
         const cx e = v[spos(C, k1)];
         const cx o = k1 == 0 ? e : cmul(e, tw.at(k1));
-        buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
+        cb.st(k1, n2, o);
     }
 }
 
@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kern
                                                           const typename Prec<T>::T2* __restrict__ mid, CztGeom g) {
     using cx = typename Prec<T>::cxt;
     const int n2 = blockIdx.x * 256 + threadIdx.x;
-    typename Prec<T>::T2* b = buf + (int64_t)blockIdx.y * g.NFFT;
+    const ColBuf<T> cb(buf + (int64_t)blockIdx.y * g.NFFT, g.NFFT);
     cx v[C];
     ColTw<T, C> twi(n2, (int)g.NFFT, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
+        const cx e = cb.ld(k1, n2);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     pair_sched_fence();
@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_mid_kern
         for (int k1 = 0; k1 < C; ++k1) {
             const cx e = u[spos(C, k1)];
             const cx o = k1 == 0 ? e : cmul(e, twf.at(k1));
-            buf_store<T>(&b[(int64_t)k1 * TILE_M + n2], o);
+            cb.st(k1, n2, o);
         }
     } else {
 #pragma unroll
         for (int n1 = 0; n1 < C; ++n1) {
             const int64_t i = (int64_t)n1 * TILE_M + n2;
             const cx o = i < g.P ? cmul(v[spos(C, n1)], to_cx(mid[i])) : cx{0, 0};
-            buf_store<T>(&b[i], o);
+            cb.st(n1, n2, o);
         }
     }
 }
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_out_kern
     using cx = typename Prec<T>::cxt;
     const int n2 = blockIdx.x * 256 + threadIdx.x;
     const int64_t pr = blockIdx.y;
-    const typename Prec<T>::T2* b = buf + pr * g.NFFT;
+    const ColBuf<T> cb(buf + pr * g.NFFT, g.NFFT);
     const int64_t off = g.K - 1;
     const bool two = 2 * pr + 1 < rows;
     cx v[C];
     ColTw<T, C> twi(n2, (int)g.NFFT, true);
 #pragma unroll
     for (int k1 = 0; k1 < C; ++k1) {
-        const cx e = buf_load<T>(&b[(int64_t)k1 * TILE_M + n2]);
+        const cx e = cb.ld(k1, n2);
         v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
     }
     pair_sched_fence();
