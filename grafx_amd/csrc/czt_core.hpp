@@ -14,6 +14,9 @@ namespace gfx {
 
 // the workspace streams through every pass once: non-temporal accesses keep it from evicting what IS reused (the chirp
 // spectrum, the twiddle tables).  -DGFX_CZT_NT=0 for A/B.
+#ifndef GFX_CZT_EARLY_SPEC_F64
+#define GFX_CZT_EARLY_SPEC_F64 0
+#endif
 #ifndef GFX_CZT_EARLY_SPEC
 #define GFX_CZT_EARLY_SPEC 1
 #endif
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
     // float: the spectrum's loads go out with the tile's, up front, as in fftconv1_kernel -- left to itself the compiler
     // issues each one right before its product and waits for it, 32 L2 round trips in the middle of the tile (in double the
     // 128 registers are not there)
-    constexpr bool EARLY = !PLAN && sizeof(T) == 4 && GFX_CZT_EARLY_SPEC;
+    constexpr bool EARLY = !PLAN && (sizeof(T) == 4 || GFX_CZT_EARLY_SPEC_F64) && GFX_CZT_EARLY_SPEC;
     cx sreg[EARLY ? 32 : 1];
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(reinterpret_cast<const cx*>(spec) + (PLAN ? 0 : (int64_t)k1 * TILE_M), TILE_BYTES);
     if constexpr (EARLY) {
