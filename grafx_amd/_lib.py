@@ -89,6 +89,8 @@ SIGNATURES = {
                                                         ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, f32p, vp, sz, vp, i64, i64,
                                                         f32p, i64, i64, i64, vp, i64, i64, ctypes.c_int, vp]),
     "gfx_ballistics_bwd_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, vp]),
+    "gfx_ballistics_bwd_ws_bytes": (sz, [i64, i64]),
+    "gfx_ballistics_bwd_ws_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, vp, sz, vp]),
     "gfx_dyn_gain_bwd_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, ctypes.c_int,
                                             ctypes.c_int, f32p, f32p, f32p, vp]),
     "gfx_dyn_dx_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, i64, i64, i64, vp]),

@@ -979,16 +979,30 @@ __global__ void onepole_fir_kernel(const float* __restrict__ z_alpha, float* __r
 }
 
 // (the ballistics recursion itself lives in ballistics.hip; its adjoint below keeps the 64 x 64 LDS tiling)
-constexpr int BROWS = 64, BCOLS = 64, BPAD = BCOLS + 4;
+constexpr int BROWS = 64;   // (columns per tile: a template parameter of the kernel)
 
 // Adjoint of the ballistics recursion (the branch choice c[n] is piecewise constant in the inputs):
 //   lambda[n] = g[n] + (1 - c[n+1]) lambda[n+1];   gx[n] = c[n] lambda[n];
 //   d/d(at) = sum over attack steps of lambda[n] (x[n] - y[n-1]),  d/d(rt) likewise over release steps,
 // walked backwards in time with the same tiling as the forward kernel (x, y, g tiles in LDS, one lane per row).
+// Chunked (gridDim.y > 1): the adjoint is a LINEAR recursion once the branch pattern is known, and a contraction -- a carry
+// entering n steps later has shrunk by prod (1 - c) <= (1 - c_min)^n.  Workgroup (b, k) walks chunk k of its 64 rows and
+// starts `warm` samples LATER in time with a zero carry (nothing stored, nothing summed there): the carry it reaches its own
+// chunk with is exact to (1 - c_min)^warm <= 6e-10, warm = 21.2 / -log(1 - c_min) of the group's slowest coefficient, at most
+// 2048 samples (c_min >= BWD_CMIN).  A group with a slower row (wave vote) takes the exact two-pass form of a linear scan
+// instead: chunk aggregates, a chain over the chunks, then the walk with the true carries.  Per-chunk sums of the two coefficient gradients go to `part` (chunks x R x 2) and are
+// added in chunk order by ballistics_bwd_finish_kernel: the same bits from run to run.  part == nullptr: one chunk, gz
+// written directly (gfx_ballistics_bwd_f32).
+constexpr float BWD_CMIN = 0.0103f;   // (1 - 0.0103)^2048 = 6e-10
+constexpr int64_t BWD_WARM = 2048;
+
+template <int BC, bool AGG = false>
 __global__ __launch_bounds__(64) void ballistics_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ g,
                                                             const float* __restrict__ z_alpha, float* __restrict__ gx,
-                                                            float* __restrict__ gz, int64_t R, int64_t L) {
+                                                            float* __restrict__ gz, int64_t R, int64_t L, int64_t chunk,
+                                                            float* __restrict__ part, float* __restrict__ agg = nullptr) {
+    constexpr int BCOLS = BC, BPAD = BC + 4, LPR = BC / 4, RPP = 64 / LPR;   // lanes per row, rows per cooperative pass
     __shared__ __attribute__((aligned(16))) float tx[BROWS * BPAD], ty[BROWS * BPAD], tg[BROWS * BPAD];
     const int lane = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * BROWS;
@@ -998,15 +1012,41 @@ __global__ __launch_bounds__(64) void ballistics_bwd_kernel(const float* __restr
         at = sigmoidf(z_alpha[2 * my]);
         rt = sigmoidf(z_alpha[2 * my + 1]);
     }
-    float carry = 0.0f, sa = 0.0f, sr = 0.0f;
-    const int cr = lane >> 4, cc = (lane & 15) * 4;
+    float carry = 0.0f, sa = 0.0f, sr = 0.0f, prod = 1.0f;
+    const int cr = lane / LPR, cc = (lane % LPR) * 4;
     const bool vec = (L % 4 == 0) && vec_ok(x) && vec_ok(y) && vec_ok(g) && vec_ok(gx);
     const int64_t ntiles = (L + BCOLS - 1) / BCOLS;
-    for (int64_t tile = ntiles - 1; tile >= 0; --tile) {
+    // this workgroup's range of tiles: [t_lo, t_hi) are its own, [t_hi, t_top) the warm-up (chunk a multiple of BCOLS)
+    int64_t t_lo = 0, t_hi = ntiles, t_top = ntiles;
+    if (part) {
+        const bool slow = __any(my < R && fminf(at, rt) < BWD_CMIN);
+        const int64_t k = blockIdx.y, per = chunk / BCOLS;
+        if (AGG && !slow) return;
+        if (slow) {
+            // no warm-up reaches far enough: the chunk's own tiles with a zero carry first (AGG: nothing stored; the product
+            // of its (1 - c) and the carry it ends with go to `agg`), ballistics_bwd_carry_kernel chains the chunks of a row,
+            // and the second launch starts every chunk with the carry that really enters it
+            t_lo = k * per;
+            t_hi = t_top = t_lo + per < ntiles ? t_lo + per : ntiles;
+            if (!AGG && my < R) carry = agg[(k * R + my) * 2];
+        } else {
+            // warm-up of this group: (1 - c_min)^warm <= e^-21.2 = 6e-10 for its slowest coefficient, at most BWD_WARM
+            float cmin = my < R ? fminf(at, rt) : 1.0f;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, d, 64));
+            int64_t wt = (int64_t)ceilf(-21.2f / (log1pf(-fminf(cmin, 0.999f)) * (float)BCOLS));
+            wt = wt < 1 ? 1 : (wt > BWD_WARM / BCOLS ? BWD_WARM / BCOLS : wt);
+            t_lo = k * per;
+            t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
+            t_top = t_hi + wt < ntiles ? t_hi + wt : ntiles;
+        }
+    }
+    for (int64_t tile = t_top - 1; tile >= t_lo; --tile) {
         const int64_t n0 = tile * BCOLS;
+        const bool own = tile < t_hi;
 #pragma unroll 4
-        for (int pass = 0; pass < BROWS / 4; ++pass) {
-            const int row = pass * 4 + cr;
+        for (int pass = 0; pass < BROWS / RPP; ++pass) {
+            const int row = pass * RPP + cr;
             const int64_t rr = r0 + row;
             float a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b[4] = {0.0f, 0.0f, 0.0f, 0.0f}, c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (rr < R) {
@@ -1020,25 +1060,41 @@ __global__ __launch_bounds__(64) void ballistics_bwd_kernel(const float* __restr
         }
         const float y_before = (my < R && n0 > 0) ? y[my * L + n0 - 1] : 1.0f;  // y[-1] = 1
         __syncthreads();
-        const int last = (int)((L - n0 < BCOLS ? L - n0 : BCOLS) - 1);
-        for (int j = last; j >= 0; --j) {
-            const float xv = tx[lane * BPAD + j];
-            const float yp = j > 0 ? ty[lane * BPAD + j - 1] : y_before;
-            const bool attack = xv < yp;
-            const float c = attack ? at : rt;
-            const float lam = tg[lane * BPAD + j] + carry;
-            tg[lane * BPAD + j] = c * lam;
-            const float d = lam * (xv - yp);
-            sa += attack ? d : 0.0f;
-            sr += attack ? 0.0f : d;
-            carry = (1.0f - c) * lam;
+        // four steps per LDS access (rows are 68 floats apart: sixteen lanes' 16-byte accesses tile the 64 banks); past the
+        // row's end the tiles hold x = y = g = 0 -- a zero gradient entering a zero carry, whatever the branch
+        const float ta = own ? 1.0f : 0.0f;
+#pragma unroll 2
+        for (int j4 = BCOLS / 4 - 1; j4 >= 0; --j4) {
+            const float4 xq = *reinterpret_cast<const float4*>(&tx[lane * BPAD + 4 * j4]);
+            const float4 yq = *reinterpret_cast<const float4*>(&ty[lane * BPAD + 4 * j4]);
+            const float4 gq = *reinterpret_cast<const float4*>(&tg[lane * BPAD + 4 * j4]);
+            const float y0 = j4 > 0 ? ty[lane * BPAD + 4 * j4 - 1] : y_before;
+            const float xs[4] = {xq.x, xq.y, xq.z, xq.w}, yp[4] = {y0, yq.x, yq.y, yq.z}, gs[4] = {gq.x, gq.y, gq.z, gq.w};
+            float o[4];
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                const bool attack = xs[i] < yp[i];
+                const float c = attack ? at : rt;
+                const float lam = gs[i] + carry;
+                o[i] = c * lam;
+                const float d = ta * lam * (xs[i] - yp[i]);
+                sa += attack ? d : 0.0f;
+                sr += attack ? 0.0f : d;
+                carry = (1.0f - c) * lam;
+                if (AGG) prod *= 1.0f - c;
+            }
+            if (!AGG) *reinterpret_cast<float4*>(&tg[lane * BPAD + 4 * j4]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (AGG) {
+            __syncthreads();
+            continue;
         }
         __syncthreads();
 #pragma unroll 4
-        for (int pass = 0; pass < BROWS / 4; ++pass) {
-            const int row = pass * 4 + cr;
+        for (int pass = 0; pass < BROWS / RPP; ++pass) {
+            const int row = pass * RPP + cr;
             const int64_t rr = r0 + row;
-            if (rr < R) {
+            if (rr < R && own) {
                 const float4 q = *reinterpret_cast<const float4*>(&tg[row * BPAD + cc]);
                 const float v[4] = {q.x, q.y, q.z, q.w};
                 store4(gx + rr * L, n0 + cc, L, vec, v);
@@ -1046,10 +1102,46 @@ __global__ __launch_bounds__(64) void ballistics_bwd_kernel(const float* __restr
         }
         __syncthreads();
     }
-    if (my < R) {
-        gz[2 * my] = sa * at * (1.0f - at);
-        gz[2 * my + 1] = sr * rt * (1.0f - rt);
+    if (AGG) {
+        if (my < R) {
+            agg[((int64_t)blockIdx.y * R + my) * 2] = prod;
+            agg[((int64_t)blockIdx.y * R + my) * 2 + 1] = carry;
+        }
+        return;
     }
+    if (my < R) {
+        if (part) {
+            part[((int64_t)blockIdx.y * R + my) * 2] = sa;
+            part[((int64_t)blockIdx.y * R + my) * 2 + 1] = sr;
+        } else {
+            gz[2 * my] = sa * at * (1.0f - at);
+            gz[2 * my + 1] = sr * rt * (1.0f - rt);
+        }
+    }
+}
+
+// agg[k][r] = (product of (1 - c) over chunk k, the carry chunk k ends with from a zero carry)  ->  agg[k][r][0] = the carry
+// that enters chunk k: carry_in[last] = 0, carry_in[k] = end[k + 1] + prod[k + 1] carry_in[k + 1]  (rows of fast groups hold
+// nothing meaningful and are not read)
+__global__ void ballistics_bwd_carry_kernel(float* __restrict__ agg, int64_t R, int chunks) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float cin = 0.0f;
+    for (int k = chunks - 1; k >= 0; --k) {
+        const float p = agg[((int64_t)k * R + r) * 2], e = agg[((int64_t)k * R + r) * 2 + 1];
+        agg[((int64_t)k * R + r) * 2] = cin;
+        cin = e + p * cin;
+    }
+}
+
+__global__ void ballistics_bwd_finish_kernel(const float* __restrict__ part, const float* __restrict__ z_alpha,
+                                             float* __restrict__ gz, int64_t R, int chunks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (row, which coefficient)
+    if (i >= 2 * R) return;
+    float s = 0.0f;
+    for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * 2 * R + i];
+    const float c = sigmoidf(z_alpha[i]);
+    gz[i] = s * c * (1.0f - c);
 }
 
 // env (R,L) -> gain (R,L):  g = log_gain(log(env + 1e-5));  out = exp(g) or g (log_out)
@@ -2195,8 +2287,50 @@ int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_l
 int gfx_ballistics_bwd_f32(const float* x, const float* y, const float* g, const float* z_alpha, float* gx, float* gz,
                            int64_t R, int64_t L, void* stream) {
     if (!x || !y || !g || !z_alpha || !gx || !gz || R <= 0 || L <= 0) return GFX_EINVAL;
-    hipLaunchKernelGGL(ballistics_bwd_kernel, dim3((unsigned)((R + BROWS - 1) / BROWS)), dim3(64), 0,
-                       (hipStream_t)stream, x, y, g, z_alpha, gx, gz, R, L);
+    hipLaunchKernelGGL(ballistics_bwd_kernel<64>, dim3((unsigned)((R + BROWS - 1) / BROWS)), dim3(64), 0,
+                       (hipStream_t)stream, x, y, g, z_alpha, gx, gz, R, L, (int64_t)0, (float*)nullptr);
+    return GFX_LAUNCH_OK();
+}
+
+// chunks of the chunked adjoint: enough workgroups for ~16 waves per CU, chunks of at least 4096 samples (the 2048-sample
+// warm-up is walked on top of every chunk), a multiple of the 64-sample tile
+static int64_t ballistics_bwd_chunk(int64_t R, int64_t L, int* chunks) {
+    const int64_t groups = (R + BROWS - 1) / BROWS;
+    int64_t want = (4096 + groups - 1) / groups;
+    const int64_t most = L / 4096 > 1 ? L / 4096 : 1;
+    if (want > most) want = most;
+    if (want > 1024) want = 1024;
+    if (want < 1) want = 1;
+    int64_t chunk = (L + want - 1) / want;
+    chunk = (chunk + 63) / 64 * 64;
+    *chunks = (int)((L + chunk - 1) / chunk);
+    return chunk;
+}
+
+size_t gfx_ballistics_bwd_ws_bytes(int64_t R, int64_t L) {
+    if (R <= 0 || L <= 0) return 0;
+    int chunks;
+    ballistics_bwd_chunk(R, L, &chunks);
+    return (size_t)chunks * R * 4 * sizeof(float);   // partial sums and chunk aggregates, (chunks, R, 2) each
+}
+
+int gfx_ballistics_bwd_ws_f32(const float* x, const float* y, const float* g, const float* z_alpha, float* gx, float* gz,
+                              int64_t R, int64_t L, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y || !g || !z_alpha || !gx || !gz || R <= 0 || L <= 0) return GFX_EINVAL;
+    int chunks;
+    const int64_t chunk = ballistics_bwd_chunk(R, L, &chunks);
+    if (chunks <= 1) return gfx_ballistics_bwd_f32(x, y, g, z_alpha, gx, gz, R, L, stream);
+    if (!ws || ws_bytes < (size_t)chunks * R * 4 * sizeof(float)) return GFX_ENOSPC;
+    float* part = (float*)ws;
+    float* agg = part + (size_t)chunks * R * 2;
+    const dim3 grid((unsigned)((R + BROWS - 1) / BROWS), (unsigned)chunks);
+    hipStream_t st = (hipStream_t)stream;
+    // (32-column tiles: 28 KB of LDS per one-wave workgroup, five per CU; 64 columns 6.4 ms, 32 4.9, 16 5.6 at 9216 rows)
+    hipLaunchKernelGGL((ballistics_bwd_kernel<32, true>), grid, dim3(64), 0, st, x, y, g, z_alpha, gx, gz, R, L, chunk, part, agg);
+    hipLaunchKernelGGL(ballistics_bwd_carry_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, agg, R, chunks);
+    hipLaunchKernelGGL((ballistics_bwd_kernel<32, false>), grid, dim3(64), 0, st, x, y, g, z_alpha, gx, gz, R, L, chunk, part, agg);
+    hipLaunchKernelGGL(ballistics_bwd_finish_kernel, dim3((unsigned)((2 * R + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                       z_alpha, gz, R, chunks);
     return GFX_LAUNCH_OK();
 }
 

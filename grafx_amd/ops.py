@@ -860,8 +860,9 @@ def ballistics_energy(x, z_alpha, coefficients=False, schedule=None):
 
 
 @_on_device
-def ballistics_bwd(x, y, g, z_alpha):
-    """Adjoint of :func:`ballistics`: -> (dL/dx (R,L), dL/dz_alpha (R,2))."""
+def ballistics_bwd(x, y, g, z_alpha, schedule="chunks"):
+    """Adjoint of :func:`ballistics`: -> (dL/dx (R,L), dL/dz_alpha (R,2)).  ``schedule``: "chunks" (rows cut into chunks
+    with a 2048-sample warm-up, gfx_ballistics_bwd_ws_f32) or "rows" (every row walked whole by one lane)."""
     _require_gpu(x, y, g, z_alpha)
     x, y, g, z_alpha = x.contiguous(), y.contiguous(), g.contiguous(), z_alpha.contiguous()
     R, L = x.shape
@@ -869,8 +870,13 @@ def ballistics_bwd(x, y, g, z_alpha):
     _expect(g, (R, L), "ballistics_bwd: g")
     _expect(z_alpha, (R, 2), "ballistics_bwd: z_alpha")
     gx, gz = torch.empty_like(x), torch.empty((R, 2), dtype=torch.float32, device=x.device)
-    check(lib().gfx_ballistics_bwd_f32(_ptr(x), _ptr(y), _ptr(g), _ptr(z_alpha), _ptr(gx), _ptr(gz), R, L, _stream()),
-          "gfx_ballistics_bwd_f32")
+    if schedule == "rows":
+        check(lib().gfx_ballistics_bwd_f32(_ptr(x), _ptr(y), _ptr(g), _ptr(z_alpha), _ptr(gx), _ptr(gz), R, L, _stream()),
+              "gfx_ballistics_bwd_f32")
+        return gx, gz
+    ws = torch.empty(max(int(lib().gfx_ballistics_bwd_ws_bytes(R, L)), 4), dtype=torch.uint8, device=x.device)
+    check(lib().gfx_ballistics_bwd_ws_f32(_ptr(x), _ptr(y), _ptr(g), _ptr(z_alpha), _ptr(gx), _ptr(gz), R, L, _ptr(ws),
+                                          ws.numel(), _stream()), "gfx_ballistics_bwd_ws_f32")
     return gx, gz
 
 

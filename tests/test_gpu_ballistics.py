@@ -199,3 +199,58 @@ def test_compressor_with_the_ballistics_smoother_matches_the_oracle(knee, gate):
     ref = o(x, **p)
     ref64 = o(x.double(), **{k: v.double() for k, v in p.items()}).float()
     assert_parity(y, ref, ref64, 1e-5, f"{cls.__name__} ballistics {knee}")
+
+
+@pytest.mark.parametrize("R,L", [(130, 40000), (64, 131072), (200, 20001)])
+def test_chunked_adjoint_equals_the_whole_row_adjoint(R, L):
+    """gfx_ballistics_bwd_ws_f32: the adjoint recursion lambda[n] = g[n] + (1 - c[n+1]) lambda[n+1] is linear and a
+    contraction, so chunks that start 2048 samples later with a zero carry reproduce the whole-row walk to (1 - c)^2048;
+    groups of 64 rows with a coefficient below 0.0103 are walked whole.  Rows of both kinds, ragged last group, L % 4 != 0;
+    the coefficient gradients are sums over the row (per-chunk partials, added in chunk order)."""
+    from grafx_amd import ops
+
+    torch.manual_seed(R + L)
+    x = torch.rand(R, L, device="cuda") * 2
+    z = torch.randn(R, 2, device="cuda") * 1.5
+    if R > 70:
+        z[70:] = torch.randn(R - 70, 2, device="cuda") * 0.5 - 6.0  # the second group onwards: coefficients ~ 2.5e-3 (whole rows)
+    z[3, 0] = -4.0                                                    # one slow row in the first group (c = 0.018: still chunked)
+    y = ops.ballistics(x, z)
+    g = torch.randn(R, L, device="cuda")
+    gx_c, gz_c = ops.ballistics_bwd(x, y, g, z, schedule="chunks")
+    gx_r, gz_r = ops.ballistics_bwd(x, y, g, z, schedule="rows")
+    assert (gx_c - gx_r).abs().max() <= 1e-6 * gx_r.abs().max(), float((gx_c - gx_r).abs().max() / gx_r.abs().max())
+    assert (gz_c - gz_r).abs().max() <= 2e-5 * gz_r.abs().max(), float((gz_c - gz_r).abs().max() / gz_r.abs().max())
+    again = ops.ballistics_bwd(x, y, g, z, schedule="chunks")
+    assert torch.equal(again[0], gx_c) and torch.equal(again[1], gz_c)      # fixed summation order: the same bits
+
+
+def test_chunked_adjoint_at_the_console_size_against_float64_on_sample_rows():
+    """9216 x 131072 (BASELINE configs[3]'s compressor rows): the chunked adjoint on the device against the float64 adjoint
+    recursion on the CPU for a few rows."""
+    from grafx_amd import ops
+
+    R, L = 9216, 131072
+    torch.manual_seed(2)
+    x = torch.rand(R, L, device="cuda") * 2
+    z = torch.randn(R, 2, device="cuda") * 0.1
+    y = ops.ballistics(x, z)
+    g = torch.randn(R, L, device="cuda")
+    gx, gz = ops.ballistics_bwd(x, y, g, z)
+    for r in (0, 4607, 9215):
+        xs, ys, gs = x[r].double().cpu().numpy(), y[r].double().cpu().numpy(), g[r].double().cpu().numpy()
+        at, rt = torch.sigmoid(z[r].double()).cpu().tolist()
+        lam, carry, sa, sr = np.zeros(L), 0.0, 0.0, 0.0
+        for n in range(L - 1, -1, -1):
+            yp = ys[n - 1] if n > 0 else 1.0
+            attack = xs[n] < yp
+            c = at if attack else rt
+            l_ = gs[n] + carry
+            lam[n] = c * l_
+            d = l_ * (xs[n] - yp)
+            sa, sr = (sa + d, sr) if attack else (sa, sr + d)
+            carry = (1.0 - c) * l_
+        ref = torch.from_numpy(lam).float()
+        assert (gx[r].cpu() - ref).abs().max() <= 2e-6 * ref.abs().max(), r
+        want = torch.tensor([sa * at * (1 - at), sr * rt * (1 - rt)])
+        assert ((gz[r].cpu().double() - want).abs() <= 1e-4 * want.abs().max()).all(), (r, gz[r].cpu(), want)

@@ -58,3 +58,18 @@ for R in a.rows:
         for name, ms, nbytes in rows:
             gbs = nbytes / ms / 1e6
             print(f"| {R} | {zname} | {name} | {ms:.3f} | {gbs:.0f} | {gbs / 8000:.3f} |", flush=True)
+
+# the adjoint (training): rows cut into chunks with a 2048-sample warm-up against one lane per row
+print()
+print("| rows | z_alpha | adjoint form | ms | GB/s (algorithmic: x, y, g in, gx out) | of 8 TB/s |")
+print("|---|---|---|---|---|---|")
+for R in a.rows:
+    torch.manual_seed(1)
+    u = torch.rand(R, L, device="cuda") * 2
+    g = torch.randn(R, L, device="cuda")
+    for zname, z in (("randn*0.1", torch.randn(R, 2, device="cuda") * 0.1), ("-6", torch.full((R, 2), -6.0, device="cuda"))):
+        y = ops.ballistics(u, z)
+        for sched in ("chunks", "rows"):
+            ms = timed(lambda: ops.ballistics_bwd(u, y, g, z, schedule=sched))
+            gbs = 16 * R * L / ms / 1e6
+            print(f"| {R} | {zname} | {sched} | {ms:.3f} | {gbs:.0f} | {gbs / 8000:.3f} |", flush=True)
