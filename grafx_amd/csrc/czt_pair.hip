@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "czt_core.hpp"
 
@@ -318,6 +319,278 @@ static void pair_chain_levels(const CztGeom& g, const float* z, float* y, int64_
     hipLaunchKernelGGL((czt_pair_outer_out_kernel<T>), og, blk, 0, st, (const T2*)buf, cQ, y, ldy, lo, len, g, rows);
 }
 
+// ---- one outer level, fused (float): the outer radix-4 pass and the column pass of its four sub-transforms in ONE kernel ----
+// With one outer level a pair's transform is 4 sub-transforms of C x 8192 points; the chain above sweeps the workspace nine
+// times (outer in, columns, tiles, columns, outer mid, columns, tiles, columns, outer out).  Here the four waves of a
+// workgroup own the same 64 columns n2, wave q playing sub-transform k3 = q in the column passes and quarter n3 = q in the
+// radix-4 passes; the values change hands through LDS ([n1][q][column], C x 2 KB).  Five sweeps, as without the level:
+//   lv_in : z -> radix-4 over the quarters, twiddle W_NFFT^(n' k3) -> C-point DFT over n1, twiddle -> workspace
+//   lv_mid: workspace -> inverse column pass -> inverse radix-4 -> bins' factors -> radix-4 -> column pass -> workspace
+//   lv_out: workspace -> inverse column pass -> inverse radix-4 -> chirp, real / imaginary part to the pair's rows
+// The outer twiddle factors as W_NFFT^(n2 k3) (one per thread) times W_4C^(n1 k3) (a 4C-entry table in LDS, read at
+// wave-uniform addresses): n' = n1 8192 + n2 and NFFT = 4C x 8192.
+constexpr int LV_COLS = 64;
+
+template <typename T, int QUARTER> __device__ __forceinline__ typename Prec<T>::cxt lv_rot(typename Prec<T>::cxt t) {
+    using cx = typename Prec<T>::cxt;        // t times i^QUARTER: a swap and signs, free once QUARTER is a constant
+    constexpr int r = QUARTER & 3;
+    return r == 0 ? t : r == 1 ? cx{-t.y, t.x} : r == 2 ? cx{-t.x, -t.y} : cx{t.y, -t.x};
+}
+
+template <typename T, int C> struct LvShared {
+    using cx = typename Prec<T>::cxt;
+    cx* ex;        // [n1][q][col]
+    cx* tab;       // e^(-2 pi i j / 4C), j < 4C
+    __device__ __forceinline__ LvShared(unsigned char* raw) : ex(reinterpret_cast<cx*>(raw)), tab(ex + C * 4 * LV_COLS) {}
+    __device__ __forceinline__ void fill_table(int tid) {
+        for (int j = tid; j < 4 * C; j += 256) {
+            float sn, cs;
+            sincospif(2.0f * (float)j / (float)(4 * C), &sn, &cs);
+            tab[j] = cx{(T)cs, (T)(-sn)};
+        }
+    }
+    __device__ __forceinline__ cx& at(int n1, int q, int col) { return ex[(n1 * 4 + q) * LV_COLS + col]; }
+};
+template <int C> constexpr size_t lv_lds_bytes() { return (size_t)(C * 4 * LV_COLS + 4 * C) * sizeof(cx); }
+
+// forward radix-4 of the four quarters' values of (n1, column) for sub-transform K3 (the wave's role: a template parameter,
+// chosen by a uniform switch -- with a run-time role the rotations are selects and the middle kernel was ALU-bound at
+// 2.7 TB/s), with the outer twiddle
+template <typename T, int C, int K3>
+__device__ __forceinline__ typename Prec<T>::cxt lv_fwd4(LvShared<T, C>& sh, int n1, int col, typename Prec<T>::cxt a0) {
+    using cx = typename Prec<T>::cxt;
+    const cx x = sh.at(n1, 0, col) + lv_rot<T, 4 - ((1 * K3) & 3)>(sh.at(n1, 1, col)) + lv_rot<T, 4 - ((2 * K3) & 3)>(sh.at(n1, 2, col)) +
+                 lv_rot<T, 4 - ((3 * K3) & 3)>(sh.at(n1, 3, col));                                     // (-i)^(n3 k3)
+    return K3 == 0 ? x : cmul(x, cmul(a0, sh.tab[n1 * K3]));
+}
+// inverse radix-4: the value of quarter N3 from the four sub-transforms' (already conj-twiddled) values
+template <typename T, int C, int N3>
+__device__ __forceinline__ typename Prec<T>::cxt lv_inv4(LvShared<T, C>& sh, int n1, int col) {
+    using cx = typename Prec<T>::cxt;
+    const cx x = sh.at(n1, 0, col) + lv_rot<T, (1 * N3) & 3>(sh.at(n1, 1, col)) + lv_rot<T, (2 * N3) & 3>(sh.at(n1, 2, col)) +
+                 lv_rot<T, (3 * N3) & 3>(sh.at(n1, 3, col));                                          // i^(n3 k3)
+    return x * (T)0.25;
+}
+// the column of sub-transform K3, conj-twiddled, to LDS for the inverse radix-4 (scaled by sc)
+template <typename T, int C, int K3>
+__device__ __forceinline__ void lv_put_inverse(LvShared<T, C>& sh, const typename Prec<T>::cxt (&v)[C], int col,
+                                               typename Prec<T>::cxt a0, T sc) {
+    using cx = typename Prec<T>::cxt;
+#pragma unroll
+    for (int n1 = 0; n1 < C; ++n1) {
+        const cx e = v[spos(C, n1)] * sc;
+        if (K3 == 0) {
+            sh.at(n1, 0, col) = e;
+        } else {
+            const cx w = cmul(a0, sh.tab[n1 * K3]);               // conj of the forward outer twiddle
+            sh.at(n1, K3, col) = cmul(e, cx{w.x, -w.y});
+        }
+    }
+}
+
+template <typename T, int C, int K3>
+__device__ __forceinline__ void lv_take_forward(LvShared<T, C>& sh, typename Prec<T>::cxt (&v)[C], int col, typename Prec<T>::cxt a0) {
+#pragma unroll
+    for (int n1 = 0; n1 < C; ++n1) v[n1] = lv_fwd4<T, C, K3>(sh, n1, col, a0);
+}
+template <typename T, int C, int N3>
+__device__ __forceinline__ void lv_take_inverse(LvShared<T, C>& sh, typename Prec<T>::cxt (&u)[C], int col) {
+#pragma unroll
+    for (int n1 = 0; n1 < C; ++n1) u[n1] = lv_inv4<T, C, N3>(sh, n1, col);
+}
+
+#define GFX_LV_ROLE(q, ...) switch (q) { case 0: { constexpr int Q = 0; __VA_ARGS__; } break; case 1: { constexpr int Q = 1; __VA_ARGS__; } break; \
+                                         case 2: { constexpr int Q = 2; __VA_ARGS__; } break; default: { constexpr int Q = 3; __VA_ARGS__; } break; }
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void czt_pair_lv_in_kernel(const float* __restrict__ z, const typename Prec<T>::T2* __restrict__ cP,
+                                                            typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t rows) {
+    using cx = typename Prec<T>::cxt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lv_raw[];
+    LvShared<T, C> sh(lv_raw);
+    const int tid = threadIdx.x, col = tid & (LV_COLS - 1), q = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the wave's role: scalar)
+    const int n2 = blockIdx.x * LV_COLS + col;
+    const int64_t pr = blockIdx.y, NS = g.NFFT / 4, off = g.K - 1;
+    const ColBuf<T> cb(buf + pr * g.NFFT, g.NFFT);
+    const bool two = 2 * pr + 1 < rows;
+    const float* z1 = z + 2 * pr * g.P;
+    const float* z2 = z1 + (two ? g.P : 0);
+    sh.fill_table(tid);
+    // the input covers two of the four quarters: the 4C (quarter, n1) slots of a column are dealt round the four waves.
+    // All loads of a thread go out first, from clamped addresses (a load inside a per-slot test is a round trip per slot:
+    // 2.4 ms for this kernel), the tests are applied to the values
+    cx ce[C];
+    float za[C], zb[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;        // (scalar)
+        const int64_t m0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;   // first column's sample
+        ce[j] = cx{0, 0};
+        za[j] = zb[j] = 0.0f;
+        if (m0 + LV_COLS > 0 && m0 < g.P) {                                     // (uniform: the slot meets the input)
+            const int64_t m = m0 + col, mm = m < 0 ? 0 : (m >= g.P ? g.P - 1 : m);
+            ce[j] = to_cx(cP[mm]);
+            za[j] = z1[mm];
+            zb[j] = z2[mm];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;
+        const int64_t m = n3 * NS + (int64_t)n1 * TILE_M + n2 - off;
+        const bool ok = m >= 0 && m < g.P;
+        const T a = ok ? (T)za[j] : (T)0, bb = ok && two ? (T)zb[j] : (T)0;
+        sh.at(n1, n3, col) = cx{ce[j].x * a - ce[j].y * bb, ce[j].x * bb + ce[j].y * a};
+    }
+    __syncthreads();
+    const cx a0 = unit_root_f(n2 * q, (int)g.NFFT, false);      // W_NFFT^(n2 k3), n2 k3 < 3 x 8192 < NFFT
+    cx v[C];
+    GFX_LV_ROLE(q, lv_take_forward<T, C, Q>(sh, v, col, a0))
+    col_dft<C, false>(v);
+    ColTw<T, C> tw(n2, (int)NS, false);
+#pragma unroll
+    for (int k1 = 0; k1 < C; ++k1) {
+        const cx e = v[spos(C, k1)];
+        cb.st(q * C + k1, n2, k1 == 0 ? e : cmul(e, tw.at(k1)));
+    }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void czt_pair_lv_mid_kernel(typename Prec<T>::T2* __restrict__ buf,
+                                                             const typename Prec<T>::T2* __restrict__ mid, CztGeom g) {
+    using cx = typename Prec<T>::cxt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lv_raw[];
+    LvShared<T, C> sh(lv_raw);
+    const int tid = threadIdx.x, col = tid & (LV_COLS - 1), q = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the wave's role: scalar)
+    const int n2 = blockIdx.x * LV_COLS + col;
+    const int64_t NS = g.NFFT / 4;
+    const ColBuf<T> cb(buf + (int64_t)blockIdx.y * g.NFFT, g.NFFT);
+    sh.fill_table(tid);
+    cx v[C];
+    {
+        ColTw<T, C> twi(n2, (int)NS, true);
+#pragma unroll
+        for (int k1 = 0; k1 < C; ++k1) {
+            const cx e = cb.ld(q * C + k1, n2);
+            v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
+        }
+    }
+    col_dft<C, true>(v);
+    __syncthreads();      // (the table is there)
+    const cx a0 = unit_root_f(n2 * q, (int)g.NFFT, false);
+    GFX_LV_ROLE(q, lv_put_inverse<T, C, Q>(sh, v, col, a0, (T)1 / (T)NS))
+    __syncthreads();
+    cx u[C];
+    GFX_LV_ROLE(q, lv_take_inverse<T, C, Q>(sh, u, col))
+    {
+        cx f[C];                                                  // quarter q: the bins' factors (zero beyond the P bins),
+#pragma unroll
+        for (int n1 = 0; n1 < C; ++n1) {                          // loaded from clamped addresses, all at once
+            const int64_t i = q * NS + (int64_t)n1 * TILE_M + n2;
+            f[n1] = to_cx(mid[i < g.P ? i : g.P - 1]);
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < C; ++n1) {
+            const int64_t i = q * NS + (int64_t)n1 * TILE_M + n2;
+            u[n1] = i < g.P ? cmul(u[n1], f[n1]) : cx{0, 0};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n1 = 0; n1 < C; ++n1) sh.at(n1, q, col) = u[n1];
+    __syncthreads();
+    GFX_LV_ROLE(q, lv_take_forward<T, C, Q>(sh, v, col, a0))
+    col_dft<C, false>(v);
+    ColTw<T, C> twf(n2, (int)NS, false);
+#pragma unroll
+    for (int k1 = 0; k1 < C; ++k1) {
+        const cx e = v[spos(C, k1)];
+        cb.st(q * C + k1, n2, k1 == 0 ? e : cmul(e, twf.at(k1)));
+    }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void czt_pair_lv_out_kernel(const typename Prec<T>::T2* __restrict__ buf,
+                                                             const typename Prec<T>::T2* __restrict__ cQ, float* __restrict__ y,
+                                                             int64_t ldy, int64_t lo, int64_t len, CztGeom g, int64_t rows) {
+    using cx = typename Prec<T>::cxt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lv_raw[];
+    LvShared<T, C> sh(lv_raw);
+    const int tid = threadIdx.x, col = tid & (LV_COLS - 1), q = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the wave's role: scalar)
+    const int n2 = blockIdx.x * LV_COLS + col;
+    const int64_t pr = blockIdx.y, NS = g.NFFT / 4, off = g.K - 1;
+    const ColBuf<T> cb(buf + pr * g.NFFT, g.NFFT);
+    const bool two = 2 * pr + 1 < rows;
+    sh.fill_table(tid);
+    cx v[C];
+    {
+        ColTw<T, C> twi(n2, (int)NS, true);
+#pragma unroll
+        for (int k1 = 0; k1 < C; ++k1) {
+            const cx e = cb.ld(q * C + k1, n2);
+            v[k1] = k1 == 0 ? e : cmul(e, twi.at(k1));
+        }
+    }
+    col_dft<C, true>(v);
+    __syncthreads();
+    const cx a0 = unit_root_f(n2 * q, (int)g.NFFT, false);
+    GFX_LV_ROLE(q, lv_put_inverse<T, C, Q>(sh, v, col, a0, (T)1 / ((T)NS * (T)g.Q)))
+    __syncthreads();
+    float* y1 = czt_out_row(g, y, ldy, 2 * pr);
+    float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
+    // the output slice covers about two of the four quarters: the 4C (quarter, n1) slots are dealt round the four waves, the
+    // chirp's loads go out together from clamped addresses, then the products and the stores
+    cx cq[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;        // (scalar)
+        const int64_t n0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;
+        cq[j] = cx{0, 0};
+        if (n0 + LV_COLS > lo && n0 < lo + len) {                               // (uniform: the slot meets the slice)
+            const int64_t n = n0 + col;
+            cq[j] = to_cx(cQ[n < 0 ? 0 : (n >= g.Q ? g.Q - 1 : n)]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;
+        const int64_t n0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;
+        if (n0 + LV_COLS > lo && n0 < lo + len) {
+            cx x;
+            GFX_LV_ROLE(n3, x = lv_inv4<T, C, Q>(sh, n1, col))
+            const int64_t n = n0 + col;
+            if (n >= lo && n < lo + len) {
+                const cx o = cmul(x, cq[j]);
+                y1[n - lo] = (float)o.x;
+                if (two) y2[n - lo] = (float)o.y;
+            }
+        }
+    }
+}
+
+template <typename T, int CC>
+static int pair_chain_one_level(const CztGeom& g, const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows,
+                                const typename Prec<T>::T2* cP, const typename Prec<T>::T2* cQ, const typename Prec<T>::T2* mid,
+                                const typename Prec<T>::T2* spec, typename Prec<T>::T2* buf, const typename Prec<T>::T2* tw,
+                                hipStream_t st) {
+    using T2 = typename Prec<T>::T2;
+    constexpr int LDS = Prec<T>::lds_bytes;
+    constexpr size_t LV = lv_lds_bytes<CC>();
+    if (!czt_allow_lds(czt_pair_lv_in_kernel<T, CC>, (int)LV) || !czt_allow_lds(czt_pair_lv_mid_kernel<T, CC>, (int)LV) ||
+        !czt_allow_lds(czt_pair_lv_out_kernel<T, CC>, (int)LV))
+        return GFX_ELAUNCH;
+    const int64_t pairs = (rows + 1) / 2;
+    const dim3 grid(TILE_M / LV_COLS, (unsigned)pairs), blk(256);
+    const int ctot = 4 * CC;
+    const unsigned tiles = (unsigned)(pairs * ctot);
+    hipLaunchKernelGGL((czt_pair_lv_in_kernel<T, CC>), grid, blk, LV, st, z, cP, buf, g, rows);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec, (T2*)nullptr, ctot, tw);
+    hipLaunchKernelGGL((czt_pair_lv_mid_kernel<T, CC>), grid, blk, LV, st, buf, mid, g);
+    hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec + g.NFFT, (T2*)nullptr, ctot, tw);
+    hipLaunchKernelGGL((czt_pair_lv_out_kernel<T, CC>), grid, blk, LV, st, (const T2*)buf, cQ, y, ldy, lo, len, g, rows);
+    return GFX_OK;
+}
+
 template <typename T, int MODE>
 static void pair_cols_fwd(const CztGeom& g, typename Prec<T>::T2* buf, int64_t pairs, hipStream_t st, ChirpSeq cs) {
     using T2 = typename Prec<T>::T2;
@@ -410,6 +683,17 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
         T2* buf = (T2*)ws + p0 * g.NFFT;
         g.row0 = row0 + 2 * p0;
         if (g.levels > 0) {
+            if constexpr (sizeof(T) == 4) {
+                static const bool fused = [] { const char* e = getenv("GRAFX_CZT_FUSED_LEVEL"); return !(e && e[0] == '0'); }();
+                if (g.levels == 1 && fused) {
+                    int rc = GFX_EINVAL;
+#define GFX_PL(CC) case CC: rc = pair_chain_one_level<T, CC>(g, zc, yc, ldy, lo, len, n, cP, cQ, mid, spec, buf, tw, st); break;
+                    switch (g.C) { GFX_CZT_SIZES(GFX_PL) default: break; }
+#undef GFX_PL
+                    if (rc != GFX_OK) return rc;
+                    continue;
+                }
+            }
             pair_chain_levels<T>(g, zc, yc, ldy, lo, len, n, cP, cQ, mid, spec, buf, tw, st);
             continue;
         }

@@ -134,10 +134,11 @@ def test_precise_pairs_are_float64_accurate(P):
     assert torch.equal(ops.odd_alias(z, lo, n, precise=True), got[..., lo : lo + n])
 
 
-@pytest.mark.parametrize("P,C", [(4001, 2), (135071, 2), (9001, 1), (9001, 3)])
+@pytest.mark.parametrize("P,C", [(4001, 2), (135071, 2), (9001, 1), (9001, 3), (262145, 2), (1000001, 1)])
 def test_pairs_write_strided_buffer_rows_in_place(P, C):
     """gfx_odd_alias_pair_rows_f32: rows 2r, 2r + 1 of the call -> row q / C, channel q % C of a strided (B, n, C, len) view
-    (the render's signal buffer); odd C makes pairs straddle signal rows; chunks keep pairs whole."""
+    (the render's signal buffer); odd C makes pairs straddle signal rows; chunks keep pairs whole.  P = 262 145: the fused
+    one-outer-level kernels; 1 000 001: two outer levels on czt.hip's passes."""
     from grafx_amd import ops
 
     B, V, n, L = 2, 5, 3, P - 1 - 7
@@ -181,3 +182,19 @@ def test_a_call_of_many_rows_gives_the_bits_of_calls_of_two(P, rows, precise):
         assert torch.equal(big, small), pairs
     want = torch.fft.irfft(torch.fft.rfft(z.double()))[:, 5:1005]
     assert (big.double() - want).abs().max() <= 3e-6 * want.abs().max()
+
+
+@pytest.mark.parametrize("P", [258049, 299999, 483999])
+def test_fused_outer_level_equals_the_separate_passes(P, monkeypatch):
+    """One outer radix-4 level: czt_pair_lv_* (outer pass + column pass in one kernel, five sweeps) against the chain of
+    separate passes (nine sweeps; GRAFX_CZT_FUSED_LEVEL=0 is read once per process, so the separate chain is reached through
+    the one-row form here, which has no fused kernels): the same transform, another factorisation of the twiddles."""
+    from grafx_amd import ops
+
+    torch.manual_seed(P)
+    z = torch.randn(5, P, device="cuda")
+    got = ops.odd_alias(z, 100, 4096)
+    single = _one_row_form(lambda: ops.odd_alias(z, 100, 4096))
+    want = _want(z)[:, 100:4196]
+    assert (got.double() - want).abs().max() <= 3e-6 * want.abs().max()
+    assert (got - single).abs().max() <= 3e-6 * single.abs().max()
