@@ -341,7 +341,7 @@ template <typename T, int C> struct LvShared {
     using cx = typename Prec<T>::cxt;
     cx* ex;        // [n1][q][col]
     cx* tab;       // e^(-2 pi i j / 4C), j < 4C
-    __device__ __forceinline__ LvShared(unsigned char* raw) : ex(reinterpret_cast<cx*>(raw)), tab(ex + C * 4 * LV_COLS) {}
+    __device__ __forceinline__ LvShared(unsigned char* raw, int exrows = C) : ex(reinterpret_cast<cx*>(raw)), tab(ex + exrows * 4 * LV_COLS) {}
     __device__ __forceinline__ void fill_table(int tid) {
         for (int j = tid; j < 4 * C; j += 256) {
             float sn, cs;
@@ -351,16 +351,18 @@ template <typename T, int C> struct LvShared {
     }
     __device__ __forceinline__ cx& at(int n1, int q, int col) { return ex[(n1 * 4 + q) * LV_COLS + col]; }
 };
-template <int C> constexpr size_t lv_lds_bytes() { return (size_t)(C * 4 * LV_COLS + 4 * C) * sizeof(cx); }
+template <int C> constexpr size_t lv_lds_bytes(int exrows = C) { return (size_t)(exrows * 4 * LV_COLS + 4 * C) * sizeof(cx); }
+// the last kernel exchanges its column in two halves of n1 (half the LDS: three workgroups per CU instead of two)
+template <int C> constexpr int lv_half() { return (C + 1) / 2; }
 
 // forward radix-4 of the four quarters' values of (n1, column) for sub-transform K3 (the wave's role: a template parameter,
 // chosen by a uniform switch -- with a run-time role the rotations are selects and the middle kernel was ALU-bound at
 // 2.7 TB/s), with the outer twiddle
 template <typename T, int C, int K3>
-__device__ __forceinline__ typename Prec<T>::cxt lv_fwd4(LvShared<T, C>& sh, int n1, int col, typename Prec<T>::cxt a0) {
-    using cx = typename Prec<T>::cxt;
-    const cx x = sh.at(n1, 0, col) + lv_rot<T, 4 - ((1 * K3) & 3)>(sh.at(n1, 1, col)) + lv_rot<T, 4 - ((2 * K3) & 3)>(sh.at(n1, 2, col)) +
-                 lv_rot<T, 4 - ((3 * K3) & 3)>(sh.at(n1, 3, col));                                     // (-i)^(n3 k3)
+__device__ __forceinline__ typename Prec<T>::cxt lv_fwd4(LvShared<T, C>& sh, int row, int n1, int col, typename Prec<T>::cxt a0) {
+    using cx = typename Prec<T>::cxt;       // (row: where the exchange holds n1's values)
+    const cx x = sh.at(row, 0, col) + lv_rot<T, 4 - ((1 * K3) & 3)>(sh.at(row, 1, col)) + lv_rot<T, 4 - ((2 * K3) & 3)>(sh.at(row, 2, col)) +
+                 lv_rot<T, 4 - ((3 * K3) & 3)>(sh.at(row, 3, col));                                    // (-i)^(n3 k3)
     return K3 == 0 ? x : cmul(x, cmul(a0, sh.tab[n1 * K3]));
 }
 // inverse radix-4: the value of quarter N3 from the four sub-transforms' (already conj-twiddled) values
@@ -372,26 +374,26 @@ __device__ __forceinline__ typename Prec<T>::cxt lv_inv4(LvShared<T, C>& sh, int
     return x * (T)0.25;
 }
 // the column of sub-transform K3, conj-twiddled, to LDS for the inverse radix-4 (scaled by sc)
-template <typename T, int C, int K3>
+template <typename T, int C, int K3, int A = 0, int B = C>
 __device__ __forceinline__ void lv_put_inverse(LvShared<T, C>& sh, const typename Prec<T>::cxt (&v)[C], int col,
                                                typename Prec<T>::cxt a0, T sc) {
-    using cx = typename Prec<T>::cxt;
+    using cx = typename Prec<T>::cxt;       // rows n1 in [A, B), stored at n1 - A
 #pragma unroll
-    for (int n1 = 0; n1 < C; ++n1) {
+    for (int n1 = A; n1 < B; ++n1) {
         const cx e = v[spos(C, n1)] * sc;
         if (K3 == 0) {
-            sh.at(n1, 0, col) = e;
+            sh.at(n1 - A, 0, col) = e;
         } else {
             const cx w = cmul(a0, sh.tab[n1 * K3]);               // conj of the forward outer twiddle
-            sh.at(n1, K3, col) = cmul(e, cx{w.x, -w.y});
+            sh.at(n1 - A, K3, col) = cmul(e, cx{w.x, -w.y});
         }
     }
 }
 
-template <typename T, int C, int K3>
+template <typename T, int C, int K3, int A = 0, int B = C>
 __device__ __forceinline__ void lv_take_forward(LvShared<T, C>& sh, typename Prec<T>::cxt (&v)[C], int col, typename Prec<T>::cxt a0) {
 #pragma unroll
-    for (int n1 = 0; n1 < C; ++n1) v[n1] = lv_fwd4<T, C, K3>(sh, n1, col, a0);
+    for (int n1 = A; n1 < B; ++n1) v[n1] = lv_fwd4<T, C, K3>(sh, n1 - A, n1, col, a0);
 }
 template <typename T, int C, int N3>
 __device__ __forceinline__ void lv_take_inverse(LvShared<T, C>& sh, typename Prec<T>::cxt (&u)[C], int col) {
@@ -407,7 +409,8 @@ __global__ __launch_bounds__(256) void czt_pair_lv_in_kernel(const float* __rest
                                                             typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t rows) {
     using cx = typename Prec<T>::cxt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lv_raw[];
-    LvShared<T, C> sh(lv_raw);
+    constexpr int CH = lv_half<C>();
+    LvShared<T, C> sh(lv_raw, CH);
     const int tid = threadIdx.x, col = tid & (LV_COLS - 1), q = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the wave's role: scalar)
     const int n2 = blockIdx.x * LV_COLS + col;
     const int64_t pr = blockIdx.y, NS = g.NFFT / 4, off = g.K - 1;
@@ -416,36 +419,44 @@ __global__ __launch_bounds__(256) void czt_pair_lv_in_kernel(const float* __rest
     const float* z1 = z + 2 * pr * g.P;
     const float* z2 = z1 + (two ? g.P : 0);
     sh.fill_table(tid);
-    // the input covers two of the four quarters: the 4C (quarter, n1) slots of a column are dealt round the four waves.
-    // All loads of a thread go out first, from clamped addresses (a load inside a per-slot test is a round trip per slot:
-    // 2.4 ms for this kernel), the tests are applied to the values
-    cx ce[C];
-    float za[C], zb[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;        // (scalar)
-        const int64_t m0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;   // first column's sample
-        ce[j] = cx{0, 0};
-        za[j] = zb[j] = 0.0f;
-        if (m0 + LV_COLS > 0 && m0 < g.P) {                                     // (uniform: the slot meets the input)
-            const int64_t m = m0 + col, mm = m < 0 ? 0 : (m >= g.P ? g.P - 1 : m);
-            ce[j] = to_cx(cP[mm]);
-            za[j] = z1[mm];
-            zb[j] = z2[mm];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;
-        const int64_t m = n3 * NS + (int64_t)n1 * TILE_M + n2 - off;
-        const bool ok = m >= 0 && m < g.P;
-        const T a = ok ? (T)za[j] : (T)0, bb = ok && two ? (T)zb[j] : (T)0;
-        sh.at(n1, n3, col) = cx{ce[j].x * a - ce[j].y * bb, ce[j].x * bb + ce[j].y * a};
-    }
-    __syncthreads();
     const cx a0 = unit_root_f(n2 * q, (int)g.NFFT, false);      // W_NFFT^(n2 k3), n2 k3 < 3 x 8192 < NFFT
     cx v[C];
-    GFX_LV_ROLE(q, lv_take_forward<T, C, Q>(sh, v, col, a0))
+    // Per half of n1 (half the LDS: more workgroups per CU).  The input covers two of the four quarters: the (quarter, n1)
+    // slots of a column are dealt round the four waves.  All loads of a thread go out first, from clamped addresses (a load
+    // inside a per-slot test is a round trip per slot: 2.4 against 1.65 ms for this kernel), the tests are applied to the values
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int A = h * CH, NH = h == 0 ? CH : C - CH;        // rows [A, A + NH) of n1
+        cx ce[CH];
+        float za[CH], zb[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int slot = 4 * j + q, n3 = slot / NH, n1 = A + slot - n3 * NH;     // (scalar)
+            const int64_t m0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;   // first column's sample
+            ce[j] = cx{0, 0};
+            za[j] = zb[j] = 0.0f;
+            if (slot < 4 * NH && m0 + LV_COLS > 0 && m0 < g.P) {                    // (uniform: the slot meets the input)
+                const int64_t m = m0 + col, mm = m < 0 ? 0 : (m >= g.P ? g.P - 1 : m);
+                ce[j] = to_cx(cP[mm]);
+                za[j] = z1[mm];
+                zb[j] = z2[mm];
+            }
+        }
+        if (h) __syncthreads();        // (the first half's values have been taken)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int slot = 4 * j + q, n3 = slot / NH, n1l = slot - n3 * NH;
+            if (slot < 4 * NH) {
+                const int64_t m = n3 * NS + (int64_t)(A + n1l) * TILE_M + n2 - off;
+                const bool ok = m >= 0 && m < g.P;
+                const T a = ok ? (T)za[j] : (T)0, bb = ok && two ? (T)zb[j] : (T)0;
+                sh.at(n1l, n3, col) = cx{ce[j].x * a - ce[j].y * bb, ce[j].x * bb + ce[j].y * a};
+            }
+        }
+        __syncthreads();
+        if (h == 0) { GFX_LV_ROLE(q, lv_take_forward<T, C, Q, 0, CH>(sh, v, col, a0)) }
+        else { GFX_LV_ROLE(q, lv_take_forward<T, C, Q, CH, C>(sh, v, col, a0)) }
+    }
     col_dft<C, false>(v);
     ColTw<T, C> tw(n2, (int)NS, false);
 #pragma unroll
@@ -515,7 +526,8 @@ __global__ __launch_bounds__(256) void czt_pair_lv_out_kernel(const typename Pre
                                                              int64_t ldy, int64_t lo, int64_t len, CztGeom g, int64_t rows) {
     using cx = typename Prec<T>::cxt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lv_raw[];
-    LvShared<T, C> sh(lv_raw);
+    constexpr int CH = lv_half<C>();
+    LvShared<T, C> sh(lv_raw, CH);
     const int tid = threadIdx.x, col = tid & (LV_COLS - 1), q = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the wave's role: scalar)
     const int n2 = blockIdx.x * LV_COLS + col;
     const int64_t pr = blockIdx.y, NS = g.NFFT / 4, off = g.K - 1;
@@ -534,35 +546,44 @@ __global__ __launch_bounds__(256) void czt_pair_lv_out_kernel(const typename Pre
     col_dft<C, true>(v);
     __syncthreads();
     const cx a0 = unit_root_f(n2 * q, (int)g.NFFT, false);
-    GFX_LV_ROLE(q, lv_put_inverse<T, C, Q>(sh, v, col, a0, (T)1 / ((T)NS * (T)g.Q)))
-    __syncthreads();
+    const T sc = (T)1 / ((T)NS * (T)g.Q);
     float* y1 = czt_out_row(g, y, ldy, 2 * pr);
     float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
-    // the output slice covers about two of the four quarters: the 4C (quarter, n1) slots are dealt round the four waves, the
-    // chirp's loads go out together from clamped addresses, then the products and the stores
-    cx cq[C];
+    // Per half of n1: the column to LDS, then -- the output slice covers about two of the four quarters -- the 4 x CH
+    // (quarter, n1) slots dealt round the four waves, the chirp's loads out together from clamped addresses, products, stores
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;        // (scalar)
-        const int64_t n0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;
-        cq[j] = cx{0, 0};
-        if (n0 + LV_COLS > lo && n0 < lo + len) {                               // (uniform: the slot meets the slice)
-            const int64_t n = n0 + col;
-            cq[j] = to_cx(cQ[n < 0 ? 0 : (n >= g.Q ? g.Q - 1 : n)]);
+    for (int h = 0; h < 2; ++h) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int A = h * CH, NH = h == 0 ? CH : C - CH;        // rows [A, A + NH) of n1
+        if (h) __syncthreads();
+        if (h == 0) { GFX_LV_ROLE(q, lv_put_inverse<T, C, Q, 0, CH>(sh, v, col, a0, sc)) }
+        else { GFX_LV_ROLE(q, lv_put_inverse<T, C, Q, CH, C>(sh, v, col, a0, sc)) }
+        __syncthreads();
+        cx cq[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int slot = 4 * j + q, n3 = slot / NH, n1 = A + slot - n3 * NH;     // (scalar)
+            const int64_t n0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;
+            cq[j] = cx{0, 0};
+            if (slot < 4 * NH && n0 + LV_COLS > lo && n0 < lo + len) {               // (uniform: the slot meets the slice)
+                const int64_t n = n0 + col;
+                cq[j] = to_cx(cQ[n < 0 ? 0 : (n >= g.Q ? g.Q - 1 : n)]);
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const int slot = 4 * j + q, n3 = slot / C, n1 = slot - n3 * C;
-        const int64_t n0 = n3 * NS + (int64_t)n1 * TILE_M + blockIdx.x * LV_COLS - off;
-        if (n0 + LV_COLS > lo && n0 < lo + len) {
-            cx x;
-            GFX_LV_ROLE(n3, x = lv_inv4<T, C, Q>(sh, n1, col))
-            const int64_t n = n0 + col;
-            if (n >= lo && n < lo + len) {
-                const cx o = cmul(x, cq[j]);
-                y1[n - lo] = (float)o.x;
-                if (two) y2[n - lo] = (float)o.y;
+        for (int j = 0; j < CH; ++j) {
+            const int slot = 4 * j + q, n3 = slot / NH, n1l = slot - n3 * NH;
+            const int64_t n0 = n3 * NS + (int64_t)(A + n1l) * TILE_M + blockIdx.x * LV_COLS - off;
+            if (slot < 4 * NH && n0 + LV_COLS > lo && n0 < lo + len) {
+                cx x;
+                GFX_LV_ROLE(n3, x = lv_inv4<T, C, Q>(sh, n1l, col))
+                const int64_t n = n0 + col;
+                if (n >= lo && n < lo + len) {
+                    const cx o = cmul(x, cq[j]);
+                    y1[n - lo] = (float)o.x;
+                    if (two) y2[n - lo] = (float)o.y;
+                }
             }
         }
     }
@@ -575,19 +596,19 @@ static int pair_chain_one_level(const CztGeom& g, const float* z, float* y, int6
                                 hipStream_t st) {
     using T2 = typename Prec<T>::T2;
     constexpr int LDS = Prec<T>::lds_bytes;
-    constexpr size_t LV = lv_lds_bytes<CC>();
-    if (!czt_allow_lds(czt_pair_lv_in_kernel<T, CC>, (int)LV) || !czt_allow_lds(czt_pair_lv_mid_kernel<T, CC>, (int)LV) ||
-        !czt_allow_lds(czt_pair_lv_out_kernel<T, CC>, (int)LV))
+    constexpr size_t LV = lv_lds_bytes<CC>(), LVH = lv_lds_bytes<CC>(lv_half<CC>());
+    if (!czt_allow_lds(czt_pair_lv_in_kernel<T, CC>, (int)LVH) || !czt_allow_lds(czt_pair_lv_mid_kernel<T, CC>, (int)LV) ||
+        !czt_allow_lds(czt_pair_lv_out_kernel<T, CC>, (int)LVH))
         return GFX_ELAUNCH;
     const int64_t pairs = (rows + 1) / 2;
     const dim3 grid(TILE_M / LV_COLS, (unsigned)pairs), blk(256);
     const int ctot = 4 * CC;
     const unsigned tiles = (unsigned)(pairs * ctot);
-    hipLaunchKernelGGL((czt_pair_lv_in_kernel<T, CC>), grid, blk, LV, st, z, cP, buf, g, rows);
+    hipLaunchKernelGGL((czt_pair_lv_in_kernel<T, CC>), grid, blk, LVH, st, z, cP, buf, g, rows);
     hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec, (T2*)nullptr, ctot, tw);
     hipLaunchKernelGGL((czt_pair_lv_mid_kernel<T, CC>), grid, blk, LV, st, buf, mid, g);
     hipLaunchKernelGGL((czt_rows_kernel<T, false>), dim3(tiles), dim3(TILE_T), LDS, st, buf, spec + g.NFFT, (T2*)nullptr, ctot, tw);
-    hipLaunchKernelGGL((czt_pair_lv_out_kernel<T, CC>), grid, blk, LV, st, (const T2*)buf, cQ, y, ldy, lo, len, g, rows);
+    hipLaunchKernelGGL((czt_pair_lv_out_kernel<T, CC>), grid, blk, LVH, st, (const T2*)buf, cQ, y, ldy, lo, len, g, rows);
     return GFX_OK;
 }
 
