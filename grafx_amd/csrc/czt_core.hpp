@@ -64,6 +64,9 @@ struct CztGeom {
     int yC;
     int64_t row0;
     gfx_rowmap_t ymap;
+    // two rows per transform (czt_pair.hip): bits of max |z| of every row of the launch chain, or null -- the second row
+    // of a pair goes through scaled by the power of two that brings it to the first row's binade (pair_scale)
+    const uint32_t* rmax;
 };
 
 __device__ __forceinline__ float* czt_out_row(const CztGeom& g, float* y, int64_t ldy, int64_t row) {
@@ -81,6 +84,7 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
     if (P < 3 || (P & 1) == 0) return false;
     g.yC = 0;
     g.row0 = 0;
+    g.rmax = nullptr;
     g.ymap = gfx_rowmap_t{1, 0, 0, 0};
     g.P = P;
     g.Q = P - 1;

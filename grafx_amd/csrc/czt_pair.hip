@@ -16,8 +16,11 @@
 // 2 x (3P - 1) / 2: a third fewer bytes through every pass (P = 135 071: 35 tiles per pair against 2 x 25), for the same
 // five passes.  Up to 63 tiles in one column pass (P <= 258 048: 5.4 s of audio at 48 kHz); longer rows take outer radix-4
 // levels around czt.hip's column passes of up to 32 tiles, as there (2P - 1 <= 2^24: P <= 8 388 607); the adjoint stays on
-// czt.hip.  The rounding error of a row now carries eps times the LARGER of the two rows -- the callers pair neighbouring
-// rows of one call (the two channels of a stereo signal, or neighbouring tracks' envelopes in double precision).
+// czt.hip.  A transform's rounding error is eps times its LARGER component, so the rows of a pair are brought to one binade
+// first: czt_rowmax_kernel takes max |z| of every row, the first column pass multiplies the second row by the power of
+// two 2^(e1 - e2) (exact), the last one divides it out again (exact), and a row that is all zero comes out all zero.
+// Every row keeps an error relative to ITS OWN peak, as the reference's independent rows do; a pair of equally loud rows
+// (same binade) is bit-identical to the unscaled pair.  (GRAFX_ALIAS_PAIR_SCALE=0: no scaling, round 5's behaviour.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -42,6 +45,7 @@ static inline bool czt_pair_geom(int64_t P, CztGeom& g) {
     if (P < 3 || (P & 1) == 0) return false;
     g.yC = 0;
     g.row0 = 0;
+    g.rmax = nullptr;
     g.ymap = gfx_rowmap_t{1, 0, 0, 0};
     g.P = P;
     g.Q = P - 1;
@@ -68,6 +72,8 @@ static inline bool czt_pair_geom(int64_t P, CztGeom& g) {
 // plan layout (T2 units): cP[P] | cQ[Q] | mid[P] | spectrum of bP over [-(P + K - 2), K - 1] | spectrum of bQ over
 // [-(K - 1), Q + K - 2];  mid[i] = cP[|k'|] cQ[|k'|] w_k' for the bin k' = i - (K - 1) stored at position i (times
 // 1 / NFFT when the transform has no outer levels: its inverse column pass leaves the scaling to this table)
+// the workspace's tail: one word per row (max |z|), rounded up to 256 bytes
+static inline size_t pair_rmax_bytes(int64_t rows) { return ((size_t)rows * sizeof(uint32_t) + 255) & ~(size_t)255; }
 static inline size_t czt_pair_plan_t2(const CztGeom& g) { return (size_t)(g.P + g.Q + g.P + 2 * g.NFFT); }
 
 template <typename T>
@@ -84,7 +90,73 @@ __global__ void czt_pair_mid_table_kernel(typename Prec<T>::T2* __restrict__ mid
 // column kernel from being hoisted above the C-point transform, where they would be live on top of the column itself
 __device__ __forceinline__ void pair_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
-// first column pass: (z1[m] + i z2[m]) cP[m] at position m + K - 1, zero elsewhere
+
+// ---- per-row scaling of a pair -------------------------------------------------------------------------------------
+// bits of max |z[r, :]| (non-negative floats order like their bit patterns; a NaN sorts above everything)
+constexpr int RMAX_SPAN = 8192;     // samples of a row per workgroup: eight 16-byte loads per thread, all in flight
+typedef float rmax_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t rmax_abs(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+template <typename T>     // (T: one instance per translation unit that includes this file)
+__global__ __launch_bounds__(256) void czt_rowmax_kernel(const float* __restrict__ z, int64_t P, uint32_t* __restrict__ rmax) {
+    const float* row = z + (int64_t)blockIdx.y * P;
+    // rows of odd length start at any multiple of four bytes: quads are taken from the 16-byte boundary below the row,
+    // the first and the last quad of a row element by element
+    const int mis = (int)(((uintptr_t)row >> 2) & 3);
+    const rmax_f4* quads = reinterpret_cast<const rmax_f4*>(row - mis);
+    const int64_t nq = (P + mis + 3) >> 2, q0 = (int64_t)blockIdx.x * (RMAX_SPAN / 4) + threadIdx.x;
+    rmax_f4 v[RMAX_SPAN / 1024];
+#pragma unroll
+    for (int j = 0; j < RMAX_SPAN / 1024; ++j) {
+        const int64_t q = q0 + j * 256;
+        v[j] = rmax_f4{0.f, 0.f, 0.f, 0.f};
+        if (q > 0 && q < nq - 1) {
+            v[j] = quads[q];
+        } else if (q < nq) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t i = 4 * q - mis + c;
+                if (i >= 0 && i < P) v[j][c] = row[i];
+            }
+        }
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < RMAX_SPAN / 1024; ++j) {
+        const uint32_t a = rmax_abs(v[j][0]), b = rmax_abs(v[j][1]), c = rmax_abs(v[j][2]), d = rmax_abs(v[j][3]);
+        const uint32_t ab = a > b ? a : b, cd = c > d ? c : d, e = ab > cd ? ab : cd;
+        m = e > m ? e : m;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(rmax + blockIdx.y, m);
+}
+
+struct PairScale {
+    int d;            // the second row goes in as z2 2^d and comes out as y2 2^-d
+    bool nz1, nz2;    // a row that is all zero comes out all zero
+};
+__device__ __forceinline__ PairScale pair_scale(const CztGeom& g, int64_t pr, bool two) {
+    PairScale s{0, true, true};
+    if (g.rmax) {
+        const uint32_t m1 = g.rmax[2 * pr], m2 = two ? g.rmax[2 * pr + 1] : 0u;     // (uniform: scalar loads)
+        s.nz1 = m1 != 0;
+        s.nz2 = m2 != 0;
+        int e1, e2;
+        (void)frexpf(__uint_as_float(m1), &e1);
+        (void)frexpf(__uint_as_float(m2), &e2);
+        // (a row holding an infinity or a NaN poisons its partner whatever the scale: left alone)
+        s.d = (m1 != 0 && m2 != 0 && m1 < 0x7f800000u && m2 < 0x7f800000u) ? e1 - e2 : 0;
+    }
+    return s;
+}
+template <typename T> __device__ __forceinline__ T pair_ldexp(T x, int d) {
+    if constexpr (sizeof(T) == 4) return ldexpf(x, d); else return ldexp(x, d);
+}
+
+// first column pass: (z1[m] + i z2[m] 2^d) cP[m] at position m + K - 1, zero elsewhere
 template <typename T, int C>
 __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restrict__ z, const typename Prec<T>::T2* __restrict__ cP,
                                                          typename Prec<T>::T2* __restrict__ buf, CztGeom g, int64_t rows) {
@@ -96,6 +168,7 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
     const bool two = 2 * pr + 1 < rows;
     const float* z1 = z + 2 * pr * g.P;
     const float* z2 = z1 + (two ? g.P : 0);
+    const PairScale ps = pair_scale(g, pr, two);
     cx v[C];
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
@@ -103,7 +176,7 @@ __global__ __launch_bounds__(256) void czt_pair_in_kernel(const float* __restric
         cx e = {0, 0};
         if (m >= 0 && m < g.P) {
             const cx c = to_cx(cP[m]);
-            const T a = (T)z1[m], bb = two ? (T)z2[m] : (T)0;
+            const T a = (T)z1[m], bb = two ? pair_ldexp((T)z2[m], ps.d) : (T)0;
             e = cx{c.x * a - c.y * bb, c.x * bb + c.y * a};
         }
         v[n1] = e;
@@ -191,13 +264,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_out_kern
     const T sc = (T)1 / ((T)g.NFFT * (T)g.Q);
     float* y1 = czt_out_row(g, y, ldy, 2 * pr);
     float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
+    const PairScale ps = pair_scale(g, pr, two);
 #pragma unroll
     for (int n1 = 0; n1 < C; ++n1) {
         const int64_t n = (int64_t)n1 * TILE_M + n2 - off;
         if (n >= lo && n < lo + len) {
             const cx o = cmul(v[spos(C, n1)], to_cx(cQ[n])) * sc;
-            y1[n - lo] = (float)o.x;
-            if (two) y2[n - lo] = (float)o.y;
+            y1[n - lo] = ps.nz1 ? (float)o.x : 0.0f;
+            if (two) y2[n - lo] = ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f;
         }
     }
 }
@@ -216,6 +290,7 @@ __global__ __launch_bounds__(256) void czt_pair_outer_in_kernel(const float* __r
     const bool two = 2 * pr + 1 < rows;
     const float* z1 = z + 2 * pr * g.P;
     const float* z2 = z1 + (two ? g.P : 0);
+    const PairScale ps = pair_scale(g, pr, two);
     cx v[4];
 #pragma unroll
     for (int n3 = 0; n3 < 4; ++n3) {
@@ -223,7 +298,7 @@ __global__ __launch_bounds__(256) void czt_pair_outer_in_kernel(const float* __r
         cx e = {0, 0};
         if (m >= 0 && m < g.P) {
             const cx c = to_cx(cP[m]);
-            const T a = (T)z1[m], bb = two ? (T)z2[m] : (T)0;
+            const T a = (T)z1[m], bb = two ? pair_ldexp((T)z2[m], ps.d) : (T)0;
             e = cx{c.x * a - c.y * bb, c.x * bb + c.y * a};
         }
         v[n3] = e;
@@ -286,13 +361,14 @@ __global__ __launch_bounds__(256) void czt_pair_outer_out_kernel(const typename 
     const T sc = (T)0.25 / (T)g.Q;
     float* y1 = czt_out_row(g, y, ldy, 2 * pr);
     float* y2 = two ? czt_out_row(g, y, ldy, 2 * pr + 1) : y1;
+    const PairScale ps = pair_scale(g, pr, two);
 #pragma unroll
     for (int n3 = 0; n3 < 4; ++n3) {
         const int64_t n = n3 * NS + np - off;
         if (n >= lo && n < lo + len) {
             const cx o = cmul(v[brev(n3, 2)], to_cx(cQ[n])) * sc;
-            y1[n - lo] = (float)o.x;
-            if (two) y2[n - lo] = (float)o.y;
+            y1[n - lo] = ps.nz1 ? (float)o.x : 0.0f;
+            if (two) y2[n - lo] = ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f;
         }
     }
 }
@@ -418,6 +494,7 @@ __global__ __launch_bounds__(256) void czt_pair_lv_in_kernel(const float* __rest
     const bool two = 2 * pr + 1 < rows;
     const float* z1 = z + 2 * pr * g.P;
     const float* z2 = z1 + (two ? g.P : 0);
+    const PairScale ps = pair_scale(g, pr, two);
     sh.fill_table(tid);
     const cx a0 = unit_root_f(n2 * q, (int)g.NFFT, false);      // W_NFFT^(n2 k3), n2 k3 < 3 x 8192 < NFFT
     cx v[C];
@@ -449,7 +526,7 @@ __global__ __launch_bounds__(256) void czt_pair_lv_in_kernel(const float* __rest
             if (slot < 4 * NH) {
                 const int64_t m = n3 * NS + (int64_t)(A + n1l) * TILE_M + n2 - off;
                 const bool ok = m >= 0 && m < g.P;
-                const T a = ok ? (T)za[j] : (T)0, bb = ok && two ? (T)zb[j] : (T)0;
+                const T a = ok ? (T)za[j] : (T)0, bb = ok && two ? pair_ldexp((T)zb[j], ps.d) : (T)0;
                 sh.at(n1l, n3, col) = cx{ce[j].x * a - ce[j].y * bb, ce[j].x * bb + ce[j].y * a};
             }
         }
@@ -533,6 +610,7 @@ __global__ __launch_bounds__(256) void czt_pair_lv_out_kernel(const typename Pre
     const int64_t pr = blockIdx.y, NS = g.NFFT / 4, off = g.K - 1;
     const ColBuf<T> cb(buf + pr * g.NFFT, g.NFFT);
     const bool two = 2 * pr + 1 < rows;
+    const PairScale ps = pair_scale(g, pr, two);
     sh.fill_table(tid);
     cx v[C];
     {
@@ -581,8 +659,8 @@ __global__ __launch_bounds__(256) void czt_pair_lv_out_kernel(const typename Pre
                 const int64_t n = n0 + col;
                 if (n >= lo && n < lo + len) {
                     const cx o = cmul(x, cq[j]);
-                    y1[n - lo] = (float)o.x;
-                    if (two) y2[n - lo] = (float)o.y;
+                    y1[n - lo] = ps.nz1 ? (float)o.x : 0.0f;
+                    if (two) y2[n - lo] = ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f;
                 }
             }
         }
@@ -688,8 +766,20 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
     }
     if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
     const int64_t pairs = (rows + 1) / 2;
-    if (!ws || ws_bytes < (size_t)pairs * g.NFFT * sizeof(T2)) return GFX_ENOSPC;
+    if (!ws || ws_bytes < (size_t)pairs * g.NFFT * sizeof(T2) + pair_rmax_bytes(rows)) return GFX_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
+    static const bool scaled = [] { const char* e = getenv("GRAFX_ALIAS_PAIR_SCALE"); return !(e && e[0] == '0'); }();
+    uint32_t* rmax = nullptr;
+    if (scaled && rows > 1) {
+        // max |z| of every row, behind the transforms' own workspace
+        rmax = (uint32_t*)((T2*)ws + pairs * g.NFFT);
+        if (hipMemsetAsync(rmax, 0, (size_t)rows * sizeof(uint32_t), st) != hipSuccess) return GFX_ELAUNCH;
+        for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+            const int64_t n = rows - r0 < 65535 ? rows - r0 : 65535;
+            hipLaunchKernelGGL(czt_rowmax_kernel<T>, dim3((unsigned)((g.P + 3 + RMAX_SPAN - 1) / RMAX_SPAN), (unsigned)n), dim3(256), 0, st,
+                               z + r0 * g.P, g.P, rmax + r0);
+        }
+    }
     const T2* tw = czt_twiddles<T>(st);
     if (!tw || !czt_allow_lds(czt_rows_kernel<T, false>, Prec<T>::lds_bytes)) return GFX_ELAUNCH;
     const T2* cP = (const T2*)plan;
@@ -703,6 +793,7 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
         float* yc = ymap ? y : y + 2 * p0 * ldy;
         T2* buf = (T2*)ws + p0 * g.NFFT;
         g.row0 = row0 + 2 * p0;
+        g.rmax = rmax ? rmax + 2 * p0 : nullptr;
         if (g.levels > 0) {
             if constexpr (sizeof(T) == 4) {
                 static const bool fused = [] { const char* e = getenv("GRAFX_CZT_FUSED_LEVEL"); return !(e && e[0] == '0'); }();
@@ -741,7 +832,7 @@ size_t gfx_odd_alias_pair_plan_bytes(int64_t P) {
 size_t gfx_odd_alias_pair_workspace_bytes(int64_t rows, int64_t P) {
     CztGeom g;
     if (rows <= 0 || !czt_pair_geom(P, g)) return 0;
-    return (size_t)((rows + 1) / 2) * g.NFFT * sizeof(float2);
+    return (size_t)((rows + 1) / 2) * g.NFFT * sizeof(float2) + pair_rmax_bytes(rows);
 }
 
 int gfx_odd_alias_pair_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream) {

@@ -388,7 +388,11 @@ def _alias_chunks(rows, P, rows_per_chunk, device, precise, pairs=False):
     ws_bytes = _alias_fns(precise, pairs)[1]
     cap = ALIAS_WS_CAP
     if not torch.cuda.is_current_stream_capturing():
-        cap = min(cap, max(torch.cuda.mem_get_info(device)[0] // 4, 1))
+        # free to this process = what the driver has left + what torch's caching allocator holds without using it
+        # (in a long-running / training process the cache holds most of the device: the driver's figure alone would
+        # collapse the chunks to a few rows)
+        free = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        cap = min(cap, max(free // 4, 1))
     unit = 2 if pairs else 1            # chunks of whole pairs: row 2r stays with row 2r + 1
     chunk = max(unit, min(rows, rows_per_chunk, unit * (cap // ws_bytes(unit, P))) // unit * unit)
     if chunk >= rows:
@@ -786,6 +790,32 @@ def onepole_fir(z_alpha, iir_len):
 BALLISTICS_SCHEDULE = "chunks"   # "chunks": rows cut into verified chunks (gfx_ballistics_ws_f32); "rows": whole rows only
 
 
+def _overlap(a, b):
+    """Whether two float32 tensors share an element.  Exact for views of one storage with the same shape and (nested)
+    strides -- two node ranges of the render's (B, V, C, L) buffer interleave in memory without touching --, the bounding
+    ranges otherwise."""
+    if a.numel() == 0 or b.numel() == 0 or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return False
+    if a.shape == b.shape and a.stride() == b.stride() and all(st > 0 for st in a.stride()):
+        dims = sorted(((st, n) for n, st in zip(a.shape, a.stride()) if n > 1), reverse=True)
+
+        def reachable(delta, i):      # delta = sum of d_i * stride_i with |d_i| < n_i over the dimensions from i on?
+            if i == len(dims):
+                return delta == 0
+            st, n = dims[i]
+            q = delta // st
+            return any(abs(c) < n and reachable(abs(delta - c * st), i + 1) for c in (q, q + 1))
+
+        return reachable(abs(a.storage_offset() - b.storage_offset()), 0)
+
+    def span(t):
+        lo = t.storage_offset() + sum((n - 1) * st for n, st in zip(t.shape, t.stride()) if st < 0)
+        return lo, lo + 1 + sum((n - 1) * abs(st) for n, st in zip(t.shape, t.stride()))
+
+    (a0, a1), (b0, b1) = span(a), span(b)
+    return a0 < b1 and b0 < a1
+
+
 @_on_device
 def ballistics(u, z_alpha, coefficients=False, schedule=None, flags=None):
     """Ballistics.forward (core/envelope.py:84-101) on (R, L) rows: the float32 sequential recursion, bit for bit, whichever
@@ -803,7 +833,8 @@ def ballistics(u, z_alpha, coefficients=False, schedule=None, flags=None):
     y = torch.empty_like(u)
     ws = None
     if schedule == "chunks":
-        ws = torch.empty(lib().gfx_ballistics_ws_bytes(R), dtype=torch.uint8, device=u.device)
+        # zeroed: the single-pass schedules (short rows, very many rows) never write the flags this buffer is returned as
+        ws = torch.zeros(lib().gfx_ballistics_ws_bytes(R), dtype=torch.uint8, device=u.device)
     with _timed("ballistics_walk_kernel", 8 * R * L):
         check(lib().gfx_ballistics_ws_f32(_ptr(u), _ptr(z_alpha), int(coefficients), _ptr(y), R, L, _ptr(ws),
                                           0 if ws is None else ws.numel(), _stream()), "gfx_ballistics_ws_f32")
@@ -827,6 +858,9 @@ def dynamics_ballistics(x, log_threshold, log_ratio, log_knee, z_alpha, knee, ga
         out = torch.empty((R, C, L), dtype=torch.float32, device=x.device)
     elif rowmap(out)[1:] != (R, C, L):
         raise ValueError(f"dynamics_ballistics: output {tuple(out.shape)} does not match input rows/channels/length {(R, C, L)}")
+    elif _overlap(x, out):
+        # the chunked schedule writes every row in its first pass and re-reads x for the rows it has to walk again
+        raise ValueError("dynamics_ballistics: out must not share memory with x (the kernel makes more than one pass over x)")
     ws = None
     if schedule == "chunks":
         ws = torch.empty(lib().gfx_ballistics_ws_bytes(R), dtype=torch.uint8, device=x.device)

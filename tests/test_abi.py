@@ -46,13 +46,15 @@ def test_size_queries_need_no_gpu():
     # transform 2P - 1 per pair (35 tiles); the pair form ends at 2^24 points, even lengths do not alias at all
     P = 131072 + 4000 - 1
     assert lib.gfx_odd_alias_workspace_bytes(2, P) == 2 * 25 * 8192 * 8
-    assert lib.gfx_odd_alias_pair_workspace_bytes(2, P) == 35 * 8192 * 8 == lib.gfx_odd_alias_pair_workspace_bytes(1, P)
-    assert lib.gfx_odd_alias_pair_workspace_bytes(3, P) == 2 * 35 * 8192 * 8
+    # (+ 256: one word per row, rounded up -- the rows' max |z|, from which the second row of a pair is scaled to the first's binade)
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, P) == 35 * 8192 * 8 + 256 == lib.gfx_odd_alias_pair_workspace_bytes(1, P)
+    assert lib.gfx_odd_alias_pair_workspace_bytes(3, P) == 2 * 35 * 8192 * 8 + 256
+    assert lib.gfx_odd_alias_pair_workspace_bytes(1024, P) == 512 * 35 * 8192 * 8 + 4096
     assert lib.gfx_odd_alias_pair_plan_bytes(P) == (P + (P - 1) + P + 2 * 35 * 8192) * 8
     assert lib.gfx_odd_alias_pair_precise_plan_bytes(P) == 2 * lib.gfx_odd_alias_pair_plan_bytes(P)
-    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 258047) == 63 * 8192 * 8          # the last length of one column pass
-    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 258049) == 4 * 16 * 8192 * 8      # then one outer radix-4 level
-    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 480000 + 4000 - 1) == 4 * 30 * 8192 * 8   # BASELINE configs[1], 4000 taps
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 258047) == 63 * 8192 * 8 + 256       # the last length of one column pass
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 258049) == 4 * 16 * 8192 * 8 + 256   # then one outer radix-4 level
+    assert lib.gfx_odd_alias_pair_workspace_bytes(2, 480000 + 4000 - 1) == 4 * 30 * 8192 * 8 + 256   # BASELINE configs[1], 4000 taps
     assert lib.gfx_odd_alias_pair_plan_bytes(8388607) > 0 and lib.gfx_odd_alias_pair_plan_bytes(8388609) == 0
     assert lib.gfx_odd_alias_pair_plan_bytes(4000) == 0 and lib.gfx_odd_alias_plan_bytes(8388609) > 0
 

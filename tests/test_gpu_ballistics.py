@@ -254,3 +254,29 @@ def test_chunked_adjoint_at_the_console_size_against_float64_on_sample_rows():
         assert (gx[r].cpu() - ref).abs().max() <= 2e-6 * ref.abs().max(), r
         want = torch.tensor([sa * at * (1 - at), sr * rt * (1 - rt)])
         assert ((gz[r].cpu().double() - want).abs() <= 1e-4 * want.abs().max()).all(), (r, gz[r].cpu(), want)
+
+
+def test_in_place_output_is_refused_and_short_rows_return_clean_flags():
+    """gfx_dynamics_ballistics_f32 makes more than one pass over x (rows that fail the bit check are walked again from the
+    input), so an output that shares memory with the input is an error, not a silent wrong answer; two node ranges of one
+    signal buffer -- interleaved in memory, never touching -- are fine.  And the diagnostics flags of a call that took a
+    single-pass schedule (rows shorter than a chunk) are zeros, not uninitialised memory."""
+    from grafx_amd import ops
+
+    torch.manual_seed(0)
+    R, C, L = 6, 2, 4096
+    x = torch.randn(R, C, L, device="cuda")
+    p = [torch.randn(R, 1, device="cuda") for _ in range(3)]
+    za = torch.randn(R, 2, device="cuda")
+    want = ops.dynamics_ballistics(x, *p, za, "quadratic", False)
+    with pytest.raises(ValueError, match="share memory"):
+        ops.dynamics_ballistics(x, *p, za, "quadratic", False, out=x)
+    buf = torch.zeros(2, 8, C, L, device="cuda")
+    buf[:, 1:4] = x.view(2, 3, C, L)
+    ops.dynamics_ballistics(buf[:, 1:4], *p, za, "quadratic", False, out=buf[:, 4:7])
+    assert torch.equal(buf[:, 4:7].reshape(R, C, L), want)
+    with pytest.raises(ValueError, match="share memory"):
+        ops.dynamics_ballistics(buf[:, 1:4], *p, za, "quadratic", False, out=buf[:, 3:6])
+    flags = []
+    ops.ballistics(torch.rand(3, 100, device="cuda"), torch.randn(3, 2, device="cuda"), flags=flags)
+    assert int(flags[0].abs().sum()) == 0

@@ -24,3 +24,22 @@ def test_mix_schedule_colours_live_ranges():
     codes, n_acc, pre, post = ops.mix_schedule([[-3, 0, 1], [1, 5]], 2)
     assert pre == [(-3, 1)] and codes == [1, 1 | (1 << 8) | 2] and post == [(5, 2 | (2 << 16))] and n_acc == 2
     assert ops.mix_schedule([[-1, 7]], 4) is None
+
+
+def test_overlap_of_buffer_views_is_exact_for_node_ranges():
+    """ops._overlap (guards the multi-pass kernels against in-place output): node ranges of one (B, V, C, L) buffer
+    interleave in memory, so their bounding address ranges intersect while no element is shared."""
+    import torch
+
+    from grafx_amd.ops import _overlap
+
+    buf = torch.zeros(3, 10, 2, 64)
+    assert not _overlap(buf[:, 2:5], buf[:, 5:8])
+    assert _overlap(buf[:, 2:5], buf[:, 4:7])
+    assert _overlap(buf[:, 2:5], buf[:, 2:5])
+    assert not _overlap(buf[:, 0:1], buf[:, 9:10])
+    assert not _overlap(buf[:, 2:5, :, :32], buf[:, 2:5, :, 32:])
+    assert _overlap(buf[:, 2:5, :, :33], buf[:, 2:5, :, 32:])
+    x = torch.zeros(4, 2, 64)
+    assert _overlap(x, x) and _overlap(x[:3], x[1:]) and not _overlap(x[:2], x[2:])
+    assert not _overlap(x, torch.zeros(4, 2, 64))
