@@ -98,6 +98,44 @@ def _sink_for(x):
     return None
 
 
+# Gradient sources (the mirror image of the sinks; same registration by the stage-wise backward): data_ptr of a stage's
+# input view -> the gradient of the stage's OUTPUT, held in a layout torch cannot express as a tensor of the output's shape
+# -- a (B k, m, C, L) view with a zero stride over m: k distinct gradient rows per graph, each shared by m consecutive
+# output rows (the adjoint of a routing sum whose sources feed the same destinations in blocks, e.g. the eight channel
+# strips of a console bus).  The node whose input IS that view reads its output gradient from the source through the row
+# map (the kernels address rows as (r / inner) * stride_outer + (r % inner) * stride_inner: stride_inner = 0) and ignores
+# the placeholder the engine hands it; the 8.6 GB of expanded rows at the headline batch are never written or read.
+_SOURCES = {}
+
+
+class grad_source:
+    def __init__(self, x, source):
+        self.key, self.entry = x.data_ptr(), [source, 0]
+
+    def __enter__(self):
+        with _SINKS_LOCK:
+            _SOURCES[self.key] = self.entry
+        return self
+
+    def __exit__(self, *exc):
+        with _SINKS_LOCK:
+            _SOURCES.pop(self.key, None)
+        return False
+
+    @property
+    def reads(self):
+        return self.entry[1]
+
+
+def _source_for(x, rows):
+    with _SINKS_LOCK:
+        e = _SOURCES.get(x.data_ptr())
+        if e is not None and e[0].shape[0] * e[0].shape[1] == rows and tuple(e[0].shape[2:]) == tuple(x.shape[-2:]):
+            e[1] += 1
+            return e[0]
+    return None
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
@@ -505,6 +543,9 @@ class DynamicsFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, log_threshold, log_ratio, log_knee, z_alpha = ctx.saved_tensors
         smoother, iir_len, knee, gate = ctx.cfg
+        src = _source_for(x, x.shape[0] * x.shape[1] if x.ndim == 4 else x.shape[0])
+        if src is not None:     # the real gradient, in a layout only the row map expresses (see grad_source)
+            gy = src
         if gy.stride(-1) != 1 or not (gy.ndim == 4 or gy.is_contiguous()):
             gy = gy.contiguous()
         lk = log_knee if knee != "hard" else None

@@ -105,6 +105,13 @@ class _Dynamics(BufferIO, nn.Module):
         gain = ops.dyn_gain(energy, log_threshold, log_ratio, log_knee, self.knee, self._gate, log_out=False)
         return ops.apply_gain(input_signals, self.gain_smoother_module(gain, z_alpha=z_alpha_post), out=_out)
 
+    def reads_grad_source(self, length):
+        """Whether the differentiable forward of a signal of this length is the ONE native node (DynamicsFn) that can take
+        its output gradient from autograd.grad_source (the stage-wise backward of render_grafx asks before it leaves a
+        routing sum's adjoint un-expanded)."""
+        return self.gain_smoother is None and (self.energy_smoother is None or (
+            self.energy_smoother == "iir" and not reference_aliases(length, self.iir_len, self.flashfftconv)))
+
     def _forward_differentiable(self, x, log_threshold, log_ratio, log_knee, z_alpha_pre, z_alpha_post, u1=None):
         """dynamics.py:390-405: one native autograd node when there is no gain smoother and the energy smoother is
         the (non-aliasing) one-pole or absent; otherwise torch ops around the native (differentiable) smoothers."""

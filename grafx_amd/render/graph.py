@@ -8,6 +8,8 @@ The loop, the routing and the parameter plumbing stay in Python, exactly as
 upstream; the processors are the HIP-backed modules of ``grafx_amd.processors``
 (or any ``nn.Module`` with the same interface, e.g. the CPU oracle in tests).
 """
+import contextlib
+
 import torch
 
 from ..data.configs import UTILITY_TYPES
@@ -32,6 +34,11 @@ KEEP_SMOOTHER_SCAN = True
 #   "inline"        no side stream: every stage designs its own filters on the main stream right before it runs.
 # Measured on the headline graph: profiles/r4/prepare_stream_ab.md.
 PREPARE_MODE = "under_first"
+
+# The adjoint of a routing sum whose sources feed the same destinations in blocks (console: eight strips -> their bus + the
+# send) stays in block form -- k rows per graph instead of k * m -- when the stage that wrote those rows can read it so
+# (see _block_fan, autograd.grad_source).  False: always expand (round 5's path: gather_sum_fanout writes every row).
+BLOCK_FAN_ADJOINT = True
 
 
 def _gather_plan(step, device):
@@ -114,6 +121,36 @@ def _transposed_plan(step, plan, device):
         cache[key] = (uniq, torch.tensor(dst, dtype=torch.long, device=device),
                       torch.tensor(ptr, dtype=torch.long, device=device),
                       uniq == list(range(uniq[0], uniq[0] + len(uniq))), fan)
+    return cache[key]
+
+
+def _block_fan(step, plan, device):
+    """Block structure of a gather plan's adjoint: when the distinct source rows are contiguous and fall into k blocks of m
+    >= 2 consecutive rows that feed the SAME destination slots (the eight channel strips of a console bus: their bus and the
+    send), the adjoint has only k distinct rows per graph -> (first source row, k, m, slot index tensor, segment pointer
+    tensor) for gfx_gather_sum_f32 over the destination gradients; else None.  The largest such m is taken."""
+    cache = step.__dict__.setdefault("_block_fan", {})
+    key = (device.type, device.index)
+    if key not in cache:
+        cache[key] = None
+        src, seg = plan[0].tolist(), plan[1].tolist()
+        by_src = {}
+        for j in range(len(seg) - 1):
+            for e in range(seg[j], seg[j + 1]):
+                by_src.setdefault(src[e], []).append(j)
+        uniq = sorted(by_src)
+        n = len(uniq)
+        if n >= 2 and uniq == list(range(uniq[0], uniq[0] + n)):
+            dests = [tuple(by_src[u]) for u in uniq]
+            for m in range(n, 1, -1):
+                if n % m == 0 and all(dests[i] == dests[i - i % m] for i in range(n)):
+                    idx, ptr = [], [0]
+                    for blk in range(n // m):
+                        idx.extend(dests[blk * m])
+                        ptr.append(len(idx))
+                    cache[key] = (uniq[0], n // m, m, torch.tensor(idx, dtype=torch.long, device=device),
+                                  torch.tensor(ptr, dtype=torch.long, device=device))
+                    break
     return cache[key]
 
 
@@ -580,8 +617,18 @@ class _BufferRenderFn(torch.autograd.Function):
         # whole: `written` tracks which rows hold a value, the first contribution to a row is a copy, later ones add.
         gbuf = torch.empty_like(buf)
         written = [False] * V
+        # Rows whose gradient exists only in block form: (a, b) -> (k distinct rows per graph (B, k, C, L), block size m),
+        # row a + i stands for distinct row i // m (see _block_fan).  A stage that reads its output gradient through a row
+        # map takes them as they are (autograd.grad_source); anything else gets them written out first.
+        virtual = {}
+
+        def materialise(a, b):
+            for va, vb in [r for r in virtual if r[0] < b and a < r[1]]:
+                rows, m = virtual.pop((va, vb))
+                gbuf.narrow(1, va, vb - va).view(B, rows.shape[1], m, C, L).copy_(rows.unsqueeze(2))
 
         def accumulate(a, b, g):  # rows [a, b) += g  (g: (B, b-a, C, L))
+            materialise(a, b)
             i = a
             while i < b:
                 j = i
@@ -598,6 +645,7 @@ class _BufferRenderFn(torch.autograd.Function):
                 i = j
 
         def settled(a, b):  # rows [a, b) as they stand; rows nothing contributed to are zero
+            materialise(a, b)
             for i in range(a, b):
                 if not written[i]:
                     gbuf.narrow(1, i, 1).zero_()
@@ -619,9 +667,14 @@ class _BufferRenderFn(torch.autograd.Function):
             d0, d1 = step.dest_write.idx
             if not any(written[d0:d1]):
                 continue  # nothing downstream depends on this stage
-            g_out = settled(d0, d1)
             plan = _gather_plan(step, dev)
             node_type = step.node_type
+            trusted = node_type in processors and type(processors[node_type]) in _tape_safe_types()
+            # block-form rows stay as they are for a stage that reads its output gradient through a row map
+            blocks = virtual.get((d0, d1)) if trusted and getattr(processors[node_type], "reads_grad_source", None) else None
+            if blocks is not None and not processors[node_type].reads_grad_source(L):
+                blocks = None
+            g_out = None if blocks is not None else settled(d0, d1)
             if node_type in processors:
                 if plan is None:
                     a, b = step.source_reads[0].idx
@@ -657,23 +710,37 @@ class _BufferRenderFn(torch.autograd.Function):
                     # autograd node that consumes the stage's input view: true for the library's own classes, not for
                     # a user subclass that post-processes super().forward(); so they are enabled for the exact types
                     # only (type(), not isinstance()).
-                    trusted = type(processors[node_type]) in _tape_safe_types()
                     if trusted and i in ctx.aux and getattr(processors[node_type], "accepts_aux", False):
                         extra["_aux"] = (ctx.aux, i)   # what the forward render kept for this stage
                     with diff.tape_only(trusted):  # only the stage's tape is wanted here, not its output values
                         y = processors[node_type](x_in, **extra, **params, **common_i)
                     y = y[0] if isinstance(y, tuple) else y
                     wrt = ([x_in] if want_gx else []) + [local[j] for j in live]
-                    grad_out = g_out if y.shape == g_out.shape else g_out.reshape(y.shape)
-                    if trusted and want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]):
-                        # first (usually only) contribution to these rows: let the stage write it in place
-                        with diff.grad_sink(x_in, gbuf.narrow(1, a, b - a)) as sink:
-                            grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
-                        if sink.writes > 1:
-                            raise RuntimeError(f"{type(processors[node_type]).__name__}: {sink.writes} autograd nodes wrote "
-                                               "the stage's input gradient in place (expected one)")
+                    source = contextlib.nullcontext()
+                    if blocks is not None:
+                        # the stage's one native node reads the k distinct rows per graph through its row map; the engine
+                        # carries a placeholder of the output's shape (one element, zero strides)
+                        rows, m = blocks
+                        grad_out = diff.tape_placeholder(y.shape, dev)
+                        source = diff.grad_source(x_in, rows.view(B * rows.shape[1], 1, C, L).expand(-1, m, -1, -1))
                     else:
-                        grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
+                        grad_out = g_out if y.shape == g_out.shape else g_out.reshape(y.shape)
+                    with source:
+                        if trusted and want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]) and not any(
+                                r[0] < b and a < r[1] for r in virtual):
+                            # first (usually only) contribution to these rows: let the stage write it in place
+                            with diff.grad_sink(x_in, gbuf.narrow(1, a, b - a)) as sink:
+                                grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
+                            if sink.writes > 1:
+                                raise RuntimeError(f"{type(processors[node_type]).__name__}: {sink.writes} autograd nodes "
+                                                   "wrote the stage's input gradient in place (expected one)")
+                        else:
+                            grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
+                    if blocks is not None:
+                        if source.reads != 1:
+                            raise RuntimeError(f"{type(processors[node_type]).__name__}: the stage's block-form output "
+                                               f"gradient was read by {source.reads} autograd nodes (expected one)")
+                        del virtual[(d0, d1)]
                 for j, g in zip(live, grads[1:] if want_gx else grads):
                     if g is not None:
                         leaf_grads[j] = g if leaf_grads[j] is None else leaf_grads[j] + g
@@ -692,6 +759,25 @@ class _BufferRenderFn(torch.autograd.Function):
             else:
                 # adjoint of the gather-sum: every source row collects the gradients of the slots it fed --
                 # the same gather-sum kernel with the transposed plan
+                fanb = _block_fan(step, plan, dev) if BLOCK_FAN_ADJOINT else None
+                if fanb is not None:
+                    # ... provided the stage that wrote exactly these rows can read the block form (else: no point)
+                    span = (fanb[0], fanb[0] + fanb[1] * fanb[2])
+                    reader = next((render_data.iter_list[j] for j in range(i - 1, 0, -1)
+                                   if tuple(render_data.iter_list[j].dest_write.idx) == span), None)
+                    proc = processors[reader.node_type] if reader is not None and reader.node_type in processors else None
+                    if not (proc is not None and type(proc) in _tape_safe_types() and hasattr(proc, "reads_grad_source")
+                            and proc.reads_grad_source(L)):
+                        fanb = None
+                if fanb is not None and not any(written[fanb[0] : fanb[0] + fanb[1] * fanb[2]]) and not any(
+                        r[0] < fanb[0] + fanb[1] * fanb[2] and fanb[0] < r[1] for r in virtual):
+                    # k distinct gradient rows per graph instead of k * m expanded ones: written out only if their reader
+                    # cannot take them in this form (materialise)
+                    u0, k, m, bidx, bptr = fanb
+                    g_in = g_in if g_in.stride(-1) == 1 else g_in.contiguous()
+                    virtual[(u0, u0 + k * m)] = (ops.gather_sum(g_in, bidx, bptr, torch.empty(B, k, C, L, device=dev)), m)
+                    written[u0 : u0 + k * m] = [True] * (k * m)
+                    continue
                 uniq, dst_idx, ptr, contiguous, fan = _transposed_plan(step, plan, dev)
                 if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]):
                     g_src = gbuf.narrow(1, uniq[0], len(uniq))  # first contribution: gather straight into the rows

@@ -398,3 +398,56 @@ def test_training_gradients_are_the_same_bits_from_run_to_run():
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
+
+
+def _console_gradients(procs, G, x, params, want_gx=False):
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+
+    rd = prepare_render(reorder_for_fast_render(convert_to_tensor(G), method="beam")).to(x.device)
+    for q in params.parameters():
+        q.grad = None
+    xin = x.clone().requires_grad_(want_gx)
+    render_grafx(procs, xin, params, rd)[0].square().mean().backward()
+    return [q.grad.clone() for q in params.parameters()] + ([xin.grad.clone()] if want_gx else [])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smoother", ["iir", "ballistics", None])
+def test_block_form_routing_adjoint_gives_the_bits_of_the_expanded_one(smoother):
+    """The adjoint of the console's routing sum has one distinct gradient row per bus and graph (bus + send), shared by
+    the bus's strips: the stage-wise backward keeps it in that form (render/graph.py: _block_fan, autograd.grad_source)
+    and the compressor's backward reads it through its row map -- the same bits as writing all rows out
+    (BLOCK_FAN_ADJOINT = False, round 5's gather_sum_fanout path).  A compressor whose differentiable forward is not the
+    one native node (the ballistics smoother) cannot read that form: the rows are written out for it, same bits again."""
+    import bench
+    from grafx_amd.processors import Compressor
+    from grafx_amd.render import graph as render_graph
+    from grafx_amd.utils import create_empty_parameters
+
+    dev = torch.device("cuda")
+    G = bench.console_graph(n_ch=8, n_bus=2)
+    procs = {k: v.to(dev) for k, v in bench.hip_processors().items()}
+    procs["compressor"] = Compressor(energy_smoother=smoother, iir_len=16383, flashfftconv=False).to(dev)
+    torch.manual_seed(7)
+    x = torch.randn(3, 8, 2, 16384, device=dev)
+    params = create_empty_parameters(procs, G, std=0.1).to(dev)
+    assert render_graph.BLOCK_FAN_ADJOINT
+    calls = []
+    real = render_graph._block_fan
+    render_graph._block_fan = lambda *a: calls.append(real(*a)) or calls[-1]
+    try:
+        got = _console_gradients(procs, G, x, params, want_gx=True)
+    finally:
+        render_graph._block_fan = real
+    assert any(c is not None and c[1:3] == (2, 4) for c in calls)              # two buses of four strips
+    render_graph.BLOCK_FAN_ADJOINT = False
+    try:
+        want = _console_gradients(procs, G, x, params, want_gx=True)
+    finally:
+        render_graph.BLOCK_FAN_ADJOINT = True
+    for a, b in zip(got, want):
+        if smoother is None:     # the smoother-less backward adds its per-row parameter sums with float atomics: same to rounding
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max()
+        else:
+            assert torch.equal(a, b)

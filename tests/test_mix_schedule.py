@@ -43,3 +43,34 @@ def test_overlap_of_buffer_views_is_exact_for_node_ranges():
     x = torch.zeros(4, 2, 64)
     assert _overlap(x, x) and _overlap(x[:3], x[1:]) and not _overlap(x[:2], x[2:])
     assert not _overlap(x, torch.zeros(4, 2, 64))
+
+
+def test_block_structure_of_a_routing_sums_adjoint():
+    """_block_fan on hand-made plans: blocks need contiguous sources with identical destination sets."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from grafx_amd.render.graph import _block_fan
+
+    dev = torch.device("cpu")
+
+    def plan(dests_per_slot):
+        src, seg = [], [0]
+        for rows in dests_per_slot:
+            src += rows
+            seg.append(len(src))
+        return torch.tensor(src), torch.tensor(seg), len(dests_per_slot), None
+
+    # console: four buses of eight strips (rows 64..95) + a send that takes them all
+    console = plan([list(range(64 + 8 * k, 72 + 8 * k)) for k in range(4)] + [list(range(64, 96))])
+    u0, k, m, idx, ptr = _block_fan(SimpleNamespace(), console, dev)
+    assert (u0, k, m) == (64, 4, 8) and idx.tolist() == [0, 4, 1, 4, 2, 4, 3, 4] and ptr.tolist() == [0, 2, 4, 6, 8]
+    # one destination fed by every source: a single block
+    assert _block_fan(SimpleNamespace(), plan([[3, 4, 5, 6]]), dev)[:3] == (3, 1, 4)
+    # every source on its own destination, gaps between the sources, unequal blocks: nothing to share
+    assert _block_fan(SimpleNamespace(), plan([[0], [1], [2]]), dev) is None
+    assert _block_fan(SimpleNamespace(), plan([[0, 1], [3, 4]]), dev) is None
+    assert _block_fan(SimpleNamespace(), plan([[0, 1, 2], [3, 4]]), dev) is None
+    # blocks of two inside groups of four
+    assert _block_fan(SimpleNamespace(), plan([[0, 1, 2, 3], [0, 1], [2, 3]]), dev)[:3] == (0, 2, 2)
