@@ -31,6 +31,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_VALU_PEAK_TFS = 157.3   # MI355X vector FP32 (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFS = 78.6    # vector FP64: half the FP32 rate (AMD's MI355X figure; the guide's table does not list it)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); a one-float4-per-thread nt copy reaches 6.6 TB/s on this
                        # pool (profiles/r2/stream2_copy_ceiling.txt), the guide measured 6.29 TB/s
 
@@ -349,6 +351,64 @@ def roofline_from_profile(prof, steps, elapsed, B, L, lens=None):
                                             for k, v in sorted(stats.items())}}
 
 
+def czt_valu_roofline(prof, steps, chains):
+    """The chirp-z chains of a compat leg against the VECTOR-ALU roofline (they are FFT work: HBM bytes are the wrong
+    yardstick for them).  ``chains``: (precise?, rows per step, P) of every odd_alias call of a step.  Arithmetic model per
+    PAIR of rows: two circular convolutions of NFFT points = 4 FFTs at 5 N log2 N real flops + 3 pointwise complex products
+    at 6 N (the chirp factors, the two spectra), NFFT from the library's own plan (gfx_odd_alias_pair_workspace_bytes)."""
+    import math
+
+    from grafx_amd._lib import lib
+
+    out = {}
+    for precise in (False, True):
+        tag = "<double>" if precise else "<float>"
+        ms = sum(sum(a.elapsed_time(b) for a, b, _ in recs) for name, recs in prof.items() if name.startswith("czt") and name.endswith(tag))
+        flops = 0.0
+        for pr, rows, P in chains:
+            if pr != precise:
+                continue
+            per_pair = lib().gfx_odd_alias_pair_workspace_bytes(2, P) - 256
+            nfft = per_pair // 8
+            flops += (rows / 2) * (4 * 5 * nfft * math.log2(nfft) + 3 * 6 * nfft)
+        if ms > 0 and flops > 0:
+            peak = FP64_VALU_PEAK_TFS if precise else FP32_VALU_PEAK_TFS
+            tfs = flops * steps / (ms * 1e-3) / 1e12
+            out["double" if precise else "float"] = {"bound": "valu", "achieved": tfs, "peak": peak, "unit": "TFLOP/s",
+                                                     "frac": tfs / peak, "ms_per_step": ms / steps,
+                                                     "flops_per_step": flops,
+                                                     "model": "per pair of rows: 4 FFTs of NFFT points at 5 N log2 N + 3 pointwise products at 6 N"}
+    return out or None
+
+
+def partitioned_conv_unit_rooflines(prof, steps, rows, L, N):
+    """The two kernels of the partitioned convolution (N > 8193 taps) against the units that bind them -- HBM is the wrong
+    yardstick for the second one (DESIGN.md section 4.3): `xspec_kernel` streams (HBM: x in, window spectra out);
+    `macinv_pair_kernel` walks 2 nparts + 1 tile-sized operands (69 632 B each) per pair of output tiles through the CUs'
+    vector-memory path, which takes 64 B per clock and CU (256 CUs x 64 B x 2.4 GHz), almost all of it L2 hits."""
+    def ms_of(part):
+        return sum(sum(a.elapsed_time(b) for a, b, _ in recs) for name, recs in prof.items() if part in name) / steps
+
+    nparts = -(-(N - 1) // 8192) if N > 8193 else 1
+    tiles = -(-L // 8192)
+    out = {}
+    # one record covers both kernels ("xspec_kernel+macinv_pair_kernel"): split by the trace's shares is not possible here, so
+    # the pair is reported as a whole against the sum of its two models
+    ms = ms_of("macinv")
+    if ms > 0:
+        spectra = rows * tiles * 69632                       # window spectra written by xspec, read back by the walk
+        hbm = 4 * rows * L + 2 * spectra + 4 * rows * L      # x in, spectra out and in (once-through), y out
+        walk = rows * -(-tiles // 2) * (2 * nparts + 1) * 69632
+        l1_peak = 256 * 64 * 2.4e9 / 1e9
+        out = {"kernels": "xspec_kernel + macinv_pair_kernel", "ms_per_step": ms,
+               "hbm": {"bound": "hbm", "bytes_once_through": hbm, "achieved": hbm / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+               "l1_intake": {"bound": "l1_intake", "bytes_through_the_cus": walk, "achieved": walk / (ms * 1e-3) / 1e9,
+                             "peak": l1_peak, "unit": "GB/s", "frac": walk / (ms * 1e-3) / 1e9 / l1_peak,
+                             "model": f"{2 * nparts + 1} operands of 69632 B per pair of 8192-sample output tiles"}}
+    return out or None
+
+
 class GpuSampler:
     """Shader clock and board power from the amdgpu hwmon files (readable without privileges), sampled by a thread every
     50 ms while a loop runs.  The box lists every card of the node (other tenants' included): the card is the one whose
@@ -656,6 +716,18 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
         out["secondary"] = secondary
     if world == 1 and not args.no_cpu_baseline and not args.dry:
         out["cpu_baseline"] = cpu_baseline_console(G, render_data, params_cpu, L)
+    # the last key of the line (a reader that keeps only the tail of the output still sees every leg's number)
+    summary = {"headline_ms": round(ms_per_step, 3), "headline_roofline_frac": None if roof is None else round(roof["frac"], 4)}
+    if sustained is not None:
+        summary["sustained_ms"] = round(sustained["ms_per_step"], 3)
+    if train is not None and "ms_per_step" in train:
+        summary["training_ms"] = round(train["ms_per_step"], 3)
+        summary["training_peak_GiB"] = None if train.get("peak_mem_GiB") is None else round(train["peak_mem_GiB"], 2)
+    for k, v in (secondary or {}).items():
+        summary[k + "_ms"] = round(v["ms_per_step"], 3) if "ms_per_step" in v else v.get("error")
+    if "cpu_baseline" in out and isinstance(out["cpu_baseline"], dict) and "value" in out["cpu_baseline"]:
+        summary["cpu_baseline_samples_per_s"] = round(out["cpu_baseline"]["value"], 1)
+    out["summary"] = summary
     return out
 
 
@@ -778,12 +850,14 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
 
     out = {}
     legs = [("cfg2", "cfg2", None, steps, warmup), ("cfg3", "cfg3", None, steps, warmup),
-            ("cfg4_longpole", "cfg4v", dict(z_alpha_pre=6.0), 10, 3), ("cfg4_ballistics", "cfg4v", dict(energy_smoother="ballistics"), 10, 3),
+            ("cfg4_longpole", "cfg4v", dict(z_alpha_pre=6.0), 10, 3), ("cfg4_clamp", "cfg4v", dict(z_alpha_pre=12.0), 10, 3),
+            ("cfg4_ballistics", "cfg4v", dict(energy_smoother="ballistics"), 10, 3),
             ("cfg4_output_only", "cfg4v", dict(keep_signal_buffer=False), 10, 3),
             ("cfg2_compat", "cfg2", REFERENCE_DEFAULT_LENS, 5, 2), ("cfg3_compat", "cfg3", REFERENCE_DEFAULT_LENS, 5, 2),
             ("cfg4_compat", "cfg4", REFERENCE_DEFAULT_LENS, 5, 2)]
     for key, cfg, lens, n, w in legs:
         torch.cuda.empty_cache()
+        moved_bytes, chains = None, None
         try:
             if cfg == "cfg4v":
                 # the headline console at the headline size with another compressor setting (SURVEY 8d "a ballistics
@@ -793,7 +867,10 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
                 variant, lens = lens, None
                 step = console_case(torch, dev, R, L, LENS, **variant)
                 what = (f"BASELINE configs[3] console graph at batch {R}, L={L}, the headline's tap counts, "
-                        + ("every compressor's smoother logit z_alpha_pre = 6 (pole 0.9975)" if "z_alpha_pre" in variant
+                        + (f"every compressor's smoother logit z_alpha_pre = {variant['z_alpha_pre']:g} "
+                           + ("(pole 0.9975: the look-back tiles)" if variant["z_alpha_pre"] < 8 else
+                              "(the clamp, pole 1 - 1e-5: the N-tap truncation term is alive, core/envelope.py:34-60)")
+                           if "z_alpha_pre" in variant
                            else "the headline's processors and parameters, render_grafx(keep_signal_buffer=False): the output node "
                                 "only -- an EXTENSION of upstream's API (which always returns every node's signal), not the headline: "
                                 "rows nothing reads are not written (the sources' copy, the channel strips' and bus compressors' "
@@ -801,17 +878,27 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
                            else "Compressor(energy_smoother='ballistics') (attack / release recursion, z_alpha_pre ~ randn * 0.1)"))
                 unit, units = "audio samples/s", R * L
                 call_bytes = 285 * R * 2 * L * 4
+                # row transfers that never cross HBM: the sources' write-through + the fused routing sums (as in the
+                # headline's graph_roofline); the ballistics compressor does not take the routing sum; the output-only
+                # render also skips the sources' copy and the rows that only feed the fused sums
+                elided = (32 + 32 if "energy_smoother" in variant else 32 + 64 + 4) + (32 + 32 + 4 if "keep_signal_buffer" in variant else 0)
+                moved_bytes = (285 - elided) * R * 2 * L * 4
             elif cfg == "cfg4":
-                R, C, L = 64, 2, 131072     # graphs (of 256): the aliasing workspaces are sized per row
+                R, C, L = 256, 2, 131072     # the stated configuration (rounds 4-5 ran a quarter of it)
                 step = console_case(torch, dev, R, L, lens)
-                what = (f"BASELINE configs[3] console graph at batch {R} (of 256), L={L}, upstream default tap counts "
+                what = (f"BASELINE configs[3] console graph at batch {R}, L={L}, upstream default tap counts "
                         f"{lens['fsm_fir_len']} / {lens['iir_len']} / {lens['ir_len']}: every convolve() aliases (odd L + N - 1)")
                 unit, units = "audio samples/s", R * L
                 call_bytes = 285 * R * 2 * L * 4
+                n, w = 3, 1
+                chains = [(False, 36 * 2 * R, L + lens["fsm_fir_len"] - 1), (True, 36 * R, L + lens["iir_len"] - 1),
+                          (False, 2 * R, L + lens["ir_len"] - 1)]
             else:
                 step, R, C, L, what = processor_case(cfg, torch, dev, 0, lens=lens)
                 unit, units = "channel-samples/s", R * C * L
                 call_bytes = 8 * R * C * L
+                if lens is not None:
+                    chains = [(False, R * C, L + (lens["fsm_fir_len"] if cfg == "cfg2" else lens["ir_len"]) - 1)]
             for _ in range(w):
                 y = step()
             sync()
@@ -824,11 +911,21 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
             assert torch.isfinite(y).all(), f"{key}: non-finite samples"
             ms = elapsed / n * 1e3
             gbps = call_bytes / (ms * 1e-3) / 1e9
+            if moved_bytes is None:
+                croof = {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
+            else:   # a console render: the fraction is of the bytes that actually cross HBM (never above 1); the 285
+                    # row-transfer yardstick of SURVEY 8d is kept beside it as an equivalent rate
+                mg = moved_bytes / (ms * 1e-3) / 1e9
+                croof = {"algorithmic_bytes_per_call": call_bytes, "moved_bytes_per_call": moved_bytes, "achieved_GBps": mg,
+                         "frac_of_hbm_peak": mg / HBM_PEAK_GBS, "algorithmic_equivalent_GBps": gbps}
             out[key] = {"workload": what, "steps": n, "warmup": w, "ms_per_step": ms,
-                        "value": units * n / elapsed, "unit": unit,
-                        "call_roofline": {"algorithmic_bytes_per_call": call_bytes, "achieved_GBps": gbps,
-                                          "frac_of_hbm_peak": gbps / HBM_PEAK_GBS},
+                        "value": units * n / elapsed, "unit": unit, "call_roofline": croof,
                         "roofline": roofline_from_profile(prof, n, elapsed, R, L, lens)}
+            if chains:
+                out[key]["valu_roofline"] = czt_valu_roofline(prof, n, chains)
+            if cfg == "cfg3":
+                N3 = (lens or LENS)["ir_len"]
+                out[key]["unit_rooflines"] = partitioned_conv_unit_rooflines(prof, n, R * C, L + N3 - 1 if lens else L, N3)
             del step, y
         except Exception as e:  # one leg must not take the others (or the headline) with it
             out[key] = {"error": f"{type(e).__name__}: {e}"}

@@ -76,6 +76,8 @@ SIGNATURES = {
                                                ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp]),
     "gfx_dynamics_bwd_u1_ws_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                   ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp, sz, vp]),
+    "gfx_dynamics_bwd_rescan_ws_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
+                                                      ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp, sz, vp]),
     "gfx_dynamics_ws_bytes": (sz, [i64]),
     "gfx_dynamics_ws_bytes_ex": (sz, [i64, i64, i64]),
     "gfx_dynamics_last_kernel": (ctypes.c_char_p, []),

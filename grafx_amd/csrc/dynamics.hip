@@ -1560,10 +1560,12 @@ __device__ __forceinline__ void dyn_bwd_u1_stream(const DynArgs& a, const OnePol
 }
 
 __global__ __launch_bounds__(DT) void dyn_bwd_u1_kernel(const float* __restrict__ x, const float* __restrict__ z_alpha,
-                                                        float* __restrict__ u1, DynArgs a) {
+                                                        float* __restrict__ u1, DynArgs a,
+                                                        const float* __restrict__ tab = nullptr) {
     __shared__ float slots[16];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x;
+    if (tab && tab[(size_t)r * DP_TAB + DP_ONESHOT] != 0.0f) return;   // a one-shot row rebuilds its scan in its own tiles
     OnePole p;
     onepole_setup(p, z_alpha[r], a.N, t & 63);
     dyn_bwd_u1_stream(a, p, x + drow_off(a.xmap, r, 0), x + drow_off(a.xmap, r, a.C == 2 ? 1 : 0), u1 + r * a.L, slots, t);
@@ -1571,10 +1573,12 @@ __global__ __launch_bounds__(DT) void dyn_bwd_u1_kernel(const float* __restrict_
 
 // dL/d(smoothed energy) at four (reversed-walk) positions from the samples, output gradients and scan values there;
 // also returns the gain and, when `acc` is given, adds the parameter-gradient terms (as pass A did).
-template <bool FAST = false>
+// (A: float in the tiles -- eight terms per thread and launch, the sums continue in double --, double in the row kernel, where
+// a thread adds hundreds of terms of both signs)
+template <bool FAST = false, typename A = float>
 __device__ __forceinline__ void dyn_denv4(const DynArgs& a, const Knee& q, const float (&xa)[DE], const float (&xb)[DE],
                                           const float (&ga)[DE], const float (&gb)[DE], const float (&lin)[DE],
-                                          float (&dv)[DE], float (&gn)[DE], float* acc) {
+                                          float (&dv)[DE], float (&gn)[DE], A* acc) {
 #pragma unroll
     for (int i = 0; i < DE; ++i) {
         const float env = fmaxf(lin[i], 0.0f);
@@ -1595,8 +1599,8 @@ __device__ __forceinline__ void dyn_denv4(const DynArgs& a, const Knee& q, const
 template <bool TRUNC, bool POLE>
 __device__ __forceinline__ void dyn_bwd_c_stream(const DynArgs& a, const OnePole& p, const Knee& q, const float* x0,
                                                  const float* x1, const float* g0, const float* g1, const float* u1,
-                                                 float* o0, float* o1, float* slots, int t, float& pole,
-                                                 float (&acc)[3]) {
+                                                 float* o0, float* o1, float* slots, int t, double& pole,
+                                                 double (&acc)[3]) {
     const int lane = t & 63, wave = t >> 6;
     const bool al = (a.L % 4) == 0;  // reversed float4 groups stay 16-byte aligned only then
     const bool vx = al && vec_ok(x0) && vec_ok(x1) && vec_ok(g0) && vec_ok(g1), vo = al;
@@ -1655,7 +1659,7 @@ __device__ __forceinline__ void dyn_bwd_c_stream(const DynArgs& a, const OnePole
             float lin2[DE], d2[DE], gn2[DE], u2[DE];
 #pragma unroll
             for (int i = 0; i < DE; ++i) lin2[i] = fmaf(-p.a_N, uu[i], u_l[i]);
-            dyn_denv4(a, q, xa2, xb2, ga2, gb2, lin2, d2, gn2, nullptr);
+            dyn_denv4(a, q, xa2, xb2, ga2, gb2, lin2, d2, gn2, (float*)nullptr);
             scan_tile(p, d2, u2, carry2, slots + 8 * (tile & 1) + 4, lane, wave);
 #pragma unroll
             for (int i = 0; i < DE; ++i) u[i] = fmaf(-p.a_N, u2[i], u[i]);
@@ -1666,8 +1670,8 @@ __device__ __forceinline__ void dyn_bwd_c_stream(const DynArgs& a, const OnePole
 #pragma unroll
             for (int i = 0; i < DE; ++i) {
                 const float prev = i + 1 < DE ? uu[i + 1] : um;
-                pole += p.one_m_a * u[i] * prev - d[i] * uu[i];
-                if (TRUNC) pole = fmaf(pole_c2 * d[i], un[i], pole);
+                pole += (double)(p.one_m_a * u[i] * prev - d[i] * uu[i]);
+                if (TRUNC) pole += (double)(pole_c2 * d[i] * un[i]);
             }
         }
         float oa[DE];
@@ -1692,7 +1696,7 @@ __global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__
                                                        float* __restrict__ gx, DynArgs a,
                                                        const float* __restrict__ oneshot_tab) {
     __shared__ float slots[16];
-    __shared__ float red[4][4];
+    __shared__ double red[4][4];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x;
     if (oneshot_tab && oneshot_tab[(size_t)r * DP_TAB + DP_ONESHOT] != 0.0f) return;   // dyn_bwd_oneshot_kernel's row
@@ -1706,7 +1710,7 @@ __global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__
     float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
     Knee q;
     knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, a.knee, a.gate);
-    float pole = 0.0f, acc[3] = {0.0f, 0.0f, 0.0f};
+    double pole = 0.0, acc[3] = {0.0, 0.0, 0.0};    // per-thread sums over the whole row: double (hundreds of terms of both signs)
     const float* ur = u1 + r * a.L;
     if (dalpha) {
         if (p.trunc)
@@ -1718,16 +1722,16 @@ __global__ __launch_bounds__(DT) void dyn_bwd_c_kernel(const float* __restrict__
     } else {
         dyn_bwd_c_stream<false, false>(a, p, q, x0, x1, g0, g1, ur, o0, o1, slots, t, pole, acc);
     }
-    float v4[4] = {acc[0], acc[1], acc[2], pole};
+    double v4[4] = {acc[0], acc[1], acc[2], pole};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float v = v4[k];
+        double v = v4[k];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         if ((t & 63) == 0) red[k][t >> 6] = v;
     }
     __syncthreads();
-    if (t < 3) gparams[3 * r + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
-    if (t == 3 && dalpha) dalpha[r] = (red[3][0] + red[3][1] + red[3][2] + red[3][3]) / p.one_m_a;  // u1 = (1-a) U
+    if (t < 3) gparams[3 * r + t] = (float)(red[t][0] + red[t][1] + red[t][2] + red[t][3]);
+    if (t == 3 && dalpha) dalpha[r] = (float)((red[3][0] + red[3][1] + red[3][2] + red[3][3]) / (double)p.one_m_a);  // u1 = (1-a) U
 }
 
 // The backward-in-time pass as dependency-free one-shot tiles (the backward twin of dyn_oneshot_kernel): in the reversed
@@ -1748,17 +1752,24 @@ __device__ __forceinline__ void rl4(const float* __restrict__ row, int64_t j, in
     v[0] = q.w; v[1] = q.z; v[2] = q.y; v[3] = q.x;
 }
 
-template <int KIND, bool GATE>
-__global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+// RESCAN (round 6): the smoother's scan u1 is not read but REBUILT from x -- in walk coordinates the forward-in-time scan is
+// a SUFFIX scan (u1[j] depends on the positions after j = the samples before it in time): the two sub-tiles' local and
+// in-wave scans run with the shuffles mirrored, the state entering the tile from its far end is the dot product of the H
+// samples beyond it (x only: one more predicated 16-byte load per channel), and the H positions in front of the tile (whose
+// denv the adjoint scan needs) continue the scan from the tile's first value.  4 of the 28 bytes per stereo sample go away
+// here, and the forward pass of a training step does not have to store the scan at all (4 of its 20).
+// (three waves per SIMD = 168 VGPRs: the rescan's 169-172 would otherwise cost a whole wave of occupancy)
+template <int KIND, bool GATE, bool RESCAN>
+__global__ __launch_bounds__(DT, 3) void dyn_bwd_oneshot_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                              gfx_rowmap_t gmap, const float* __restrict__ log_threshold,
                                                              const float* __restrict__ log_ratio,
                                                              const float* __restrict__ log_knee,
                                                              const float* __restrict__ tab, const float* __restrict__ u1,
                                                              const float* __restrict__ dalpha /* only: wanted? */,
-                                                             float* __restrict__ partial,
+                                                             double* __restrict__ partial,
                                                              float* __restrict__ gx, DynArgs a, unsigned ngroups,
                                                              unsigned nblocks) {
-    __shared__ float red[4][4];
+    __shared__ double red[4][4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned per_xcd = gridDim.x >> 3;
     const unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -1775,14 +1786,14 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
     const float* g1 = gy + drow_off(gmap, r, a.C == 2 ? 1 : 0);
     float* o0 = gx + drow_off(a.ymap, r, 0);
     float* o1 = gx + drow_off(a.ymap, r, a.C == 2 ? 1 : 0);
-    const float* ur = u1 + (int64_t)r * a.L;
+    const float* ur = RESCAN ? nullptr : u1 + (int64_t)r * a.L;
     const bool stereo = a.C == 2;
     const int64_t j0 = s + DE * lane;
 
     float uu[OS_SUB][DE], xa[OS_SUB][DE], xb[OS_SUB][DE], ga[OS_SUB][DE], gb[OS_SUB][DE];
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
-        rl4(ur, j0 + 256 * k, L, uu[k]);
+        if constexpr (!RESCAN) rl4(ur, j0 + 256 * k, L, uu[k]);
         rl4(x0, j0 + 256 * k, L, xa[k]);
         rl4(g0, j0 + 256 * k, L, ga[k]);
         rl4(x1, j0 + 256 * k, stereo ? L : 0, xb[k]);
@@ -1793,20 +1804,87 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
     const bool hist = s != 0 && DE * lane < H;
     const int64_t Lh = hist ? L : 0, jh = s - DE * (lane + 1);
     float hu[DE], hxa[DE], hxb[DE], hga[DE], hgb[DE];
-    rl4(ur, jh, Lh, hu);
+    if constexpr (!RESCAN) rl4(ur, jh, Lh, hu);
     rl4(x0, jh, Lh, hxa);
     rl4(g0, jh, Lh, hga);
     rl4(x1, jh, stereo ? Lh : 0, hxb);
     rl4(g1, jh, stereo ? Lh : 0, hgb);
     // u1 one walk position past the tile (the pole term pairs every position with the next one)
     const int64_t edge = a.L - 1 - (s + OS_WTILE);
-    const float u_edge = (dalpha && L != 0 && edge >= 0) ? ur[edge] : 0.0f;
+    float u_edge = 0.0f;
+    if constexpr (!RESCAN) u_edge = (dalpha && L != 0 && edge >= 0) ? ur[edge] : 0.0f;
     const float a1 = tb[77], one_m_a = tb[78], a_sub = tb[70];
     const float apk[DE] = {tb[73], tb[74], tb[75], tb[76]};
     const float a_lane = tb[lane];
     float a_step[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) a_step[d] = tb[64 + d];
+    if constexpr (RESCAN) {
+        const float invC = 1.0f / (float)a.C;
+        // the H samples beyond the far end of the tile (walk positions s + 512 + 4 lane + i: EARLIER in time; zeros past
+        // the row start), taps a^(4 lane + i)
+        float fxa[DE], fxb[DE];
+        const int64_t Lf = DE * lane < H ? L : 0;
+        rl4(x0, s + OS_WTILE + DE * lane, Lf, fxa);
+        rl4(x1, s + OS_WTILE + DE * lane, stereo ? Lf : 0, fxb);
+        // local and in-wave SUFFIX scans of the two sub-tiles (independent of each other)
+        float fl[OS_SUB][DE], fexcl[OS_SUB], ftot[OS_SUB];
+#pragma unroll
+        for (int k = 0; k < OS_SUB; ++k) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = DE - 1; i >= 0; --i) {
+                const float e = (stereo ? (xa[k][i] * xa[k][i] + xb[k][i] * xb[k][i]) : xa[k][i] * xa[k][i]) * invC;
+                acc = fmaf(a1, acc, e);
+                fl[k][i] = acc;
+            }
+            float inc = acc;
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const float dn = __shfl_down(inc, 1 << st, 64);
+                if (lane + (1 << st) < 64) inc = fmaf(a_step[st], dn, inc);
+            }
+            const float ex = __shfl_down(inc, 1, 64);
+            fexcl[k] = lane == 63 ? 0.0f : ex;
+            ftot[k] = __shfl(inc, 0, 64);
+        }
+        float w = 0.0f;
+#pragma unroll
+        for (int i = DE - 1; i >= 0; --i) {
+            const float e = (stereo ? (fxa[i] * fxa[i] + fxb[i] * fxb[i]) : fxa[i] * fxa[i]) * invC;
+            w = fmaf(a1, w, e);
+        }
+        float fc = w * a_lane;                    // (lanes without a live tap loaded zeros)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) fc += __shfl_xor(fc, o, 64);
+        u_edge = one_m_a * fc;                    // the scan one walk position past the tile (0 past the row start)
+        const float a_far = tb[63 - lane];        // a^(4 (63 - lane)): from the sub-tile's far end to this lane's
+#pragma unroll
+        for (int k = OS_SUB - 1; k >= 0; --k) {
+            const float pre = fmaf(a_far, fc, fexcl[k]);
+            fc = fmaf(a_sub, fc, ftot[k]);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) uu[k][i] = one_m_a * fmaf(apk[DE - 1 - i], pre, fl[k][i]);
+        }
+        // the scan continued over the H positions in front of the tile (lane l: s - 4 (l + 1) + i), from its value at s
+        float hl[DE], acc = 0.0f;
+#pragma unroll
+        for (int i = DE - 1; i >= 0; --i) {
+            const float e = (stereo ? (hxa[i] * hxa[i] + hxb[i] * hxb[i]) : hxa[i] * hxa[i]) * invC;
+            acc = fmaf(a1, acc, e);
+            hl[i] = acc;
+        }
+        float inc = acc;
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            const float up = __shfl_up(inc, 1 << st, 64);
+            if (lane >= (1 << st)) inc = fmaf(a_step[st], up, inc);
+        }
+        const float ex = __shfl_up(inc, 1, 64);
+        const float pre = fmaf(a_lane, fc, lane == 0 ? 0.0f : ex);
+#pragma unroll
+        for (int i = 0; i < DE; ++i) hu[i] = one_m_a * fmaf(apk[DE - 1 - i], pre, hl[i]);
+    }
     Knee q;
     knee_setup(q, log_threshold[r], log_ratio[r], log_knee ? log_knee[r] : 0.0f, KIND, GATE ? 1 : 0);
     q.kind = KIND;
@@ -1837,7 +1915,7 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
     float carry = 0.0f;
     if (s != 0 && H > 0) {                       // uniform
         float hd[DE], hgn[DE];
-        dyn_denv4<true>(a, q, hxa, hxb, hga, hgb, hu, hd, hgn, nullptr);   // (lanes without a live tap hold zeros: denv = 0)
+        dyn_denv4<true>(a, q, hxa, hxb, hga, hgb, hu, hd, hgn, (float*)nullptr);   // (lanes without a live tap hold zeros: denv = 0)
         float w = 0.0f;                          // Horner, farthest walk position first
 #pragma unroll
         for (int i = 0; i < DE; ++i) w = fmaf(a1, w, hd[i]);
@@ -1877,10 +1955,10 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
             if (stereo) *reinterpret_cast<f4*>(o1 + n) = ob;
         }
     }
-    float v4[4] = {acc[0], acc[1], acc[2], pole};
+    double v4[4] = {acc[0], acc[1], acc[2], pole};      // eight terms per thread in float, everything above them in double
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float v = v4[k];
+        double v = v4[k];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) red[k][wave] = v;
@@ -1893,15 +1971,15 @@ __global__ __launch_bounds__(DT) void dyn_bwd_oneshot_kernel(const float* __rest
 
 // gparams[r] (3 sums) and dalpha[r] of the rows dyn_bwd_oneshot_kernel took: its workgroups' partials in group order, one
 // wave per row (lane l adds groups l, l + 64, ... in order, then a shuffle tree).
-__global__ __launch_bounds__(64) void dyn_bwd_sums_kernel(const float* __restrict__ partial, const float* __restrict__ tab,
+__global__ __launch_bounds__(64) void dyn_bwd_sums_kernel(const double* __restrict__ partial, const float* __restrict__ tab,
                                                           float* __restrict__ gparams, float* __restrict__ dalpha,
                                                           unsigned ngroups) {
     const unsigned r = blockIdx.x;
     const float* tb = tab + (size_t)r * DP_TAB;
     if (tb[DP_ONESHOT] == 0.0f) return;                 // dyn_bwd_c_kernel wrote this row's sums itself
-    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
     for (unsigned g = threadIdx.x; g < ngroups; g += 64) {
-        const float* p = partial + ((size_t)r * ngroups + g) * 4;
+        const double* p = partial + ((size_t)r * ngroups + g) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += p[k];
     }
@@ -1909,10 +1987,10 @@ __global__ __launch_bounds__(64) void dyn_bwd_sums_kernel(const float* __restric
     for (int k = 0; k < 4; ++k)
         for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
     if (threadIdx.x == 0) {
-        gparams[3 * (size_t)r + 0] = v[0];
-        gparams[3 * (size_t)r + 1] = v[1];
-        gparams[3 * (size_t)r + 2] = v[2];
-        if (dalpha) dalpha[r] = v[3] / tb[78];   // u1 = (1 - a) U
+        gparams[3 * (size_t)r + 0] = (float)v[0];
+        gparams[3 * (size_t)r + 1] = (float)v[1];
+        gparams[3 * (size_t)r + 2] = (float)v[2];
+        if (dalpha) dalpha[r] = (float)(v[3] / (double)tb[78]);   // u1 = (1 - a) U
     }
 }
 
@@ -2072,7 +2150,8 @@ size_t gfx_dynamics_ws_bytes_ex(int64_t param_rows, int64_t R, int64_t L) {
 
 size_t gfx_dynamics_bwd_ws_bytes(int64_t R, int64_t L) {   // the pole table + four partial sums per one-shot workgroup
     if (R <= 0 || L <= 0) return 0;
-    return ((size_t)R * DP_TAB + (size_t)R * (size_t)((L + OS_GTILE - 1) / OS_GTILE) * 4) * sizeof(float);
+    // (the table padded to 8 bytes: the partial sums behind it are doubles)
+    return (((size_t)R * DP_TAB + 1) & ~(size_t)1) * sizeof(float) + (size_t)R * (size_t)((L + OS_GTILE - 1) / OS_GTILE) * 4 * sizeof(double);
 }
 
 static thread_local const char* t_dyn_last_kernel = "";   // see gfx_dynamics_last_kernel
@@ -2391,11 +2470,13 @@ int gfx_dynamics_bwd_u1_f32(const float* x, gfx_rowmap_t xmap, const float* gy, 
                                       gate, gx, gxmap, gparams, u1, dalpha, nullptr, 0, stream);
 }
 
-int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
-                               const float* log_threshold, const float* log_ratio, const float* log_knee,
-                               const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
-                               float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* ws,
-                               size_t ws_bytes, void* stream) {
+// `rescan`: u1 is SCRATCH (R x L floats) -- one-shot rows rebuild the scan inside their tiles and never touch it, the rows of
+// the row kernel get theirs from dyn_bwd_u1_kernel first
+static int dyn_bwd_launch(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                          const float* log_threshold, const float* log_ratio, const float* log_knee,
+                          const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                          float* gx, gfx_rowmap_t gxmap, float* gparams, float* u1, float* dalpha, void* ws,
+                          size_t ws_bytes, void* stream, bool rescan) {
     if (!x || !gy || !log_threshold || !log_ratio || !z_alpha || !gx || !gparams || !u1) return GFX_EINVAL;
     if (R <= 0 || L <= 0 || (C != 1 && C != 2) || iir_len < 1 || knee < 0 || knee > 2 || (knee != 0 && !log_knee))
         return GFX_EINVAL;
@@ -2415,26 +2496,53 @@ int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* g
         // rows with a short smoother memory (chosen on the device, as in gfx_dynamics_fused_ws_f32) run as one-shot tiles
         // whose workgroups leave partial sums behind the pole table; the row kernel writes the other rows
         float* t = (float*)ws;
-        float* partial = t + (size_t)R * DP_TAB;
+        double* partial = reinterpret_cast<double*>(t + (((size_t)R * DP_TAB + 1) & ~(size_t)1));
         hipLaunchKernelGGL(dyn_pole_table_kernel, dim3((unsigned)R), dim3(64), 0, st, z_alpha, t, R, iir_len, (unsigned*)nullptr);
         const unsigned nblocks = (unsigned)(R * ngroups);
         const dim3 grid((nblocks + 7u) & ~7u);
 #define GFX_BWD_OS(K, G)                                                                                                \
-    hipLaunchKernelGGL((dyn_bwd_oneshot_kernel<K, G>), grid, dim3(DT), 0, st, x, gy, gmap, log_threshold, log_ratio,     \
-                       log_knee, (const float*)t, u1, (const float*)dalpha, partial, gx, a, (unsigned)ngroups, nblocks)
+    do {                                                                                                                \
+        if (rescan)                                                                                                     \
+            hipLaunchKernelGGL((dyn_bwd_oneshot_kernel<K, G, true>), grid, dim3(DT), 0, st, x, gy, gmap, log_threshold,  \
+                               log_ratio, log_knee, (const float*)t, (const float*)u1, (const float*)dalpha, partial, gx, \
+                               a, (unsigned)ngroups, nblocks);                                                          \
+        else                                                                                                            \
+            hipLaunchKernelGGL((dyn_bwd_oneshot_kernel<K, G, false>), grid, dim3(DT), 0, st, x, gy, gmap, log_threshold, \
+                               log_ratio, log_knee, (const float*)t, (const float*)u1, (const float*)dalpha, partial, gx, \
+                               a, (unsigned)ngroups, nblocks);                                                          \
+    } while (0)
         if (gate) {
             if (knee == 0) GFX_BWD_OS(0, true); else if (knee == 1) GFX_BWD_OS(1, true); else GFX_BWD_OS(2, true);
         } else {
             if (knee == 0) GFX_BWD_OS(0, false); else if (knee == 1) GFX_BWD_OS(1, false); else GFX_BWD_OS(2, false);
         }
 #undef GFX_BWD_OS
-        hipLaunchKernelGGL(dyn_bwd_sums_kernel, dim3((unsigned)R), dim3(64), 0, st, (const float*)partial, (const float*)t,
+        hipLaunchKernelGGL(dyn_bwd_sums_kernel, dim3((unsigned)R), dim3(64), 0, st, (const double*)partial, (const float*)t,
                            gparams, dalpha, (unsigned)ngroups);
         tab = t;
     }
+    if (rescan) hipLaunchKernelGGL(dyn_bwd_u1_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, z_alpha, u1, a, tab);
     hipLaunchKernelGGL(dyn_bwd_c_kernel, dim3((unsigned)R), dim3(DT), 0, st, x, gy, gmap, log_threshold,
                        log_ratio, log_knee, z_alpha, u1, dalpha, gparams, gx, a, tab);
     return GFX_LAUNCH_OK();
+}
+
+int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                               const float* log_threshold, const float* log_ratio, const float* log_knee,
+                               const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                               float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha, void* ws,
+                               size_t ws_bytes, void* stream) {
+    return dyn_bwd_launch(x, xmap, gy, gmap, log_threshold, log_ratio, log_knee, z_alpha, R, C, L, iir_len, knee, gate, gx, gxmap,
+                          gparams, const_cast<float*>(u1), dalpha, ws, ws_bytes, stream, false);
+}
+
+int gfx_dynamics_bwd_rescan_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                                   const float* log_threshold, const float* log_ratio, const float* log_knee,
+                                   const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                                   float* gx, gfx_rowmap_t gxmap, float* gparams, float* u1_scratch, float* dalpha, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    return dyn_bwd_launch(x, xmap, gy, gmap, log_threshold, log_ratio, log_knee, z_alpha, R, C, L, iir_len, knee, gate, gx, gxmap,
+                          gparams, u1_scratch, dalpha, ws, ws_bytes, stream, true);
 }
 
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,

@@ -571,6 +571,9 @@ def _rowvec(p, R):
 # gfx_dynamics_fused_ws_f32) and as one workgroup per row for the others; "rows" forces one workgroup per row.
 MIX_FUSION = True          # dynamics stages take the routing sum that follows them (see dynamics_fused(mix=))
 DYN_SCHEDULE = "oneshot"
+# the compressor backward without a kept scan rebuilds it inside its tiles (gfx_dynamics_bwd_rescan_ws_f32); False: a pass
+# over every row writes it out first (gfx_dynamics_bwd_f32, rounds 2-5)
+DYN_BWD_RESCAN = os.environ.get("GRAFX_DYN_BWD_RESCAN", "1") != "0"
 # rows with a long smoother memory stay on the tile grid (gfx_dynamics_ws_bytes_ex); False / GRAFX_DYN_LOOKBACK=0: round 4
 DYN_LOOKBACK = os.environ.get("GRAFX_DYN_LOOKBACK", "1") != "0"
 
@@ -692,11 +695,13 @@ def dyn_gain_bwd(x, gy, env, log_threshold, log_ratio, log_knee, knee, gate):
 
 @_on_device
 def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, knee, gate, out=None, pole=True, u1=None,
-                 schedule=None):
+                 schedule=None, rescan=None):
     """Fused backward of the smoothed compressor / gate -> (gx (R,C,L), gparams (R,3), dalpha (R) or None).
     ``out``: optional destination for gx ((R,C,L) or a strided (B,n,C,L) view).  ``dalpha`` is the gradient with
     respect to the clamped pole a = min(sigmoid(z_alpha), 1 - 1e-5); the caller applies the chain rule to z_alpha.
-    ``u1``: the scan kept by the forward pass (``dynamics_fused(..., u1_out=)``); without it the scan is recomputed.
+    ``u1``: the scan kept by the forward pass (``dynamics_fused(..., u1_out=)``); without it the scan is recomputed --
+    inside the backward tiles for rows with a short smoother memory (``rescan``, default DYN_BWD_RESCAN: the scratch the
+    other rows' scan goes to is allocated but normally never touched), or by a pass of its own over every row.
     ``schedule`` (with ``u1``): "oneshot" (default, see DYN_SCHEDULE) or "rows"."""
     _require_gpu(x, gy, out)
     xmap, R, C, L = rowmap(x)
@@ -720,6 +725,14 @@ def dynamics_bwd(x, gy, log_threshold, log_ratio, log_knee, z_alpha, iir_len, kn
                                                0 if ws is None else ws.numel(), _stream()), "gfx_dynamics_bwd_u1_ws_f32")
         return gx, gp, da
     u1 = torch.empty((R, L), dtype=torch.float32, device=x.device)
+    if DYN_BWD_RESCAN if rescan is None else rescan:
+        ws = torch.empty(lib().gfx_dynamics_bwd_ws_bytes(R, L), dtype=torch.uint8, device=x.device)
+        check(lib().gfx_dynamics_bwd_rescan_ws_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
+                                                   pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)),
+                                                   pin(_rowvec(z_alpha, R)), R, C, L, iir_len, KNEES[knee], int(gate),
+                                                   _ptr(gx), rowmap(gx)[0], _ptr(gp), _ptr(u1), _ptr(da), _ptr(ws), ws.numel(),
+                                                   _stream()), "gfx_dynamics_bwd_rescan_ws_f32")
+        return gx, gp, da
     check(lib().gfx_dynamics_bwd_f32(_ptr(x), xmap, _ptr(gy), gmap, pin(_rowvec(log_threshold, R)),
                                      pin(_rowvec(log_ratio, R)), pin(_rowvec(log_knee, R)), pin(_rowvec(z_alpha, R)),
                                      R, C, L, iir_len, KNEES[knee], int(gate), _ptr(gx), rowmap(gx)[0], _ptr(gp), None,

@@ -9,6 +9,8 @@ upstream; the processors are the HIP-backed modules of ``grafx_amd.processors``
 (or any ``nn.Module`` with the same interface, e.g. the CPU oracle in tests).
 """
 import contextlib
+import os
+import warnings
 
 import torch
 
@@ -23,10 +25,11 @@ from .core import (
 )
 
 
-# Training forward: keep the dynamics stages' smoother scan (R x L floats per stage) for their backward instead of
-# re-scanning the input there (-4 % step time at the console graph, +4.8 GB at 256 graphs).  Set to False to trade the
-# memory back for the recompute pass.
-KEEP_SMOOTHER_SCAN = True
+# Training forward: keep the dynamics stages' smoother scan (R x L floats per stage) for their backward.  Rounds 2-5 kept it
+# (the alternative was a pass of its own over every row); since round 6 the backward tiles rebuild the scan from the
+# samples they read anyway (gfx_dynamics_bwd_rescan_ws_f32), which takes 4 bytes per sample out of the forward AND the
+# backward kernel and 4.8 GB at 256 graphs out of the step's peak: off by default (GRAFX_KEEP_SCAN=1: round 5's path).
+KEEP_SMOOTHER_SCAN = os.environ.get("GRAFX_KEEP_SCAN", "0") == "1"
 # Where the parameter-only work of the later stages (filter design, the reverb's impulse response and spectra) runs:
 #   "under_first"   on a side stream underneath the first processor stage's signal kernel (the convolution of the first
 #                   equaliser stage in a console: compute-bound, the side kernels take CUs from it);
@@ -277,21 +280,41 @@ def _wants_grad(input_signals, per_type_parameters, common_parameters):
                                         or (common_parameters is not None and _any_requires_grad(common_parameters)))
 
 
-def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
-    """Structural conditions of the in-place buffer path (gradients are handled by _BufferRenderFn around it)."""
-    if not input_signals.is_cuda or render_data.method == "one-by-one" or not render_data.siso_only:
-        return False
+class GenericRenderPathWarning(UserWarning):
+    """A render of CUDA signals that does not take the in-place buffer path (see _buffer_io_reason)."""
+
+
+def _buffer_io_reason(processors, input_signals, render_data, per_type_parameters):
+    """None when the render can take the in-place buffer path (gradients are handled by _BufferRenderFn around it), else
+    what keeps it off: the render then runs upstream's loop (render/graph.py:104-175 of the reference: copies on read,
+    torch routing, one processor call per stage -- the processors themselves still run their HIP kernels)."""
+    if not input_signals.is_cuda:
+        return "the signals are not on a GPU"
+    if render_data.method == "one-by-one":
+        return "the schedule is 'one-by-one' (no type batching)"
+    if not render_data.siso_only:
+        return "the graph holds multi-input / multi-output processors (render/prepare.py:109-192 of the reference)"
     for step in render_data.iter_list[1:]:
         if step.node_type in processors:
             if not hasattr(processors[step.node_type], "render_into"):
-                return False
+                return f"processor type {step.node_type!r} ({type(processors[step.node_type]).__name__}) has no render_into()"
         elif step.node_type not in UTILITY_TYPES:
-            return False
+            return f"node type {step.node_type!r} has no processor"
         if step.dest_write.method != "slice" or len(step.source_reads) != 1 or step.source_reads[0].method == "none":
-            return False
+            return f"stage {step.node_type!r} does not read one input and write a contiguous range of rows"
         if _gather_plan(step, input_signals.device) is False:
-            return False
-    return True
+            return f"stage {step.node_type!r} aggregates through an unsorted scatter"
+    return None
+
+
+def _buffer_io_ok(processors, input_signals, render_data, per_type_parameters):
+    """Structural conditions of the in-place buffer path."""
+    reason = _buffer_io_reason(processors, input_signals, render_data, per_type_parameters)
+    if reason is not None and input_signals.is_cuda:
+        # not silent: a CUDA render off the fast path says so (once per reason and call site)
+        warnings.warn(f"render_grafx: taking the generic loop instead of the in-place buffer render because {reason}",
+                      GenericRenderPathWarning, stacklevel=3)
+    return reason is None
 
 
 def _render_buffer_io(processors, input_signals, per_type_parameters, render_data, common_parameters, aux=None,
@@ -613,10 +636,31 @@ class _BufferRenderFn(torch.autograd.Function):
             g_buf = None if g_buf is None else g_buf.unsqueeze(0)
         B, V, C, L = buf.shape
         dev = buf.device
-        # Gradient of every node's signal, accumulated while walking the schedule backwards.  Never zero-filled as a
-        # whole: `written` tracks which rows hold a value, the first contribution to a row is a copy, later ones add.
-        gbuf = torch.empty_like(buf)
+        # Gradient of every node's signal, accumulated while walking the schedule backwards.  Held per PART -- the sources
+        # and every stage's output rows are one part each, allocated when something first contributes to them and dropped as
+        # soon as their stage has been back-propagated (round 6; one buffer-sized tensor before: 28 GiB at the headline batch,
+        # of which the sources' and the block-form rows' 16 GiB were never used).  Never zero-filled as a whole: `written`
+        # tracks which rows hold a value, the first contribution to a row is a copy, later ones add.
+        edges = sorted({(0, ctx.n_src)} | {tuple(render_data.iter_list[j].dest_write.idx)
+                                           for j in range(1, render_data.max_order + 1)})
+        parts = {}
         written = [False] * V
+
+        def part_view(a, b):  # rows [a, b) when they lie inside one part (allocated on demand), else None
+            for pa, pb in edges:
+                if pa <= a and b <= pb:
+                    t = parts.get((pa, pb))
+                    if t is None:
+                        t = parts[(pa, pb)] = torch.empty(B, pb - pa, C, L, dtype=buf.dtype, device=dev)
+                    return t.narrow(1, a - pa, b - a)
+            return None
+
+        def pieces(a, b):  # [a, b) cut at the part boundaries
+            cuts = [(max(a, pa), min(b, pb)) for pa, pb in edges if pa < b and a < pb]
+            if not cuts or cuts[0][0] != a or cuts[-1][1] != b or any(x[1] != y[0] for x, y in zip(cuts, cuts[1:])):
+                raise RuntimeError(f"render backward: rows [{a}, {b}) are not covered by the schedule's write ranges")
+            return cuts
+
         # Rows whose gradient exists only in block form: (a, b) -> (k distinct rows per graph (B, k, C, L), block size m),
         # row a + i stands for distinct row i // m (see _block_fan).  A stage that reads its output gradient through a row
         # map takes them as they are (autograd.grad_source); anything else gets them written out first.
@@ -625,35 +669,38 @@ class _BufferRenderFn(torch.autograd.Function):
         def materialise(a, b):
             for va, vb in [r for r in virtual if r[0] < b and a < r[1]]:
                 rows, m = virtual.pop((va, vb))
-                gbuf.narrow(1, va, vb - va).view(B, rows.shape[1], m, C, L).copy_(rows.unsqueeze(2))
+                part_view(va, vb).view(B, rows.shape[1], m, C, L).copy_(rows.unsqueeze(2))
 
         def accumulate(a, b, g):  # rows [a, b) += g  (g: (B, b-a, C, L))
             materialise(a, b)
-            i = a
-            while i < b:
-                j = i
-                while j < b and written[j] == written[i]:
-                    j += 1
-                dst, src = gbuf.narrow(1, i, j - i), g.narrow(1, i - a, j - i)
-                if src.data_ptr() == dst.data_ptr():
-                    pass  # the stage wrote its input gradient straight into these rows (autograd.GRAD_SINK)
-                elif written[i]:
-                    dst.add_(src)
-                else:
-                    dst.copy_(src)
-                written[i:j] = [True] * (j - i)
-                i = j
+            for pa, pb in pieces(a, b):
+                i = pa
+                while i < pb:
+                    j = i
+                    while j < pb and written[j] == written[i]:
+                        j += 1
+                    dst, src = part_view(i, j), g.narrow(1, i - a, j - i)
+                    if src.data_ptr() == dst.data_ptr():
+                        pass  # the stage wrote its input gradient straight into these rows (autograd.GRAD_SINK)
+                    elif written[i]:
+                        dst.add_(src)
+                    else:
+                        dst.copy_(src)
+                    written[i:j] = [True] * (j - i)
+                    i = j
 
         def settled(a, b):  # rows [a, b) as they stand; rows nothing contributed to are zero
             materialise(a, b)
             for i in range(a, b):
                 if not written[i]:
-                    gbuf.narrow(1, i, 1).zero_()
+                    part_view(i, i + 1).zero_()
                     written[i] = True
-            return gbuf.narrow(1, a, b - a)
+            whole = part_view(a, b)
+            return whole if whole is not None else torch.cat([part_view(x, y) for x, y in pieces(a, b)], 1)
 
         if g_buf is not None:
-            gbuf.copy_(g_buf)
+            for pa, pb in edges:
+                part_view(pa, pb).copy_(g_buf.narrow(1, pa, pb - pa))
             written = [True] * V
         if g_out_rows is not None:
             accumulate(*ctx.out_rows, g_out_rows)
@@ -662,11 +709,16 @@ class _BufferRenderFn(torch.autograd.Function):
         leaf_grads = [None] * len(leaves)
         live = [i for i, t in enumerate(leaves) if t.requires_grad]
 
+        done = None
         for i in range(render_data.max_order, 0, -1):
+            if done is not None:
+                parts.pop(done, None)  # the previous stage has been back-propagated: nobody reads its output gradient again
+                done = None
             step = render_data.iter_list[i]
             d0, d1 = step.dest_write.idx
             if not any(written[d0:d1]):
                 continue  # nothing downstream depends on this stage
+            done = (d0, d1)
             plan = _gather_plan(step, dev)
             node_type = step.node_type
             trusted = node_type in processors and type(processors[node_type]) in _tape_safe_types()
@@ -726,10 +778,10 @@ class _BufferRenderFn(torch.autograd.Function):
                     else:
                         grad_out = g_out if y.shape == g_out.shape else g_out.reshape(y.shape)
                     with source:
-                        if trusted and want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]) and not any(
-                                r[0] < b and a < r[1] for r in virtual):
+                        if (trusted and want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]) and not any(
+                                r[0] < b and a < r[1] for r in virtual) and len(pieces(a, b)) == 1):
                             # first (usually only) contribution to these rows: let the stage write it in place
-                            with diff.grad_sink(x_in, gbuf.narrow(1, a, b - a)) as sink:
+                            with diff.grad_sink(x_in, part_view(a, b)) as sink:
                                 grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
                             if sink.writes > 1:
                                 raise RuntimeError(f"{type(processors[node_type]).__name__}: {sink.writes} autograd nodes "
@@ -779,8 +831,8 @@ class _BufferRenderFn(torch.autograd.Function):
                     written[u0 : u0 + k * m] = [True] * (k * m)
                     continue
                 uniq, dst_idx, ptr, contiguous, fan = _transposed_plan(step, plan, dev)
-                if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]):
-                    g_src = gbuf.narrow(1, uniq[0], len(uniq))  # first contribution: gather straight into the rows
+                if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]) and len(pieces(uniq[0], uniq[0] + len(uniq))) == 1:
+                    g_src = part_view(uniq[0], uniq[0] + len(uniq))  # first contribution: gather straight into the rows
                 else:
                     g_src = torch.empty(B, len(uniq), C, L, device=dev)
                 g_in = g_in if g_in.stride(-1) == 1 else g_in.contiguous()
@@ -791,6 +843,8 @@ class _BufferRenderFn(torch.autograd.Function):
                 else:
                     for k, u in enumerate(uniq):
                         accumulate(u, u + 1, g_src.narrow(1, k, 1))
+        if done is not None:
+            parts.pop(done, None)
         # parameters of stages nothing downstream depends on: upstream's taped loop hands back zeros for them (their
         # rows are part of the returned buffer), not None -- optimisers treat the two differently
         # (parameters of a type that has no node in the graph never entered upstream's tape: those stay None)

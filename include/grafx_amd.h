@@ -440,6 +440,16 @@ int gfx_dynamics_bwd_u1_ws_f32(const float* x, gfx_rowmap_t xmap, const float* g
                                const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
                                float* gx, gfx_rowmap_t gxmap, float* gparams, const float* u1, float* dalpha,
                                void* ws, size_t ws_bytes, void* stream);
+/* The same WITHOUT a scan kept by the forward pass (round 6): `u1_scratch` is R x L floats of scratch.  The one-shot tiles
+ * rebuild the scan from x inside the tile (in the backward walk it is a suffix scan; the state entering a tile from its
+ * far end is the dot product of the H samples beyond it), so for rows with a short smoother memory the scratch is never
+ * touched and the forward pass of a training step has nothing to store; the rows of the row kernel get their scan written
+ * to the scratch first.  Reference: autograd through dynamics.py:390-405 and core/envelope.py:34-60. */
+int gfx_dynamics_bwd_rescan_ws_f32(const float* x, gfx_rowmap_t xmap, const float* gy, gfx_rowmap_t gmap,
+                                   const float* log_threshold, const float* log_ratio, const float* log_knee,
+                                   const float* z_alpha, int64_t R, int64_t C, int64_t L, int64_t iir_len, int knee, int gate,
+                                   float* gx, gfx_rowmap_t gxmap, float* gparams, float* u1_scratch, float* dalpha,
+                                   void* ws, size_t ws_bytes, void* stream);
 /* Pole gradient of TruncatedOnePoleIIRFilter (core/envelope.py:34-60) from the un-truncated scan U of its input and
  * the scan S of U:  da[r] = sum_n g[r,n] (c0 U[n] + c2 U[n-N]) + g[r,n+1] (c1 S[n] + c3 S[n-N]),  coef = (R, 4). */
 int gfx_onepole_dz_f32(const float* g, const float* U, const float* D, const float* coef, float* da, int64_t R,

@@ -357,8 +357,11 @@ def test_compressor_backward_with_and_without_the_kept_scan_agree():
     z = torch.tensor([[20.0], [6.0], [3.0], [0.0], [-2.0], [1.0]], device="cuda")   # clamp, live truncation, fast poles
     for knee in ("quadratic", "hard"):
         lkk = None if knee == "hard" else lk
-        a = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False)
+        a = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False, rescan=False)
         assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all() and torch.isfinite(a[2]).all()
+        c = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, False, rescan=True)    # the scan rebuilt inside the backward tiles
+        for ta, tc, name in zip(a, c, ("gx", "gparams", "dalpha")):
+            assert (ta - tc).abs().max() <= 2e-5 * ta.abs().max().clamp_min(1e-12), (name, "rescan")
         for sched in ("rows", "oneshot"):
             y0 = ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=False, schedule=sched)
             u1 = torch.empty(R, L, device="cuda")
@@ -371,6 +374,42 @@ def test_compressor_backward_with_and_without_the_kept_scan_agree():
                 else:                   # one-shot tiles (forward and backward) rebuild the state from a history dot product and
                                         # add the per-row sums tile by tile (ordered partials): same to rounding
                     assert (ta - tb).abs().max() <= 2e-5 * ta.abs().max().clamp_min(1e-12), (name, sched)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [1, 2])
+@pytest.mark.parametrize("gate", [False, True])
+@pytest.mark.parametrize("knee", ["hard", "quadratic", "exponential"])
+def test_backward_tiles_rebuild_the_smoother_scan(knee, gate, C):
+    """gfx_dynamics_bwd_rescan_ws_f32: the one-shot backward tiles rebuild u1 from x (a suffix scan in the backward walk, the
+    entry state from the H samples beyond the tile's far end, continued over the H positions in front of it) instead of
+    reading the scan the forward kept.  Against the kept scan (gfx_dynamics_bwd_u1_ws_f32) at a length of many tiles: poles
+    from instant to the longest one-shot history (H = 256 taps at a = 0.897), rows that leave the tile grid (slower poles:
+    their scan goes through the scratch), rows of silence and a row that ends in silence; every row by its own size."""
+    from grafx_amd import ops
+
+    torch.manual_seed(3)
+    L, N = 32768, 16383
+    z = torch.tensor([[-20.0], [-3.0], [0.0], [1.0], [2.0], [2.16], [2.18], [4.0], [9.0], [0.5], [0.5]], device="cuda")
+    R = z.shape[0]
+    x = 0.5 * torch.randn(R, C, L, device="cuda")
+    x[9] = 0
+    x[10, :, L // 2:] = 0
+    gy = torch.randn(R, C, L, device="cuda")
+    lt, lr, lk = torch.randn(R, 1, device="cuda") - 3, torch.randn(R, 1, device="cuda"), torch.randn(R, 1, device="cuda")
+    lkk = None if knee == "hard" else lk
+    u1 = torch.empty(R, L, device="cuda")
+    ops.dynamics_fused(x, lt, lr, lkk, z, smoother=1, iir_len=N, knee=knee, gate=gate, u1_out=u1)
+    want = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, gate, u1=u1)
+    got = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, gate, rescan=True)
+    for name, a, b in zip(("gx", "gparams", "dalpha"), got, want):
+        a, b = a.reshape(R, -1).double(), b.reshape(R, -1).double()
+        err = (a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-20)
+        assert float(err.max()) <= 2e-5, (name, err.tolist())
+    # twice the same bits (ordered partial sums, no atomics)
+    again = ops.dynamics_bwd(x, gy, lt, lr, lkk, z, N, knee, gate, rescan=True)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu

@@ -197,3 +197,30 @@ def test_output_only_render_gives_the_same_output_bits(seed):
         y_lean, _, none = render_grafx(procs, x, params, rd, parameters_grad=False, keep_signal_buffer=False)
     assert none is None and buf is not None
     assert torch.equal(y_full, y_lean)
+
+
+def test_a_cuda_render_off_the_buffer_path_says_so(golden):
+    """A render of CUDA signals that cannot take the in-place buffer path (here: the 'one-by-one' schedule) runs upstream's
+    loop around the HIP processors -- and says why (GenericRenderPathWarning) instead of silently being slow; the result is
+    the fast path's."""
+    import warnings
+
+    from grafx_amd.data import convert_to_tensor
+    from grafx_amd.processors import BiquadFilter, StereoGain
+    from grafx_amd.render import prepare_render, render_grafx, reorder_for_fast_render
+    from grafx_amd.render.graph import GenericRenderPathWarning
+
+    g = golden("g8_render")
+    procs = {"gain": StereoGain().cuda(), "biquad": BiquadFilter(num_filters=1, flashfftconv=False, fsm_fir_len=257).cuda()}
+    params = {"gain": {"log_gain": g["cfg1_p_gain_log_gain"].cuda()},
+              "biquad": {k: g[f"cfg1_p_biquad_{k}"].cuda() for k in ("Bs", "A1_pre", "A2_pre")}}
+    x = g["cfg1_x"].cuda()
+    fast = prepare_render(reorder_for_fast_render(convert_to_tensor(build_cfg1()), method="beam")).to("cuda")
+    slow = prepare_render(reorder_for_fast_render(convert_to_tensor(build_cfg1()), method="one-by-one")).to("cuda")
+    with torch.no_grad():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", GenericRenderPathWarning)
+            y_fast = render_grafx(procs, x, params, fast)[0]
+        with pytest.warns(GenericRenderPathWarning, match="one-by-one"):
+            y_slow = render_grafx(procs, x[0] if slow.method == "one-by-one" and x.ndim == 4 else x, params, slow)[0]
+    assert_close(y_slow.reshape(y_fast.shape).cpu(), y_fast.cpu(), 1e-6, "one-by-one vs beam")
