@@ -63,6 +63,7 @@ SIGNATURES = {
     "gfx_iir_fsm_plan_f32": (ctypes.c_int, [vp, i64, vp]),
     "gfx_iir_fsm_fir_f32": (ctypes.c_int, [f32p, f32p, vp, f32p, i64, i64, i64, vp]),
     "gfx_iir_fsm_fir_f64c_f32": (ctypes.c_int, [vp, vp, vp, f32p, i64, i64, i64, vp]),
+    "gfx_iir_fsm_bwd_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, i64, i64, vp]),
     "gfx_peq_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, i64, i64, ctypes.c_int, vp]),
     "gfx_peq_coeffs_bwd_f32": (ctypes.c_int, [f32p] * 8 + [i64, i64, ctypes.c_int, vp]),
     "gfx_biquad_coeffs_f32": (ctypes.c_int, [f32p, f32p, f32p, f32p, f32p, f32p, i64, vp]),
@@ -78,6 +79,7 @@ SIGNATURES = {
                                                   ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp, sz, vp]),
     "gfx_dynamics_bwd_rescan_ws_f32": (ctypes.c_int, [f32p, RowMap, f32p, RowMap, f32p, f32p, f32p, f32p, i64, i64, i64, i64,
                                                       ctypes.c_int, ctypes.c_int, f32p, RowMap, f32p, f32p, f32p, vp, sz, vp]),
+    "gfx_stft_f32": (ctypes.c_int, [f32p, f32p, f32p, i64, i64, i64, i64, vp]),
     "gfx_dynamics_ws_bytes": (sz, [i64]),
     "gfx_dynamics_ws_bytes_ex": (sz, [i64, i64, i64]),
     "gfx_dynamics_last_kernel": (ctypes.c_char_p, []),

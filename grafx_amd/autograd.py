@@ -296,6 +296,8 @@ def fsm_fir(Bs, As, fir_len):
         resp = resp * sections[..., i, :]
     if resp.is_cuda and resp.dtype == torch.complex64 and fir_len <= ops.IRDFT_MAX_N:
         return irfft_small(resp, fir_len)       # any length up to 8192: direct-sum kernels both ways, no FFT library
+    if resp.is_cuda:
+        ops.fft_library_reached(f"frequency-sampled taps of {fir_len} points (differentiable design)")
     if fir_len % 2 == 1 and resp.is_cuda:
         return _irfft_odd(resp, fir_len)
     return torch.fft.irfft(resp, dim=-1, n=fir_len)
@@ -325,6 +327,8 @@ def irfft_small(X, n):
     """torch.fft.irfft(X, n=n, dim=-1) for complex64 X on the GPU and n <= 8192, off the FFT library (differentiable)."""
     if X.is_cuda and X.dtype == torch.complex64 and n <= ops.IRDFT_MAX_N:
         return IrdftFn.apply(X, n)
+    if X.is_cuda:
+        ops.fft_library_reached(f"inverse real DFT of {n} points (differentiable design)")
     return torch.fft.irfft(X, n=n, dim=-1)
 
 
@@ -359,6 +363,9 @@ def _fsm_delays(N, device):
     return _DELAYS[key]
 
 
+FSM_BWD_NATIVE = True     # FsmFirFn's backward on gfx_iir_fsm_bwd_f32 (False: the batched torch ops of rounds 4-5)
+
+
 class FsmFirFn(torch.autograd.Function):
     """(R,Cf,K,3) biquad coefficients -> (R,Cf,N) frequency-sampled taps (core/iir.py:147-150): forward is the native
     response + Bluestein kernel; backward is written out (a dozen batched complex ops instead of autograd's ~80):
@@ -379,6 +386,17 @@ class FsmFirFn(torch.autograd.Function):
     def backward(ctx, gh):
         Bs, As = ctx.saved_tensors
         N = ctx.N
+        if (FSM_BWD_NATIVE and gh.is_cuda and N <= ops.IRDFT_MAX_N and Bs.dtype == torch.float32 and Bs.shape[-1] == 3):
+            # round 6: the bins' sums in ONE native launch, double precision inside (gfx_iir_fsm_bwd_f32), after the native
+            # real DFT of the incoming gradient -- ~40 complex128 torch kernels per equaliser stage and step before
+            G = ops.rdft(gh.contiguous(), N)
+            gB, gA = ops.iir_fsm_bwd(Bs, As, G, _fsm_delays(N, Bs.device), N, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            return gB, gA, None, None
+        return FsmFirFn.backward_torch(Bs, As, gh, N, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+    @staticmethod
+    def backward_torch(Bs, As, gh, N, want_B=True, want_A=True):
+        """The same gradient as batched torch ops (any length; the reference the native kernel is tested against)."""
         # Parameter-side math ((R, Cf, K, F) values, F <= 2049) in DOUBLE precision since round 5: the sums over the bins
         # cancel to a few 1e-5 of their terms, and in complex64 the w0 / q_inv gradients behind them carried 0.9 .. 1.6e-5
         # of rounding -- as much as the reference's own float32 autograd (0.7 .. 1.5e-5), so "at least as close to
@@ -394,6 +412,8 @@ class FsmFirFn(torch.autograd.Function):
         resp = sections[..., 0, :]
         for i in range(1, sections.shape[-2]):
             resp = resp * sections[..., i, :]
+        if N > ops.IRDFT_MAX_N and gh.is_cuda:
+            ops.fft_library_reached(f"gradient of frequency-sampled taps of {N} points")
         G = (ops.rdft(gh, N) if N <= ops.IRDFT_MAX_N else torch.fft.rfft(gh, n=N, dim=-1)).to(torch.complex128) * (2.0 / N)
         G[..., 0] = G[..., 0] * 0.5
         if N % 2 == 0:
@@ -403,8 +423,8 @@ class FsmFirFn(torch.autograd.Function):
         def contract(Q):  # Re sum_k Q[..., k] D_d[k], d = 0..2  ->  (..., 3)
             return torch.stack([(Q * D[d]).real.sum(-1) for d in range(3)], -1)
 
-        gB = contract(T / num).to(out_dtype) if ctx.needs_input_grad[0] else None
-        gA = (-contract(T / den)).to(out_dtype) if ctx.needs_input_grad[1] else None
+        gB = contract(T / num).to(out_dtype) if want_B else None
+        gA = (-contract(T / den)).to(out_dtype) if want_A else None
         return gB, gA, None, None
 
 

@@ -366,6 +366,74 @@ static int allow_lds(K kernel) {
 
 using namespace gfx;
 
+
+namespace gfx {
+// ---- gradient of the frequency-sampled taps with respect to the biquad coefficients (training path) -------------------
+// h = irfft(resp, n = N), resp = prod_i num_i / den_i, num_i = sum_d B[i, d] D_d, D_d[k] = e^(-j phi[d, k]) (core/iir.py:
+// 147-152, 263-276); autograd through it is
+//     dL/dB[i, d] =  Re sum_k T_k D_d[k] / num_i[k],     dL/dA[i, d] = -Re sum_k T_k D_d[k] / den_i[k],
+//     T_k = conj(G_k) w_k resp_k,   G = rfft(dL/dh),  w = (1, 2, ..., 2, [1 at N / 2]) / N
+// -- the sums over the bins cancel to a few 1e-5 of their terms, so everything here is double (as the torch form of rounds
+// 4-5 was: ~40 complex128 kernels per equaliser stage and step; this is one).  One workgroup per (filter row, section i):
+// every thread recomputes the response of its bins (K complex divisions) and keeps six sums.  `delays`: the (3, F)
+// complex64 table of the forward pass, float32 phases as upstream forms them.
+__global__ __launch_bounds__(256) void iir_fsm_bwd_kernel(const float* __restrict__ Bs, const float* __restrict__ As,
+                                                          const float2* __restrict__ G, const float2* __restrict__ delays,
+                                                          float* __restrict__ gB, float* __restrict__ gA, int K, int N,
+                                                          int wantB, int wantA) {
+    __shared__ double red[6][4];
+    const int64_t rc = blockIdx.x;
+    const int sec = blockIdx.y;
+    const int F = N / 2 + 1;
+    const float* B = Bs + rc * K * 3;
+    const float* A = As + rc * K * 3;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = threadIdx.x; k < F; k += blockDim.x) {
+        double2 D[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) D[d] = make_double2((double)delays[d * F + k].x, (double)delays[d * F + k].y);
+        double2 resp = make_double2(1.0, 0.0), mynum = resp, myden = resp;
+        for (int i = 0; i < K; ++i) {
+            double2 num = make_double2(0.0, 0.0), den = num;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                num.x += (double)B[i * 3 + d] * D[d].x; num.y += (double)B[i * 3 + d] * D[d].y;
+                den.x += (double)A[i * 3 + d] * D[d].x; den.y += (double)A[i * 3 + d] * D[d].y;
+            }
+            const double dd = den.x * den.x + den.y * den.y;
+            const double2 q = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
+            resp = make_double2(resp.x * q.x - resp.y * q.y, resp.x * q.y + resp.y * q.x);
+            if (i == sec) { mynum = num; myden = den; }
+        }
+        const double w = ((k == 0 || (!(N & 1) && k == N / 2)) ? 1.0 : 2.0) / (double)N;
+        const float2 g = G[rc * F + k];
+        // T = conj(G) w resp
+        const double2 T = make_double2(w * ((double)g.x * resp.x + (double)g.y * resp.y), w * ((double)g.x * resp.y - (double)g.y * resp.x));
+        const double nn = mynum.x * mynum.x + mynum.y * mynum.y, dn = myden.x * myden.x + myden.y * myden.y;
+        const double2 tn = make_double2((T.x * mynum.x + T.y * mynum.y) / nn, (T.y * mynum.x - T.x * mynum.y) / nn);   // T / num
+        const double2 td = make_double2((T.x * myden.x + T.y * myden.y) / dn, (T.y * myden.x - T.x * myden.y) / dn);   // T / den
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            acc[d] += tn.x * D[d].x - tn.y * D[d].y;          // Re((T / num) D_d)
+            acc[3 + d] -= td.x * D[d].x - td.y * D[d].y;      // -Re((T / den) D_d)
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        double x = acc[v];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double x = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        const int64_t o = (rc * K + sec) * 3;
+        if (threadIdx.x < 3) { if (wantB) gB[o + threadIdx.x] = (float)x; }
+        else if (wantA) gA[o + threadIdx.x - 3] = (float)x;
+    }
+}
+}  // namespace gfx
+
 extern "C" {
 
 int gfx_iir_fsm_native(int64_t N) { return (N >= 1 && N <= FSM_MAX_N) || fsm_pow2(N); }
@@ -437,6 +505,16 @@ int gfx_biquad_coeffs_f32(const float* Bin, const float* A1_pre, const float* A2
     if (!Bin || !A1_pre || !A2_pre || !Bs || !As || n <= 0) return GFX_EINVAL;
     hipLaunchKernelGGL(biquad_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Bin,
                        A1_pre, A2_pre, A0, Bs, As, n);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
+
+int gfx_iir_fsm_bwd_f32(const float* Bs, const float* As, const float* G, const float* delays, float* gB, float* gA,
+                        int64_t RC, int64_t K, int64_t N, void* stream) {
+    if (!Bs || !As || !G || !delays || (!gB && !gA) || RC <= 0 || RC > 0x7fffffffLL || K < 1 || K > 65535 || N < 1 ||
+        N > 0x3fffffffLL)
+        return GFX_EINVAL;
+    hipLaunchKernelGGL(iir_fsm_bwd_kernel, dim3((unsigned)RC, (unsigned)K), dim3(256), 0, (hipStream_t)stream, Bs, As,
+                       (const float2*)G, (const float2*)delays, gB, gA, (int)K, (int)N, gB ? 1 : 0, gA ? 1 : 0);
     return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
 }
 

@@ -640,7 +640,62 @@ __global__ __launch_bounds__(256) void noise_shaping_ir_kernel(const float* __re
 
 using namespace gfx;
 
+
+namespace gfx {
+// ---- forward STFT of real rows (fixed_noise=False: fresh noise per call, reverb.py:116-128) ---------------------------
+// torch.stft(x, n_fft, hop, window, center=True, pad_mode="reflect", return_complex=True) as a direct sum: one workgroup
+// per (row, frame) holds the windowed frame and the n_fft roots of unity in LDS, thread k sums bin k (phase index j k mod
+// n_fft carried incrementally: exact).  n_fft <= 2048 (384 in the reverb: 313 frames x 193 bins x 384 terms per row of
+// 60 000 samples -- microseconds; the FFT library this replaces was the last one on the reverb's forward path).
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                                          float2* __restrict__ out, int64_t T, int n_fft, int hop,
+                                                          int frames) {
+    extern __shared__ float2 stft_lds[];                 // tab[n_fft], then the windowed frame
+    float2* tab = stft_lds;
+    float* fr = reinterpret_cast<float*>(tab + n_fft);
+    const int64_t row = blockIdx.y;
+    const int m = blockIdx.x;
+    const int bins = n_fft / 2 + 1, half = n_fft / 2;
+    const float* xr = x + row * T;
+    for (int j = threadIdx.x; j < n_fft; j += blockDim.x) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)n_fft, &s, &c);
+        tab[j] = make_float2((float)c, (float)s);
+        int64_t n = (int64_t)m * hop - half + j;        // reflect padding (no edge repeat), as torch / numpy "reflect"
+        if (n < 0) n = -n;
+        if (n >= T) n = 2 * (T - 1) - n;
+        fr[j] = window[j] * xr[n];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < bins; k += blockDim.x) {
+        float re = 0.0f, im = 0.0f;
+        int idx = 0;
+        for (int j = 0; j < n_fft; ++j) {
+            const float2 w = tab[idx];
+            re = fmaf(fr[j], w.x, re);
+            im = fmaf(-fr[j], w.y, im);
+            idx += k;
+            if (idx >= n_fft) idx -= n_fft;
+        }
+        out[((int64_t)row * bins + k) * frames + m] = make_float2(re, im);
+    }
+}
+}  // namespace gfx
+
 extern "C" {
+
+int gfx_stft_f32(const float* x, const float* window, float* out, int64_t rows, int64_t T, int64_t n_fft, int64_t hop,
+                 void* stream) {
+    if (!x || !window || !out || rows <= 0 || rows > 65535 || n_fft < 2 || n_fft > 2048 || (n_fft & 1) || hop < 1 ||
+        T <= n_fft / 2)      // (reflect padding needs more than n_fft / 2 samples, as torch.stft does)
+        return GFX_EINVAL;
+    const int64_t frames = 1 + T / hop;
+    if (frames > 0x7fffffffLL) return GFX_EINVAL;
+    const size_t lds = (size_t)n_fft * (sizeof(float2) + sizeof(float));
+    hipLaunchKernelGGL(gfx::stft_frames_kernel, dim3((unsigned)frames, (unsigned)rows), dim3(256), lds, (hipStream_t)stream, x,
+                       window, (float2*)out, T, (int)n_fft, (int)hop, (int)frames);
+    return hipGetLastError() == hipSuccess ? GFX_OK : GFX_ELAUNCH;
+}
 
 int gfx_noise_shaping_ir_f32(const float* noise, int64_t noise_stride, const float* log_decay, const float* log_gain,
                              const float* log_fade_in, const float* z_fade_in_gain, float* ir, int64_t R, int64_t C,

@@ -265,6 +265,18 @@ def fir_direct(x, h, Lout=None, off=0, out=None, h_rows=None):
 IRDFT_MAX_N = 8192
 
 
+class FftLibraryWarning(UserWarning):
+    """A parameter-sized transform left the library's own kernels for torch.fft (rocFFT): see fft_library_reached."""
+
+
+def fft_library_reached(what):
+    """The few parameter-sized transforms that are longer than the direct-sum / tile kernels cover (DESIGN.md section 8:
+    never a signal, never on a BASELINE configuration) go to torch.fft -- and say so, once per call site."""
+    import warnings
+
+    warnings.warn(f"{what}: beyond the native transform sizes, computed by torch.fft (rocFFT)", FftLibraryWarning, stacklevel=3)
+
+
 @_on_device
 def irdft(X, n, roll=0, window=None):
     """irfft(X, n) for short transforms (n <= 8192, any n) as a direct sum on the GPU, rolled by ``roll`` and windowed:
@@ -509,6 +521,29 @@ def iir_fsm_fir(Bs, As, N, plan):
         return h
     check(lib().gfx_iir_fsm_fir_f32(_ptr(Bs), _ptr(As), _ptr(plan), _ptr(h), RC, K, N, _stream()), "gfx_iir_fsm_fir_f32")
     return h
+
+
+@_on_device
+def iir_fsm_bwd(Bs, As, G, delays, N, want_B=True, want_A=True):
+    """Gradient of iir_fsm_fir's taps with respect to (R, Cf, K, 3) float32 coefficients from G = rfft(dL/dh, n = N)
+    ((R, Cf, N // 2 + 1) complex64) and the forward pass's (3, N // 2 + 1) complex64 delay table: one native launch in double
+    precision (gfx_iir_fsm_bwd_f32) -> (gB, gA), None for the one not wanted."""
+    _require_gpu(Bs, As)
+    if not (G.is_cuda and delays.is_cuda):
+        _require_gpu(torch.view_as_real(G), torch.view_as_real(delays))
+    Bs, As = Bs.contiguous(), As.contiguous()
+    K = Bs.shape[-2]
+    RC = Bs.numel() // (K * 3)
+    F = N // 2 + 1
+    if G.dtype != torch.complex64 or delays.dtype != torch.complex64 or G.numel() != RC * F or tuple(delays.shape) != (3, F):
+        raise ValueError(f"iir_fsm_bwd: G {tuple(G.shape)} {G.dtype} / delays {tuple(delays.shape)} {delays.dtype} do not "
+                         f"match {RC} filters of {N} taps")
+    Gr, Dr = torch.view_as_real(G.contiguous()), torch.view_as_real(delays.contiguous())
+    gB = torch.empty_like(Bs) if want_B else None
+    gA = torch.empty_like(As) if want_A else None
+    check(lib().gfx_iir_fsm_bwd_f32(_ptr(Bs), _ptr(As), _ptr(Gr), _ptr(Dr), _ptr(gB), _ptr(gA), RC, K, N, _stream()),
+          "gfx_iir_fsm_bwd_f32")
+    return gB, gA
 
 
 @_on_device
@@ -1089,6 +1124,23 @@ def istft_basis(window):
     pin = _Pin()
     check(lib().gfx_istft_basis_f32(pin(window), _ptr(basis), n_fft, _stream()), "gfx_istft_basis_f32")
     return basis
+
+
+@_on_device
+def stft(x, window, hop):
+    """torch.stft(x, n_fft, hop, window, center=True, pad_mode="reflect", return_complex=True) for rows x (rows, T) on the
+    direct-sum kernel (gfx_stft_f32): -> (rows, n_fft // 2 + 1, 1 + T // hop) complex64."""
+    _require_gpu(x, window)
+    x = x.contiguous()
+    rows, T = x.shape
+    n_fft = window.numel()
+    frames = 1 + T // hop
+    out = torch.empty((rows, n_fft // 2 + 1, frames, 2), dtype=torch.float32, device=x.device)
+    pin = _Pin()
+    for i in range(0, rows, 65535):     # rows ride on a grid dimension
+        n = min(65535, rows - i)
+        check(lib().gfx_stft_f32(_ptr(x[i:]), pin(window), _ptr(out[i:]), n, T, n_fft, hop, _stream()), "gfx_stft_f32")
+    return torch.view_as_complex(out)
 
 
 ISTFT_SCHEDULES = {"auto": 0, "gemm": 1, "fft": 2}   # GFX_ISTFT_* (include/grafx_amd.h)

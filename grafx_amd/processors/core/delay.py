@@ -46,6 +46,8 @@ class SurrogateDelay(nn.Module):
             # gfx_rdft_f32)
             soft = diff.irfft_small(spec.contiguous(), n) if needs_grad(z) else ops.irdft(spec, n)
         else:
+            if spec.is_cuda:
+                ops.fft_library_reached(f"surrogate delay's soft impulse of {n} samples")
             soft = torch.fft.irfft(spec)
         irs = self.apply_straight_through(soft) if self.straight_through else soft
         return irs.view(*shape, -1), loss

@@ -23,6 +23,8 @@ def _zerophase_ir(magnitude, fir_len, window):
 
         ir = diff.irfft_small(torch.complex(magnitude, torch.zeros_like(magnitude)), fir_len)
     else:
+        if magnitude.is_cuda:
+            ops.fft_library_reached(f"zero-phase FIR design of {fir_len} taps")
         ir = torch.fft.irfft(magnitude, n=fir_len)
     ir = torch.roll(ir, shifts=fir_len // 2, dims=-1)
     return ir if window is None else ir * window[None, :]

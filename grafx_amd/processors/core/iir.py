@@ -60,6 +60,8 @@ class IIRFilter(nn.Module):
         resp = ((Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)).prod(-2)
         if N <= ops.IRDFT_MAX_N and resp.dtype == torch.complex64:   # any length up to 8192: direct-sum kernel, no FFT library
             return ops.irdft(resp.contiguous(), N).reshape(-1, N)
+        if resp.is_cuda:
+            ops.fft_library_reached(f"IIRFilter(fsm_fir_len={N}): the taps' inverse real DFT")
         return torch.fft.irfft(resp.to(torch.complex128), dim=-1, n=N).float().reshape(-1, N)
 
     def fsm_fir(self, Bs, As):

@@ -47,7 +47,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
     def sample_noise(self, num_noises, device):
         """Fresh uniform noise per row and its STFT (reverb.py:116-128), drawn with the device generator."""
         noise = torch.rand(num_noises * 2, self.ir_len, device=device) * 2 - 1
-        spec = torch.stft(noise, n_fft=self.n_fft, hop_length=self.hop_length, window=self.window, return_complex=True)
+        # (round 6: the frames on the direct-sum kernel gfx_stft_f32 -- this was the last FFT-library call of the reverb)
+        spec = ops.stft(noise, self.window, self.hop_length)
         return spec.view(num_noises, 2, self.num_bins, self.num_frames)
 
     def _istft_basis(self, device):
@@ -58,8 +59,8 @@ class STFTMaskedNoiseReverb(BufferIO, nn.Module):
 
     def _ir_and_gain(self, init_log_magnitude, delta_log_magnitude, gain_env_log_magnitude, ms_lr):
         genv = gain_env_log_magnitude if self.gain_envelope else None
-        # fixed_noise=False (reverb.py:63, 80-82, 165): fresh noise for every row, its STFT from the device FFT library
-        # (torch.stft), mask + inverse STFT + overlap-add + normalisation on the same native kernels as the fixed noise
+        # fixed_noise=False (reverb.py:63, 80-82, 165): fresh noise for every row, its STFT on gfx_stft_f32, mask + inverse
+        # STFT + overlap-add + normalisation on the same native kernels as the fixed noise
         noise = self.noise_stft if self.fixed_noise else self.sample_noise(init_log_magnitude.shape[0],
                                                                           init_log_magnitude.device)
         return ops.stft_reverb_ir(noise, init_log_magnitude, delta_log_magnitude, genv, self.window,

@@ -655,6 +655,16 @@ class _BufferRenderFn(torch.autograd.Function):
                     return t.narrow(1, a - pa, b - a)
             return None
 
+        def span_view(a, b):  # rows [a, b) as ONE tensor: inside a part, or over whole parts none of which exists yet
+            v = part_view(a, b) if len(pieces(a, b)) == 1 else None
+            if v is None:
+                cover = [e for e in edges if e[0] < b and a < e[1]]
+                if cover[0][0] == a and cover[-1][1] == b and not any(e in parts for e in cover):
+                    v = torch.empty(B, b - a, C, L, dtype=buf.dtype, device=dev)
+                    for pa, pb in cover:       # (the parts are views of it: it lives until the last of them is dropped)
+                        parts[(pa, pb)] = v.narrow(1, pa - a, pb - pa)
+            return v
+
         def pieces(a, b):  # [a, b) cut at the part boundaries
             cuts = [(max(a, pa), min(b, pb)) for pa, pb in edges if pa < b and a < pb]
             if not cuts or cuts[0][0] != a or cuts[-1][1] != b or any(x[1] != y[0] for x, y in zip(cuts, cuts[1:])):
@@ -778,10 +788,13 @@ class _BufferRenderFn(torch.autograd.Function):
                     else:
                         grad_out = g_out if y.shape == g_out.shape else g_out.reshape(y.shape)
                     with source:
+                        sink_rows = None
                         if (trusted and want_gx and plan is None and x_in.ndim == 4 and not any(written[a:b]) and not any(
-                                r[0] < b and a < r[1] for r in virtual) and len(pieces(a, b)) == 1):
+                                r[0] < b and a < r[1] for r in virtual)):
+                            sink_rows = span_view(a, b)
+                        if sink_rows is not None:
                             # first (usually only) contribution to these rows: let the stage write it in place
-                            with diff.grad_sink(x_in, part_view(a, b)) as sink:
+                            with diff.grad_sink(x_in, sink_rows) as sink:
                                 grads = torch.autograd.grad(y, wrt, grad_outputs=grad_out, allow_unused=True)
                             if sink.writes > 1:
                                 raise RuntimeError(f"{type(processors[node_type]).__name__}: {sink.writes} autograd nodes "
@@ -831,9 +844,10 @@ class _BufferRenderFn(torch.autograd.Function):
                     written[u0 : u0 + k * m] = [True] * (k * m)
                     continue
                 uniq, dst_idx, ptr, contiguous, fan = _transposed_plan(step, plan, dev)
-                if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]) and len(pieces(uniq[0], uniq[0] + len(uniq))) == 1:
-                    g_src = part_view(uniq[0], uniq[0] + len(uniq))  # first contribution: gather straight into the rows
-                else:
+                g_src = None
+                if contiguous and not any(written[uniq[0] : uniq[0] + len(uniq)]):
+                    g_src = span_view(uniq[0], uniq[0] + len(uniq))  # first contribution: gather straight into the rows
+                if g_src is None:
                     g_src = torch.empty(B, len(uniq), C, L, device=dev)
                 g_in = g_in if g_in.stride(-1) == 1 else g_in.contiguous()
                 if fan is None or not ops.gather_sum_fanout(g_in, fan[0], fan[1], g_src):

@@ -246,6 +246,12 @@ int gfx_iir_fsm_fir_f32(const float* Bs, const float* As, const void* plan, floa
  * where the reference's own float32 result is 1e-4 .. 4e-4 from a float64 evaluation of its formulas. */
 int gfx_iir_fsm_fir_f64c_f32(const double* Bs, const double* As, const void* plan, float* h, int64_t RC, int64_t K,
                              int64_t N, void* stream);
+/* Gradient of gfx_iir_fsm_fir_f32's taps with respect to the coefficients (what autograd derives from core/iir.py:147-152):
+ * G = rfft(dL/dh, n = N) as (RC, N / 2 + 1) interleaved complex64 (gfx_rdft_f32), `delays` = the (3, N / 2 + 1) complex64
+ * table e^(-j phi[d, k]) of the forward pass (float32 phases); gB / gA: (RC, K, 3), either may be NULL.  Double precision
+ * inside (the sums over the bins cancel to 1e-5 of their terms); one launch instead of ~40 complex128 torch kernels. */
+int gfx_iir_fsm_bwd_f32(const float* Bs, const float* As, const float* G, const float* delays, float* gB, float* gA,
+                        int64_t RC, int64_t K, int64_t N, void* stream);
 
 /* coefficient front-ends (elementwise over n = rows*channels items of K biquads)
  * gfx_peq_coeffs_f32    replaces ParametricEqualizer.forward's activations + RBJ formulas:
@@ -472,6 +478,11 @@ int gfx_stereo_gain_mix_f32(const float* x, gfx_rowmap_t xmap, const float* log_
                             float* mix, int64_t mix_sb, int64_t mix_sv, int64_t mix_sc, const int64_t* extras,
                             int64_t n_pre, int64_t n_post, void* stream);
 
+/* Forward STFT of real rows: what torch.stft(x, n_fft, hop, window, center=True, pad_mode="reflect", return_complex=True)
+ * returns, out = (rows, n_fft / 2 + 1, 1 + T / hop) complex64 (interleaved re, im).  Replaces the torch.stft call of
+ * STFTMaskedNoiseReverb.sample_noise (reverb.py:116-128, fixed_noise=False).  n_fft even, <= 2048; rows <= 65535. */
+int gfx_stft_f32(const float* x, const float* window, float* out, int64_t rows, int64_t T, int64_t n_fft, int64_t hop,
+                 void* stream);
 /* ---- STFT-masked noise reverb: impulse response ------------------------------------------
  * replaces STFTMaskedNoiseReverb.compute_stft_mask + compute_ir (reverb.py:161-200: mask, torch.istft),
  * ms_to_lr (core/midside.py:4-8) and the energy of normalize_impulse (core/utils.py:14-18).

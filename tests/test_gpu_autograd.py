@@ -338,6 +338,11 @@ def test_fsm_taps_backward_matches_torch_autograd(N):
     want = torch.autograd.grad((h64 * w.double()).sum(), (B64, A64))
     for g, wv, name in zip(got, want, ("Bs", "As")):
         assert_close(g.cpu(), wv.float().cpu(), GRAD_TOL["fsm taps"], f"fsm taps grad {name} N={N}")
+    # the one native launch (gfx_iir_fsm_bwd_f32) against the batched complex128 torch ops it replaced: both double inside
+    assert diff.FSM_BWD_NATIVE
+    tB, tA, _, _ = diff.FsmFirFn.backward_torch(Bs.detach(), As.detach(), w, N)
+    for g, t, name in zip(got, (tB, tA), ("Bs", "As")):
+        assert (g - t).abs().max() <= 2e-6 * t.abs().max(), (name, float((g - t).abs().max() / t.abs().max()))
 
 
 @pytest.mark.gpu

@@ -236,6 +236,48 @@ def test_stft_reverb_with_fresh_noise_per_forward():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,n_fft,hop", [(3001, 384, 192), (60000, 384, 192), (60001, 384, 192), (193, 384, 192), (5000, 256, 64),
+                                         (4097, 2048, 512), (1000, 2, 1)])
+def test_native_stft_matches_torch_stft(T, n_fft, hop):
+    """gfx_stft_f32 (the frames of fixed_noise=False reverbs: reverb.py:116-128) against torch.stft in float64: centred,
+    reflect-padded, periodic Hann; frame count and layout as torch returns them."""
+    from grafx_amd import ops
+
+    torch.manual_seed(T)
+    x = torch.rand(5, T, device="cuda") * 2 - 1
+    w = torch.hann_window(n_fft, device="cuda")
+    got = ops.stft(x, w, hop)
+    want = torch.stft(x.double(), n_fft=n_fft, hop_length=hop, window=w.double(), return_complex=True)
+    assert got.shape == want.shape and got.dtype == torch.complex64
+    assert (got.to(torch.complex128) - want).abs().max() <= 2e-6 * want.abs().max()
+
+
+@pytest.mark.gpu
+def test_transforms_beyond_the_native_sizes_say_that_they_use_the_fft_library():
+    """The parameter-sized transforms longer than the direct-sum kernels cover go to torch.fft and
+    warn (ops.FftLibraryWarning); the sizes of every BASELINE configuration do not."""
+    import warnings
+
+    import oracle
+    from grafx_amd import ops
+    from grafx_amd.processors.core.iir import IIRFilter
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 1, 4096, device="cuda")
+    Bs, As = torch.randn(2, 1, 2, 3, device="cuda") * 0.1, torch.randn(2, 1, 2, 3, device="cuda") * 0.1
+    Bs[..., 0] += 1
+    As[..., 0] += 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", ops.FftLibraryWarning)
+        for N in (4001, 8192, 16384):
+            IIRFilter(order=2, backend="fsm", fsm_fir_len=N, flashfftconv=False).cuda()(x, Bs, As)
+    with pytest.warns(ops.FftLibraryWarning, match="fsm_fir_len=10001"):
+        y = IIRFilter(order=2, backend="fsm", fsm_fir_len=10001, flashfftconv=False).cuda()(x, Bs, As)
+    ref = oracle.convolve(x.cpu(), oracle.iir_fsm_fir(Bs.cpu(), As.cpu(), 10001), "causal")
+    assert_close(y.cpu(), ref, 1e-5, "IIRFilter(fsm_fir_len=10001)")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 3, 8, 255, 256, 2047, 2048, 4001, 8191, 8192])
 def test_small_inverse_real_dft_matches_torch_irfft(n):
     """gfx_irdft_f32 (direct-sum inverse real DFT of any length n <= 8192: the zero-phase FIR design's and the surrogate
