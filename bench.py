@@ -46,9 +46,10 @@ def parse_args(argv=None):
     ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--config", choices=["cfg4", "cfg2", "cfg3"], default="cfg4",
                     help="cfg4: the headline console graph (default); cfg2 / cfg3: BASELINE configs[1] / configs[2]")
-    ap.add_argument("--console-variant", choices=["headline", "longpole", "ballistics"], default="headline",
+    ap.add_argument("--console-variant", choices=["headline", "longpole", "clamp", "ballistics"], default="headline",
                     help="cfg4 only, for profiles of the secondary legs: longpole = every compressor's smoother logit at 6 "
-                         "(pole 0.9975), ballistics = Compressor(energy_smoother='ballistics'); the line's config says so")
+                         "(pole 0.9975), clamp = logit 12 (pole 1 - 1e-5: live truncation term), ballistics = "
+                         "Compressor(energy_smoother='ballistics'); the line's config says so")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only with --dry)")
     ap.add_argument("--dry", action="store_true",
@@ -589,8 +590,9 @@ def bench_console(args, torch, dist, dev, world, rank, sync, fence):
                                                hip_processors(args.reference_default_args, energy_smoother=smoother).items()}
     torch.manual_seed(1234)  # identical parameters on every rank (a shared mixing console)
     params_cpu = {t: {k: v.detach() for k, v in d.items()} for t, d in create_empty_parameters(procs, G, std=0.1).items()}
-    if args.console_variant == "longpole":
-        params_cpu["compressor"]["z_alpha_pre"] = torch.full_like(params_cpu["compressor"]["z_alpha_pre"], 6.0)
+    if args.console_variant in ("longpole", "clamp"):
+        params_cpu["compressor"]["z_alpha_pre"] = torch.full_like(params_cpu["compressor"]["z_alpha_pre"],
+                                                                  6.0 if args.console_variant == "longpole" else 12.0)
     params = {t: {k: v.to(dev) for k, v in d.items()} for t, d in params_cpu.items()}
     torch.manual_seed(1000 + rank)  # each rank renders its own shard of the batch
     x = torch.randn(B, 32, 2, L, device=dev)

@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r5"))
+DST = os.path.join(ROOT, "profiles", os.environ.get("GRAFX_ROUND", "r6"))
 
 
 def bare(name):
@@ -46,7 +46,7 @@ def counter(dirname, cname):
 def main():
     os.makedirs(DST, exist_ok=True)
     bench = json.loads(open(os.path.join(RAW, "bench.json")).read().strip().splitlines()[-1])
-    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, f"bench_{os.environ.get('GRAFX_ROUND', 'r5')}.json"))
+    shutil.copy(os.path.join(RAW, "bench.json"), os.path.join(DST, f"bench_{os.environ.get('GRAFX_ROUND', 'r6')}.json"))
     shutil.copy(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(DST, "bench_under_rocprof.json"))
     stats = glob.glob(os.path.join(RAW, "trace", "**", "*kernel_stats.csv"), recursive=True)
     shutil.copy(stats[0], os.path.join(DST, "rocprofv3_kernel_stats.csv"))
@@ -72,7 +72,7 @@ def main():
     # round 5: the same two passes for the console with long compressor poles / the ballistics smoother, and for the
     # ballistics recursion alone (tools/ballistics_bench.py: 9216 x 131072 rows) -- launches of different sizes are averaged
     # per kernel name, so read these next to the kernel statistics of the same runs
-    for suffix in ("_longpole", "_ballistics", "_ballistics_rows"):
+    for suffix in ("_longpole", "_ballistics", "_ballistics_rows", "_train"):
         if glob.glob(os.path.join(RAW, "pmc_fetch" + suffix, "**", "*counter_collection.csv"), recursive=True):
             json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md; averages over the launches of the run, the single-graph "
                                "warm-up launches dropped", "kernels": traffic(suffix)},
