@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void czt_cols_fwd_kernel(const float* __restri
 // One tile per (row, k1): forward, times the chirp spectrum, inverse -- in place.  PLAN: forward only, spectrum stored
 // in thread layout.
 template <typename T, bool PLAN>
-__global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kernel(
+__global__ __launch_bounds__(TILE_T, (sizeof(T) == 4 || GFX_F64_SPLIT) ? 2 : 1) void czt_rows_kernel(
     typename Prec<T>::T2* __restrict__ buf, const typename Prec<T>::T2* __restrict__ spec,
     typename Prec<T>::T2* __restrict__ spec_out, int C, const typename Prec<T>::T2* __restrict__ twtab) {
     using cx = typename Prec<T>::cxt;
@@ -306,8 +306,9 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
     constexpr uint32_t TILE_BYTES = TILE_M * sizeof(cx);
     constexpr int NT = GFX_CZT_NT ? 2 : 0;
     const __amdgpu_buffer_rsrc_t rb = tile_rsrc(reinterpret_cast<cx*>(buf) + tile * TILE_M, TILE_BYTES);
+    constexpr bool SPLIT = sizeof(T) == 8 && GFX_F64_SPLIT;     // (fft_tile_f64.hpp: exchanges in two rounds, twiddles per pass)
     typename Prec<T>::Tw tw;
-    tile_twiddles(tw, twtab, t);
+    if constexpr (!SPLIT) tile_twiddles(tw, twtab, t);
     cx v[32], w[2][16];
     // (descriptor accesses in float: 10.1 -> 9.3 ms per 4096 rows; in double the global form measured 1 % better)
     cx* b = reinterpret_cast<cx*>(buf) + tile * TILE_M;
@@ -327,18 +328,35 @@ __global__ __launch_bounds__(TILE_T, sizeof(T) == 4 ? 2 : 1) void czt_rows_kerne
         for (int q = 0; q < 32; ++q) sreg[q] = tile_ld<0>(rs, t, q, (cx*)nullptr);
         __builtin_amdgcn_sched_barrier(0);
     }
-    tile_forward(v, w, tw, lds, t);
+    if constexpr (SPLIT) tile_forward(v, w, twtab, lds, t);
+    else tile_forward(v, w, tw, lds, t);
     if (PLAN) {
         cx* o = reinterpret_cast<cx*>(spec_out) + (int64_t)k1 * TILE_M;
 #pragma unroll
         for (int q = 0; q < 32; ++q) o[q * TILE_T + t] = w[q >> 4][q & 15];
         return;
     }
+    if constexpr (SPLIT) {
+        // eight spectrum values at a time, fenced: left to itself the scheduler requests all 32 (128 registers) on top of the
+        // 128 of the tile, and at two workgroups per CU there are 256 in all
 #pragma unroll
-    for (int q = 0; q < 32; ++q)
-        w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], EARLY ? sreg[EARLY ? q : 0] : tile_ld<0>(rs, t, q, (cx*)nullptr));
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            cx sp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sp[q] = tile_ld<0>(rs, t, 8 * g + q, (cx*)nullptr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[(8 * g + q) >> 4][(8 * g + q) & 15] = cmul(w[(8 * g + q) >> 4][(8 * g + q) & 15], sp[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q)
+            w[q >> 4][q & 15] = cmul(w[q >> 4][q & 15], EARLY ? sreg[EARLY ? q : 0] : tile_ld<0>(rs, t, q, (cx*)nullptr));
+    }
     __syncthreads();
-    tile_inverse(w, v, tw, lds, t);
+    if constexpr (SPLIT) tile_inverse(w, v, twtab, lds, t);
+    else tile_inverse(w, v, tw, lds, t);
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         if constexpr (sizeof(T) == 4) tile_st<NT>(rb, t, a, v[brev(a, 5)]);

@@ -12,7 +12,16 @@
 namespace gfx {
 
 using cxd = double __attribute__((ext_vector_type(2)));
-constexpr int TILE_LDS_BYTES_F64 = TILE_LDS_F2 * 16;      // 147,456 B
+// GFX_F64_SPLIT (round 6, default): every LDS exchange of the tile moves the real parts and the imaginary parts in two
+// rounds through an image of DOUBLES -- 73,728 B, the float tile's footprint, so that TWO workgroups share a CU and one's
+// loads and stores run under the other's arithmetic (with the 147,456-byte double2 images a CU held one workgroup whose
+// load, transform and store phases ran strictly one after the other: 20 us per tile, half memory, half arithmetic).  The
+// price is four barriers per exchange instead of one or two, and 256 registers per thread instead of 461: the twiddles are
+// fetched per pass (tile_twiddles_1 / _2) instead of living through the tile.  -DGFX_F64_SPLIT=0: the one-round images.
+#ifndef GFX_F64_SPLIT
+#define GFX_F64_SPLIT 1
+#endif
+constexpr int TILE_LDS_BYTES_F64 = TILE_LDS_F2 * (GFX_F64_SPLIT ? 8 : 16);      // 73,728 B (147,456 B in one round)
 
 __device__ __forceinline__ cxd to_cx(double2 a) { return cxd{a.x, a.y}; }
 __device__ __forceinline__ cxd cmul(cxd a, cxd w) { return cxd{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
@@ -88,6 +97,129 @@ __device__ __forceinline__ void tile_twiddles(TileTwD& tw, const double2* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) tw.hi2[i] = to_cx(table[(16 + i) * TILE_T + t]);
 }
+
+__device__ __forceinline__ void tile_twiddles_1(TileTwD& tw, const double2* __restrict__ table, int t) {   // pass 1's
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tw.lo1[i] = to_cx(table[i * TILE_T + t]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tw.hi1[i] = to_cx(table[(4 + i) * TILE_T + t]);
+}
+__device__ __forceinline__ void tile_twiddles_2(TileTwD& tw, const double2* __restrict__ table, int t) {   // pass 2's
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tw.lo2[i] = to_cx(table[(12 + i) * TILE_T + t]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tw.hi2[i] = to_cx(table[(16 + i) * TILE_T + t]);
+}
+
+#if GFX_F64_SPLIT
+// The same two transforms with every exchange in two rounds (real parts, then imaginary parts) through `lds` read as an
+// image of doubles; `table`: the twiddle table, from which each pass fetches what it needs.
+__device__ __forceinline__ void tile_forward(cxd (&v)[32], cxd (&w)[2][16], const double2* __restrict__ table, cxd* lds_c, int t) {
+    double* lds = reinterpret_cast<double*>(lds_c);
+    TileTwD tw;
+    tile_twiddles_1(tw, table, t);
+    dif<32, false>(v);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r] = tw.fwd1(v[r], brev(r, 5));
+    const int kk = t >> 4, d = t & 15;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) lds[s1_at(brev(r, 5), t)] = v[r][part];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) w[s][c][part] = lds[s1_at(kk + 16 * s, 16 * c + d)];
+        }
+        __syncthreads();
+    }
+    tile_twiddles_2(tw, table, t);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        dif<16, false>(w[s]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[s][r] = tw.fwd2(w[s][r], brev(r, 4));
+    }
+    cxd u[2][16];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[s2_row(brev(r, 4), kk + 16 * s) + d] = w[s][r][part];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int bf = 0; bf < 2; ++bf) {
+            const int j = bf ? bf_b(t) : bf_a(t);
+            const double* row = lds + s2_row(j >> 5, j & 31);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) u[bf][q][part] = row[q];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[bf][q] = u[bf][q];
+        dif<16, false>(w[bf]);
+    }
+}
+
+__device__ __forceinline__ void tile_inverse(cxd (&w)[2][16], cxd (&v)[32], const double2* __restrict__ table, cxd* lds_c, int t) {
+    double* lds = reinterpret_cast<double*>(lds_c);
+    TileTwD tw;
+    cxd p[2][16];
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[bf][k] = w[bf][brev(k, 4)];
+        dif<16, true>(p[bf]);
+    }
+    const int kk = t >> 4, d = t & 15;
+    tile_twiddles_2(tw, table, t);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int bf = 0; bf < 2; ++bf) {
+            const int j = bf ? bf_b(t) : bf_a(t);
+            double* row = lds + s2_row(j >> 5, j & 31);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) row[q] = p[bf][brev(q, 4)][part];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) w[s][k2][part] = lds[s2_row(k2, kk + 16 * s) + d];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) w[s][k2] = tw.inv2(w[s][k2], k2);
+        dif<16, true>(w[s]);
+    }
+    tile_twiddles_1(tw, table, t);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[s1_at(kk + 16 * s, 16 * brev(r, 4) + d)] = w[s][r][part];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) v[k1][part] = lds[s1_at(k1, t)];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) v[k1] = tw.inv1(v[k1], k1);
+    dif<32, true>(v);
+}
+#endif
 
 // Forward: v[a] = z[t + 256*a]  ->  w[bf][brev4(k3)] = Z[j_bf + 512*k3]   (see fft_tile.hpp)
 __device__ __forceinline__ void tile_forward(cxd (&v)[32], cxd (&w)[2][16], const TileTwD& tw, cxd* lds, int t) {
