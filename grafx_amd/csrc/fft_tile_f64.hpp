@@ -112,6 +112,8 @@ __device__ __forceinline__ void tile_twiddles_2(TileTwD& tw, const double2* __re
 }
 
 #if GFX_F64_SPLIT
+// (the scheduler may not carry loads or twiddles of a later phase across these points: at 256 registers there is no room)
+__device__ __forceinline__ void f64_fence() { __builtin_amdgcn_sched_barrier(0); }
 // The same two transforms with every exchange in two rounds (real parts, then imaginary parts) through `lds` read as an
 // image of doubles; `table`: the twiddle table, from which each pass fetches what it needs.
 __device__ __forceinline__ void tile_forward(cxd (&v)[32], cxd (&w)[2][16], const double2* __restrict__ table, cxd* lds_c, int t) {
@@ -134,6 +136,7 @@ __device__ __forceinline__ void tile_forward(cxd (&v)[32], cxd (&w)[2][16], cons
         }
         __syncthreads();
     }
+    f64_fence();
     tile_twiddles_2(tw, table, t);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -141,6 +144,7 @@ __device__ __forceinline__ void tile_forward(cxd (&v)[32], cxd (&w)[2][16], cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[s][r] = tw.fwd2(w[s][r], brev(r, 4));
     }
+    f64_fence();
     cxd u[2][16];
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -159,6 +163,7 @@ __device__ __forceinline__ void tile_forward(cxd (&v)[32], cxd (&w)[2][16], cons
         }
         __syncthreads();
     }
+    f64_fence();
 #pragma unroll
     for (int bf = 0; bf < 2; ++bf) {
 #pragma unroll
@@ -178,7 +183,7 @@ __device__ __forceinline__ void tile_inverse(cxd (&w)[2][16], cxd (&v)[32], cons
         dif<16, true>(p[bf]);
     }
     const int kk = t >> 4, d = t & 15;
-    tile_twiddles_2(tw, table, t);
+    f64_fence();
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -196,13 +201,15 @@ __device__ __forceinline__ void tile_inverse(cxd (&w)[2][16], cxd (&v)[32], cons
         }
         __syncthreads();
     }
+    f64_fence();
+    tile_twiddles_2(tw, table, t);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) w[s][k2] = tw.inv2(w[s][k2], k2);
         dif<16, true>(w[s]);
     }
-    tile_twiddles_1(tw, table, t);
+    f64_fence();
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -215,6 +222,8 @@ __device__ __forceinline__ void tile_inverse(cxd (&w)[2][16], cxd (&v)[32], cons
         for (int k1 = 0; k1 < 32; ++k1) v[k1][part] = lds[s1_at(k1, t)];
         __syncthreads();
     }
+    f64_fence();
+    tile_twiddles_1(tw, table, t);
 #pragma unroll
     for (int k1 = 0; k1 < 32; ++k1) v[k1] = tw.inv1(v[k1], k1);
     dif<32, true>(v);
