@@ -883,7 +883,9 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
                 # row transfers that never cross HBM: the sources' write-through + the fused routing sums (as in the
                 # headline's graph_roofline); the ballistics compressor does not take the routing sum; the output-only
                 # render also skips the sources' copy and the rows that only feed the fused sums
-                elided = (32 + 32 if "energy_smoother" in variant else 32 + 64 + 4) + (32 + 32 + 4 if "keep_signal_buffer" in variant else 0)
+                # (at the clamp the compressors' rows leave the tile grid: written by the row kernel, read back by the sums)
+                elided = (32 + 32 if "energy_smoother" in variant else 32 if variant.get("z_alpha_pre", 0) >= 8 else 32 + 64 + 4) \
+                    + (32 + 32 + 4 if "keep_signal_buffer" in variant else 0)
                 moved_bytes = (285 - elided) * R * 2 * L * 4
             elif cfg == "cfg4":
                 R, C, L = 256, 2, 131072     # the stated configuration (rounds 4-5 ran a quarter of it)
