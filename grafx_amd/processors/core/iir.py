@@ -33,8 +33,10 @@ class IIRFilter(nn.Module):
         elif backend in ("lfilter", "ssm"):
             # upstream: torchaudio.functional.lfilter per section / a state-space form on torchlpc (iir.py:154-261).
             # Here both are the exact recursive cascade as one parallel-scan HIP kernel (gfx_biquad_cascade_f32).
-            if order != 2:
-                raise NotImplementedError("the HIP recursive kernel runs second-order sections (order=2)")
+            # (first-order sections ride on it with a zero third coefficient; upstream's "ssm" asserts order 2, iir.py:226)
+            if order not in (1, 2) or (order == 1 and backend == "ssm"):
+                raise NotImplementedError("the HIP recursive kernel runs first- and second-order sections (order 1 or 2; "
+                                          "backend='ssm': 2, as upstream); use backend='fsm' for higher orders")
         else:
             raise ValueError(f"Unsupported backend: {backend}")
 
@@ -83,6 +85,8 @@ class IIRFilter(nn.Module):
         return (Bs.unsqueeze(-1) * delays).sum(-2) / (As.unsqueeze(-1) * delays).sum(-2)
 
     def _process_recursive(self, input_signal, Bs, As, out=None):
+        if Bs.shape[-1] == 2 and As.shape[-1] == 2:     # first-order sections: b2 = a2 = 0 (differentiable: a zero pad)
+            Bs, As = torch.nn.functional.pad(Bs, (0, 1)), torch.nn.functional.pad(As, (0, 1))
         if needs_grad(input_signal, Bs, As):
             if self.backend == "ssm" and Bs.shape[2] > 1:
                 raise NotImplementedError("backend='ssm' with more than one section reproduces an upstream quirk (every "

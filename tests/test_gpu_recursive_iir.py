@@ -126,6 +126,49 @@ def test_recursive_backend_refuses_bad_orders():
 
     with pytest.raises(NotImplementedError):
         IIRFilter(order=4, backend="ssm", flashfftconv=False)
+    with pytest.raises(NotImplementedError):
+        IIRFilter(order=3, backend="lfilter", flashfftconv=False)
+    with pytest.raises(NotImplementedError):
+        IIRFilter(order=1, backend="ssm", flashfftconv=False)      # upstream's ssm asserts order 2 (core/iir.py:226)
+
+
+def test_first_order_sections_on_the_recursive_backend():
+    """IIRFilter(order=1, backend="lfilter") (reference core/iir.py:154-183 with two coefficients per section): first-order
+    sections ride on the biquad kernel with a zero third coefficient -- against the direct-form recursion in float64,
+    forward and gradients."""
+    from grafx_amd.processors import IIRFilter
+
+    torch.manual_seed(1)
+    R, K, L = 4, 3, 3000
+    x = torch.randn(R, 2, L)
+    pole = torch.tensor([0.5, -0.9, 0.995]).expand(R, 1, K)
+    As = torch.stack([torch.ones_like(pole), -pole], -1)
+    Bs = torch.stack([torch.ones_like(pole) * 0.7, 0.3 * torch.ones_like(pole)], -1) + 0.05 * torch.randn(R, 1, K, 2)
+
+    def direct(xd, B, A):
+        y = xd
+        for k in range(K):
+            b, a = B[:, 0, k], A[:, 0, k]
+            out, w1 = [], torch.zeros(R, 2, dtype=xd.dtype)
+            for n in range(L):
+                w = y[..., n] - a[:, 1:2] * w1
+                out.append(b[:, 0:1] * w + b[:, 1:2] * w1)
+                w1 = w
+            y = torch.stack(out, -1)
+        return y
+
+    m = IIRFilter(order=1, backend="lfilter", flashfftconv=False).cuda()
+    with torch.no_grad():
+        y = m(x.cuda(), Bs.cuda(), As.cuda())
+    assert_close(y.cpu(), direct(x.double(), Bs.double(), As.double()).float(), 2e-5, "first-order cascade")
+    Bg, Ag = Bs.cuda().requires_grad_(), As.cuda().requires_grad_()
+    w = torch.randn(R, 2, L)
+    gB, gA = torch.autograd.grad((m(x.cuda(), Bg, Ag) * w.cuda()).sum(), (Bg, Ag))
+    B64, A64 = Bs.double().requires_grad_(), As.double().requires_grad_()
+    rB, rA = torch.autograd.grad((direct(x.double(), B64, A64) * w.double()).sum(), (B64, A64))
+    assert gB.shape == Bs.shape and gA.shape == As.shape
+    assert_close(gB.cpu(), rB.float(), 1e-4, "first-order cascade grad Bs")
+    assert_close(gA.cpu(), rA.float(), 1e-4, "first-order cascade grad As")
 
 
 def test_graphic_equalizer_on_the_exact_backend_with_31_sections():
