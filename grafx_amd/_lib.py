@@ -26,6 +26,7 @@ SIGNATURES = {
     "gfx_fftconv_f32": (ctypes.c_int, [f32p, RowMap, vp, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_fftconv_ex_f32": (ctypes.c_int, [f32p, RowMap, vp, i64, i64, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp]),
     "gfx_fftconv_sched_f32": (ctypes.c_int, [f32p, RowMap, vp, i64, i64, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, ctypes.c_int, vp]),
+    "gfx_fftconv_rowmax_f32": (ctypes.c_int, [f32p, RowMap, vp, i64, i64, f32p, RowMap, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp, sz, vp, ctypes.POINTER(ctypes.c_int), vp]),
     "gfx_fftconv_last_kernel": (ctypes.c_char_p, []),
     "gfx_fir_direct_max_taps": (i64, []),
     "gfx_fir_direct_f32": (ctypes.c_int, [f32p, RowMap, f32p, i64, f32p, RowMap, i64, i64, i64, i64, i64, i64, i64, vp]),
@@ -52,6 +53,8 @@ SIGNATURES = {
     "gfx_odd_alias_pair_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),
     "gfx_odd_alias_pair_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_odd_alias_pair_rows_f32": (ctypes.c_int, [f32p, f32p, RowMap, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
+    "gfx_odd_alias_pair_max_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp, vp]),
+    "gfx_odd_alias_pair_rows_max_f32": (ctypes.c_int, [f32p, f32p, RowMap, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp, vp]),
     "gfx_odd_alias_pair_precise_plan_bytes": (sz, [i64]),
     "gfx_odd_alias_pair_precise_workspace_bytes": (sz, [i64, i64]),
     "gfx_odd_alias_pair_precise_plan_f32": (ctypes.c_int, [vp, i64, vp, sz, vp]),

@@ -34,7 +34,9 @@ ARG_NAMES = ["x_lo", "x_hi", "h_lo", "h_hi", "y_lo", "y_hi", "c_lo", "c_hi", "tw
              "m_ntiles", "sh_ntiles", "inner", "m_inner", "sh_inner", "hrows", "m_hrows", "sh_hrows",
              "cout_shift", "cout_mask", "cin_mask", "cf_mask", "Cf", "per_xcd", "wgs_per_xcd", "pad0",
              "xs_outer_lo", "xs_outer_hi", "xs_inner", "xs_ch", "ys_outer_lo", "ys_outer_hi", "ys_inner", "ys_ch",
-             "cs_outer_lo", "cs_outer_hi", "cs_inner", "cs_ch", "stamp_lo", "stamp_hi", "pad1", "pad2"]
+             "cs_outer_lo", "cs_outer_hi", "cs_inner", "cs_ch", "rm_lo", "rm_hi", "rm_rec", "rm_flags"]
+# (rm_*: a ready buffer descriptor of one word per output row-channel -- bits of max |y| of the row, for the odd-length
+# aliasing's pair scaling (czt_pair.hip) -- or zeros: with no records the atomics below are dropped by the range check)
 ARG0 = 8
 KERNARG_BYTES = 4 * len(ARG_NAMES)
 
@@ -63,6 +65,7 @@ def pack_args(**kw):
 
 # ---- register map ---------------------------------------------------------------------------------------------------
 V_TID, V_OFF8, V_OFF16, V_P1HI, V_P2, V_P3, V_P3HI, V_P4A, V_P4B = (v(i) for i in range(9))
+V_MAX = v(9)                                               # running max |output| of the row-channel being walked
 TMP = [v(10 + 2 * i, 2) for i in range(6)]                  # v[10:21]
 TW_BASE = 22
 LO1 = {i: v(TW_BASE + 2 * (i - 1), 2) for i in (1, 2, 3)}                 # W_8192^(t i)
@@ -102,6 +105,7 @@ S_GEN_EXEC = s(98, 2)
 S_WAVE0 = s(100)
 S_OFF = s(101)
 SCR = [s(i) for i in range(8)]      # s[0:7]: scratch once the arguments are loaded
+RM_DESC = s(ARG0 + ARG_NAMES.index("rm_lo"), 4)            # s[52:55]: the rows' maxima (arguments rm_*)
 NUM_SGPR = 102
 
 H_TILE_BYTES = 17 * 256 * 16
@@ -119,6 +123,10 @@ KNOBS = dict(
     carry=1,                    # 1: a workgroup walks CONSECUTIVE tiles and copies the window overlap (the last a_lo rows)
                                 # from the running tile's registers into the next window instead of re-reading it
     fake_epilogue=0,            # timing experiment: that many junk VALU instructions + 24 extra stores per tile
+    rowmax=0,                   # 1: keep max |output| per row-channel and add it into the rm_* buffer (carry=1 only).  NOT in
+                                # the build: the kernel needs an even output length (8-byte stores), and the full-length convolution
+                                # in front of the odd-length aliasing -- the one consumer of the maxima -- has an odd one, so it
+                                # always runs on fftconv1_kernel, which takes them itself; the emulator test keeps this alive
     codelet="dit",              # dit: radix-2 DIT with fused multiply-adds (3 instructions per general butterfly, values
                                 # rotate through a spare pair); dif: the in-place DIF of fft_tile.hpp (4 instructions)
 )
@@ -304,6 +312,40 @@ class PipeGen(TileGen):
                         Inst("buffer_load_dwordx4", HQ[q], (V_OFF16, NX_H, S_OFF), {})])
         return out
 
+    # ---- the rows' maxima (round 6) ------------------------------------------------------------------------------------
+    # Every lane keeps max |y| over the outputs it stores (one v_max3_f32 with |.| modifiers per stored register pair, the
+    # overlap rows excluded); after the LAST tile of a row-channel -- and when the workgroup's run of tiles ends -- every
+    # lane adds its word into the row's slot with a return-less atomic maximum (non-negative floats order like their bit
+    # patterns) and starts again from zero.  No branch goes round the atomic (the wait-count pass counts memory
+    # instructions statically): a tile that does not flush aims it past the end of the buffer, where the range check drops it.
+    def rowmax_accumulate(self, regs_of_row):
+        for a in range(self.a_lo, 32):
+            r = regs_of_row(a)
+            self.add("v_max3_f32", V_MAX, (r.sub(0), r.sub(1), V_MAX), abs=[1, 1, 0])
+
+    def rowmax_flush(self, tiles_back, always):
+        """tile S_LB - tiles_back is the one whose outputs were just accumulated.  always: the exit (flush whatever is there)."""
+        q, rem, t0, lb, off, keep = SCR[0], SCR[1], SCR[2], SCR[3], SCR[4], SCR[5]
+        self.sop("s_sub_u32", lb, S_LB, Lit(tiles_back))
+        self.udiv(q, rem, lb, A("ntiles"), A("m_ntiles"), A("sh_ntiles"), t0)
+        self.sop("s_lshl_b32", off, q, Lit(2))
+        if not always:
+            # flush = (this was the last tile of its row) and (the tile was a real one: its store descriptor has records)
+            self.sop("s_add_u32", rem, rem, Lit(1))
+            self.add("s_cmp_eq_u32", None, (rem, A("ntiles")))
+            self.sop("s_cselect_b32", t0, Lit(1), Lit(0))
+            self.add("s_cmp_lg_u32", None, (ST_Y.sub(2), Lit(0)))
+            self.sop("s_cselect_b32", t0, t0, Lit(0))                  # flush
+            self.sop("s_cselect_b32", keep, Lit(-1), Lit(0))           # a tile that was never there leaves garbage: dropped
+            self.add("s_cmp_lg_u32", None, (t0, Lit(0)))
+            self.sop("s_cselect_b32", off, off, S_HUGE)
+            self.sop("s_cselect_b32", keep, Lit(0), keep)
+        self.add("buffer_atomic_umax", None, (V_MAX, RM_DESC, off))
+        self.add("s_nop", imm=0)
+        if always:
+            return
+        self.add("v_and_b32", V_MAX, (keep, V_MAX))
+
     # ---- LDS exchanges + register passes -----------------------------------------------------------------------------
     def barrier(self):
         self.add("s_barrier")
@@ -454,6 +496,10 @@ class PipeGen(TileGen):
         for k in range(4):
             self.sop("s_mov_b32", CUR_Y.sub(k), NX_Y.sub(k))
         self.decode(first=False)
+        if self.k["rowmax"]:
+            # the previous tile's outputs are still in Y (they leave during this tile's forward transform): tile S_LB - 3
+            self.rowmax_accumulate(lambda a: Y.rows[a])
+            self.rowmax_flush(3, always=False)
         out += self.sub()
         # forward transform of X; meanwhile: outputs of the previous tile leave Y, then the next window lands in Y
         self.fwd_pass1(X)
@@ -549,6 +595,7 @@ class PipeGen(TileGen):
         self.mov_lit(S_C2.sub(1), 2.0)
         self.mov_lit(S_HUGE, 0x7FFF0000)
         # per-thread addresses
+        self.add("v_mov_b32", V_MAX, (Lit(0),))
         self.add("v_lshlrev_b32", V_OFF8, (Lit(3), V_TID))
         self.add("v_lshlrev_b32", V_OFF16, (Lit(4), V_TID))
         self.add("v_add_u32", V_P1HI, (Lit(8 * S1_ROW * 16), V_OFF8))
@@ -622,6 +669,9 @@ class PipeGen(TileGen):
 
     def exit_block(self, X):
         self.sub()
+        if self.k["rowmax"]:
+            self.rowmax_accumulate(lambda a: X.rows[a])       # the run's last tile: S_LB - 2 (the decode went one past it)
+            self.rowmax_flush(2, always=True)
         for grp in self.g_stores(lambda a: X.rows[a], CUR_Y):
             self.prog.extend(grp)
         self.add("s_endpgm")

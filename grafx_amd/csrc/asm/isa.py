@@ -110,6 +110,13 @@ def render_inst(i):
         ops = ", ".join(map(repr, (i.dst,) + i.src))
         mods = _fmt_mods(m, ("op_sel", "op_sel_hi", "neg_lo", "neg_hi"))
         return f"\t{op} {ops} {mods}".rstrip() + c
+    if op == "v_max3_f32":      # |x| on the sources named by the `abs` modifier list
+        ab = m.get("abs") or [0, 0, 0]
+        srcs = ", ".join(f"|{x!r}|" if ab[k] else repr(x) for k, x in enumerate(i.src))
+        return f"\t{op} {i.dst!r}, {srcs}" + c
+    if op == "buffer_atomic_umax":   # (data, rsrc, soffset): no vector address ("off"), every lane hits rsrc + soffset
+        data, rsrc, soff = i.src
+        return f"\t{op} {data!r}, off, {rsrc!r}, {soff!r}" + c
     if op.startswith("buffer_load") or op.startswith("buffer_store"):
         data = i.dst if op.startswith("buffer_load") else i.src[0]
         vaddr, rsrc, soff = (i.src if op.startswith("buffer_load") else i.src[1:])
@@ -595,6 +602,28 @@ class Emulator:
             w.at_barrier = True
         elif op == "s_endpgm":
             w.done = True
+        elif op == "v_max3_f32":
+            ab = m.get("abs") or [0, 0, 0]
+            vals = []
+            for k, x in enumerate(i.src):
+                f = self.rd(w, x).astype(np.uint32).view(np.float32)
+                vals.append(np.abs(f) if ab[k] else f)
+            # IEEE maximum that prefers numbers over NaN (fmax), as the hardware's max3
+            r = np.fmax(np.fmax(vals[0], vals[1]), vals[2]).astype(np.float32)
+            self.wrv(w, i.dst, 0, r.view(np.uint32))
+        elif op == "buffer_atomic_umax":
+            data, rsrc, soff = i.src
+            self._check_ready(w, data, "atomic of")
+            self._check_ready(w, rsrc, "read of")
+            base = int(w.s[rsrc.idx]) | ((int(w.s[rsrc.idx + 1]) & 0xFFFF) << 32)
+            nrec = int(w.s[rsrc.idx + 2])
+            so = int(self.rds(w, soff)) if not isinstance(soff, Lit) else int(soff.val)
+            if 0 <= so and so + 4 <= nrec:
+                arr, k = self.mem.find(base + so)
+                for l in range(WAVE):
+                    if w.exec[l]:
+                        arr[k] = max(np.uint32(arr[k]), np.uint32(w.v[data.idx, l]))
+            self._issue(w, "vm", [])
         elif op.startswith("buffer_load_dword"):
             self._buffer_load(w, i, {"buffer_load_dword": 1, "buffer_load_dwordx2": 2, "buffer_load_dwordx4": 4}[op])
         elif op.startswith("buffer_store_dword"):

@@ -292,7 +292,7 @@ def cluster_at(main, side, anchors, before=True, weights=None):
 
 # ---- automatic s_waitcnt placement --------------------------------------------------------------------------------
 _VM_LOAD = ("buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx4")
-_VM_STORE = ("buffer_store_dword", "buffer_store_dwordx2", "buffer_store_dwordx4")
+_VM_STORE = ("buffer_store_dword", "buffer_store_dwordx2", "buffer_store_dwordx4", "buffer_atomic_umax")
 _DS_READ = ("ds_read_b32", "ds_read_b64", "ds_read_b128")
 _DS_WRITE = ("ds_write_b32", "ds_write_b64", "ds_write_b128")
 _SMEM = ("s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16", "s_memrealtime")

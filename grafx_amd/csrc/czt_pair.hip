@@ -754,7 +754,7 @@ static void pair_chain(const CztGeom& g, const float* z, float* y, int64_t ldy, 
 template <typename T>
 static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                           const void* plan, void* ws, size_t ws_bytes, void* stream, const gfx_rowmap_t* ymap = nullptr,
-                          int yC = 0, int64_t row0 = 0) {
+                          int yC = 0, int64_t row0 = 0, const uint32_t* given_max = nullptr) {
     using T2 = typename Prec<T>::T2;
     CztGeom g;
     if (!z || !y || !plan || rows <= 0 || !czt_pair_geom(P, g)) return GFX_EINVAL;
@@ -770,7 +770,9 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
     hipStream_t st = (hipStream_t)stream;
     static const bool scaled = [] { const char* e = getenv("GRAFX_ALIAS_PAIR_SCALE"); return !(e && e[0] == '0'); }();
     uint32_t* rmax = nullptr;
-    if (scaled && rows > 1) {
+    if (scaled && rows > 1 && given_max) {
+        rmax = const_cast<uint32_t*>(given_max);     // the producer of z left them (gfx_fftconv_rowmax_f32)
+    } else if (scaled && rows > 1) {
         // max |z| of every row, behind the transforms' own workspace
         rmax = (uint32_t*)((T2*)ws + pairs * g.NFFT);
         if (hipMemsetAsync(rmax, 0, (size_t)rows * sizeof(uint32_t), st) != hipSuccess) return GFX_ELAUNCH;
@@ -848,6 +850,18 @@ int gfx_odd_alias_pair_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int
                                 int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream) {
     if (C < 1 || C > 0x7fffffffLL || (row0 & 1)) return GFX_EINVAL;
     return czt_pair_alias<float>(z, y, len, lo, len, rows, P, plan, ws, ws_bytes, stream, &ymap, (int)C, row0);
+}
+
+int gfx_odd_alias_pair_max_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                               const void* plan, void* ws, size_t ws_bytes, const uint32_t* rowmax, void* stream) {
+    return czt_pair_alias<float>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream, nullptr, 0, 0, rowmax);
+}
+
+int gfx_odd_alias_pair_rows_max_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo, int64_t len,
+                                    int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes,
+                                    const uint32_t* rowmax, void* stream) {
+    if (C < 1 || C > 0x7fffffffLL || (row0 & 1)) return GFX_EINVAL;
+    return czt_pair_alias<float>(z, y, len, lo, len, rows, P, plan, ws, ws_bytes, stream, &ymap, (int)C, row0, rowmax);
 }
 
 #else

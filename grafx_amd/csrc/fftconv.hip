@@ -264,7 +264,8 @@ __global__ __launch_bounds__(TILE_T, 2) void hspec_kernel(const float* __restric
 template <bool TEE>
 __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __restrict__ x, const float4* __restrict__ Hs,
                                                              float* __restrict__ y, float* __restrict__ xcopy,
-                                                             ConvArgs a, const float2* __restrict__ twtab) {
+                                                             ConvArgs a, const float2* __restrict__ twtab,
+                                                             uint32_t* __restrict__ rowmax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
@@ -304,6 +305,27 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     // this thread read at the end of the forward transform -- nobody else touches them in between
     tile_inverse(w, v, tw, lds, t);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
+    if (rowmax) {
+        // max |y| of the row-channel as a by-product (round 6; gfx_fftconv_rowmax_f32): the odd-length aliasing that follows a
+        // full-length convolution scales the second row of every pair of rows by these (czt_pair.hip) and does not have to
+        // read z once more.  Non-negative floats order like their bit patterns: one atomic maximum per wave and tile.
+        const int64_t room = a.Lout - (tile * a.V - a.O);
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int64_t q = 2 * (t + 256 * k);
+            const cx e = v[brev(k, 5)];
+            const uint32_t ex = __float_as_uint(e.x) & 0x7fffffffu, ey = __float_as_uint(e.y) & 0x7fffffffu;
+            if (q >= a.O && q < room) m = ex > m ? ex : m;
+            if (q >= a.O && q + 1 < room) m = ey > m ? ey : m;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t u = (uint32_t)__shfl_xor((int)m, o);
+            m = u > m ? u : m;
+        }
+        if ((t & 63) == 0 && m) atomicMax(rowmax + rco, m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -783,10 +805,18 @@ static int pipe_variant(const ConvArgs& a, const ConvGeom& g, bool tee, int64_t 
     return -1;
 }
 
+// `rowmax` (nullable): R * Cout zeroed words that receive the bits of max |y| of every output row-channel (see the generator:
+// rowmax_accumulate / rowmax_flush); passed to the kernel as a ready buffer descriptor, all zeros when not wanted
 static int launch_pipe(PipeModule* pm, int variant, const float* x, const void* Hs, float* y, float* xcopy,
-                       const ConvArgs& a, const float2* tw, hipStream_t st) {
+                       const ConvArgs& a, const float2* tw, hipStream_t st, uint32_t* rowmax = nullptr, int64_t rowmax_words = 0) {
     PipeKernArgs k;
     memset(&k, 0, sizeof(k));
+    if (rowmax) {
+        k.rm_lo = (uint32_t)reinterpret_cast<uint64_t>(rowmax);
+        k.rm_hi = (uint32_t)(reinterpret_cast<uint64_t>(rowmax) >> 32) & 0xffffu;
+        k.rm_rec = (uint32_t)(rowmax_words * 4);
+        k.rm_flags = 0x00020000u;
+    }
     auto lo = [](const void* p) { return (uint32_t)reinterpret_cast<uint64_t>(p); };
     auto hi = [](const void* p) { return (uint32_t)(reinterpret_cast<uint64_t>(p) >> 32); };
     k.x_lo = lo(x); k.x_hi = hi(x); k.h_lo = lo(Hs); k.h_hi = hi(Hs); k.y_lo = lo(y); k.y_hi = hi(y);
@@ -1025,10 +1055,33 @@ int gfx_fftconv_ex_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_
 }
 
 
+static int fftconv_sched(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len, float* y,
+                         gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
+                         int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, int schedule,
+                         void* stream, uint32_t* rowmax, int* rowmax_written);
+
 int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len, float* y,
                           gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
                           int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, int schedule,
                           void* stream) {
+    return fftconv_sched(x, xmap, Hs, h_rows, part_len, y, ymap, xcopy, cmap, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes,
+                         schedule, stream, nullptr, nullptr);
+}
+
+int gfx_fftconv_rowmax_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len, float* y,
+                           gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
+                           int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, uint32_t* rowmax,
+                           int* rowmax_written, void* stream) {
+    if (!rowmax || !rowmax_written) return GFX_EINVAL;
+    *rowmax_written = 0;
+    return fftconv_sched(x, xmap, Hs, h_rows, part_len, y, ymap, xcopy, cmap, R, C_in, C_f, L, Lout, off, N, ws, ws_bytes,
+                         GFX_SCHED_AUTO, stream, rowmax, rowmax_written);
+}
+
+static int fftconv_sched(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len, float* y,
+                         gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap, int64_t R, int64_t C_in, int64_t C_f,
+                         int64_t L, int64_t Lout, int64_t off, int64_t N, void* ws, size_t ws_bytes, int schedule,
+                         void* stream, uint32_t* rowmax, int* rowmax_written) {
     if (schedule != GFX_SCHED_AUTO && schedule != GFX_SCHED_TILE && schedule != GFX_SCHED_PIPE) return GFX_EINVAL;
     if (!x || !Hs || !y || R <= 0 || L <= 0 || Lout <= 0 || N <= 0) return GFX_EINVAL;
     if (h_rows < 1 || h_rows > R || h_rows > 0x7fffffffLL) return GFX_EINVAL;
@@ -1070,6 +1123,8 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
     }
     if (schedule == GFX_SCHED_PIPE || (schedule == GFX_SCHED_AUTO && pv >= 0 && GFX_PIPE_AUTO && a.nblocks >= 16 * pm->cus))
     {
+        // (the shipped code object is generated without the rowmax knob: this kernel takes even output lengths only, and the
+        // one consumer of the maxima -- the odd-length aliasing -- has an odd one)
         const int rc = launch_pipe(pm, pv, x, Hs, y, xcopy, a, tw, st);
         if (rc == GFX_OK) t_last_kernel = kPipeVariants[pv].name;
         return rc;
@@ -1078,12 +1133,13 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
         if (allow_lds(fftconv1_kernel<false>) || allow_lds(fftconv1_kernel<true>)) return GFX_ELAUNCH;
         if (xcopy)
             hipLaunchKernelGGL(fftconv1_kernel<true>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
-                               (const float4*)Hs, y, xcopy, a, tw);
+                               (const float4*)Hs, y, xcopy, a, tw, rowmax);
         else
             hipLaunchKernelGGL(fftconv1_kernel<false>, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, x,
-                               (const float4*)Hs, y, (float*)nullptr, a, tw);
+                               (const float4*)Hs, y, (float*)nullptr, a, tw, rowmax);
         if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
         t_last_kernel = xcopy ? "fftconv1_kernel<true>" : "fftconv1_kernel<false>";
+        if (rowmax && rowmax_written) *rowmax_written = 1;
         return GFX_OK;
     }
     if (g.ntiles == 1) {

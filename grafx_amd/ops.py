@@ -6,6 +6,7 @@ and stream plumbing; all arithmetic happens in the HIP kernels.  CPU tensors are
 rejected: there is no fallback path.
 """
 import contextvars
+import ctypes
 import os
 
 import torch
@@ -188,10 +189,13 @@ SCHEDULES = {"auto": 0, "tile": 1, "pipe": 2}   # GFX_SCHED_* of include/grafx_a
 # What `schedule="auto"` means to fftconv(): "auto" (the library decides: the persistent hand-scheduled kernel for large
 # launches it covers) or "pipe" (prefer that kernel at every size it covers -- tests and latency experiments).
 FFTCONV_SCHEDULE = "auto"
+# the full-length convolution in front of the odd-length aliasing leaves the rows' maxima for its pair scaling (round 6;
+# GRAFX_ROWMAX_BYPRODUCT=0: the aliasing takes them in a pass of its own over z, as for every other producer of z)
+ROWMAX_BYPRODUCT = os.environ.get("GRAFX_ROWMAX_BYPRODUCT", "1") != "0"
 
 
 @_on_device
-def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, part_len=0, schedule="auto"):
+def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, part_len=0, schedule="auto", rowmax=None):
     """y[r,c,n] = sum_k h[r % h_rows,cf,k] x[r,cx,n+off-k], n < Lout (x zero outside [0,L)).
 
     ``x`` / ``out`` may be (R,C,L) tensors or strided (B,n,C,L) views (see :func:`rowmap`).
@@ -200,6 +204,9 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
     ``h_rows = nodes`` shares one filter per node across the batch); default: one filter per row.
     ``schedule``: "auto" (the library picks), "tile" (one tile per workgroup, compiler-scheduled) or "pipe" (the
     hand-scheduled persistent kernel, N <= 8193); see gfx_fftconv_sched_f32.
+    ``rowmax`` (with schedule "auto"): a dict that receives ``rowmax["words"]`` -- an int32 tensor of R * max(C, Cf) words,
+    the bits of max |y| of every output row-channel -- when the kernel that ran leaves them as a by-product
+    (gfx_fftconv_rowmax_f32: the one-partition tile kernel, N <= 8193 taps); untouched otherwise.  For odd_alias(rowmax=).
     """
     _require_gpu(x, out, tee)
     xmap, R, Cin, L = rowmap(x)
@@ -224,6 +231,18 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
         return lib().gfx_fftconv_sched_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R, Cin,
                                            Cf, L, Lout, off, N, _ptr(ws), nbytes, SCHEDULES[sched], _stream())
 
+    if rowmax is not None and schedule == "auto" and FFTCONV_SCHEDULE == "auto" and ROWMAX_BYPRODUCT:
+        words = torch.zeros(R * Cout, dtype=torch.int32, device=x.device)
+        written = ctypes.c_int(0)
+        with _timed("fftconv", 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)) as t:
+            check(lib().gfx_fftconv_rowmax_f32(_ptr(x), xmap, _ptr(Hs), h_rows, part_len, _ptr(out), ymap, _ptr(tee), cmap, R,
+                                               Cin, Cf, L, Lout, off, N, _ptr(ws), nbytes, words.data_ptr(),
+                                               ctypes.byref(written), _stream()), "gfx_fftconv_rowmax_f32")
+            if t.rec is not None:
+                t.name = lib().gfx_fftconv_last_kernel().decode()
+        if written.value:
+            rowmax["words"] = words
+        return out
     with _timed("fftconv", 4 * R * ((2 if tee is not None else 1) * Cin * L + Cout * Lout)) as t:
         rc = GFX_EINVAL
         if schedule == "auto" and FFTCONV_SCHEDULE == "pipe":
@@ -419,11 +438,13 @@ def _alias_chunks(rows, P, rows_per_chunk, device, precise, pairs=False):
 
 
 @_on_device
-def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None):
+def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None, rowmax=None):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
     full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (1.6 MB of
     workspace per row at P ~ 135 k: 25 tiles of 8192 points).  ``precise``: transforms in double precision (twice the
-    workspace), for results that feed a logarithm -- the energy envelope, core/envelope.py:34-49."""
+    workspace), for results that feed a logarithm -- the energy envelope, core/envelope.py:34-49.
+    ``rowmax``: int32 words, one per row of z, holding the bits of max |z| of the row (what fftconv(rowmax=) leaves): the
+    two-rows-per-transform form then skips its own pass over z (float transforms only)."""
     _require_gpu(z)
     P = z.shape[-1]
     Q = P - 1
@@ -435,6 +456,9 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None
     plan = _alias_plan(P, z.device, precise, pairs)
     fwd, tag = _alias_fns(precise, pairs)[3], _alias_fns(precise, pairs)[5]
     chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise, pairs)
+    if rowmax is not None and (not pairs or precise or rowmax.numel() != rows or rowmax.dtype != torch.int32
+                               or not rowmax.is_cuda):
+        rowmax = None
     if out is not None:
         # ``out``: a (R, C, length) tensor or a strided (B, n, C, length) view whose rows, channels flattened, are z's
         # rows: the last column pass writes them in place (gfx_odd_alias_rows_f32; float transforms only)
@@ -448,8 +472,13 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None
         for i in range(0, rows, chunk):
             n = min(chunk, rows - i)
             with _timed(name, 4 * n * (P + length)):
-                check(rows_fn(_ptr(flat[i : i + n]), _ptr(out), omap, Co, i, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
-                              _stream()), tag + "rows_f32")
+                if rowmax is not None:
+                    check(lib().gfx_odd_alias_pair_rows_max_f32(_ptr(flat[i : i + n]), _ptr(out), omap, Co, i, lo, length, n, P,
+                                                                _ptr(plan), _ptr(ws), ws.numel(), rowmax[i : i + n].data_ptr(),
+                                                                _stream()), "gfx_odd_alias_pair_rows_max_f32")
+                else:
+                    check(rows_fn(_ptr(flat[i : i + n]), _ptr(out), omap, Co, i, lo, length, n, P, _ptr(plan), _ptr(ws),
+                                  ws.numel(), _stream()), tag + "rows_f32")
         return out
     out = torch.empty((rows, length), dtype=torch.float32, device=z.device)
     # one record per chunk: the column / tile / column passes of the two chirp-z transforms (czt.hip), read z + write y
@@ -458,8 +487,13 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
         with _timed(name, 4 * n * (P + length)):
-            check(fwd(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
-                      _stream()), tag + "f32")
+            if rowmax is not None:
+                check(lib().gfx_odd_alias_pair_max_f32(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P,
+                                                       _ptr(plan), _ptr(ws), ws.numel(), rowmax[i : i + n].data_ptr(), _stream()),
+                      "gfx_odd_alias_pair_max_f32")
+            else:
+                check(fwd(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P, _ptr(plan), _ptr(ws), ws.numel(),
+                          _stream()), tag + "f32")
     return out.view(*z.shape[:-1], length)
 
 

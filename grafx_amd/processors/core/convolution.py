@@ -132,9 +132,13 @@ def convolve_taps(x, Hs, N, Cf, mode, out=None, tee=None, exact=False, h_rows=No
             return ops.fftconv(x, Hs, N, Cf, Lout=L, off=N // 2, out=out, h_rows=h_rows)
         return ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, out=out, h_rows=h_rows)
     lo, length = {"causal": (0, L), "zerophase": (N // 2, L)}.get(mode, (0, L + N - 2))
-    z = ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows, tee=tee)
+    rm = {}     # the rows' maxima, when the convolution kernel leaves them (the pair scaling of the aliasing: ops.odd_alias)
+    z = ops.fftconv(x, Hs, N, Cf, Lout=L + N - 1, off=0, h_rows=h_rows, tee=tee, rowmax=rm)
     if out is not None and not (torch.is_grad_enabled() and z.requires_grad):
-        return ops.odd_alias(z, lo, length, out=out)   # the last chirp-z pass writes the rows of the buffer view in place
+        # the last chirp-z pass writes the rows of the buffer view in place
+        return ops.odd_alias(z, lo, length, out=out, rowmax=rm.get("words"))
+    if not (torch.is_grad_enabled() and z.requires_grad):
+        return ops.odd_alias(z, lo, length, rowmax=rm.get("words")).contiguous()
     y = odd_length_alias(z, lo, length)
     if out is None:
         return y.contiguous()

@@ -142,6 +142,17 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
                           void* ws, size_t ws_bytes, int schedule, void* stream);
 
+/* gfx_fftconv_sched_f32(GFX_SCHED_AUTO) that may also leave the bits of max |y| of every output row-channel in `rowmax`
+ * (R * max(C_in, C_f) words, zeroed by the caller, row-major (row, channel)): the one-partition tile kernel (N <= 8193 taps)
+ * takes them as a by-product of its stores (one atomic maximum per wave and tile) and sets *rowmax_written = 1; the
+ * partitioned convolution leaves the words alone and *rowmax_written = 0.  For the full-length convolution
+ * that feeds the odd-length aliasing (core/convolution.py:119-134), whose two-rows-per-transform form scales the second
+ * row of a pair by these maxima (gfx_odd_alias_pair_max_f32): the separate pass over z is not needed then. */
+int gfx_fftconv_rowmax_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,
+                           float* y, gfx_rowmap_t ymap, float* xcopy, gfx_rowmap_t cmap,
+                           int64_t R, int64_t C_in, int64_t C_f, int64_t L, int64_t Lout, int64_t off, int64_t N,
+                           void* ws, size_t ws_bytes, uint32_t* rowmax, int* rowmax_written, void* stream);
+
 /* Diagnostic: the name -- as rocprofv3's kernel trace prints it -- of the (dominant) kernel that the calling thread's last
  * successful gfx_fftconv_* call launched: "gfx_fftconv_pipe_t1_o8", "fftconv1_kernel<true>", "winmac_kernel",
  * "xspec_kernel+macinv_pair_kernel"; "" before the first call.  The string is static.  (bench.py labels its live per-launch
@@ -194,8 +205,10 @@ int gfx_odd_alias_precise_adjoint_f32(const float* gy, int64_t ldg, int64_t lo, 
 /* The forward maps with TWO real rows per complex transform (csrc/czt_pair.hip): the pair z1 + i z2 goes through the
  * two chirp-z transforms as one complex row with the spectrum kept on both sides (P bins) and comes out as
  * A z1 + i A z2 -- 2P - 1 points per pair instead of (3P - 1) / 2 per row, a third fewer bytes through each of the same
- * passes.  Rows 2r and 2r + 1 of a call form a pair (an odd row count leaves the last row alone); each row's rounding error
- * scales with the larger row of its pair.  3 <= P <= 8 388 607 odd (2P - 1 <= 2^24 points), else the size queries return
+ * passes.  Rows 2r and 2r + 1 of a call form a pair (an odd row count leaves the last row alone); the second row of a pair
+ * goes through scaled by the exact power of two that brings it to the first row's binade (from max |z| of the rows: a pass
+ * of the call itself, one word per row behind the workspace, or -- the _max forms -- words the producer of z left:
+ * gfx_fftconv_rowmax_f32), so every row keeps an error relative to its own peak.  3 <= P <= 8 388 607 odd (2P - 1 <= 2^24 points), else the size queries return
  * 0 and the calls GFX_EINVAL (use the one-row forms above); own plan (gfx_odd_alias_pair_plan_f32, workspace of
  * gfx_odd_alias_pair_workspace_bytes(1, P)) and workspace (gfx_odd_alias_pair_workspace_bytes(rows, P)); for
  * gfx_odd_alias_pair_rows_f32 row0 must be even.  The `precise` forms carry the transforms in double (plan and
@@ -207,6 +220,11 @@ int gfx_odd_alias_pair_f32(const float* z, float* y, int64_t ldy, int64_t lo, in
                            const void* plan, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_pair_rows_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo, int64_t len,
                                 int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes, void* stream);
+int gfx_odd_alias_pair_max_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                               const void* plan, void* ws, size_t ws_bytes, const uint32_t* rowmax, void* stream);
+int gfx_odd_alias_pair_rows_max_f32(const float* z, float* y, gfx_rowmap_t ymap, int64_t C, int64_t row0, int64_t lo,
+                                    int64_t len, int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes,
+                                    const uint32_t* rowmax, void* stream);
 size_t gfx_odd_alias_pair_precise_plan_bytes(int64_t P);
 size_t gfx_odd_alias_pair_precise_workspace_bytes(int64_t rows, int64_t P);
 int gfx_odd_alias_pair_precise_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);

@@ -45,7 +45,7 @@ def _spectra(h):
     return out
 
 
-def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0, **knobs):
+def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0, rowmax_out=None, Lout=None, **knobs):
     from grafx_amd.csrc.asm import gen_fftconv_pipe as gen
     from grafx_amd.csrc.asm.isa import Buffer, Emulator
 
@@ -55,45 +55,52 @@ def _run(tee, B, n, C, Cf, L, N, hrows, tiles_per_wg=None, seed=0, **knobs):
     a_lo = O // 512
     Cout = max(C, Cf)
     R = B * n
-    ntiles = (L + V - 1) // V
+    Lout = L if Lout is None else Lout
+    ntiles = (Lout + V - 1) // V
     nblocks = R * Cout * ntiles
     prog = gen.PipeGen(tee, a_lo, **knobs).build()
     # signals live in a (B, nodes, C, L) buffer with more node rows than the stage uses (strided views, as in the render)
     nodes = n + 3
     xbuf = rng.standard_normal((B, nodes, C, L)).astype(np.float32)
-    ybuf = np.full((B, nodes, Cout, L), np.nan, np.float32)
+    ybuf = np.full((B, nodes, Cout, Lout), np.nan, np.float32)
     cbuf = np.full((B, nodes, C, L), np.nan, np.float32)
     h = (rng.standard_normal((hrows * Cf, N)) / np.sqrt(N)).astype(np.float32)
     mem = Buffer()
     xa, ya, ca = mem.alloc(xbuf), mem.alloc(ybuf), mem.alloc(cbuf)
     ha, ta = mem.alloc(_spectra(h)), mem.alloc(_twiddle_table())
     x0 = xa + 4 * (1 * C * L)            # the stage reads node rows 1 .. n
-    y0 = ya + 4 * (2 * Cout * L)         # and writes node rows 2 .. n + 1
+    y0 = ya + 4 * (2 * Cout * Lout)      # and writes node rows 2 .. n + 1
+    rm = {}
+    if rowmax_out is not None:           # one word per output row-channel, zeroed by the caller (the rm_* descriptor)
+        rma = mem.alloc(np.zeros(R * Cout + 3, np.uint32).view(np.float32))
+        rm = dict(rm_lo=rma & 0xFFFFFFFF, rm_hi=(rma >> 32) & 0xFFFF, rm_rec=4 * R * Cout, rm_flags=gen.RSRC_FLAGS)
     c0 = ca + 4 * (0 * C * L)
     per_xcd = nblocks if tiles_per_wg is None else tiles_per_wg
     m = {k: gen.magic(d) for k, d in (("ntiles", ntiles), ("inner", n), ("hrows", hrows))}
     args = gen.pack_args(
         x_lo=x0, x_hi=x0 >> 32, h_lo=ha, h_hi=ha >> 32, y_lo=y0, y_hi=y0 >> 32, c_lo=c0, c_hi=c0 >> 32, tw_lo=ta, tw_hi=ta >> 32,
-        L_bytes=4 * L, Lout_bytes=4 * L, V_bytes=4 * V, O_bytes=4 * O, ntiles=ntiles, nblocks=nblocks,
+        L_bytes=4 * L, Lout_bytes=4 * Lout, V_bytes=4 * V, O_bytes=4 * O, ntiles=ntiles, nblocks=nblocks,
         m_ntiles=m["ntiles"][0], sh_ntiles=m["ntiles"][1], inner=n, m_inner=m["inner"][0], sh_inner=m["inner"][1],
         hrows=hrows, m_hrows=m["hrows"][0], sh_hrows=m["hrows"][1], cout_shift=Cout - 1, cout_mask=Cout - 1,
         cin_mask=0 if C == 1 else 1, cf_mask=0 if Cf == 1 else 1, Cf=Cf, per_xcd=per_xcd, wgs_per_xcd=1,
         xs_outer_lo=4 * nodes * C * L, xs_inner=4 * C * L, xs_ch=4 * L,
-        ys_outer_lo=4 * nodes * Cout * L, ys_inner=4 * Cout * L, ys_ch=4 * L,
-        cs_outer_lo=4 * nodes * C * L, cs_inner=4 * C * L, cs_ch=4 * L)
+        ys_outer_lo=4 * nodes * Cout * Lout, ys_inner=4 * Cout * Lout, ys_ch=4 * Lout,
+        cs_outer_lo=4 * nodes * C * L, cs_inner=4 * C * L, cs_ch=4 * L, **rm)
     nwg = (nblocks + per_xcd - 1) // per_xcd      # consecutive runs of `per_xcd` tiles, one workgroup each
     for wg in range(nwg):
         Emulator(prog, mem, gen.TILE_LDS_BYTES, kernarg=args, wg_id=wg, rng=np.random.default_rng(100 + wg)).run()
     y = mem.read_back(ya).reshape(ybuf.shape)[:, 2: 2 + n]
     cc = mem.read_back(ca).reshape(cbuf.shape)[:, 0: n]
     x = xbuf[:, 1: 1 + n]
-    want = np.zeros((B, n, Cout, L))
+    want = np.zeros((B, n, Cout, Lout))
     for b in range(B):
         for j in range(n):
             r = b * n + j
             for c in range(Cout):
                 hh = h[(r % hrows) * Cf + (c if Cf == 2 else 0)].astype(np.float64)
-                want[b, j, c] = np.convolve(x[b, j, c if C == 2 else 0].astype(np.float64), hh)[:L]
+                want[b, j, c] = np.convolve(x[b, j, c if C == 2 else 0].astype(np.float64), hh)[:Lout]
+    if rowmax_out is not None:
+        rowmax_out.append(mem.read_back(rma).view(np.uint32))
     untouched = np.concatenate([mem.read_back(ya).reshape(ybuf.shape)[:, :2].ravel(),
                                 mem.read_back(ya).reshape(ybuf.shape)[:, 2 + n:].ravel()])
     return y, want, cc, x, untouched
@@ -111,6 +118,26 @@ def test_pipe_kernel_in_the_emulator(tee, C, Cf, L, tiles_per_wg):
         assert np.array_equal(cc, x)
     else:
         assert np.isnan(cc).all()
+
+
+@pytest.mark.parametrize("C,Cf,L,N,tiles_per_wg", [(2, 1, 30000, 4001, 2), (1, 2, 12288 * 2 - 5, 4001, None), (2, 2, 9000, 513, 1)])
+def test_pipe_kernel_leaves_the_rows_maxima(C, Cf, L, N, tiles_per_wg):
+    """(The generator's `rowmax` knob: not in the shipped build -- this kernel needs an even output length, the convolution in
+    front of the odd-length aliasing has an odd one and runs on fftconv1_kernel, which takes the maxima itself -- kept and
+    tested as a generator capability.)  A full-length convolution with the rm_* descriptor set: one
+    word per output row-channel receives the bits of max |y| over the row -- whatever the split of the row's tiles over
+    workgroups (atomic maximum) -- to within the rounding noise of the samples past the row's end that a tile also
+    computes (exact zeros in exact arithmetic); rows of zeros give zero; the words behind the buffer stay untouched."""
+    B, n = 2, 2
+    got = []
+    y, want, _, _, _ = _run(False, B, n, C, Cf, L, N, hrows=n, tiles_per_wg=tiles_per_wg, rowmax_out=got, Lout=L + N - 1, rowmax=1)
+    assert np.abs(y - want).max() / np.abs(want).max() < 5e-6
+    words = got[0]
+    Cout = max(C, Cf)
+    mx = np.abs(y.reshape(B * n * Cout, -1)).max(1)
+    kernel = words[: B * n * Cout].view(np.float32)
+    assert (kernel >= mx).all() and (kernel <= mx * (1 + 1e-6) + 1e-6 * np.abs(y).max()).all(), (kernel, mx)
+    assert (words[B * n * Cout:] == 0).all()
 
 
 @pytest.mark.parametrize("knobs", [dict(place="barrier"), dict(place="after"), dict(fwd_window=(0.0, 1.0), inv_window=(0.0, 1.0))])

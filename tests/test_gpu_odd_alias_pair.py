@@ -251,3 +251,39 @@ def test_fused_outer_level_equals_the_separate_passes(P, monkeypatch):
     want = _want(z)[:, 100:4196]
     assert (got.double() - want).abs().max() <= 3e-6 * want.abs().max()
     assert (got - single).abs().max() <= 3e-6 * single.abs().max()
+
+
+def test_the_convolution_kernel_leaves_the_rows_maxima_for_the_pair_scaling():
+    """gfx_fftconv_rowmax_f32: the tile kernel of the full-length convolution keeps max |y| per output row-channel as a
+    by-product of its stores, and the aliasing's pair form takes the words instead of reading z once more
+    (gfx_odd_alias_pair_max_f32); the partitioned convolution (more than 8193 taps) leaves the dict empty and the aliasing
+    takes its own pass.  Rows at very different levels, a silent row; with and without the by-product: the same bits."""
+    from grafx_amd import ops
+
+    torch.manual_seed(0)
+    R, C, L, N = 300, 2, 65536, 4000
+    x = torch.randn(R, C, L, device="cuda") * torch.logspace(0, -6, R, device="cuda")[:, None, None]
+    x[7] = 0
+    h = torch.randn(R, 1, N, device="cuda") / N ** 0.5
+    Hs = ops.fir_spectrum(h.reshape(R, N))
+    rm = {}
+    z = ops.fftconv(x, Hs, N, 1, Lout=L + N - 1, rowmax=rm)
+    assert "words" in rm
+    got = rm["words"].view(torch.float32).view(R, C)
+    assert torch.equal(got, z.abs().amax(-1))                    # the maxima of exactly what was stored
+    assert float(got[7].abs().max()) == 0.0
+    y1 = ops.odd_alias(z, 0, L, rowmax=rm["words"])
+    y0 = ops.odd_alias(z, 0, L)
+    assert torch.equal(y1, y0)
+    ref = _want(z)[..., :L]
+    err = (y1.double() - ref).abs().amax(-1) / ref.abs().amax(-1).clamp_min(1e-300)
+    assert float(err[torch.isfinite(err)].max()) <= 3e-6
+    assert float(y1[7].abs().max()) == 0.0
+    # strided output rows of a buffer view, in chunks
+    buf = torch.zeros(3, 250, C, L, device="cuda")
+    ops.odd_alias(z, 0, L, out=buf[:, 50:150], rowmax=rm["words"], rows_per_chunk=64)
+    assert torch.equal(buf[:, 50:150].reshape(R, C, L), y0)
+    long = {}
+    hl = torch.randn(2, 1, 9000, device="cuda") / 95.0
+    ops.fftconv(x[:2], ops.fir_spectrum(hl.reshape(2, 9000)), 9000, 1, Lout=L + 8999, rowmax=long)
+    assert "words" not in long

@@ -150,8 +150,8 @@ def test_first_order_sections_on_the_recursive_backend():
         for k in range(K):
             b, a = B[:, 0, k], A[:, 0, k]
             out, w1 = [], torch.zeros(R, 2, dtype=xd.dtype)
-            for n in range(L):
-                w = y[..., n] - a[:, 1:2] * w1
+            for n in range(L):      # a0 y[n] = b0 x[n] + b1 x[n-1] - a1 y[n-1] (lfilter normalises by a0, as the kernel does)
+                w = (y[..., n] - a[:, 1:2] * w1) / a[:, 0:1]
                 out.append(b[:, 0:1] * w + b[:, 1:2] * w1)
                 w1 = w
             y = torch.stack(out, -1)
