@@ -223,6 +223,29 @@ __device__ __forceinline__ void store_valid(const cx (&v)[32], float* __restrict
 }
 
 
+// max |y| over what store_valid has just stored of this tile (positions O <= q < room of the tile), into rowmax[rco]: the
+// by-product for the odd-length aliasing's pair scaling (round 6; gfx_fftconv_rowmax_f32).  Non-negative floats order like
+// their bit patterns: a wave reduction and one atomic maximum per wave and tile.
+__device__ __forceinline__ void tile_rowmax(const cx (&v)[32], uint32_t* __restrict__ rowmax, unsigned rco, int64_t n0, int64_t O,
+                                            int64_t Lout, int t) {
+    const int64_t room = Lout - (n0 - O);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int64_t q = 2 * (t + 256 * k);
+        const cx e = v[brev(k, 5)];
+        const uint32_t ex = __float_as_uint(e.x) & 0x7fffffffu, ey = __float_as_uint(e.y) & 0x7fffffffu;
+        if (q >= O && q < room) m = ex > m ? ex : m;
+        if (q >= O && q + 1 < room) m = ey > m ? ey : m;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t u = (uint32_t)__shfl_xor((int)m, o);
+        m = u > m ? u : m;
+    }
+    if ((t & 63) == 0 && m) atomicMax(rowmax + rco, m);
+}
+
 #define NAT(arr, i) arr[(i) >> 4][brev((i) & 15, 4)]
 
 // ------------------------------------------------------------------------------------------------
@@ -305,27 +328,7 @@ __global__ __launch_bounds__(TILE_T, 2) void fftconv1_kernel(const float* __rest
     // this thread read at the end of the forward transform -- nobody else touches them in between
     tile_inverse(w, v, tw, lds, t);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
-    if (rowmax) {
-        // max |y| of the row-channel as a by-product (round 6; gfx_fftconv_rowmax_f32): the odd-length aliasing that follows a
-        // full-length convolution scales the second row of every pair of rows by these (czt_pair.hip) and does not have to
-        // read z once more.  Non-negative floats order like their bit patterns: one atomic maximum per wave and tile.
-        const int64_t room = a.Lout - (tile * a.V - a.O);
-        uint32_t m = 0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int64_t q = 2 * (t + 256 * k);
-            const cx e = v[brev(k, 5)];
-            const uint32_t ex = __float_as_uint(e.x) & 0x7fffffffu, ey = __float_as_uint(e.y) & 0x7fffffffu;
-            if (q >= a.O && q < room) m = ex > m ? ex : m;
-            if (q >= a.O && q + 1 < room) m = ey > m ? ey : m;
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t u = (uint32_t)__shfl_xor((int)m, o);
-            m = u > m ? u : m;
-        }
-        if ((t & 63) == 0 && m) atomicMax(rowmax + rco, m);
-    }
+    if (rowmax) tile_rowmax(v, rowmax, rco, tile * a.V, a.O, a.Lout, t);   // (see tile_rowmax)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(TILE_T, 2) void xspec_kernel(const float* __restric
 
 __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restrict__ Zs, const float4* __restrict__ Hs,
                                                            float* __restrict__ y, ConvArgs a, int64_t nwin,
-                                                           const float2* __restrict__ twtab) {
+                                                           const float2* __restrict__ twtab,
+                                                           uint32_t* __restrict__ rowmax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x;
     const unsigned lb = xcd_logical_block();
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(TILE_T, 2) void macinv_kernel(const float2* __restr
     tile_twiddles(tw, twtab, t);
     tile_inverse(pz, v, tw, lds, t);
     store_valid(v, yrow, tile * a.V, a.O, a.Lout, t);
+    if (rowmax) tile_rowmax(v, rowmax, rco, tile * a.V, a.O, a.Lout, t);
 }
 
 // ---- two consecutive output tiles per 512-thread workgroup ---------------------------------------------------------
@@ -575,7 +580,8 @@ __device__ __forceinline__ void macinv_pair_gather(const cx (&own)[16], const cx
 __global__ __launch_bounds__(2 * TILE_T, 1) void macinv_pair_kernel(const float2* __restrict__ Zs,
                                                                     const float4* __restrict__ Hs,
                                                                     float* __restrict__ y, ConvArgs a, int64_t nwin,
-                                                                    const float2* __restrict__ twtab) {
+                                                                    const float2* __restrict__ twtab,
+                                                                    uint32_t* __restrict__ rowmax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) cx lds[];
     const int t = threadIdx.x & (TILE_T - 1);
     const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
@@ -605,6 +611,7 @@ __global__ __launch_bounds__(2 * TILE_T, 1) void macinv_pair_kernel(const float2
     tile_twiddles(tw, twtab, t);
     tile_inverse(pz, v, tw, lds_mine, t);
     if (grp == 0 || two) store_valid(v, yrow, (tile + grp) * a.V, a.O, a.Lout, t);
+    if (rowmax && (grp == 0 || two)) tile_rowmax(v, rowmax, rco, (tile + grp) * a.V, a.O, a.Lout, t);
 }
 
 // One output tile per row (ntiles == 1, the filter-gradient shape: a long "filter", few outputs): every signal window
@@ -1167,15 +1174,17 @@ static int fftconv_sched(const float* x, gfx_rowmap_t xmap, const void* Hs, int6
         ConvArgs ap = a;
         ap.nblocks = R * a.Cout * ((g.ntiles + 1) / 2);
         hipLaunchKernelGGL(macinv_pair_kernel, dim3(pad8(ap.nblocks)), dim3(2 * TILE_T), 2 * TILE_LDS_BYTES, st,
-                           (const float2*)ws, (const float4*)Hs, y, ap, nwin, tw);
+                           (const float2*)ws, (const float4*)Hs, y, ap, nwin, tw, rowmax);
         if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
         t_last_kernel = "xspec_kernel+macinv_pair_kernel";
+        if (rowmax && rowmax_written) *rowmax_written = 1;
         return GFX_OK;
     }
     hipLaunchKernelGGL(macinv_kernel, dim3(pad8(a.nblocks)), dim3(TILE_T), TILE_LDS_BYTES, st, (const float2*)ws,
-                       (const float4*)Hs, y, a, nwin, tw);
+                       (const float4*)Hs, y, a, nwin, tw, rowmax);
     if (hipGetLastError() != hipSuccess) return GFX_ELAUNCH;
     t_last_kernel = "xspec_kernel+macinv_kernel";
+    if (rowmax && rowmax_written) *rowmax_written = 1;
     return GFX_OK;
 }
 

@@ -206,7 +206,7 @@ def fftconv(x, Hs, N, Cf, Lout=None, off=0, out=None, tee=None, h_rows=None, par
     hand-scheduled persistent kernel, N <= 8193); see gfx_fftconv_sched_f32.
     ``rowmax`` (with schedule "auto"): a dict that receives ``rowmax["words"]`` -- an int32 tensor of R * max(C, Cf) words,
     the bits of max |y| of every output row-channel -- when the kernel that ran leaves them as a by-product
-    (gfx_fftconv_rowmax_f32: the one-partition tile kernel, N <= 8193 taps); untouched otherwise.  For odd_alias(rowmax=).
+    (gfx_fftconv_rowmax_f32: the compiler-built tile kernels, one partition or many); untouched otherwise.  For odd_alias(rowmax=).
     """
     _require_gpu(x, out, tee)
     xmap, R, Cin, L = rowmap(x)

@@ -143,9 +143,10 @@ int gfx_fftconv_sched_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int
                           void* ws, size_t ws_bytes, int schedule, void* stream);
 
 /* gfx_fftconv_sched_f32(GFX_SCHED_AUTO) that may also leave the bits of max |y| of every output row-channel in `rowmax`
- * (R * max(C_in, C_f) words, zeroed by the caller, row-major (row, channel)): the one-partition tile kernel (N <= 8193 taps)
- * takes them as a by-product of its stores (one atomic maximum per wave and tile) and sets *rowmax_written = 1; the
- * partitioned convolution leaves the words alone and *rowmax_written = 0.  For the full-length convolution
+ * (R * max(C_in, C_f) words, zeroed by the caller, row-major (row, channel)): the compiler-built tile kernels (one
+ * partition, and the partitioned convolution's product kernels) take them as a by-product of their stores (one atomic
+ * maximum per wave and tile) and set *rowmax_written = 1; the hand-scheduled kernel and the one-output-tile form leave the
+ * words alone and *rowmax_written = 0.  For the full-length convolution
  * that feeds the odd-length aliasing (core/convolution.py:119-134), whose two-rows-per-transform form scales the second
  * row of a pair by these maxima (gfx_odd_alias_pair_max_f32): the separate pass over z is not needed then. */
 int gfx_fftconv_rowmax_f32(const float* x, gfx_rowmap_t xmap, const void* Hs, int64_t h_rows, int64_t part_len,

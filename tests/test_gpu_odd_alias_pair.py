@@ -256,8 +256,7 @@ def test_fused_outer_level_equals_the_separate_passes(P, monkeypatch):
 def test_the_convolution_kernel_leaves_the_rows_maxima_for_the_pair_scaling():
     """gfx_fftconv_rowmax_f32: the tile kernel of the full-length convolution keeps max |y| per output row-channel as a
     by-product of its stores, and the aliasing's pair form takes the words instead of reading z once more
-    (gfx_odd_alias_pair_max_f32); the partitioned convolution (more than 8193 taps) leaves the dict empty and the aliasing
-    takes its own pass.  Rows at very different levels, a silent row; with and without the by-product: the same bits."""
+    (gfx_odd_alias_pair_max_f32); the partitioned convolution (more than 8193 taps) does the same.  Rows at very different levels, a silent row; with and without the by-product: the same bits."""
     from grafx_amd import ops
 
     torch.manual_seed(0)
@@ -283,7 +282,9 @@ def test_the_convolution_kernel_leaves_the_rows_maxima_for_the_pair_scaling():
     buf = torch.zeros(3, 250, C, L, device="cuda")
     ops.odd_alias(z, 0, L, out=buf[:, 50:150], rowmax=rm["words"], rows_per_chunk=64)
     assert torch.equal(buf[:, 50:150].reshape(R, C, L), y0)
+    # the partitioned convolution (more than 8193 taps: the reverb's impulse responses) leaves them too
     long = {}
-    hl = torch.randn(2, 1, 9000, device="cuda") / 95.0
-    ops.fftconv(x[:2], ops.fir_spectrum(hl.reshape(2, 9000)), 9000, 1, Lout=L + 8999, rowmax=long)
-    assert "words" not in long
+    hl = torch.randn(6, 1, 20000, device="cuda") / 140.0
+    zl = ops.fftconv(x[:6], ops.fir_spectrum(hl.reshape(6, 20000)), 20000, 1, Lout=L + 19999, rowmax=long)
+    assert "words" in long
+    assert torch.equal(long["words"].view(torch.float32).view(6, C), zl.abs().amax(-1))
