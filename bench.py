@@ -375,10 +375,23 @@ def czt_valu_roofline(prof, steps, chains):
         if ms > 0 and flops > 0:
             peak = FP64_VALU_PEAK_TFS if precise else FP32_VALU_PEAK_TFS
             tfs = flops * steps / (ms * 1e-3) / 1e12
+            # what the chain MOVES: five sweeps of the pair's workspace (in: write; two tile passes and the fused middle
+            # pass: read + write each; out: read) = 8 x NFFT complex points per pair, plus z in and y out -- the yardstick
+            # for how well the sweeps run, next to the algorithmic bytes (z + y) the call rooflines above are priced on
+            sweep = 0.0
+            for pr, rows, P in chains:
+                if pr != precise:
+                    continue
+                ws_pair = (lib().gfx_odd_alias_pair_workspace_bytes(2, P) - 256) * (2 if precise else 1)
+                sweep += (rows / 2) * (8 * ws_pair + 2 * 4 * (2 * P - 1))
+            gbps = sweep * steps / (ms * 1e-3) / 1e9
             out["double" if precise else "float"] = {"bound": "valu", "achieved": tfs, "peak": peak, "unit": "TFLOP/s",
                                                      "frac": tfs / peak, "ms_per_step": ms / steps,
                                                      "flops_per_step": flops,
-                                                     "model": "per pair of rows: 4 FFTs of NFFT points at 5 N log2 N + 3 pointwise products at 6 N"}
+                                                     "model": "per pair of rows: 4 FFTs of NFFT points at 5 N log2 N + 3 pointwise products at 6 N",
+                                                     "sweeps": {"bound": "hbm", "moved_bytes_per_step": sweep, "achieved": gbps,
+                                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                                                "model": "five sweeps of the pair's workspace (8 x NFFT points moved per pair) + z in + y out"}}
     return out or None
 
 
