@@ -2296,7 +2296,12 @@ static int dynamics_fused_launch(const float* x, gfx_rowmap_t xmap, float* y, gf
 #undef GFX_MIX
     }
     const int rc = GFX_LAUNCH_OK();
-    if (rc == GFX_OK) t_dyn_last_kernel = mix ? "dyn_oneshot_mix_kernel" : (oneshot ? "dyn_oneshot_kernel" : "dyn_fused_kernel");
+    // (a call without a routing sum whose workspace holds the look-back granules also launches the row-group walk,
+    // dyn_oneshot_mix_kernel<0, ...>: which of the two produced the rows is decided on the device, so both are named)
+    if (rc == GFX_OK)
+        t_dyn_last_kernel = mix ? "dyn_oneshot_mix_kernel"
+                                : (oneshot ? (lb.gran ? "dyn_oneshot_kernel+dyn_oneshot_mix_kernel" : "dyn_oneshot_kernel")
+                                           : "dyn_fused_kernel");
     return rc;
 }
 

@@ -341,8 +341,10 @@ int gfx_dynamics_fused_ws_f32(const float* x, gfx_rowmap_t xmap, float* y, gfx_r
                               void* ws, size_t ws_bytes, void* stream);
 /* Diagnostic, the twin of gfx_fftconv_last_kernel: the name -- as rocprofv3's kernel trace prints it -- of the kernel that
  * carries the rows of the calling thread's last successful gfx_dynamics_fused_* call: "dyn_oneshot_mix_kernel" (tiles with
- * the routing sums), "dyn_oneshot_kernel" (tiles; rows the pole table rejects ride on dyn_fused_kernel in the same call)
- * or "dyn_fused_kernel" (one workgroup per row: no workspace, or no smoother); "" before the first call. */
+ * the routing sums), "dyn_oneshot_kernel" (tiles; rows the pole table rejects ride on dyn_fused_kernel in the same call),
+ * "dyn_oneshot_kernel+dyn_oneshot_mix_kernel" (the same with the look-back workspace: rows with a long smoother memory
+ * are produced by the row-group walk, an instance of the routing-sum kernel without sums -- which of the two ran is
+ * decided on the device) or "dyn_fused_kernel" (one workgroup per row: no workspace, or no smoother); "" before the first call. */
 const char* gfx_dynamics_last_kernel(void);
 /* The same with the routing sum that follows fused in (render/core.py:36-112, a "mix" stage that sums this call's rows):
  * rows come in graphs of `inner` consecutive rows (r = g * inner + j, R % inner == 0); destination d of graph g is
