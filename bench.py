@@ -907,7 +907,7 @@ def secondary_leg(torch, dev, sync, steps=20, warmup=5):
                         f"{lens['fsm_fir_len']} / {lens['iir_len']} / {lens['ir_len']}: every convolve() aliases (odd L + N - 1)")
                 unit, units = "audio samples/s", R * L
                 call_bytes = 285 * R * 2 * L * 4
-                n, w = 3, 1
+                n, w = 3, 3     # (three warm-ups: the caching allocator needs them to hold the 4-5 GB transients of this path)
                 chains = [(False, 36 * 2 * R, L + lens["fsm_fir_len"] - 1), (True, 36 * R, L + lens["iir_len"] - 1),
                           (False, 2 * R, L + lens["ir_len"] - 1)]
             else:

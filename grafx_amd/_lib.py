@@ -54,6 +54,8 @@ SIGNATURES = {
     "gfx_odd_alias_pair_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_odd_alias_pair_rows_f32": (ctypes.c_int, [f32p, f32p, RowMap, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "gfx_odd_alias_pair_max_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp, vp]),
+    "gfx_odd_alias_pair_precise_max_f32": (ctypes.c_int, [f32p, f32p, i64, i64, i64, i64, i64, vp, vp, sz, vp, ctypes.c_int, vp]),
+    "gfx_onepole_energy_f32": (ctypes.c_int, [f32p, RowMap, i64, f32p, f32p, i64, i64, i64, i64, ctypes.c_int, vp, vp]),
     "gfx_odd_alias_pair_rows_max_f32": (ctypes.c_int, [f32p, f32p, RowMap, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp, vp]),
     "gfx_odd_alias_pair_precise_plan_bytes": (sz, [i64]),
     "gfx_odd_alias_pair_precise_workspace_bytes": (sz, [i64, i64]),

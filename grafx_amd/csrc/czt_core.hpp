@@ -67,6 +67,7 @@ struct CztGeom {
     // two rows per transform (czt_pair.hip): bits of max |z| of every row of the launch chain, or null -- the second row
     // of a pair goes through scaled by the power of two that brings it to the first row's binade (pair_scale)
     const uint32_t* rmax;
+    int relu;                // the last pass stores max(y, 0) (the envelope smoother's relu, core/envelope.py:48, fused in)
 };
 
 __device__ __forceinline__ float* czt_out_row(const CztGeom& g, float* y, int64_t ldy, int64_t row) {
@@ -85,6 +86,7 @@ static inline bool czt_geom(int64_t P, CztGeom& g) {
     g.yC = 0;
     g.row0 = 0;
     g.rmax = nullptr;
+    g.relu = 0;
     g.ymap = gfx_rowmap_t{1, 0, 0, 0};
     g.P = P;
     g.Q = P - 1;

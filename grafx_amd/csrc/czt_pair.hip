@@ -46,6 +46,7 @@ static inline bool czt_pair_geom(int64_t P, CztGeom& g) {
     g.yC = 0;
     g.row0 = 0;
     g.rmax = nullptr;
+    g.relu = 0;
     g.ymap = gfx_rowmap_t{1, 0, 0, 0};
     g.P = P;
     g.Q = P - 1;
@@ -152,6 +153,7 @@ __device__ __forceinline__ PairScale pair_scale(const CztGeom& g, int64_t pr, bo
     }
     return s;
 }
+__device__ __forceinline__ float pair_out(const CztGeom& g, float v) { return g.relu ? fmaxf(v, 0.0f) : v; }
 template <typename T> __device__ __forceinline__ T pair_ldexp(T x, int d) {
     if constexpr (sizeof(T) == 4) return ldexpf(x, d); else return ldexp(x, d);
 }
@@ -270,8 +272,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) void czt_pair_out_kern
         const int64_t n = (int64_t)n1 * TILE_M + n2 - off;
         if (n >= lo && n < lo + len) {
             const cx o = cmul(v[spos(C, n1)], to_cx(cQ[n])) * sc;
-            y1[n - lo] = ps.nz1 ? (float)o.x : 0.0f;
-            if (two) y2[n - lo] = ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f;
+            y1[n - lo] = pair_out(g, ps.nz1 ? (float)o.x : 0.0f);
+            if (two) y2[n - lo] = pair_out(g, ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f);
         }
     }
 }
@@ -367,8 +369,8 @@ __global__ __launch_bounds__(256) void czt_pair_outer_out_kernel(const typename 
         const int64_t n = n3 * NS + np - off;
         if (n >= lo && n < lo + len) {
             const cx o = cmul(v[brev(n3, 2)], to_cx(cQ[n])) * sc;
-            y1[n - lo] = ps.nz1 ? (float)o.x : 0.0f;
-            if (two) y2[n - lo] = ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f;
+            y1[n - lo] = pair_out(g, ps.nz1 ? (float)o.x : 0.0f);
+            if (two) y2[n - lo] = pair_out(g, ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f);
         }
     }
 }
@@ -659,8 +661,8 @@ __global__ __launch_bounds__(256) void czt_pair_lv_out_kernel(const typename Pre
                 const int64_t n = n0 + col;
                 if (n >= lo && n < lo + len) {
                     const cx o = cmul(x, cq[j]);
-                    y1[n - lo] = ps.nz1 ? (float)o.x : 0.0f;
-                    if (two) y2[n - lo] = ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f;
+                    y1[n - lo] = pair_out(g, ps.nz1 ? (float)o.x : 0.0f);
+                    if (two) y2[n - lo] = pair_out(g, ps.nz2 ? (float)pair_ldexp(o.y, -ps.d) : 0.0f);
                 }
             }
         }
@@ -754,7 +756,7 @@ static void pair_chain(const CztGeom& g, const float* z, float* y, int64_t ldy, 
 template <typename T>
 static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                           const void* plan, void* ws, size_t ws_bytes, void* stream, const gfx_rowmap_t* ymap = nullptr,
-                          int yC = 0, int64_t row0 = 0, const uint32_t* given_max = nullptr) {
+                          int yC = 0, int64_t row0 = 0, const uint32_t* given_max = nullptr, int relu = 0) {
     using T2 = typename Prec<T>::T2;
     CztGeom g;
     if (!z || !y || !plan || rows <= 0 || !czt_pair_geom(P, g)) return GFX_EINVAL;
@@ -765,6 +767,7 @@ static int czt_pair_alias(const float* z, float* y, int64_t ldy, int64_t lo, int
         g.ymap = *ymap;
     }
     if (lo < 0 || len < 1 || lo + len > g.Q || ldy < len) return GFX_EINVAL;
+    g.relu = relu ? 1 : 0;
     const int64_t pairs = (rows + 1) / 2;
     if (!ws || ws_bytes < (size_t)pairs * g.NFFT * sizeof(T2) + pair_rmax_bytes(rows)) return GFX_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
@@ -877,6 +880,12 @@ int gfx_odd_alias_pair_precise_plan_f32(void* plan, int64_t P, void* ws, size_t 
 int gfx_odd_alias_pair_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
                                    const void* plan, void* ws, size_t ws_bytes, void* stream) {
     return czt_pair_alias<double>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream);
+}
+
+int gfx_odd_alias_pair_precise_max_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                                       const void* plan, void* ws, size_t ws_bytes, const uint32_t* rowmax, int relu,
+                                       void* stream) {
+    return czt_pair_alias<double>(z, y, ldy, lo, len, rows, P, plan, ws, ws_bytes, stream, nullptr, 0, 0, rowmax, relu);
 }
 
 #endif

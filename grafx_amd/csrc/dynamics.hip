@@ -922,24 +922,39 @@ __global__ void energy_kernel(const float* __restrict__ x, gfx_rowmap_t xmap, fl
 }
 
 // truncated one-pole on (R, L) rows -> (R, Lout); Lout may extend to L + N - 1 (full convolution)
-template <bool TRUNC>
-__device__ __forceinline__ void onepole_stream(const OnePole& p, const float* u_in, float* out, int64_t L,
-                                               int64_t Lout, int64_t N, int relu, float* slots, int t) {
+// ESRC (round 6): the rows are the energy mean_c x^2 of a signal read in place (dynamics.py:390) -- the envelope of a
+// compressor whose smoother's convolve() aliases (upstream's default tap counts) no longer goes through an energy buffer.
+// rowmax (nullable): receives the bits of max |out| of the row (one workgroup walks the row: a plain store), the by-product
+// the odd-length aliasing's pair scaling asks for (czt_pair.hip).
+template <bool TRUNC, bool ESRC>
+__device__ __forceinline__ void onepole_stream(const OnePole& p, const float* u_in, const float* x1, int C, float* out, int64_t L,
+                                               int64_t Lout, int64_t N, int relu, float* slots, int t, uint32_t* rowmax) {
     const int lane = t & 63, wave = t >> 6;
-    const bool vi = vec_ok(u_in), vo = vec_ok(out);
-    float carry = 0.0f, carry2 = 0.0f;
+    const bool vi = vec_ok(u_in) && (!ESRC || vec_ok(x1)), vo = vec_ok(out);
+    const float invC = 1.0f / (float)C;
+    auto load_e = [&](int64_t n, bool vec, float (&e)[DE]) {
+        load4(u_in, n, L, vec, e);
+        if (ESRC) {
+            float b[DE] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (C == 2) load4(x1, n, L, vec, b);
+#pragma unroll
+            for (int i = 0; i < DE; ++i) e[i] = (C == 2 ? (e[i] * e[i] + b[i] * b[i]) : e[i] * e[i]) * invC;
+        }
+    };
+    float carry = 0.0f;
+    uint32_t mx = 0;
     const int64_t ntiles = (Lout + DTILE - 1) / DTILE;
     float ne[DE];  // software prefetch of the next tile (see dyn_stream)
-    load4(u_in, (int64_t)DE * t, L, vi, ne);
+    load_e((int64_t)DE * t, vi, ne);
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         const int64_t n = tile * DTILE + DE * t;
         float e[DE], u[DE];
 #pragma unroll
         for (int i = 0; i < DE; ++i) e[i] = ne[i];
-        if (tile + 1 < ntiles) load4(u_in, n + DTILE, L, vi, ne);
+        if (tile + 1 < ntiles) load_e(n + DTILE, vi, ne);
         if (TRUNC) {  // one scan of e[n] - a^N e[n-N] (see dyn_stream)
             float e2[DE];
-            load4(u_in, n - N, L, false, e2);
+            load_e(n - N, false, e2);
 #pragma unroll
             for (int i = 0; i < DE; ++i) e[i] = fmaf(-p.a_N, e2[i], e[i]);
         }
@@ -948,24 +963,48 @@ __device__ __forceinline__ void onepole_stream(const OnePole& p, const float* u_
         for (int i = 0; i < DE; ++i) {
             u[i] = p.one_m_a * u[i];
             if (relu) u[i] = fmaxf(u[i], 0.0f);
+            const uint32_t b = __float_as_uint(u[i]) & 0x7fffffffu;
+            if (rowmax && n + i < Lout) mx = b > mx ? b : mx;
         }
         store4(out, n, Lout, vo, u);
     }
+    if (rowmax) {      // (uniform)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t v = (uint32_t)__shfl_xor((int)mx, o);
+            mx = v > mx ? v : mx;
+        }
+        __syncthreads();
+        if (lane == 0) slots[wave] = __uint_as_float(mx);
+        __syncthreads();
+        if (t == 0) {
+            uint32_t m = 0;
+            for (int w = 0; w < DT / 64; ++w) {
+                const uint32_t v = __float_as_uint(slots[w]);
+                m = v > m ? v : m;
+            }
+            *rowmax = m;
+        }
+    }
 }
 
-__global__ __launch_bounds__(DT) void onepole_kernel(const float* __restrict__ u, const float* __restrict__ z_alpha,
-                                                     float* __restrict__ out, int64_t L, int64_t Lout, int64_t N,
-                                                     int relu) {
+template <bool ESRC>
+__global__ __launch_bounds__(DT) void onepole_kernel(const float* __restrict__ u, gfx_rowmap_t xmap, int C,
+                                                     const float* __restrict__ z_alpha, float* __restrict__ out, int64_t L,
+                                                     int64_t Lout, int64_t N, int relu, uint32_t* __restrict__ rowmax) {
     __shared__ float slots[16];
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x;
     OnePole p;
     onepole_setup(p, z_alpha[r], N, t & 63);
+    const float* in0 = ESRC ? u + drow_off(xmap, r, 0) : u + r * L;
+    const float* in1 = ESRC ? u + drow_off(xmap, r, C == 2 ? 1 : 0) : nullptr;
+    uint32_t* rm = rowmax ? rowmax + r : nullptr;
     // the FIR has exactly N taps: when Lout > L the tail still needs the a^N term once n >= N
     if (p.trunc)
-        onepole_stream<true>(p, u + r * L, out + r * Lout, L, Lout, N, relu, slots, t);
+        onepole_stream<true, ESRC>(p, in0, in1, C, out + r * Lout, L, Lout, N, relu, slots, t, rm);
     else
-        onepole_stream<false>(p, u + r * L, out + r * Lout, L, Lout, N, relu, slots, t);
+        onepole_stream<false, ESRC>(p, in0, in1, C, out + r * Lout, L, Lout, N, relu, slots, t, rm);
 }
 
 // one-pole FIR taps themselves, h[n] = (1-a) * exp(n * log a)  (envelope.py:51-60), for the generic conv path
@@ -2357,8 +2396,19 @@ int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream) {
     if (!u || !z_alpha || !out || R <= 0 || L <= 0 || Lout <= 0 || iir_len < 1 || R > 0x7fffffffLL) return GFX_EINVAL;
-    hipLaunchKernelGGL(onepole_kernel, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, u, z_alpha, out, L, Lout,
-                       iir_len, relu);
+    const gfx_rowmap_t none = {1, 0, 0, 0};
+    hipLaunchKernelGGL(onepole_kernel<false>, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, u, none, 1, z_alpha, out, L,
+                       Lout, iir_len, relu, (uint32_t*)nullptr);
+    return GFX_LAUNCH_OK();
+}
+
+int gfx_onepole_energy_f32(const float* x, gfx_rowmap_t xmap, int64_t C, const float* z_alpha, float* out, int64_t R,
+                           int64_t L, int64_t Lout, int64_t iir_len, int relu, uint32_t* rowmax, void* stream) {
+    if (!x || !z_alpha || !out || R <= 0 || L <= 0 || Lout <= 0 || iir_len < 1 || R > 0x7fffffffLL || (C != 1 && C != 2) ||
+        xmap.inner <= 0)
+        return GFX_EINVAL;
+    hipLaunchKernelGGL(onepole_kernel<true>, dim3((unsigned)R), dim3(DT), 0, (hipStream_t)stream, x, xmap, (int)C, z_alpha, out,
+                       L, Lout, iir_len, relu, rowmax);
     return GFX_LAUNCH_OK();
 }
 

@@ -438,13 +438,14 @@ def _alias_chunks(rows, P, rows_per_chunk, device, precise, pairs=False):
 
 
 @_on_device
-def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None, rowmax=None):
+def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None, rowmax=None, relu=False):
     """irfft_{P-1}(rfft_P(z))[..., lo : lo + length] for z (..., P), P odd: the reference convolve()'s aliasing of a
     full linear convolution (core/convolution.py:123-126), on the chirp-z kernels.  Rows go through in chunks (1.6 MB of
     workspace per row at P ~ 135 k: 25 tiles of 8192 points).  ``precise``: transforms in double precision (twice the
     workspace), for results that feed a logarithm -- the energy envelope, core/envelope.py:34-49.
     ``rowmax``: int32 words, one per row of z, holding the bits of max |z| of the row (what fftconv(rowmax=) leaves): the
-    two-rows-per-transform form then skips its own pass over z (float transforms only)."""
+    two-rows-per-transform form then skips its own pass over z.  ``relu`` (with ``precise`` and pairs): the last pass stores
+    max(y, 0) -- the envelope smoother's clamp (core/envelope.py:48) without a pass of its own."""
     _require_gpu(z)
     P = z.shape[-1]
     Q = P - 1
@@ -456,9 +457,10 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None
     plan = _alias_plan(P, z.device, precise, pairs)
     fwd, tag = _alias_fns(precise, pairs)[3], _alias_fns(precise, pairs)[5]
     chunk, ws = _alias_chunks(rows, P, rows_per_chunk, z.device, precise, pairs)
-    if rowmax is not None and (not pairs or precise or rowmax.numel() != rows or rowmax.dtype != torch.int32
-                               or not rowmax.is_cuda):
+    if rowmax is not None and (not pairs or rowmax.numel() != rows or rowmax.dtype != torch.int32 or not rowmax.is_cuda):
         rowmax = None
+    if relu and not (pairs and precise and out is None):
+        raise ValueError("odd_alias: relu is fused into the two-rows-per-transform double-precision form only")
     if out is not None:
         # ``out``: a (R, C, length) tensor or a strided (B, n, C, length) view whose rows, channels flattened, are z's
         # rows: the last column pass writes them in place (gfx_odd_alias_rows_f32; float transforms only)
@@ -487,7 +489,12 @@ def odd_alias(z, lo=0, length=None, rows_per_chunk=None, precise=False, out=None
     for i in range(0, rows, chunk):
         n = min(chunk, rows - i)
         with _timed(name, 4 * n * (P + length)):
-            if rowmax is not None:
+            if precise and pairs and (rowmax is not None or relu):
+                check(lib().gfx_odd_alias_pair_precise_max_f32(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P,
+                                                               _ptr(plan), _ptr(ws), ws.numel(),
+                                                               None if rowmax is None else rowmax[i : i + n].data_ptr(),
+                                                               int(relu), _stream()), "gfx_odd_alias_pair_precise_max_f32")
+            elif rowmax is not None:
                 check(lib().gfx_odd_alias_pair_max_f32(_ptr(flat[i : i + n]), _ptr(out[i : i + n]), length, lo, length, n, P,
                                                        _ptr(plan), _ptr(ws), ws.numel(), rowmax[i : i + n].data_ptr(), _stream()),
                       "gfx_odd_alias_pair_max_f32")
@@ -856,6 +863,23 @@ def onepole(u, z_alpha, iir_len, Lout=None, relu=True):
     out = torch.empty((R, Lout), dtype=torch.float32, device=u.device)
     pin = _Pin()
     check(lib().gfx_onepole_f32(_ptr(u), pin(_rowvec(z_alpha, R)), _ptr(out), R, L, Lout, iir_len, int(relu), _stream()), "gfx_onepole_f32")
+    return out
+
+
+@_on_device
+def onepole_energy(x, z_alpha, iir_len, Lout=None, relu=True, rowmax=None):
+    """onepole(energy(x), ...) in one pass over the signal x ((R, C, L) or a strided (B, n, C, L) view): gfx_onepole_energy_f32.
+    ``rowmax``: a dict that receives ``rowmax["words"]``, the bits of max |out| of every row (for odd_alias(rowmax=))."""
+    _require_gpu(x, z_alpha)
+    xmap, R, C, L = rowmap(x)
+    Lout = L if Lout is None else Lout
+    out = torch.empty((R, Lout), dtype=torch.float32, device=x.device)
+    words = torch.empty(R, dtype=torch.int32, device=x.device) if rowmax is not None else None
+    pin = _Pin()
+    check(lib().gfx_onepole_energy_f32(_ptr(x), xmap, C, pin(_rowvec(z_alpha, R)), _ptr(out), R, L, Lout, iir_len, int(relu),
+                                       None if words is None else words.data_ptr(), _stream()), "gfx_onepole_energy_f32")
+    if rowmax is not None:
+        rowmax["words"] = words
     return out
 
 

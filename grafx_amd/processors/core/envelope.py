@@ -30,6 +30,22 @@ class TruncatedOnePoleIIRFilter(nn.Module):
         full = ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L + self.iir_len - 1, relu=False)
         return torch.relu(odd_length_alias(full, 0, L, precise=True)).contiguous()
 
+    def forward_energy(self, signal, z_alpha):
+        """forward(mean_c signal^2, z_alpha) for a signal (R, C, L) or a strided (B, n, C, L) view, inference only: the
+        compressors' envelope when this smoother's convolve() aliases (upstream's default tap counts, dynamics.py:390 +
+        envelope.py:34-49) in three passes instead of six -- the energy is formed inside the scan
+        (gfx_onepole_energy_f32), which also leaves the rows' maxima the aliasing scales its pairs by, and the relu rides
+        on the aliasing's last pass (gfx_odd_alias_pair_precise_max_f32)."""
+        L = signal.shape[-1]
+        if not reference_aliases(L, self.iir_len, self.flashfftconv):
+            return ops.onepole_energy(signal, z_alpha, self.iir_len, Lout=L, relu=True)
+        P = L + self.iir_len - 1
+        rm = {}
+        full = ops.onepole_energy(signal, z_alpha, self.iir_len, Lout=P, relu=False, rowmax=rm)
+        if not ops.odd_alias_supported(P) or not ops._alias_pairs(P, full.shape[0]):
+            return torch.relu(odd_length_alias(full, 0, L, precise=True)).contiguous()
+        return ops.odd_alias(full, 0, L, precise=True, rowmax=rm["words"], relu=True)
+
     def compute_impulse(self, z_alpha):
         if needs_grad(z_alpha):
             return diff.one_pole_fir(z_alpha, self.iir_len)

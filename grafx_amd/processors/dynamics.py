@@ -92,6 +92,9 @@ class _Dynamics(BufferIO, nn.Module):
                                            out=_out, param_rows=_shared_rows)
         if self.energy_smoother == "ballistics":   # energy and recursion in one pass over the signal (ballistics.hip)
             energy = ops.ballistics_energy(input_signals, z_alpha_pre)
+        elif self.energy_smoother == "iir" and type(self.energy_smoother_module) is TruncatedOnePoleIIRFilter:
+            # energy -> truncated one-pole (-> the reference's odd-length aliasing, in double) without an energy buffer
+            energy = self.energy_smoother_module.forward_energy(input_signals, z_alpha_pre)
         else:
             energy = ops.energy(input_signals)
             if self.energy_smoother is not None:

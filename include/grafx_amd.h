@@ -227,6 +227,11 @@ int gfx_odd_alias_pair_rows_max_f32(const float* z, float* y, gfx_rowmap_t ymap,
                                     int64_t len, int64_t rows, int64_t P, const void* plan, void* ws, size_t ws_bytes,
                                     const uint32_t* rowmax, void* stream);
 size_t gfx_odd_alias_pair_precise_plan_bytes(int64_t P);
+/* gfx_odd_alias_pair_precise_f32 with the rows' maxima given (`rowmax`, or NULL: taken by a pass of the call) and the envelope
+ * smoother's relu (core/envelope.py:48) fused into the last pass (`relu` != 0): no separate clamp over the rows. */
+int gfx_odd_alias_pair_precise_max_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
+                                       const void* plan, void* ws, size_t ws_bytes, const uint32_t* rowmax, int relu,
+                                       void* stream);
 size_t gfx_odd_alias_pair_precise_workspace_bytes(int64_t rows, int64_t P);
 int gfx_odd_alias_pair_precise_plan_f32(void* plan, int64_t P, void* ws, size_t ws_bytes, void* stream);
 int gfx_odd_alias_pair_precise_f32(const float* z, float* y, int64_t ldy, int64_t lo, int64_t len, int64_t rows, int64_t P,
@@ -377,6 +382,11 @@ int gfx_dynamics_fused_mix_flags_f32(const float* x, gfx_rowmap_t xmap, float* y
 int gfx_energy_f32(const float* x, gfx_rowmap_t xmap, float* e, int64_t R, int64_t C, int64_t L, void* stream);
 int gfx_onepole_f32(const float* u, const float* z_alpha, float* out, int64_t R, int64_t L, int64_t Lout,
                     int64_t iir_len, int relu, void* stream);
+/* gfx_onepole_f32 on the energy mean_c x^2 of a signal read in place through its row map (dynamics.py:390 + core/envelope.py:
+ * 34-60 in one pass: no energy buffer), optionally leaving the bits of max |out| of every row in `rowmax` (R words; NULL: not
+ * wanted) -- the by-product the odd-length aliasing of a full-length result (Lout = L + iir_len - 1) scales its pairs by. */
+int gfx_onepole_energy_f32(const float* x, gfx_rowmap_t xmap, int64_t C, const float* z_alpha, float* out, int64_t R,
+                           int64_t L, int64_t Lout, int64_t iir_len, int relu, uint32_t* rowmax, void* stream);
 int gfx_onepole_fir_f32(const float* z_alpha, float* h, int64_t R, int64_t iir_len, void* stream);
 /* Ballistics.forward (core/envelope.py:84-101): at, rt = sigmoid(z_alpha[:, 0]), sigmoid(z_alpha[:, 1]);  y[-1] = 1;
  * c = at if u[n] < y[n-1] else rt;  y[n] = (1 - c) y[n-1] + c u[n], the two products and the sum rounded separately
