@@ -288,3 +288,37 @@ def test_the_convolution_kernel_leaves_the_rows_maxima_for_the_pair_scaling():
     zl = ops.fftconv(x[:6], ops.fir_spectrum(hl.reshape(6, 20000)), 20000, 1, Lout=L + 19999, rowmax=long)
     assert "words" in long
     assert torch.equal(long["words"].view(torch.float32).view(6, C), zl.abs().amax(-1))
+
+
+@pytest.mark.parametrize("C,L,N,view", [(2, 8192, 4000, False), (1, 5000, 300, False), (2, 12001, 16384, True), (2, 4097, 64, True)])
+def test_the_envelope_in_three_passes_equals_the_six_it_replaces(C, L, N, view):
+    """A compressor whose smoother's convolve() aliases (upstream's default tap counts): energy -> truncated one-pole (full
+    length) -> aliasing in double -> relu.  gfx_onepole_energy_f32 forms the energy inside the scan and leaves the rows'
+    maxima, gfx_odd_alias_pair_precise_max_f32 takes them and clamps in its last pass: the same values as energy_kernel +
+    onepole_kernel + the aliasing's own pass over the rows + torch.relu (the scan is the same arithmetic; the maxima are those
+    of what was stored), poles from fast to the clamp (live truncation term), silence, strided buffer views."""
+    from grafx_amd import ops
+    from grafx_amd.processors.core.envelope import TruncatedOnePoleIIRFilter
+
+    torch.manual_seed(L + N)
+    R = 6
+    if view:
+        buf = torch.randn(2, 7, C, L, device="cuda")
+        x = buf[:, 2:5]
+    else:
+        x = torch.randn(R, C, L, device="cuda")
+    x[1] = 0
+    z = torch.tensor([[0.0], [1.0], [-3.0], [6.0], [12.0], [3.0]], device="cuda")
+    rm = {}
+    full = ops.onepole_energy(x, z, N, Lout=L + N - 1, relu=False, rowmax=rm)
+    want_full = ops.onepole(ops.energy(x), z, N, Lout=L + N - 1, relu=False)
+    assert (full - want_full).abs().max() <= 2e-6 * want_full.abs().max()
+    assert torch.equal(rm["words"].view(torch.float32), full.abs().amax(-1))
+    assert (ops.onepole_energy(x, z, N) - ops.onepole(ops.energy(x), z, N)).abs().max() <= 2e-6 * want_full.abs().max()
+    if (L + N - 1) % 2 == 1:
+        a = ops.odd_alias(full, 0, L, precise=True, rowmax=rm["words"], relu=True)
+        b = torch.relu(ops.odd_alias(full, 0, L, precise=True))
+        assert torch.equal(a, b)
+    m = TruncatedOnePoleIIRFilter(iir_len=N, flashfftconv=False).cuda()
+    with torch.no_grad():
+        assert (m.forward_energy(x, z) - m(ops.energy(x), z)).abs().max() <= 2e-6 * want_full.abs().max()
