@@ -35,6 +35,9 @@ constexpr int DE = 4;              // samples per thread per tile
 constexpr int DTILE = DT * DE;     // 1024 samples per tile
 // per-parameter-row pole table (dyn_pole_table_kernel), floats per row:
 //   a^(4 l) l < 64 | a_step[6] | a_wave | a_N | ap[0..4] | a | 1 - a | trunc | one-shot | H | look-back | M | a^(512 i) i < 64
+#ifndef GFX_DYN_BWD_FAST
+#define GFX_DYN_BWD_FAST true     // hardware log / exp / reciprocal in the backward tiles (false: the library functions)
+#endif
 constexpr int DP_TAB = 148;
 constexpr int DP_ONESHOT = 80, DP_HIST = 81, DP_LOOKBACK = 82, DP_LB_TILES = 83, DP_LB_W = 84;
 
@@ -1934,7 +1937,7 @@ __global__ __launch_bounds__(DT, 3) void dyn_bwd_oneshot_kernel(const float* __r
     float d[OS_SUB][DE], gn[OS_SUB][DE], loc[OS_SUB][DE], excl[OS_SUB], total[OS_SUB];
 #pragma unroll
     for (int k = 0; k < OS_SUB; ++k) {
-        dyn_denv4<true>(a, q, xa[k], xb[k], ga[k], gb[k], uu[k], d[k], gn[k], acc);
+        dyn_denv4<GFX_DYN_BWD_FAST>(a, q, xa[k], xb[k], ga[k], gb[k], uu[k], d[k], gn[k], acc);
         float run = 0.0f;
 #pragma unroll
         for (int i = 0; i < DE; ++i) {
@@ -1954,7 +1957,7 @@ __global__ __launch_bounds__(DT, 3) void dyn_bwd_oneshot_kernel(const float* __r
     float carry = 0.0f;
     if (s != 0 && H > 0) {                       // uniform
         float hd[DE], hgn[DE];
-        dyn_denv4<true>(a, q, hxa, hxb, hga, hgb, hu, hd, hgn, (float*)nullptr);   // (lanes without a live tap hold zeros: denv = 0)
+        dyn_denv4<GFX_DYN_BWD_FAST>(a, q, hxa, hxb, hga, hgb, hu, hd, hgn, (float*)nullptr);   // (lanes without a live tap hold zeros: denv = 0)
         float w = 0.0f;                          // Horner, farthest walk position first
 #pragma unroll
         for (int i = 0; i < DE; ++i) w = fmaf(a1, w, hd[i]);
