@@ -457,6 +457,40 @@ def _console_gradients(procs, G, x, params, want_gx=False):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_ch,n_bus", [(12, 3), (6, 1), (4, 4)])
+def test_block_form_routing_adjoint_on_other_console_shapes(n_ch, n_bus):
+    """Blocks of four strips on three buses, ONE bus (a single block: every strip feeds the same two destinations) and one
+    strip per bus (no two strips share their destinations: nothing to share, the expanded path) -- block form on and off give
+    the same bits."""
+    import bench
+    from grafx_amd.render import graph as render_graph
+    from grafx_amd.utils import create_empty_parameters
+
+    dev = torch.device("cuda")
+    G = bench.console_graph(n_ch=n_ch, n_bus=n_bus)
+    procs = {k: v.to(dev) for k, v in bench.hip_processors().items()}
+    torch.manual_seed(n_ch)
+    x = torch.randn(2, n_ch, 2, 16384, device=dev)
+    params = create_empty_parameters(procs, G, std=0.1).to(dev)
+    calls = []
+    real = render_graph._block_fan
+    render_graph._block_fan = lambda *a: calls.append(real(*a)) or calls[-1]
+    try:
+        got = _console_gradients(procs, G, x, params, want_gx=True)
+    finally:
+        render_graph._block_fan = real
+    shapes = {c[1:3] for c in calls if c is not None}
+    assert ((n_bus, n_ch // n_bus) in shapes) == (n_ch // n_bus >= 2), shapes
+    render_graph.BLOCK_FAN_ADJOINT = False
+    try:
+        want = _console_gradients(procs, G, x, params, want_gx=True)
+    finally:
+        render_graph.BLOCK_FAN_ADJOINT = True
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("smoother", ["iir", "ballistics", None])
 def test_block_form_routing_adjoint_gives_the_bits_of_the_expanded_one(smoother):
     """The adjoint of the console's routing sum has one distinct gradient row per bus and graph (bus + send), shared by
