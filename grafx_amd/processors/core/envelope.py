@@ -28,6 +28,9 @@ class TruncatedOnePoleIIRFilter(nn.Module):
         if not reference_aliases(L, self.iir_len, self.flashfftconv):
             return ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L, relu=True)
         full = ops.onepole(input_signals, z_alpha, self.iir_len, Lout=L + self.iir_len - 1, relu=False)
+        P = L + self.iir_len - 1
+        if full.ndim == 2 and ops.odd_alias_supported(P) and ops._alias_pairs(P, full.shape[0]):
+            return ops.odd_alias(full, 0, L, precise=True, relu=True)      # (the clamp rides on the aliasing's last pass)
         return torch.relu(odd_length_alias(full, 0, L, precise=True)).contiguous()
 
     def forward_energy(self, signal, z_alpha):
