@@ -88,12 +88,11 @@ class IIRFilter(nn.Module):
         if Bs.shape[-1] == 2 and As.shape[-1] == 2:     # first-order sections: b2 = a2 = 0 (differentiable: a zero pad)
             Bs, As = torch.nn.functional.pad(Bs, (0, 1)), torch.nn.functional.pad(As, (0, 1))
         if needs_grad(input_signal, Bs, As):
-            if self.backend == "ssm" and Bs.shape[2] > 1:
-                raise NotImplementedError("backend='ssm' with more than one section reproduces an upstream quirk (every "
-                                          "section's recursion is driven by the original input, core/iir.py:226-246) in "
-                                          "the forward pass only; train with backend='lfilter' or 'fsm'")
             x3 = input_signal.reshape(-1, *input_signal.shape[-2:]) if input_signal.ndim == 4 else input_signal
-            y = diff.BiquadCascadeFn.apply(x3, Bs, As)   # native recursion both ways (autograd.BiquadCascadeFn)
+            if self.backend == "ssm" and Bs.shape[2] > 1:
+                y = self._ssm_quirk_differentiable(x3, Bs, As)
+            else:
+                y = diff.BiquadCascadeFn.apply(x3, Bs, As)   # native recursion both ways (autograd.BiquadCascadeFn)
             if input_signal.ndim == 4:
                 y = y.view(*input_signal.shape[:2], *y.shape[1:])
             if out is None:
@@ -104,6 +103,26 @@ class IIRFilter(nn.Module):
             assert Bs.shape[-1] == As.shape[-1] == 3, "The filter order must be 2."
         # "ssm" with K > 1: upstream drives every section's recursion with the original input (iir.py:226-246)
         return ops.biquad_cascade(input_signal, Bs, As, ssm_quirk=self.backend == "ssm", out=out)
+
+    @staticmethod
+    def _ssm_quirk_differentiable(x, Bs, As):
+        """Upstream's "ssm" with K > 1 sections (core/iir.py:186-260) is not a cascade: every section's RECURSION is driven by
+        the ORIGINAL input and only its direct term b0 by the previous section's output,
+            y_k = b0_k y_{k-1} + z^-1 (b12_k / A_k) x,      b12 = b[1:] / a0 - b0 a[1:] / a0,  b0 = b[0] / a0,
+        i.e. K parallel one-section filters of the input folded with the direct gains.  Spelled out like that it is K native
+        single-section recursions (autograd.BiquadCascadeFn: native backward) and a few products -- the same values as the
+        forward-only kernel path (gfx_biquad_cascade_f32 with ssm_quirk), with gradients (round 6: this used to raise)."""
+        a0 = As[..., :1]
+        Bn, a12 = Bs / a0, As[..., 1:] / a0
+        b0 = Bn[..., :1]                                   # (R, Cf, K, 1)
+        b12 = Bn[..., 1:] - b0 * a12                       # (R, Cf, K, 2)
+        one, zero = torch.ones_like(b0[:, :, 0]), torch.zeros_like(b0[:, :, 0])
+        y = x
+        for k in range(Bs.shape[2]):
+            Bk = torch.cat([zero, b12[:, :, k]], -1).unsqueeze(2)          # z^-1 (b12_0 + b12_1 z^-1)
+            Ak = torch.cat([one, a12[:, :, k]], -1).unsqueeze(2)
+            y = b0[:, :, k] * y + diff.BiquadCascadeFn.apply(x, Bk, Ak)
+        return y
 
     def forward(self, input_signal, Bs, As, out=None, tee=None, shared_rows=None, final=False):
         """``shared_rows``: Bs/As hold that many rows, shared by the batch (signal row r uses r % shared_rows).

@@ -256,11 +256,53 @@ def test_recursive_backends_are_differentiable(backend, K, C, Cf):
         assert err <= 2e-4, f"{backend} K={K} C={C}/{Cf} grad {name}: {err:.2e}"
 
 
-def test_ssm_quirk_with_several_sections_is_forward_only():
+@pytest.mark.parametrize("K,C,Cf", [(2, 2, 1), (3, 1, 2), (4, 2, 2)])
+def test_ssm_quirk_with_several_sections_trains(K, C, Cf):
+    """Upstream's "ssm" with K > 1 (core/iir.py:186-260: every section's recursion driven by the ORIGINAL input) used to be
+    forward-only here; spelled out as K parallel single-section recursions folded with the direct gains it has gradients.
+    Forward: the values of the kernel's ssm_quirk path; gradients: torch autograd of the same formula as a float64 loop."""
     from grafx_amd.processors import IIRFilter
 
-    x = torch.randn(2, 2, 100, device="cuda", requires_grad=True)
-    Bs = torch.randn(2, 1, 2, 3, device="cuda")
-    As = torch.tensor([1.0, -0.5, 0.2], device="cuda").expand(2, 1, 2, 3).contiguous()
-    with pytest.raises(NotImplementedError):
-        IIRFilter(order=2, backend="ssm", flashfftconv=False)(x, Bs, As)
+    torch.manual_seed(K + C + 2 * Cf)
+    R, L = 3, 300
+    x = torch.randn(R, C, L)
+    radius = 0.4 + 0.5 * torch.rand(R, Cf, K)
+    theta = torch.rand(R, Cf, K) * 2.8 + 0.1
+    As = torch.stack([1.0 + 0.2 * torch.rand(R, Cf, K), -2 * radius * torch.cos(theta), radius.square()], -1)
+    Bs = torch.randn(R, Cf, K, 3)
+    wgt = torch.randn(R, max(C, Cf), L)
+
+    def ref(x, Bs, As):
+        Co = max(C, Cf)
+        x0 = x.expand(R, Co, L)
+        y = x0
+        for k in range(K):
+            b, a = Bs[:, :, k].expand(R, Co, 3), As[:, :, k].expand(R, Co, 3)
+            b0 = b[..., 0] / a[..., 0]
+            a1, a2 = a[..., 1] / a[..., 0], a[..., 2] / a[..., 0]
+            c1, c2 = b[..., 1] / a[..., 0] - b0 * a1, b[..., 2] / a[..., 0] - b0 * a2
+            w1 = torch.zeros(R, Co, dtype=x.dtype)
+            w2 = torch.zeros(R, Co, dtype=x.dtype)
+            out = []
+            for n in range(L):      # d[n] = (c1 z^-1 + c2 z^-2) / A applied to the ORIGINAL input
+                w = x0[..., n] - a1 * w1 - a2 * w2
+                out.append(b0 * y[..., n] + c1 * w1 + c2 * w2)
+                w2, w1 = w1, w
+            y = torch.stack(out, -1)
+        return y
+
+    m = IIRFilter(order=2, backend="ssm", flashfftconv=False)
+    with torch.no_grad():
+        y_kernel = m(x.cuda(), Bs.cuda(), As.cuda()).cpu()
+    x64, B64, A64 = (t.double().requires_grad_(True) for t in (x, Bs, As))
+    y64 = ref(x64, B64, A64)
+    assert (y_kernel.double() - y64.detach()).abs().max() <= 2e-5 * y64.abs().max()
+    (y64 * wgt.double()).sum().backward()
+    xg, Bg, Ag = (t.cuda().requires_grad_(True) for t in (x, Bs, As))
+    y = m(xg, Bg, Ag)
+    assert (y.detach().cpu().double() - y64.detach()).abs().max() <= 2e-5 * y64.abs().max()
+    (y * wgt.cuda()).sum().backward()
+    for name, got, want in (("x", xg.grad, x64.grad), ("Bs", Bg.grad, B64.grad), ("As", Ag.grad, A64.grad)):
+        assert got is not None and got.shape == want.shape, name
+        err = (got.cpu().double() - want).abs().max() / want.abs().max()
+        assert err <= 2e-4, f"ssm quirk K={K} C={C}/{Cf} grad {name}: {err:.2e}"
