@@ -185,11 +185,13 @@ def test_loud_failures():
         m(torch.zeros(1, 2, 8), torch.zeros(1, 2))  # CPU tensors are refused
     y = m(torch.ones(1, 2, 8).cuda(), torch.zeros(1, 2, device="cuda", requires_grad=True))
     assert y.requires_grad  # gradient requested -> differentiable path
-    with pytest.raises(NotImplementedError):  # a missing backward fails loudly (the upstream "ssm" quirk for K > 1)
-        P.IIRFilter(backend="ssm", flashfftconv=False)(torch.rand(1, 1, 64).cuda(),
-                                                        torch.ones(1, 1, 2, 3, device="cuda", requires_grad=True),
-                                                        torch.tensor([1.0, 0.1, 0.1], device="cuda").expand(1, 1, 2, 3))
-    with pytest.raises(NotImplementedError):  # the recursive kernel runs second-order sections only
+    # (the upstream "ssm" quirk for K > 1 used to be forward-only and raised here; it trains since round 6:
+    # tests/test_gpu_recursive_iir.py::test_ssm_quirk_with_several_sections_trains)
+    ys = P.IIRFilter(backend="ssm", flashfftconv=False)(torch.rand(1, 1, 64).cuda(),
+                                                         torch.ones(1, 1, 2, 3, device="cuda", requires_grad=True),
+                                                         torch.tensor([1.0, 0.1, 0.1], device="cuda").expand(1, 1, 2, 3))
+    assert ys.requires_grad
+    with pytest.raises(NotImplementedError):  # the recursive kernel runs first- and second-order sections only
         P.IIRFilter(order=3, backend="lfilter", flashfftconv=False)
     with pytest.raises(ValueError):
         P.IIRFilter(backend="nope", flashfftconv=False)
