@@ -315,7 +315,7 @@ def profile_traffic(kernel, B, L, lens):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rN/pmc_hbm_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied) -- a PROFILE figure,
     not one measured in this run; None when no committed profile matches the workload."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         pmc = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
         if not os.path.exists(pmc):
             continue
